@@ -1,0 +1,1 @@
+"""empty stand-in so the reference modules import; fixture tooling only"""

@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by IMPORTING the reference (dgaddy/silent_speech) in the
+build container.  Run from the repo root:   python tests/golden/make_golden.py
+
+The reference lives at /root/reference (read-only, never copied).  Modules it needs that are not
+installed here (absl, numba, librosa, soundfile, textgrids, jiwer, unidecode, deepspeech, the
+empty hifi_gan submodule) are satisfied by the throw-away stand-ins in tests/golden/_stubs
+(ours, not reference code).  Only the resulting DATA (.npz, KB-scale) is committed.
+
+Version drift neutralised without editing the reference: torch>=2.1's
+nn.TransformerEncoder reads layers[0].self_attn.batch_first, which the reference's
+MultiHeadAttention lacks -> set that attribute (False) on each constructed layer.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get('SS_REFERENCE', '/root/reference')
+sys.path.insert(0, os.path.join(HERE, '_stubs'))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, '..', '..')))
+
+from absl import flags  # noqa: E402  (stub)
+FLAGS = flags.FLAGS
+
+import transformer as ref_transformer  # noqa: E402
+import architecture as ref_arch  # noqa: E402
+import align as ref_align  # noqa: E402
+import data_utils as ref_data  # noqa: E402
+import transduction_model as ref_tm  # noqa: E402
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes')
+
+
+def build_model(d_model, num_layers, num_outs=80, num_aux=48, seed=0, perturb=True):
+    FLAGS.model_size = d_model
+    FLAGS.num_layers = num_layers
+    FLAGS.dropout = 0.0
+    torch.manual_seed(seed)
+    m = ref_arch.Model(112, num_outs, num_aux)
+    for layer in m.transformer.layers:
+        layer.self_attn.batch_first = False
+    if perturb:
+        # nn.TransformerEncoder deep-copies one layer -> identical layers; BN/LN affine start at 1/0.
+        # Perturb so that layer order, gamma/beta and running stats are all exercised.
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if 'relative_positional' in n:
+                    continue
+                p.add_(torch.randn(p.shape, generator=g) * 0.05 * (p.abs().mean() + 0.1))
+            for n, b in m.named_buffers():
+                if n.endswith('running_mean'):
+                    b.add_(torch.randn(b.shape, generator=g) * 0.1)
+                elif n.endswith('running_var'):
+                    b.mul_(1 + 0.2 * torch.rand(b.shape, generator=g))
+    return m
+
+
+def synth_raw(B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, 8 * T, 8, generator=g) * 5.0
+    return 50.0 * torch.tanh(z / 50.0)
+
+
+def gen_model(tag, d_model, num_layers, B, T, r, training, seed):
+    m = build_model(d_model, num_layers, seed=seed)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    x_raw = synth_raw(B, T, seed + 10)
+    x_in = x_raw.clone()
+    m.train(training)
+    if training:
+        class _R(object):
+            @staticmethod
+            def randrange(n):
+                return r
+        ref_arch.random = _R  # the reference draws r = random.randrange(8) (architecture.py:65)
+    g = torch.Generator().manual_seed(seed + 20)
+    wp = torch.randn(B, T, 80, generator=g)
+    wa = torch.randn(B, T, 48, generator=g)
+    pred, aux = m(torch.zeros(B, T, 112), x_raw, torch.zeros(B, T, dtype=torch.long))
+    loss = (pred * wp).sum() + (aux * wa).sum()
+    arrs = dict(x_raw=x_in, pred=pred, aux=aux, wp=wp, wa=wa, r=np.int64(r), training=np.int64(training))
+    if training:
+        loss.backward()
+        import random as _random
+        ref_arch.random = _random
+        for n, p in m.named_parameters():
+            if p.grad is None:
+                arrs['nograd/' + n] = np.zeros(1)
+            else:
+                arrs['grad/' + n] = p.grad
+        for n, b in m.named_buffers():
+            arrs['after/' + n] = b
+        arrs['x_raw_after'] = x_raw  # mutated in place by the shift
+    for k, v in sd0.items():
+        arrs['sd/' + k] = v
+    save(tag, **arrs)
+
+
+def gen_mha():
+    for T in (50, 100, 200, 250):
+        torch.manual_seed(100 + T)
+        d_model, H = 16, 2
+        mha = ref_transformer.MultiHeadAttention(d_model, H, dropout=0.0, relative_positional=True,
+                                                 relative_positional_distance=100)
+        x = torch.randn(T, 3, d_model, requires_grad=True)
+        out = mha(x)
+        w = torch.randn(T, 3, d_model)
+        (out * w).sum().backward()
+        # positional logits alone (closed-form check)
+        q = torch.einsum('tbf,hfa->bhta', x, mha.w_q)
+        pos, _ = mha.relative_positional(q.permute(2, 0, 1, 3).reshape(T, 3 * H, d_model // H))
+        assert mha.relative_positional.embeddings.grad is None
+        save('mha_T%d' % T, x=x, out=out, w=w, dx=x.grad, w_q=mha.w_q, w_k=mha.w_k, w_v=mha.w_v, w_o=mha.w_o,
+             E=mha.relative_positional.embeddings, pos=pos.view(3, H, T, T)[:1],
+             dw_q=mha.w_q.grad, dw_k=mha.w_k.grad, dw_v=mha.w_v.grad, dw_o=mha.w_o.grad)
+
+
+def gen_dtw():
+    rng = np.random.default_rng(0)
+    cases = {}
+    cases['rand_37x53'] = rng.random((37, 53), dtype=np.float32)
+    cases['rand_64x64'] = rng.random((64, 64), dtype=np.float32)
+    cases['rand_130x71'] = (rng.standard_normal((130, 71)) ** 2).astype(np.float32)
+    cases['const_6x5'] = np.ones((6, 5), dtype=np.float32)
+    cases['const_5x6'] = np.ones((5, 6), dtype=np.float32)
+    cases['zeros_9x9'] = np.zeros((9, 9), dtype=np.float32)
+    cases['row_1x7'] = rng.random((1, 7), dtype=np.float32)
+    cases['col_7x1'] = rng.random((7, 1), dtype=np.float32)
+    cases['one_1x1'] = rng.random((1, 1), dtype=np.float32)
+    cases['two_2x2'] = rng.random((2, 2), dtype=np.float32)
+    cases['ties_20x24'] = rng.integers(0, 3, (20, 24)).astype(np.float32)
+    cases['ties_65x129'] = rng.integers(0, 2, (65, 129)).astype(np.float32)
+    # realistic: transposed (non-contiguous) view of a cdist-like matrix, as at transduction_model.py:126
+    a = np.cumsum(rng.standard_normal((90, 8)), 0).astype(np.float32)
+    b = np.cumsum(rng.standard_normal((75, 8)), 0).astype(np.float32)
+    cases['walk_T_75x90'] = np.sqrt(((a[:, None] - b[None]) ** 2).sum(-1)).astype(np.float32).T
+    arrs = {}
+    for k, c in cases.items():
+        res = ref_align.align_from_distances(c)
+        dtw = ref_align.time_warp(c)
+        assert dtw.dtype == np.float32
+        arrs['costs/' + k] = np.ascontiguousarray(c)
+        arrs['dtw/' + k] = dtw
+        arrs['align/' + k] = np.asarray(res, dtype=np.int64)
+    save('dtw_small', **arrs)
+    # one big matrix: store only the seed recipe, the alignment and a checksum of the dtw matrix
+    big = np.random.default_rng(7).random((1000, 1000), dtype=np.float32)
+    res = ref_align.align_from_distances(big)
+    dtw = ref_align.time_warp(big)
+    save('dtw_big', seed=np.int64(7), shape=np.array([1000, 1000]), align=np.asarray(res, dtype=np.int64),
+         dtw_last=dtw[-1].copy(), dtw_sum64=np.float64(dtw[1:, 1:].astype(np.float64).sum()))
+
+
+def gen_dtw_loss():
+    FLAGS.phoneme_loss_weight = 0.5
+    g = torch.Generator().manual_seed(5)
+    lengths = [37, 64, 50, 49]
+    silent = [False, True, True, False]
+    t2 = [37, 71, 44, 49]
+    total = sum(lengths)
+    B = (total + 49) // 50
+    pred = torch.randn(B, 50, 80, generator=g, requires_grad=True)
+    aux = torch.randn(B, 50, 48, generator=g, requires_grad=True)
+    audio = [torch.randn(n, 80, generator=g) * 0.7 for n in t2]
+    phones = [torch.randint(0, 48, (n,), generator=g) for n in t2]
+    example = dict(lengths=lengths, audio_features=audio, phonemes=phones, silent=silent)
+    loss, acc = ref_tm.dtw_loss(pred, aux, example)
+    loss.backward()
+    conf = np.zeros((48, 48))
+    with torch.no_grad():
+        loss_e, acc_e = ref_tm.dtw_loss(pred.detach(), aux.detach(), example, True, conf)
+    arrs = dict(pred=pred, aux=aux, loss=loss, acc=np.float64(acc), dpred=pred.grad, daux=aux.grad,
+                lengths=np.array(lengths), silent=np.array(silent), t2=np.array(t2),
+                loss_eval=loss_e, acc_eval=np.float64(acc_e), confusion=conf)
+    for i in range(len(lengths)):
+        arrs['audio/%d' % i] = audio[i]
+        arrs['phones/%d' % i] = phones[i]
+    save('dtw_loss_mixed', **arrs)
+    # voiced-only (cfg1)
+    g = torch.Generator().manual_seed(6)
+    pred = torch.randn(1, 200, 80, generator=g, requires_grad=True)
+    aux = torch.randn(1, 200, 48, generator=g, requires_grad=True)
+    audio = [torch.randn(200, 80, generator=g) * 0.5]
+    phones = [torch.randint(0, 48, (200,), generator=g)]
+    example = dict(lengths=[200], audio_features=audio, phonemes=phones, silent=[False])
+    loss, acc = ref_tm.dtw_loss(pred, aux, example)
+    loss.backward()
+    save('dtw_loss_voiced', pred=pred, aux=aux, loss=loss, acc=np.float64(acc), dpred=pred.grad, daux=aux.grad,
+         audio=audio[0], phones=phones[0])
+
+
+def gen_pack():
+    g = torch.Generator().manual_seed(8)
+    ts = [torch.randn(n, 8, generator=g) for n in (13, 40, 7, 20)]
+    packed = ref_data.combine_fixed_length(ts, 16)
+    outs = ref_data.decollate_tensor(packed, [13, 40, 7, 20])
+    for a, b in zip(ts, outs):
+        assert torch.equal(a, b)
+    save('pack', packed=packed, **{'t/%d' % i: t for i, t in enumerate(ts)})
+
+
+def gen_mel():
+    from oracle.mel_ref import slaney_mel_basis
+    g = torch.Generator().manual_seed(9)
+    T = 40
+    L = 256 * (T + 1)
+    noise = (0.1 * torch.randn(2, L, generator=g)).clamp(-1, 1)
+    t = torch.arange(L) / 22050.0
+    chirp = 0.5 * torch.sin(2 * np.pi * (200.0 + 4000.0 * t) * t)
+    y = torch.cat([noise, chirp[None]], 0)
+    mel = ref_data.mel_spectrogram(y, 1024, 80, 22050, 256, 1024, 0, 8000, center=False)
+    basis = slaney_mel_basis(22050, 1024, 80, 0, 8000)
+    save('mel', y=y, mel=mel, basis=basis)
+    # FeatureNormalizer constants shipped with the reference (normalizers.pkl; defines mel-L1 units)
+    import pickle
+    with open(os.path.join(REF, 'normalizers.pkl'), 'rb') as f:
+        mfcc_norm, emg_norm = pickle.load(f)
+    save('normalizers', mfcc_means=mfcc_norm.feature_means, mfcc_std=np.float64(mfcc_norm.feature_stddevs),
+         emg_means=emg_norm.feature_means, emg_stds=emg_norm.feature_stddevs)
+
+
+def gen_adamw():
+    torch.manual_seed(11)
+    p = torch.nn.Parameter(torch.randn(257))
+    opt = torch.optim.AdamW([p], weight_decay=1e-7)
+    hist = [p.detach().clone()]
+    grads = []
+    for it in range(3):
+        lr = (it + 1) * 1e-3 / 500           # transduction_model.py:186-189
+        for gparam in opt.param_groups:
+            gparam['lr'] = lr
+        opt.zero_grad()
+        gr = torch.randn(257)
+        p.grad = gr.clone()
+        opt.step()
+        grads.append(gr)
+        hist.append(p.detach().clone())
+    save('adamw', p=torch.stack(hist), g=torch.stack(grads))
+
+
+if __name__ == '__main__':
+    random.seed(0)
+    # architecture.py:67 copies x_raw[:, r:] onto x_raw[:, :-r] IN PLACE (overlapping views); with a
+    # multi-threaded copy that is racy (observed: 24 samples shifted twice at a chunk boundary).
+    # One thread gives the intended, deterministic left shift -- the semantics the build implements.
+    torch.set_num_threads(1)
+    gen_dtw()
+    gen_pack()
+    gen_mha()
+    gen_model('model_d8_L1_eval', 8, 1, 2, 200, 0, False, 1)          # BASELINE cfg1 size
+    gen_model('model_d8_L1_train_r0', 8, 1, 2, 200, 0, True, 2)
+    gen_model('model_d16_L2_train_r3', 16, 2, 3, 200, 3, True, 3)
+    gen_model('model_d16_L2_train_r7_T120', 16, 2, 2, 120, 7, True, 4)
+    gen_dtw_loss()
+    gen_mel()
+    gen_adamw()
