@@ -1,0 +1,85 @@
+/* silent_speech_hip.h -- C ABI of libsilent_speech_hip.so: the MI355X (gfx950) implementation of the
+ * EMG->mel transduction TRAINING hot path of dgaddy/silent_speech.
+ *
+ * The reference is pure Python/PyTorch and has no FFI seam; its seam for this path is the set of
+ * torch operator calls made by architecture.py / transformer.py / transduction_model.py / align.py /
+ * data_utils.py.  Each entry point below replaces the reference call sites cited next to it
+ * (file:line are relative to the reference repository root).  Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer (HBM) unless marked [host];
+ *   - `stream` is a hipStream_t passed as void*; nothing here synchronises the device;
+ *   - `dtype`: SS_F32 (0) or SS_BF16 (1) is the activation/compute type; statistics, losses,
+ *     gradients of parameters and optimizer state are always f32;
+ *   - return 0 on success; non-zero on error, with a message available from ss_last_error();
+ *   - inputs are never modified unless documented (the reference's in-place EMG shift,
+ *     architecture.py:67-68, is such a case and is mirrored by ss_emg_conv0_forward's `shift`).
+ * The Python binding a maintainer of the reference would add is a ctypes stub.
+ */
+#ifndef SILENT_SPEECH_HIP_H
+#define SILENT_SPEECH_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_F32 0
+#define SS_BF16 1
+
+const char* ss_last_error(void);
+/* Library/ABI version and the GPU architecture the kernels were compiled for ("gfx950"). */
+int ss_abi_version(void);
+const char* ss_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row addressing: logical row i starts at element
+ *      base + (i / rows_per_batch) * batch_stride + (i % rows_per_batch) * row_stride
+ * (rows_per_batch <= 0 means "one batch").  Expresses plain matrices, the zero-padded (B, T+2, C)
+ * activation buffers, the overlapping 3C-wide im2col rows of the k=3 convolutions and strided
+ * scatter of their input gradients. */
+typedef struct ss_rowmap {
+    int64_t base;
+    int64_t batch_stride;
+    int64_t row_stride;
+    int32_t rows_per_batch;
+} ss_rowmap;
+
+typedef struct ss_gemm_epilogue {
+    const float* bias;      /* [N] f32 or NULL                                                        */
+    const void* gate;       /* out-typed tensor addressed like C or NULL: out = gate>0 ? out*gate_scale : 0
+                               (ReLU + inverted-dropout backward from the SAVED activation)           */
+    float gate_scale;
+    float alpha;            /* scale applied to the accumulator first                                 */
+    int32_t relu;           /* F.relu  (architecture.py:32; transformer.py:57)                        */
+    float dropout_p;        /* nn.Dropout in training mode (transformer.py:57), Philox4x32-10         */
+    uint64_t seed;
+    uint32_t rng_stream;    /* dropout site id; element index = row*N + col                           */
+    int32_t mode;           /* 0 store, 1 C += v, 2 atomicAdd(C, v) (f32 out; required for split_k>1) */
+    int32_t col_mod, col_mul, col_div_mul; /* optional output column permutation
+                               col -> (col % col_mod)*col_mul + (col / col_mod)*col_div_mul           */
+} ss_gemm_epilogue;
+
+#define SS_OP_KC 0   /* reduction index contiguous:  elem(o, r) = p[rowmap(o) + r] */
+#define SS_OP_OC 1   /* outer index contiguous:      elem(o, r) = p[rowmap(r) + o] */
+
+/* C[m][n] (+)= alpha * sum_k A(m,k) * B(n,k) on the MFMA units, f32 accumulate.
+ * Replaces: nn.Conv1d k=3/k=1 (architecture.py:18,20,24 -> F.conv1d) as implicit GEMM over padded
+ * activation buffers; nn.Linear (architecture.py:51,55,59; transformer.py:32,34); the per-head
+ * einsum projections 'tbf,hfa->bhta' / 'bhta,haf->tbf' (transformer.py:96-98,111); and the autograd
+ * backward of all of them (transduction_model.py:209): dX = dY.W (b_mode = OC), dW = dY^T.X
+ * (a_mode = b_mode = OC, split_k > 1 with atomic f32 accumulation). */
+int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, const void* B, void* C,
+            int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap,
+            const ss_gemm_epilogue* epilogue, int split_k, void* stream);
+
+/* out[a][b][c] (contiguous, dims d0 x d1 x d2) (+)= scale * in[a*s0 + b*s1 + c*s2] for b < valid1 and
+ * c < valid2, else 0 (zero padding).  Converts between the reference's parameter layouts (state_dict:
+ * conv (O,I,k) architecture.py:18; w_q/w_k/w_v (H,d,dh), w_o (H,dh,d) transformer.py:71-74; embeddings
+ * (H,2D-1,dh,1) transformer.py:159) and the GEMM-ready, head-dim-padded layouts, in both directions
+ * (weights forward, gradients back).  in/out dtype: SS_F32 or SS_BF16. */
+int ss_permute3d(const void* in, int in_dtype, void* out, int out_dtype, int d0, int d1, int d2,
+                 int64_t s0, int64_t s1, int64_t s2, int valid1, int valid2, float scale, int accumulate,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,115 @@
+"""ctypes binding of libsilent_speech_hip.so (C ABI declared in include/silent_speech_hip.h).
+
+The product path has exactly one backend: the gfx950 shared library built by __graft_entry__.build()
+(or `make -C silent_speech_amd/csrc`).  If it is missing, or a tensor is not on an AMD GPU, calls
+raise -- there is no CPU fallback.  tests/ may inject a different handle (the host-emulator build of
+the same kernel sources, tools/emu) through `use_library_for_testing`; nothing in the package does.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'lib', 'libsilent_speech_hip.so')
+
+SS_F32, SS_BF16 = 0, 1
+OP_KC, OP_OC = 0, 1
+
+
+class RowMap(ctypes.Structure):
+    _fields_ = [('base', ctypes.c_int64), ('batch_stride', ctypes.c_int64), ('row_stride', ctypes.c_int64),
+                ('rows_per_batch', ctypes.c_int32)]
+
+
+class GemmEpilogue(ctypes.Structure):
+    _fields_ = [('bias', ctypes.c_void_p), ('gate', ctypes.c_void_p), ('gate_scale', ctypes.c_float),
+                ('alpha', ctypes.c_float), ('relu', ctypes.c_int32), ('dropout_p', ctypes.c_float),
+                ('seed', ctypes.c_uint64), ('rng_stream', ctypes.c_uint32), ('mode', ctypes.c_int32),
+                ('col_mod', ctypes.c_int32), ('col_mul', ctypes.c_int32), ('col_div_mul', ctypes.c_int32)]
+
+
+_P, _I, _F, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+_U64, _U32 = ctypes.c_uint64, ctypes.c_uint32
+
+# name -> argtypes; every function returns int (0 = ok) unless listed in _RESTYPES
+SIGNATURES = {
+    'ss_gemm': [_I, _I, _I, _I, _P, _P, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap),
+                ctypes.POINTER(RowMap), ctypes.POINTER(GemmEpilogue), _I, _P],
+    'ss_permute3d': [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _I, _P],
+}
+_RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}
+
+_lib = None
+_is_emulator = False
+
+
+def _declare(lib):
+    for name, restype in _RESTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    return lib
+
+
+def load(path=None):
+    global _lib, _is_emulator
+    path = path or _LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError('silent_speech_amd: %s not found -- build the gfx950 kernels first '
+                           '(python -c "import __graft_entry__ as g; g.build()" or make -C silent_speech_amd/csrc). '
+                           'There is no CPU fallback.' % path)
+    _lib = _declare(ctypes.CDLL(path))
+    _is_emulator = _lib.ss_target_arch() != b'gfx950'
+    return _lib
+
+
+def use_library_for_testing(path):
+    """tests/ only: run the same kernel sources on the host emulator (CPU tensors)."""
+    return load(path)
+
+
+def lib():
+    if _lib is None:
+        load()
+    return _lib
+
+
+def is_emulator():
+    lib()
+    return _is_emulator
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise RuntimeError('%s failed: %s' % (what or 'silent_speech_hip call', lib().ss_last_error().decode()))
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return SS_F32
+    if dt == torch.bfloat16:
+        return SS_BF16
+    raise TypeError('unsupported dtype %s (float32 or bfloat16)' % dt)
+
+
+def ptr(t):
+    """Device pointer of a tensor, enforcing that the product library only ever sees GPU memory."""
+    if t is None:
+        return None
+    if not is_emulator() and not t.is_cuda:
+        raise RuntimeError('silent_speech_amd: tensor is on %s; the HIP kernels need an AMD GPU tensor '
+                           '(no CPU fallback exists)' % t.device)
+    if is_emulator() and t.is_cuda:
+        raise RuntimeError('emulator backend (tests only) needs CPU tensors')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    if t is not None and t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(0)

@@ -1,0 +1,160 @@
+// common.h -- shared device/host helpers for the gfx950 kernels of the transduction hot path.
+// One source, two builds: hipcc --offload-arch=gfx950 (the product) and, for the CPU test tier
+// only, host clang with -DSS_EMU against tools/emu/hipemu.h (see that header).
+#pragma once
+#if defined(SS_EMU)
+#include "hipemu.h"
+#else
+#include <hip/hip_runtime.h>
+#define SS_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+// ------------------------------------------------------------------ error reporting (C ABI)
+extern "C" const char* ss_last_error(void);
+void ss_set_error(const char* fmt, ...);
+#define SS_CHECK(cond, ...)                         \
+    do {                                            \
+        if (!(cond)) { ss_set_error(__VA_ARGS__); return 1; } \
+    } while (0)
+int ss_check_launch(const char* what);
+#define SS_LAUNCH_CHECK(what) do { int rc_ = ss_check_launch(what); if (rc_) return rc_; } while (0)
+
+#if defined(SS_EMU)
+#define SS_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipemu::launch(grid, block, smem, [&]() { kernel(__VA_ARGS__); })
+#else
+#define SS_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+#endif
+#define SS_KERNEL(...) (__VA_ARGS__)   // protects template commas inside SS_LAUNCH
+
+// ------------------------------------------------------------------ element types
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+enum { SS_F32 = 0, SS_BF16 = 1 };
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, NaN-preserving
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+template <class T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <class T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <class T> __device__ __forceinline__ float rnd(float v);   // round through the storage type
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rnd<bf16_t>(float v) { return bf2f(f2bf(v)); }
+
+// 8-element vector load/store as floats (16 B for bf16, 32 B for f32); p must be 16-B aligned
+template <class T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)p = a; *(f32x4*)(p + 4) = b;
+    }
+};
+template <> struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        u32x4 r = *(const u32x4*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        u32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+        *(u32x4*)p = r;
+    }
+};
+
+// ------------------------------------------------------------------ wave helpers (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// ------------------------------------------------------------------ MFMA wrappers
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+#if defined(SS_EMU)
+    return hipemu::mfma_16x16x32_bf16(a, b, c);
+#else
+    typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+#if defined(SS_EMU)
+    return hipemu::mfma_16x16x4_f32(a, b, c);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 (dropout RNG)
+struct Philox4 { unsigned v[4]; };
+__device__ __forceinline__ Philox4 philox4x32(unsigned long long seed, unsigned long long ctr, unsigned stream) {
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = stream, c3 = 0x5eed5eedu;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+// keep-decision for element `idx` of dropout site `stream`: true with probability 1-p.
+// One Philox block serves 4 consecutive elements (idx>>2), lane idx&3.
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned stream, unsigned long long idx, unsigned thresh /* p * 2^32 */) {
+    Philox4 r = philox4x32(seed, idx >> 2, stream);
+    return r.v[idx & 3] >= thresh;
+}
+static inline unsigned dropout_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t <= 0) return 0u;
+    if (t >= 4294967295.0) return 4294967295u;
+    return (unsigned)t;
+}
+
+// ------------------------------------------------------------------ row addressing
+// Logical row i of a (possibly batched / strided / overlapping) matrix starts at element offset
+//   base + (i / rows_per_batch) * batch_stride + (i % rows_per_batch) * row_stride.
+// This one map expresses plain matrices, the zero-padded (B, T+2, C) activation buffers, the
+// overlapping 3C-wide im2col rows of the k=3 convolutions (architecture.py:18,20) with stride 1/2,
+// and the stride-2 scatter of their input gradients.
+struct RowMap {
+    long long base;
+    long long batch_stride;
+    long long row_stride;
+    int rows_per_batch;
+};
+__device__ __host__ __forceinline__ long long rowmap_off(const RowMap& m, int i) {
+    int b = i / m.rows_per_batch, t = i - b * m.rows_per_batch;
+    return m.base + (long long)b * m.batch_stride + (long long)t * m.row_stride;
+}
+static inline RowMap rowmap_plain(long long ld) { RowMap m; m.base = 0; m.batch_stride = 0; m.row_stride = ld; m.rows_per_batch = 0x7fffffff; return m; }

@@ -1,0 +1,348 @@
+// gemm.hip -- the MFMA contraction core of the transduction hot path (gfx950).
+//
+//   C[m][n] (+)= alpha * sum_k A(m,k) * B(n,k)   -> epilogue (bias, ReLU, dropout, gate, scatter)
+//
+// Every dense contraction of the reference's training step lands here:
+//   * nn.Conv1d k=3 / k=1, stride 1|2   (architecture.py:18,20,24)  -- implicit GEMM: the three taps of
+//     a (B, T+2, C) zero-padded activation buffer are one contiguous 3C-wide row, so im2col is just a
+//     RowMap with row_stride = stride*C (overlapping rows, nothing is materialised);
+//   * nn.Linear                         (architecture.py:51,55,59; transformer.py:32,34)
+//   * the per-head einsum projections   (transformer.py:96-98,111)  -- fused QKV / W_o GEMMs;
+//   * and their autograd transposes: dX = dY.W ("B outer-contiguous") and dW = dY^T.X (both operands
+//     outer-contiguous, reduction over the B*T rows, split-K with f32 atomics).
+//
+// Operand modes: KC = reduction index contiguous (elem(o,r) = p[rowmap(o) + r]);
+//                OC = outer index contiguous     (elem(o,r) = p[rowmap(r) + o])  -> transposed while
+//                staging (register 4x8 / 4x4 transposes), so the LDS image and the MFMA loop are identical.
+// Tile 128x128x(128 bytes of K), 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16 tiles,
+// double-buffered LDS (64 KiB), XOR-swizzled 16-B chunks (conflict-free ds_read_b128), global->register->
+// LDS staging with the next tile's loads issued before the current tile's MFMAs.
+//   bf16: v_mfma_f32_16x16x32_bf16 (f32 accumulate);  f32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain).
+#include "common.h"
+#include "silent_speech_hip.h"
+
+enum { OP_KC = 0, OP_OC = 1 };
+constexpr int BM = 128, BN = 128, ROWB = 128;   // ROWB: bytes of K per tile row
+
+struct GemmEpi {
+    const float* bias;       // [N] or null
+    const void* gate;        // TO-typed, addressed like C; out = gate>0 ? out*gate_scale : 0
+    float gate_scale;
+    float alpha;
+    int relu;
+    unsigned drop_thresh;    // 0 = none
+    float drop_scale;
+    unsigned long long seed;
+    unsigned stream;
+    int mode;                // 0 store, 1 accumulate (C += v), 2 atomicAdd (f32 out only)
+    RowMap cmap;
+    int col_mod, col_mul, col_div_mul;   // output column permutation: c -> (c % col_mod)*col_mul + (c / col_mod)*col_div_mul
+};
+
+template <class T> struct Elem;
+template <> struct Elem<float> { static constexpr int EPC = 4; static constexpr int BK = 32; };
+template <> struct Elem<bf16_t> { static constexpr int EPC = 8; static constexpr int BK = 64; };
+
+__device__ __forceinline__ unsigned swz(int row, int chunk) { return (unsigned)row * ROWB + (unsigned)((chunk ^ (row & 7)) << 4); }
+
+// ---------------------------------------------------------------- staging: KC (copy) mode
+template <class T>
+struct StageKC {
+    long long off[4];
+    const T* p;
+    u32x4 reg[4];
+    int c, r0;
+    __device__ __forceinline__ void init(const T* p_, const RowMap& map, int outer0, int outer_size, int tid) {
+        p = p_; c = tid & 7; r0 = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int o = outer0 + r0 + 32 * i;
+            off[i] = o < outer_size ? rowmap_off(map, o) : -1;
+        }
+    }
+    __device__ __forceinline__ void seek(int) {}
+    __device__ __forceinline__ void load(int k0, int kend) {
+        int kk = k0 + c * Elem<T>::EPC;
+        bool kv = kk < kend;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            reg[i] = (kv && off[i] >= 0) ? *(const u32x4*)(p + off[i] + kk) : z;
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { int r = r0 + 32 * i; *(u32x4*)(tile + swz(r, c)) = reg[i]; }
+    }
+};
+
+// ---------------------------------------------------------------- staging: OC (transposing) mode
+template <class T> struct StageOC;
+template <>
+struct StageOC<bf16_t> {   // thread: 8 outer x 4 reduction
+    const bf16_t* p; RowMap map; int ob, rb, bb, tt; bool ov;
+    u32x4 in[4];
+    __device__ __forceinline__ void init(const bf16_t* p_, const RowMap& map_, int outer0, int outer_size, int tid) {
+        map = map_; ob = (tid & 15) * 8; rb = (tid >> 4) * 4;
+        ov = outer0 + ob < outer_size;     // outer_size % 8 == 0 (checked on the host)
+        p = p_ + outer0 + ob;
+    }
+    __device__ __forceinline__ void seek(int k_begin) { int r = k_begin + rb; bb = r / map.rows_per_batch; tt = r - bb * map.rows_per_batch; }
+    __device__ __forceinline__ void load(int k0, int kend) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int t = tt + j, b = bb;
+            while (t >= map.rows_per_batch) { t -= map.rows_per_batch; ++b; }
+            u32x4 z = {0u, 0u, 0u, 0u};
+            bool v = ov && (k0 + rb + j < kend);
+            in[j] = v ? *(const u32x4*)(p + map.base + (long long)b * map.batch_stride + (long long)t * map.row_stride) : z;
+        }
+        tt += Elem<bf16_t>::BK;
+        while (tt >= map.rows_per_batch) { tt -= map.rows_per_batch; ++bb; }
+    }
+    __device__ __forceinline__ void store(unsigned char* tile) {
+        int q = rb >> 2;                    // 8-byte slot index within the row (0..15)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            unsigned x0 = in[0][o >> 1], x1 = in[1][o >> 1], x2 = in[2][o >> 1], x3 = in[3][o >> 1];
+            u32x2 w;
+            if (o & 1) { w[0] = (x0 >> 16) | (x1 & 0xffff0000u); w[1] = (x2 >> 16) | (x3 & 0xffff0000u); }
+            else       { w[0] = (x0 & 0xffffu) | (x1 << 16);     w[1] = (x2 & 0xffffu) | (x3 << 16); }
+            int r = ob + o;
+            *(u32x2*)(tile + swz(r, q >> 1) + ((q & 1) << 3)) = w;
+        }
+    }
+};
+template <>
+struct StageOC<float> {    // thread: 4 outer x 4 reduction
+    const float* p; RowMap map; int ob, rb, bb, tt; bool ov;
+    f32x4 in[4];
+    __device__ __forceinline__ void init(const float* p_, const RowMap& map_, int outer0, int outer_size, int tid) {
+        map = map_; ob = (tid & 31) * 4; rb = (tid >> 5) * 4;
+        ov = outer0 + ob < outer_size;     // outer_size % 4 == 0
+        p = p_ + outer0 + ob;
+    }
+    __device__ __forceinline__ void seek(int k_begin) { int r = k_begin + rb; bb = r / map.rows_per_batch; tt = r - bb * map.rows_per_batch; }
+    __device__ __forceinline__ void load(int k0, int kend) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int t = tt + j, b = bb;
+            while (t >= map.rows_per_batch) { t -= map.rows_per_batch; ++b; }
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bool v = ov && (k0 + rb + j < kend);
+            in[j] = v ? *(const f32x4*)(p + map.base + (long long)b * map.batch_stride + (long long)t * map.row_stride) : z;
+        }
+        tt += Elem<float>::BK;
+        while (tt >= map.rows_per_batch) { tt -= map.rows_per_batch; ++bb; }
+    }
+    __device__ __forceinline__ void store(unsigned char* tile) {
+        int chunk = rb >> 2;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            f32x4 w = {in[0][o], in[1][o], in[2][o], in[3][o]};
+            *(f32x4*)(tile + swz(ob + o, chunk)) = w;
+        }
+    }
+};
+
+template <class T, int MODE> struct StagerSel { typedef StageKC<T> type; };
+template <class T> struct StagerSel<T, OP_OC> { typedef StageOC<T> type; };
+
+// ---------------------------------------------------------------- MFMA over one staged K tile
+template <class T> struct TileMma;
+template <>
+struct TileMma<bf16_t> {
+    static __device__ __forceinline__ void run(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+        int r = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(As + swz(wm * 64 + i * 16 + r, kk * 4 + q));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(Bs + swz(wn * 64 + j * 16 + r, kk * 4 + q));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+        }
+    }
+};
+template <>
+struct TileMma<float> {
+    // lane (r,q) reads the 8 consecutive k = q*8 .. q*8+7 of its row; MFMA e pairs element e of every
+    // quarter: a permutation of k shared by A and B, so the sum over the 32-deep tile is unchanged.
+    static __device__ __forceinline__ void run(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+        int r = lane & 15, q = lane >> 4;
+        f32x4 a[4][2], b[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i][0] = *(const f32x4*)(As + swz(wm * 64 + i * 16 + r, q * 2)); a[i][1] = *(const f32x4*)(As + swz(wm * 64 + i * 16 + r, q * 2 + 1)); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { b[j][0] = *(const f32x4*)(Bs + swz(wn * 64 + j * 16 + r, q * 2)); b[j][1] = *(const f32x4*)(Bs + swz(wn * 64 + j * 16 + r, q * 2 + 1)); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f32_16x16x4(a[i][e >> 2][e & 3], b[j][e >> 2][e & 3], acc[i][j]);
+    }
+};
+
+__device__ __forceinline__ void out_add(float* p, float v, int mode) {
+    if (mode == 2) atomicAdd(p, v); else if (mode == 1) *p += v; else *p = v;
+}
+__device__ __forceinline__ void out_add(bf16_t* p, float v, int mode) {
+    if (mode == 1) *p = f2bf(bf2f(*p) + v); else *p = f2bf(v);
+}
+
+// one 16x16 accumulator tile: this lane holds rows row0..row0+3 of column col
+template <class TO>
+__device__ __forceinline__ void epilogue_tile(const f32x4& a, TO* __restrict__ C, const GemmEpi& epi, int row0, int col, int M, int N)
+{
+    if (col >= N) return;
+    const float bias = epi.bias ? epi.bias[col] : 0.f;
+    const int pcol = epi.col_mod ? (col % epi.col_mod) * epi.col_mul + (col / epi.col_mod) * epi.col_div_mul : col;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = row0 + reg;
+        if (row < M) {
+            const long long off = rowmap_off(epi.cmap, row) + pcol;
+            float v = a[reg] * epi.alpha + bias;
+            if (epi.relu) v = fmaxf(v, 0.f);
+            if (epi.drop_thresh) v = dropout_keep(epi.seed, epi.stream, (unsigned long long)row * (unsigned)N + col, epi.drop_thresh) ? v * epi.drop_scale : 0.f;
+            if (epi.gate) v = ldf((const TO*)epi.gate + off) > 0.f ? v * epi.gate_scale : 0.f;
+            out_add(C + off, v, epi.mode);
+        }
+    }
+}
+
+template <class T, class TO, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C,
+                                                   int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi,
+                                                   int k_chunk, int tiles_m, int tiles_n)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BM * ROWB];
+    constexpr int BK = Elem<T>::BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: consecutive tile ids (sharing an A row panel) stay on one XCD's L2.
+    int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+    {
+        int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = bid / tiles_n, nt = bid - mt * tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int k_begin = blockIdx.z * k_chunk;
+    const int k_end = min(K, k_begin + k_chunk);
+
+    typename StagerSel<T, AMODE>::type sa;
+    typename StagerSel<T, BMODE>::type sb;
+    sa.init(A, amap, m0, M, tid);
+    sb.init(B, bmap, n0, N, tid);
+    sa.seek(k_begin); sb.seek(k_begin);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+
+    const int nsteps = (k_end - k_begin + BK - 1) / BK;
+    if (nsteps > 0) {
+        sa.load(k_begin, k_end); sb.load(k_begin, k_end);
+        sa.store(lds[0][0]); sb.store(lds[0][1]);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        const bool more = s + 1 < nsteps;
+        if (more) { int k0 = k_begin + (s + 1) * BK; sa.load(k0, k_end); sb.load(k0, k_end); }
+        TileMma<T>::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
+        if (more) { sa.store(lds[cur ^ 1][0]); sb.store(lds[cur ^ 1][1]); }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds rows (lane>>4)*4+reg, column lane&15 of each 16x16 tile
+    const int cq = lane >> 4, cr = lane & 15;
+#define SS_EPI(I, J) epilogue_tile<TO>(acc[I][J], C, epi, m0 + wm * 64 + I * 16 + cq * 4, n0 + wn * 64 + J * 16 + cr, M, N)
+#define SS_EPI_ROW(I) SS_EPI(I, 0); SS_EPI(I, 1); SS_EPI(I, 2); SS_EPI(I, 3)
+    SS_EPI_ROW(0); SS_EPI_ROW(1); SS_EPI_ROW(2); SS_EPI_ROW(3);
+#undef SS_EPI_ROW
+#undef SS_EPI
+}
+
+// ---------------------------------------------------------------- host launcher
+static RowMap to_rowmap(const ss_rowmap* m) {
+    RowMap r; r.base = m->base; r.batch_stride = m->batch_stride; r.row_stride = m->row_stride; r.rows_per_batch = m->rows_per_batch > 0 ? m->rows_per_batch : 0x7fffffff;
+    return r;
+}
+
+template <class T, class TO>
+static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, void* C, int M, int N, int K,
+                       const RowMap& am, const RowMap& bm, const GemmEpi& epi, int split_k, void* stream)
+{
+    constexpr int BK = Elem<T>::BK;
+    int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    if (split_k < 1) split_k = 1;
+    int ksteps = (K + BK - 1) / BK;
+    int per = (ksteps + split_k - 1) / split_k;
+    int k_chunk = per * BK;
+    split_k = (ksteps + per - 1) / per;
+    dim3 grid(tiles_m * tiles_n, 1, split_k), block(256);
+#define SS_GEMM_CASE(AM, BMD)                                                                                     \
+    SS_LAUNCH(SS_KERNEL(gemm_kernel<T, TO, AM, BMD>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n)
+    if (a_mode == OP_KC && b_mode == OP_KC) SS_GEMM_CASE(OP_KC, OP_KC);
+    else if (a_mode == OP_KC && b_mode == OP_OC) SS_GEMM_CASE(OP_KC, OP_OC);
+    else if (a_mode == OP_OC && b_mode == OP_OC) SS_GEMM_CASE(OP_OC, OP_OC);
+    else if (a_mode == OP_OC && b_mode == OP_KC) SS_GEMM_CASE(OP_OC, OP_KC);
+#undef SS_GEMM_CASE
+    SS_LAUNCH_CHECK("ss_gemm");
+    return 0;
+}
+
+extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, const void* B, void* C,
+                       int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap,
+                       const ss_gemm_epilogue* e, int split_k, void* stream)
+{
+    SS_CHECK(A && B && C && amap && bmap && cmap, "ss_gemm: null pointer");
+    SS_CHECK(M >= 0 && N >= 0 && K >= 0, "ss_gemm: negative size");
+    if (M == 0 || N == 0) return 0;
+    SS_CHECK(dtype_in == SS_F32 || dtype_in == SS_BF16, "ss_gemm: bad input dtype %d", dtype_in);
+    SS_CHECK(dtype_out == SS_F32 || dtype_out == SS_BF16, "ss_gemm: bad output dtype %d", dtype_out);
+    SS_CHECK(!(dtype_in == SS_F32 && dtype_out == SS_BF16), "ss_gemm: f32 inputs with bf16 output is not a supported combination");
+    const int epc = dtype_in == SS_BF16 ? 8 : 4;
+    const size_t esz = dtype_in == SS_BF16 ? 2 : 4;
+    // 16-byte vector staging: reduction extent (KC) / outer extent (OC) and all strides in whole chunks
+    if (a_mode == OP_KC) SS_CHECK(K % epc == 0, "ss_gemm: K=%d must be a multiple of %d for a KC operand", K, epc);
+    else SS_CHECK(M % epc == 0, "ss_gemm: M=%d must be a multiple of %d for an OC A operand", M, epc);
+    if (b_mode == OP_KC) SS_CHECK(K % epc == 0, "ss_gemm: K=%d must be a multiple of %d for a KC operand", K, epc);
+    else SS_CHECK(N % epc == 0, "ss_gemm: N=%d must be a multiple of %d for an OC B operand", N, epc);
+    const ss_rowmap* maps[2] = {amap, bmap};
+    const void* ptrs[2] = {A, B};
+    for (int i = 0; i < 2; ++i) {
+        SS_CHECK(maps[i]->base % epc == 0 && maps[i]->batch_stride % epc == 0 && maps[i]->row_stride % epc == 0,
+                 "ss_gemm: operand %d strides must be multiples of %d elements (16-byte rows)", i, epc);
+        SS_CHECK(((uintptr_t)ptrs[i]) % 16 == 0, "ss_gemm: operand %d is not 16-byte aligned", i);
+    }
+    (void)esz;
+    GemmEpi epi;
+    memset(&epi, 0, sizeof(epi));
+    epi.alpha = 1.f; epi.gate_scale = 1.f; epi.drop_scale = 1.f;
+    epi.cmap = to_rowmap(cmap);
+    if (e) {
+        epi.bias = e->bias; epi.gate = e->gate; epi.gate_scale = e->gate_scale; epi.alpha = e->alpha; epi.relu = e->relu;
+        if (e->dropout_p > 0.f) { epi.drop_thresh = dropout_threshold(e->dropout_p); epi.drop_scale = 1.f / (1.f - e->dropout_p); }
+        epi.seed = e->seed; epi.stream = e->rng_stream; epi.mode = e->mode;
+        epi.col_mod = e->col_mod; epi.col_mul = e->col_mul; epi.col_div_mul = e->col_div_mul;
+        SS_CHECK(e->mode >= 0 && e->mode <= 2, "ss_gemm: bad output mode %d", e->mode);
+        SS_CHECK(!(e->mode == 2 && dtype_out != SS_F32), "ss_gemm: atomic accumulation needs f32 output");
+        SS_CHECK(!(split_k > 1 && e->mode != 2), "ss_gemm: split_k > 1 needs mode 2 (atomic accumulate)");
+    } else {
+        SS_CHECK(split_k <= 1, "ss_gemm: split_k > 1 needs mode 2 (atomic accumulate)");
+    }
+    RowMap am = to_rowmap(amap), bm = to_rowmap(bmap);
+    if (dtype_in == SS_BF16 && dtype_out == SS_BF16) return launch_gemm<bf16_t, bf16_t>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
+    if (dtype_in == SS_BF16 && dtype_out == SS_F32) return launch_gemm<bf16_t, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
+    return launch_gemm<float, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
+}

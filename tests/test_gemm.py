@@ -1,0 +1,104 @@
+"""ss_gemm parity: every operand-mode / dtype / epilogue combination against a torch fp32 matmul."""
+import pytest
+import torch
+
+from silent_speech_amd import ops
+from silent_speech_amd._lib import OP_KC, OP_OC
+from tests.backend import dev, is_emu  # noqa: F401
+from tests.util import assert_close_robust
+
+
+def _tol(dt):
+    return 2e-5 if dt == torch.float32 else 1.5e-2
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('modes', [(OP_KC, OP_KC), (OP_KC, OP_OC), (OP_OC, OP_OC), (OP_OC, OP_KC)])
+def test_gemm_modes(dev, dt, modes):
+    am, bm = modes
+    big = not is_emu(dev)
+    M, N, K = (520, 264, 328) if big else (136, 72, 104)   # ragged vs the 128x128x{32,64} tile
+    g = torch.Generator().manual_seed(M + am * 2 + bm)
+    a = torch.randn(M, K, generator=g).to(dt)
+    b = torch.randn(N, K, generator=g).to(dt)     # asymmetric operands: a transposed C fails
+    want = a.float() @ b.float().t()
+    A = (a if am == OP_KC else a.t().contiguous()).to(dev)
+    B = (b if bm == OP_KC else b.t().contiguous()).to(dev)
+    out_dt = dt
+    C = torch.full((M, N), 7.0, dtype=out_dt, device=dev)
+    ops.gemm(A, B, C, M, N, K, ops.rowmap(K if am == OP_KC else M), ops.rowmap(K if bm == OP_KC else N), ops.rowmap(N),
+             a_mode=am, b_mode=bm)
+    assert_close_robust(C, want, rtol=_tol(dt), name='gemm', max_outlier_frac=0)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_gemm_epilogue_bias_relu_gate_accumulate(dev, dt):
+    M, N, K = 70, 40, 64
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(M, K, generator=g).to(dt); b = torch.randn(N, K, generator=g).to(dt)
+    bias = torch.randn(N, generator=g)
+    want = torch.relu(0.5 * (a.float() @ b.float().t()) + bias)
+    C = torch.zeros(M, N, dtype=dt, device=dev)
+    ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), bias=bias.to(dev), relu=True, alpha=0.5)
+    assert_close_robust(C, want, rtol=_tol(dt), name='bias_relu', max_outlier_frac=0)
+    # gate (ReLU/dropout backward from the saved activation) + accumulate
+    gate = (torch.randn(M, N, generator=g) > 0).to(dt)
+    base = torch.randn(M, N, generator=g).to(dt)
+    C2 = base.clone().to(dev)
+    ops.gemm(a.to(dev), b.to(dev), C2, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), gate=gate.to(dev), gate_scale=1.25, mode=1)
+    want2 = base.float() + (a.float() @ b.float().t()) * gate.float() * 1.25
+    assert_close_robust(C2, want2, rtol=_tol(dt), name='gate_acc', max_outlier_frac=0)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_gemm_split_k_atomic(dev, dt):
+    """dW = dY^T X : both operands outer-contiguous, reduction over rows, f32 atomic split-K."""
+    big = not is_emu(dev)
+    R, N, K = (1000, 136, 264) if big else (200, 24, 40)
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(R, N, generator=g).to(dt); x = torch.randn(R, K, generator=g).to(dt)
+    want = dy.float().t() @ x.float()
+    dW = torch.zeros(N, K, dtype=torch.float32, device=dev)
+    ops.gemm(dy.to(dev), x.to(dev), dW, N, K, R, ops.rowmap(N), ops.rowmap(K), ops.rowmap(K), a_mode=OP_OC, b_mode=OP_OC,
+             mode=2, split_k=3)
+    assert_close_robust(dW, want, rtol=_tol(dt), name='splitk', max_outlier_frac=0)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('stride', [1, 2])
+def test_conv_k3_as_implicit_gemm(dev, dt, stride):
+    """k=3 conv over a zero-padded (B, T+2, C) buffer == GEMM with overlapping 3C-wide rows."""
+    Bn, T, Ci, Co = 3, 24, 16, 40
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(Bn, T, Ci, generator=g).to(dt)
+    w = (torch.randn(Co, Ci, 3, generator=g) * 0.3).to(dt)
+    bias = torch.randn(Co, generator=g)
+    want = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.float(), bias, stride=stride, padding=1).transpose(1, 2)
+    To = want.shape[1]
+    xpad = torch.zeros(Bn, T + 2, Ci, dtype=dt); xpad[:, 1:-1] = x
+    wg = w.permute(0, 2, 1).reshape(Co, 3 * Ci).contiguous()          # [o][kk*Ci + i]
+    y = torch.zeros(Bn, To, Co, dtype=dt, device=dev)
+    ops.gemm(xpad.to(dev), wg.to(dev), y, Bn * To, Co, 3 * Ci,
+             ops.rowmap(stride * Ci, rows_per_batch=To, batch_stride=(T + 2) * Ci), ops.rowmap(3 * Ci), ops.rowmap(Co), bias=bias.to(dev))
+    assert_close_robust(y, want, rtol=_tol(dt), name='conv', max_outlier_frac=0)
+
+
+def test_gemm_dropout_statistics(dev):
+    M, N, K = 64, 128, 32
+    a = torch.ones(M, K); b = torch.ones(N, K) / K
+    C = torch.zeros(M, N, device=dev)
+    ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), dropout_p=0.2, seed=1234, rng_stream=3)
+    c = C.cpu()
+    kept = (c != 0)
+    assert torch.allclose(c[kept], torch.full_like(c[kept], 1.25), atol=1e-5)
+    frac = kept.float().mean().item()
+    assert abs(frac - 0.8) < 0.02, frac
+    C2 = torch.zeros(M, N, device=dev)
+    ops.gemm(a.to(dev), b.to(dev), C2, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), dropout_p=0.2, seed=1234, rng_stream=3)
+    assert torch.equal(C2.cpu(), c)               # same seed/stream -> same mask
+
+
+def test_gemm_rejects_bad_arguments(dev):
+    a = torch.zeros(8, 6, device=dev); c = torch.zeros(8, 8, device=dev)
+    with pytest.raises(RuntimeError, match='multiple of'):
+        ops.gemm(a, a, c, 8, 8, 6, ops.rowmap(6), ops.rowmap(6), ops.rowmap(8))
