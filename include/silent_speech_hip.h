@@ -79,6 +79,23 @@ int ss_permute3d(const void* in, int in_dtype, void* out, int out_dtype, int d0,
                  int64_t s0, int64_t s1, int64_t s2, int valid1, int valid2, float scale, int accumulate,
                  void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * DTW alignment (align.py:5-14 time_warp + align.py:16-34 align_from_distances; call site
+ * transduction_model.py:126,131 and :88).  Batched: one workgroup per matrix.
+ * desc_dev: device array [n][10] of int64:
+ *   {N, M, cost_off (elements from `costs`), stride_i, stride_j (elements), sk_off, dirs_off, bnd_off
+ *    (BYTE offsets into `workspace`, sizes from ss_dtw_workspace_bytes), res_off (elements into
+ *    `results`), 0}.
+ * results[res_off + i], i < N: the reference's `results` list (smallest j visited in row i; 0 for
+ * row 0 and for degenerate 1xM / Nx1 inputs).  Bit-exact: f32, one add per cell, first-minimum tie
+ * order (up, left, diag).  The cumulative matrix itself is never written (2-bit directions are). */
+int64_t ss_dtw_workspace_bytes(int n, int m, int64_t* sk_bytes, int64_t* dirs_bytes, int64_t* bnd_bytes); /* [host] */
+int ss_dtw_align(const float* costs, const int64_t* desc_dev, int n, int max_n, int max_m, void* workspace,
+                 int32_t* results, void* stream);
+/* Same, for costs already in the skewed strip layout (written by ss_silent_cost_skewed); results must
+ * have been zeroed by the producer. */
+int ss_dtw_align_skewed(const int64_t* desc_dev, int n, void* workspace, int32_t* results, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

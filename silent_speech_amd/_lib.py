@@ -37,7 +37,11 @@ SIGNATURES = {
     'ss_gemm': [_I, _I, _I, _I, _P, _P, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap),
                 ctypes.POINTER(RowMap), ctypes.POINTER(GemmEpilogue), _I, _P],
     'ss_permute3d': [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _I, _P],
+    'ss_dtw_align': [_P, _P, _I, _I, _I, _P, _P, _P],
+    'ss_dtw_align_skewed': [_P, _I, _P, _P, _P],
 }
+_LP = ctypes.POINTER(ctypes.c_int64)
+_HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int64)}
 _RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}
 
 _lib = None
@@ -53,6 +57,10 @@ def _declare(lib):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    for name, (argtypes, restype) in _HOST_FUNCS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
     return lib
 
 

@@ -1,0 +1,75 @@
+"""DTW alignment on the MI355X -- drop-in for the reference's align.py.
+
+  align_from_distances(distance_matrix: np.ndarray, debug=False) -> list[int]      (align.py:16)
+
+plus the batched, device-resident form used by dtw_loss (no D2H of the cost matrix, no per-utterance
+sync): `dtw_align_batch`.  The HIP kernel (csrc/dtw.hip) is bit-exact against the reference's f32
+recurrence and first-minimum (up, left, diag) backtrace.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DESC = 10
+
+
+def _workspace_layout(shapes):
+    """Per-matrix byte offsets (sk, dirs, bnd) into one workspace; returns (rows, total_bytes)."""
+    rows, off = [], 0
+    sk, dr, bd = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    for n, m in shapes:
+        _lib.lib().ss_dtw_workspace_bytes(int(n), int(m), ctypes.byref(sk), ctypes.byref(dr), ctypes.byref(bd))
+        rows.append((off, off + sk.value, off + sk.value + dr.value))
+        off += sk.value + dr.value + bd.value
+    return rows, off
+
+
+def dtw_align_batch(costs, shapes, offsets, strides):
+    """costs: one f32 device tensor holding every matrix; matrix b has logical shape shapes[b] = (N, M),
+    starts at element offsets[b] and element (i, j) sits at offsets[b] + i*strides[b][0] + j*strides[b][1].
+    Returns (results int32 device tensor, list of per-matrix offsets into it).  No host sync."""
+    assert costs.dtype == torch.float32
+    n = len(shapes)
+    for N, M in shapes:
+        if N < 1 or M < 1:
+            raise ValueError('DTW cost matrix must be non-empty, got %dx%d' % (N, M))
+    dev = costs.device
+    layout, ws_bytes = _workspace_layout(shapes)
+    res_offs, tot = [], 0
+    desc = np.zeros((n, _DESC), dtype=np.int64)
+    for b, ((N, M), off, st, (sk, dr, bd)) in enumerate(zip(shapes, offsets, strides, layout)):
+        desc[b] = [N, M, off, st[0], st[1], sk, dr, bd, tot, 0]
+        res_offs.append(tot)
+        tot += N
+    desc_dev = torch.from_numpy(desc).to(dev, non_blocking=True)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
+    results = torch.empty(max(tot, 1), dtype=torch.int32, device=dev)
+    rc = _lib.lib().ss_dtw_align(_lib.ptr(costs), _lib.ptr(desc_dev), n, max(s[0] for s in shapes), max(s[1] for s in shapes),
+                                 _lib.ptr(ws), _lib.ptr(results), _lib.stream_of(costs))
+    _lib.check(rc, 'ss_dtw_align')
+    return results, res_offs
+
+
+def align_from_distances(distance_matrix, debug=False, device=None):
+    """Reference-compatible entry point (align.py:16): numpy (N, M) matrix in, list[int] of length N out.
+    The matrix may be any strided view (the reference passes costs.T).  float32 follows the reference's
+    torch->numpy path; float64 input is rounded to float32 first (documented deviation: the HIP
+    recurrence is f32)."""
+    if isinstance(distance_matrix, torch.Tensor):
+        t = distance_matrix.detach()
+    else:
+        t = torch.from_numpy(np.asarray(distance_matrix))
+    if t.dim() != 2:
+        raise ValueError('distance_matrix must be 2-D')
+    N, M = t.shape
+    if N < 1 or M < 1:
+        raise IndexError('align_from_distances: empty matrix')      # the reference raises at shape[0]-1 indexing too
+    if device is None:
+        device = t.device if (t.is_cuda or _lib.is_emulator()) else torch.device('cuda')
+    t = t.to(device=device, dtype=torch.float32)
+    # keep the caller's strides: no transposed copy is materialised, the skew kernel reads strided
+    results, _ = dtw_align_batch(t, [(N, M)], [0], [t.stride()])
+    return results[:N].cpu().tolist()

@@ -1,0 +1,78 @@
+"""DTW HIP kernel vs golden vectors from the reference and vs the oracle (bit-exact indices)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dtw_ref
+from silent_speech_amd import align
+from tests.backend import dev, is_emu  # noqa: F401
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_dtw_golden_small(dev):
+    z = np.load(os.path.join(GOLD, 'dtw_small.npz'))
+    names = [k[6:] for k in z.files if k.startswith('costs/')]
+    if is_emu(dev):
+        names = [n for n in names if z['costs/' + n].size <= 2600]      # emulator: keep the CPU tier quick
+    for name in names:
+        got = align.align_from_distances(z['costs/' + name], device=dev)
+        assert got == z['align/' + name].tolist(), name
+
+
+def test_dtw_strided_transposed_view(dev):
+    """costs.T as passed at transduction_model.py:126 (non-contiguous view)."""
+    rng = np.random.default_rng(3)
+    c = rng.random((30, 41), dtype=np.float32)
+    want = dtw_ref.align_from_distances_c(c.T)
+    assert align.align_from_distances(c.T, device=dev) == want
+    assert align.align_from_distances(torch.from_numpy(c).t(), device=dev) == want
+
+
+def test_dtw_degenerate(dev):
+    rng = np.random.default_rng(4)
+    assert align.align_from_distances(rng.random((1, 7), dtype=np.float32), device=dev) == [0]
+    assert align.align_from_distances(rng.random((7, 1), dtype=np.float32), device=dev) == [0] * 7
+    assert align.align_from_distances(rng.random((1, 1), dtype=np.float32), device=dev) == [0]
+    assert align.align_from_distances(np.ones((6, 5), dtype=np.float32), device=dev) == [0, 1, 2, 3, 4, 4]
+    assert align.align_from_distances(np.ones((5, 6), dtype=np.float32), device=dev) == [0, 1, 2, 3, 4]
+    with pytest.raises((IndexError, ValueError)):
+        align.align_from_distances(np.zeros((0, 4), dtype=np.float32), device=dev)
+
+
+def test_dtw_multiwave_rows(dev):
+    """> 256 rows: crosses the wave boundary (LDS ring hand-off between waves)."""
+    rng = np.random.default_rng(5)
+    n, m = (300, 40) if is_emu(dev) else (700, 333)
+    c = rng.integers(0, 4, (n, m)).astype(np.float32)       # many exact ties
+    assert align.align_from_distances(c, device=dev) == dtw_ref.align_from_distances_c(c)
+
+
+def test_dtw_batch_ragged(dev):
+    rng = np.random.default_rng(6)
+    shapes = [(17, 23), (64, 64), (5, 90), (1, 4)] if is_emu(dev) else [(517, 623), (1000, 1000), (64, 64), (5, 900), (1, 4), (1300, 700)]
+    mats = [rng.random(s, dtype=np.float32) for s in shapes]
+    flat = torch.from_numpy(np.concatenate([m.ravel() for m in mats])).to(dev)
+    offs = np.cumsum([0] + [m.size for m in mats[:-1]]).tolist()
+    res, roffs = align.dtw_align_batch(flat, shapes, offs, [(s[1], 1) for s in shapes])
+    res = res.cpu().numpy()
+    for m, s, ro in zip(mats, shapes, roffs):
+        assert res[ro:ro + s[0]].tolist() == dtw_ref.align_from_distances_c(m), s
+
+
+@pytest.mark.gpu
+def test_dtw_big_golden_and_strips():
+    """BASELINE cfg3 size (1000x1000, golden from the reference) and a >1024-row matrix (2 strips)."""
+    from silent_speech_amd import _lib
+    _lib.load()
+    d = torch.device('cuda')
+    z = np.load(os.path.join(GOLD, 'dtw_big.npz'))
+    big = np.random.default_rng(int(z['seed'])).random(tuple(z['shape']), dtype=np.float32)
+    assert align.align_from_distances(big, device=d) == z['align'].tolist()
+    rng = np.random.default_rng(8)
+    tall = rng.integers(0, 3, (2500, 300)).astype(np.float32)
+    assert align.align_from_distances(tall, device=d) == dtw_ref.align_from_distances_c(tall)
+    wide = (rng.standard_normal((300, 2500)) ** 2).astype(np.float32)
+    assert align.align_from_distances(wide, device=d) == dtw_ref.align_from_distances_c(wide)
