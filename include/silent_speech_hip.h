@@ -55,6 +55,12 @@ typedef struct ss_gemm_epilogue {
     int32_t mode;           /* 0 store, 1 C += v, 2 atomicAdd(C, v) (f32 out; required for split_k>1) */
     int32_t col_mod, col_mul, col_div_mul; /* optional output column permutation
                                col -> (col % col_mod)*col_mul + (col / col_mod)*col_div_mul           */
+    float log_clamp;        /* > 0: v = log(max(v, log_clamp)) (data_utils.py:29-30 dynamic range compression) */
+    void* c2;               /* optional second copy of the result, element (row, col) at
+                               c2[rowmap2(row) + col*col_stride2] -- the [b][col][t] transposed copies
+                               the attention kernels read as MFMA B operands                          */
+    ss_rowmap cmap2;
+    int64_t col_stride2;
 } ss_gemm_epilogue;
 
 #define SS_OP_KC 0   /* reduction index contiguous:  elem(o, r) = p[rowmap(o) + r] */
@@ -95,6 +101,77 @@ int ss_dtw_align(const float* costs, const int64_t* desc_dev, int n, int max_n, 
 /* Same, for costs already in the skewed strip layout (written by ss_silent_cost_skewed); results must
  * have been zeroed by the producer. */
 int ss_dtw_align_skewed(const int64_t* desc_dev, int n, void* workspace, int32_t* results, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm1d fused with ReLU / the ResBlock residual add (architecture.py:19,21,25 nn.BatchNorm1d,
+ * :32 relu(bn1(conv1)), :33 bn2(conv2), :36 res_norm(residual_path), :40 relu(x + res)).
+ * Activations are (B, T + 2*pad, C), C contiguous, pad in {0,1}: padded buffers carry a zero row on
+ * each side of every sequence (the conv halo); pad rows of outputs are written as zeros.
+ * ss_bn_stats: training: per-channel batch mean / 1/sqrt(biased var + eps) over B*T, running stats
+ * updated in place (momentum, unbiased variance) as torch does; eval: from the running stats.
+ * scratch: ss_bn_scratch_floats(B,T,C) floats. */
+int64_t ss_bn_scratch_floats(int B, int T, int C); /* [host] */
+int ss_bn_stats(int dtype, const void* x, int B, int T, int C, int pad, float* scratch, float* mean, float* invstd,
+                float* running_mean, float* running_var, float momentum, float eps, int training, void* stream);
+/* y = act( bn_a(xa) [+ bn_b(xb)] ),  act = ReLU if relu */
+int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const float* invstd_a, const float* gamma_a, const float* beta_a, int pad_xa,
+                const void* xb, const float* mean_b, const float* invstd_b, const float* gamma_b, const float* beta_b, int pad_xb,
+                void* y, int pad_y, int B, int T, int C, int relu, void* stream);
+/* autograd backward of the above (transduction_model.py:209): dgamma/dbeta are ACCUMULATED (+=). */
+int ss_bn_backward(int dtype, const void* dy, int pad_dy, const void* y, int pad_y,
+                   const void* xa, int pad_xa, const float* mean_a, const float* invstd_a, const float* gamma_a,
+                   const void* xb, int pad_xb, const float* mean_b, const float* invstd_b, const float* gamma_b,
+                   void* dxa, int pad_dxa, void* dxb, int pad_dxb,
+                   float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
+                   float* scratch, int B, int T, int C, int relu, void* stream);
+/* out[c] += sum_r x[r][c]  (bias gradients of nn.Linear / nn.Conv1d) */
+int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, float* out_accum, void* stream);
+
+/* Post-norm residual block of the encoder layer (transformer.py:55-56, 58-59):
+ *   z = x + dropout(branch);  y = LayerNorm(z) * gamma + beta        (eps 1e-5)
+ * branch_inout is overwritten with z (saved for backward); mean/rstd: [rows] f32. */
+int ss_add_dropout_layernorm_forward(int dtype, const void* x, void* branch_inout, const float* gamma, const float* beta, void* y,
+                                     float* mean, float* rstd, int rows, int C, float eps, float dropout_p, uint64_t seed,
+                                     uint32_t rng_stream, void* stream);
+/* dres = dL/dz (gradient of the residual stream; may alias dy), dbranch = dres * keep/(1-p) (may be NULL);
+ * dgamma/dbeta accumulated. */
+int ss_layernorm_backward(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                          void* dres, void* dbranch, float* dgamma, float* dbeta, int rows, int C, float dropout_p, uint64_t seed,
+                          uint32_t rng_stream, void* stream);
+
+/* EMG input conditioning: training-time shift augmentation (architecture.py:64-68: x[:, :-r] = x[:, r:],
+ * x[:, -r:] = 0), cast to the compute dtype and zero halo rows: x_raw (B,T0,Cin) f32 ->
+ * out_padded (B,T0+2,Cin).  shifted_copy (optional, f32 (B,T0,Cin)) receives the shifted signal so the
+ * caller can mirror the reference's in-place mutation of its input. */
+int ss_emg_prepare(int dtype, const float* x_raw, void* out_padded, float* shifted_copy, int B, int T0, int Cin, int shift, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * dtw_loss (transduction_model.py:98-157).  `head` = [pred (n_mel) | phoneme logits (n_phone)] per
+ * packed frame, f32, row stride ld.  All kernels produce value AND gradient (dhead, same layout,
+ * must be zero-initialised; scaled by inv_total = 1/sum(T2)); loss_accum/correct_accum are += . */
+int ss_frame_lse(const float* head, int64_t ld, int col0, int ncls, int rows, float* lse, int32_t* argmax, void* stream);
+int ss_voiced_loss(const float* head, int64_t ld, int n_mel, int n_phone, const float* lse, const int32_t* argmax, const float* Y,
+                   const int64_t* phones, const int32_t* pred_row, const int32_t* tgt_row, int nframes, float lam, float inv_total,
+                   float* dhead, float* loss_accum, int32_t* correct_accum, void* stream);
+/* Cost matrices of the silent utterances written directly in the DTW strip layout (never dense);
+ * desc as for ss_dtw_align with fields [2],[3] = first packed pred row, first target row. */
+int ss_silent_cost_skewed(const float* head, int64_t ld, int n_mel, const float* lse, const float* Y, const int64_t* phones,
+                          const int64_t* desc_dev, int n, int max_n, int max_m, float lam, void* workspace, int32_t* results, void* stream);
+int ss_silent_loss(const float* head, int64_t ld, int n_mel, int n_phone, const float* lse, const int32_t* argmax, const float* Y,
+                   const int64_t* phones, const int32_t* results, const int32_t* tgt_row, const int32_t* pred_base,
+                   const int32_t* res_idx, int nframes, float lam, float inv_total, float* dhead, float* loss_accum,
+                   int32_t* correct_accum, void* stream);
+
+/* AdamW over a flat f32 arena (transduction_model.py:178,210).  step is 1-based. */
+int ss_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, float grad_scale, void* stream);
+int ss_cast_f32(const float* in, void* out, int out_dtype, int64_t n, void* stream);
+
+/* mel target extraction (data_utils.py:39-62): reflect pad (:51); the STFT itself is ss_gemm against a
+ * windowed DFT matrix with overlapping hop-strided rows; magnitude (:57); mel matmul + log clamp (:59-60)
+ * is ss_gemm with epilogue.log_clamp. */
+int ss_reflect_pad(const float* y, float* out, int B, int L, int pad, int64_t ld_out, void* stream);
+int ss_stft_magnitude(const float* spec, int64_t ld_spec, int n_bins, float* mag, int64_t ld_mag, int rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,8 @@ class GemmEpilogue(ctypes.Structure):
     _fields_ = [('bias', ctypes.c_void_p), ('gate', ctypes.c_void_p), ('gate_scale', ctypes.c_float),
                 ('alpha', ctypes.c_float), ('relu', ctypes.c_int32), ('dropout_p', ctypes.c_float),
                 ('seed', ctypes.c_uint64), ('rng_stream', ctypes.c_uint32), ('mode', ctypes.c_int32),
-                ('col_mod', ctypes.c_int32), ('col_mul', ctypes.c_int32), ('col_div_mul', ctypes.c_int32)]
+                ('col_mod', ctypes.c_int32), ('col_mul', ctypes.c_int32), ('col_div_mul', ctypes.c_int32),
+                ('log_clamp', ctypes.c_float), ('c2', ctypes.c_void_p), ('cmap2', RowMap), ('col_stride2', ctypes.c_int64)]
 
 
 _P, _I, _F, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
@@ -39,9 +40,25 @@ SIGNATURES = {
     'ss_permute3d': [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _I, _P],
     'ss_dtw_align': [_P, _P, _I, _I, _I, _P, _P, _P],
     'ss_dtw_align_skewed': [_P, _I, _P, _P, _P],
+    'ss_bn_stats': [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P],
+    'ss_bn_apply': [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    'ss_bn_backward': [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'ss_colsum': [_I, _P, _I, _I, _L, _P, _P],
+    'ss_add_dropout_layernorm_forward': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_layernorm_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _P],
+    'ss_emg_prepare': [_I, _P, _P, _P, _I, _I, _I, _I, _P],
+    'ss_frame_lse': [_P, _L, _I, _I, _I, _P, _P, _P],
+    'ss_voiced_loss': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],
+    'ss_silent_cost_skewed': [_P, _L, _I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
+    'ss_silent_loss': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],
+    'ss_adamw_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    'ss_cast_f32': [_P, _P, _I, _L, _P],
+    'ss_reflect_pad': [_P, _P, _I, _I, _I, _L, _P],
+    'ss_stft_magnitude': [_P, _L, _I, _P, _L, _I, _P],
 }
 _LP = ctypes.POINTER(ctypes.c_int64)
-_HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int64)}
+_HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int64),
+               'ss_bn_scratch_floats': ([_I, _I, _I], ctypes.c_int64)}
 _RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}
 
 _lib = None

@@ -37,6 +37,10 @@ struct GemmEpi {
     int mode;                // 0 store, 1 accumulate (C += v), 2 atomicAdd (f32 out only)
     RowMap cmap;
     int col_mod, col_mul, col_div_mul;   // output column permutation: c -> (c % col_mod)*col_mul + (c / col_mod)*col_div_mul
+    float log_clamp;         // > 0: v = log(max(v, log_clamp))   (data_utils.py:29-30)
+    void* c2;                // optional second copy of the result at rowmap2(row) + col*col_stride2 (transposed layouts)
+    RowMap cmap2;
+    long long col_stride2;
 };
 
 template <class T> struct Elem;
@@ -211,7 +215,9 @@ __device__ __forceinline__ void epilogue_tile(const f32x4& a, TO* __restrict__ C
             if (epi.relu) v = fmaxf(v, 0.f);
             if (epi.drop_thresh) v = dropout_keep(epi.seed, epi.stream, (unsigned long long)row * (unsigned)N + col, epi.drop_thresh) ? v * epi.drop_scale : 0.f;
             if (epi.gate) v = ldf((const TO*)epi.gate + off) > 0.f ? v * epi.gate_scale : 0.f;
+            if (epi.log_clamp > 0.f) v = logf(fmaxf(v, epi.log_clamp));
             out_add(C + off, v, epi.mode);
+            if (epi.c2) stf((TO*)epi.c2 + rowmap_off(epi.cmap2, row) + (long long)col * epi.col_stride2, v);
         }
     }
 }
@@ -335,6 +341,8 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
         if (e->dropout_p > 0.f) { epi.drop_thresh = dropout_threshold(e->dropout_p); epi.drop_scale = 1.f / (1.f - e->dropout_p); }
         epi.seed = e->seed; epi.stream = e->rng_stream; epi.mode = e->mode;
         epi.col_mod = e->col_mod; epi.col_mul = e->col_mul; epi.col_div_mul = e->col_div_mul;
+        epi.log_clamp = e->log_clamp;
+        if (e->c2) { epi.c2 = e->c2; epi.cmap2 = to_rowmap(&e->cmap2); epi.col_stride2 = e->col_stride2; }
         SS_CHECK(e->mode >= 0 && e->mode <= 2, "ss_gemm: bad output mode %d", e->mode);
         SS_CHECK(!(e->mode == 2 && dtype_out != SS_F32), "ss_gemm: atomic accumulation needs f32 output");
         SS_CHECK(!(split_k > 1 && e->mode != 2), "ss_gemm: split_k > 1 needs mode 2 (atomic accumulate)");

@@ -1,0 +1,178 @@
+// loss.hip -- dtw_loss of the transduction trainer on gfx950 (reference transduction_model.py:98-157).
+//   voiced utterance : sum_t ||y_t - pred_t + 1e-6||_2 + lambda * CE_sum(aux, y_phone)          (:141-145)
+//   silent utterance : costs[q][k] = ||pred_q - y_k||_2 - lambda * log_softmax(aux_q)[phone_k]   (:116-124)
+//                      alignment = DTW(costs.T) (dtw.hip), loss = sum_k costs[alignment[k]][k]    (:126-128)
+//   batch            : sum(losses) / sum(T2);  phoneme accuracy on the side                       (:157)
+// The T1 x T2 cost matrix exists only in the DTW kernel's skewed strip layout and is never read back: the
+// loss and its gradient touch only the T2 aligned (q, k) pairs, which are recomputed here, so no dense
+// T1 x T2 gradient is ever materialised.  Forward value and gradient are produced by the same kernels
+// (d loss / d head is written directly; upstream gradient of the scalar loss is folded in via inv_total).
+// `head` is the fused output of the two linear heads: row = packed frame, columns [0,n_mel) = mel
+// prediction (w_out, architecture.py:55), [n_mel, n_mel+n_phone) = phoneme logits (w_aux, :59), f32.
+#include "common.h"
+#include "silent_speech_hip.h"
+#include <math.h>
+
+namespace {
+constexpr int DESC = 10;
+enum { D_N = 0, D_M, D_PRED_ROW0, D_TGT_ROW0, D_UNUSED, D_SK_OFF, D_DIRS_OFF, D_BND_OFF, D_RES_OFF };
+constexpr int DW = 4, DR = 4;
+__device__ __forceinline__ long long dtw_strips_d(long long n) { long long rows = n - 1, cap = DW * 64 * DR; return rows <= 0 ? 0 : (rows + cap - 1) / cap; }
+__device__ __forceinline__ long long dtw_tsteps_d(long long m) { return m <= 1 ? 0 : (m - 1) + 63; }
+}
+
+// ---------------------------------------------------------------- per-frame log-sum-exp + argmax of the phoneme logits
+__global__ void frame_lse_kernel(const float* __restrict__ head, long long ld, int col0, int ncls, int rows, float* __restrict__ lse, int* __restrict__ amax)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += gridDim.x * wpb) {
+        const float* a = head + (long long)r * ld + col0;
+        float mx = -INFINITY; int mi = 0x7fffffff;
+        for (int c = lane; c < ncls; c += 64) { float v = a[c]; if (v > mx) { mx = v; mi = c; } }
+        const float gmx = wave_max(mx);
+        int cand = (mx == gmx) ? mi : 0x7fffffff;               // first maximal index, like torch.argmax
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(cand, m); cand = o < cand ? o : cand; }
+        float s = 0.f;
+        for (int c = lane; c < ncls; c += 64) s += expf(a[c] - gmx);
+        s = wave_sum(s);
+        if (lane == 0) { lse[r] = gmx + logf(s); amax[r] = cand; }
+    }
+}
+
+extern "C" int ss_frame_lse(const float* head, int64_t ld, int col0, int ncls, int rows, float* lse, int32_t* argmax, void* stream)
+{
+    SS_CHECK(head && lse && argmax, "ss_frame_lse: null pointer");
+    if (rows <= 0) return 0;
+    int blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096;
+    SS_LAUNCH(frame_lse_kernel, dim3(blocks), dim3(256), 0, stream, head, (long long)ld, col0, ncls, rows, lse, argmax);
+    SS_LAUNCH_CHECK("ss_frame_lse");
+    return 0;
+}
+
+// ---------------------------------------------------------------- voiced frames: value + gradient, one wave per frame
+__global__ void voiced_loss_kernel(const float* __restrict__ head, long long ld, int n_mel, int n_ph, const float* __restrict__ lse, const int* __restrict__ amax,
+                                   const float* __restrict__ Y, const long long* __restrict__ phones, const int* __restrict__ pred_row, const int* __restrict__ tgt_row,
+                                   int nframes, float lam, float inv_total, float* __restrict__ dhead, float* __restrict__ loss_acc, int* __restrict__ correct_acc)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    float lsum = 0.f; int csum = 0;
+    for (int f = blockIdx.x * wpb + (threadIdx.x >> 6); f < nframes; f += gridDim.x * wpb) {
+        const int pr = pred_row[f], tr = tgt_row[f];
+        const float* p = head + (long long)pr * ld; const float* y = Y + (long long)tr * n_mel;
+        float* dp = dhead + (long long)pr * ld;
+        float ss = 0.f;
+        for (int c = lane; c < n_mel; c += 64) { float d = y[c] - p[c] + 1e-6f; ss += d * d; }        // F.pairwise_distance eps (:141)
+        const float dist = sqrtf(wave_sum(ss));
+        const float gs = dist > 0.f ? inv_total / dist : 0.f;
+        for (int c = lane; c < n_mel; c += 64) dp[c] = -(y[c] - p[c] + 1e-6f) * gs;
+        const int ph = (int)phones[tr];
+        const float L = lse[pr];
+        for (int c = lane; c < n_ph; c += 64) dp[n_mel + c] = lam * inv_total * (expf(p[n_mel + c] - L) - (c == ph ? 1.f : 0.f));
+        if (lane == 0) { lsum += dist + lam * (L - p[n_mel + ph]); csum += amax[pr] == ph; }
+    }
+    if (lane == 0) { if (lsum != 0.f) atomicAdd(loss_acc, lsum * inv_total); if (csum) atomicAdd(correct_acc, csum); }
+}
+
+extern "C" int ss_voiced_loss(const float* head, int64_t ld, int n_mel, int n_phone, const float* lse, const int32_t* argmax, const float* Y, const int64_t* phones,
+                              const int32_t* pred_row, const int32_t* tgt_row, int nframes, float lam, float inv_total,
+                              float* dhead, float* loss_accum, int32_t* correct_accum, void* stream)
+{
+    SS_CHECK(nframes >= 0, "ss_voiced_loss: negative frame count");
+    if (nframes == 0) return 0;
+    SS_CHECK(head && lse && argmax && Y && phones && pred_row && tgt_row && dhead && loss_accum && correct_accum, "ss_voiced_loss: null pointer");
+    int blocks = (nframes + 3) / 4; if (blocks > 2048) blocks = 2048;
+    SS_LAUNCH(voiced_loss_kernel, dim3(blocks), dim3(256), 0, stream, head, (long long)ld, n_mel, n_phone, lse, (const int*)argmax, Y, (const long long*)phones,
+              (const int*)pred_row, (const int*)tgt_row, nframes, lam, inv_total, dhead, loss_accum, (int*)correct_accum);
+    SS_LAUNCH_CHECK("ss_voiced_loss");
+    return 0;
+}
+
+// ---------------------------------------------------------------- silent utterances: cost matrix straight into the DTW strip layout
+// DTW runs on costs.T: row i = target frame k, column j = predicted frame q (transduction_model.py:126).
+__global__ void silent_cost_skewed_kernel(const float* __restrict__ head, long long ld, int n_mel, const float* __restrict__ lse, const float* __restrict__ Y,
+                                          const long long* __restrict__ phones, const long long* __restrict__ desc, float lam, unsigned char* __restrict__ ws, int* __restrict__ results)
+{
+    const long long* d = desc + (long long)blockIdx.y * DESC;
+    const int N = (int)d[D_N], M = (int)d[D_M];
+    const long long p0 = d[D_PRED_ROW0], y0 = d[D_TGT_ROW0];
+    int* res = results + d[D_RES_OFF];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) res[i] = 0;
+    const long long ts = dtw_tsteps_d(M), total = dtw_strips_d(N) * DW * ts * 64 * DR;
+    float* sk = (float*)(ws + d[D_SK_OFF]);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e % DR); long long x = e / DR; const int l = (int)(x % 64); x /= 64; const long long t = x % ts, kw = x / ts;
+        const long long i = 1 + (kw * 64 + l) * DR + r, j = t + 1 - l;
+        float c = INFINITY;
+        if (i < N && j >= 1 && j < M) {
+            const float* p = head + (p0 + j) * ld; const float* y = Y + (y0 + i) * n_mel;
+            float ss = 0.f;
+            for (int q = 0; q < n_mel; q += 4) {
+                const f32x4 a = *(const f32x4*)(p + q), b = *(const f32x4*)(y + q);
+                const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2], d3 = a[3] - b[3];
+                ss += d0 * d0; ss += d1 * d1; ss += d2 * d2; ss += d3 * d3;
+            }
+            const int ph = (int)phones[y0 + i];
+            c = sqrtf(ss) + lam * (lse[p0 + j] - p[n_mel + ph]);
+        }
+        sk[e] = c;
+    }
+}
+
+extern "C" int ss_silent_cost_skewed(const float* head, int64_t ld, int n_mel, const float* lse, const float* Y, const int64_t* phones,
+                                     const int64_t* desc_dev, int n, int max_n, int max_m, float lam, void* workspace, int32_t* results, void* stream)
+{
+    SS_CHECK(n >= 0, "ss_silent_cost_skewed: negative batch");
+    if (n == 0) return 0;
+    SS_CHECK(head && lse && Y && phones && desc_dev && workspace && results, "ss_silent_cost_skewed: null pointer");
+    SS_CHECK(n_mel % 4 == 0 && ld % 4 == 0, "ss_silent_cost_skewed: n_mel and ld must be multiples of 4 (16-byte rows)");
+    long long strips = max_n <= 1 ? 0 : (max_n - 1 + DW * 64 * DR - 1) / (DW * 64 * DR);
+    long long total = strips * DW * (max_m <= 1 ? 0 : max_m - 1 + 63) * 64 * DR;
+    long long blocks = (total + 255) / 256;
+    if (blocks < (max_n + 255) / 256) blocks = (max_n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    SS_LAUNCH(silent_cost_skewed_kernel, dim3((unsigned)blocks, n), dim3(256), 0, stream, head, (long long)ld, n_mel, lse, Y, (const long long*)phones,
+              (const long long*)desc_dev, lam, (unsigned char*)workspace, (int*)results);
+    SS_LAUNCH_CHECK("ss_silent_cost_skewed");
+    return 0;
+}
+
+// ---------------------------------------------------------------- silent utterances: value + gradient over the aligned pairs only
+__global__ void silent_loss_kernel(const float* __restrict__ head, long long ld, int n_mel, int n_ph, const float* __restrict__ lse, const int* __restrict__ amax,
+                                   const float* __restrict__ Y, const long long* __restrict__ phones, const int* __restrict__ results,
+                                   const int* __restrict__ tgt_row, const int* __restrict__ pred_base, const int* __restrict__ res_idx,
+                                   int nframes, float lam, float inv_total, float* __restrict__ dhead, float* __restrict__ loss_acc, int* __restrict__ correct_acc)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    float lsum = 0.f; int csum = 0;
+    for (int f = blockIdx.x * wpb + (threadIdx.x >> 6); f < nframes; f += gridDim.x * wpb) {
+        const int tr = tgt_row[f], pr = pred_base[f] + results[res_idx[f]];
+        const float* p = head + (long long)pr * ld; const float* y = Y + (long long)tr * n_mel;
+        float* dp = dhead + (long long)pr * ld;
+        float ss = 0.f;
+        for (int c = lane; c < n_mel; c += 64) { float d = p[c] - y[c]; ss += d * d; }
+        const float dist = sqrtf(wave_sum(ss));
+        const float gs = dist > 0.f ? inv_total / dist : 0.f;                          // cdist backward: 0 where the distance is 0
+        for (int c = lane; c < n_mel; c += 64) atomicAdd(dp + c, (p[c] - y[c]) * gs);     // several k may align to one q
+        const int ph = (int)phones[tr];
+        const float L = lse[pr];
+        for (int c = lane; c < n_ph; c += 64) atomicAdd(dp + n_mel + c, lam * inv_total * (expf(p[n_mel + c] - L) - (c == ph ? 1.f : 0.f)));
+        if (lane == 0) { lsum += dist + lam * (L - p[n_mel + ph]); csum += amax[pr] == ph; }
+    }
+    if (lane == 0) { if (lsum != 0.f) atomicAdd(loss_acc, lsum * inv_total); if (csum) atomicAdd(correct_acc, csum); }
+}
+
+extern "C" int ss_silent_loss(const float* head, int64_t ld, int n_mel, int n_phone, const float* lse, const int32_t* argmax, const float* Y, const int64_t* phones,
+                              const int32_t* results, const int32_t* tgt_row, const int32_t* pred_base, const int32_t* res_idx, int nframes,
+                              float lam, float inv_total, float* dhead, float* loss_accum, int32_t* correct_accum, void* stream)
+{
+    SS_CHECK(nframes >= 0, "ss_silent_loss: negative frame count");
+    if (nframes == 0) return 0;
+    SS_CHECK(head && lse && argmax && Y && phones && results && tgt_row && pred_base && res_idx && dhead && loss_accum && correct_accum, "ss_silent_loss: null pointer");
+    int blocks = (nframes + 3) / 4; if (blocks > 2048) blocks = 2048;
+    SS_LAUNCH(silent_loss_kernel, dim3(blocks), dim3(256), 0, stream, head, (long long)ld, n_mel, n_phone, lse, (const int*)argmax, Y, (const long long*)phones,
+              (const int*)results, (const int*)tgt_row, (const int*)pred_base, (const int*)res_idx, nframes, lam, inv_total, dhead, loss_accum, (int*)correct_accum);
+    SS_LAUNCH_CHECK("ss_silent_loss");
+    return 0;
+}

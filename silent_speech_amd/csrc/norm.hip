@@ -1,0 +1,520 @@
+// norm.hip -- the HBM-bound normalisation / elementwise kernels of the transduction hot path (gfx950):
+//   BatchNorm1d training/eval forward + backward, fused with ReLU and the residual add of ResBlock
+//   (architecture.py:19,21,25,32,36,40), LayerNorm fused with the residual add and dropout of the
+//   post-norm encoder layer (transformer.py:55-56,58-59), bias-gradient column sums, and the EMG
+//   input conditioning (shift augmentation architecture.py:64-68 + cast + zero padding).
+// Activations are (B, T[+2], C) row-major with C contiguous; every access is a 16-byte vector of 8
+// (bf16) / 2x16 bytes (f32) channels, statistics are f32.  Padded buffers carry one zero row on each
+// side of every sequence so the k=3 convolutions read their taps as one contiguous 3C row (gemm.hip).
+#include "common.h"
+#include "silent_speech_hip.h"
+
+namespace {
+struct Seq {            // logical row r of a (B, T + 2*pad, C) buffer
+    int T, pad;
+    __device__ __forceinline__ long long row(int r) const { int b = r / T, t = r - b * T; return (long long)b * (T + 2 * pad) + pad + t; }
+};
+
+// thread -> (vector column cx0 (+k*CVb), row lane ry) for column reductions over a [rows][C] matrix
+struct ColMap {
+    int CV, CVb, RY, cx0, ry; bool active;
+    __device__ __forceinline__ ColMap(int C, int tid, int nthreads) {
+        CV = C >> 3; CVb = CV < nthreads ? CV : nthreads; RY = nthreads / CVb;
+        cx0 = tid % CVb; ry = tid / CVb; active = ry < RY;
+    }
+};
+constexpr int RED_THREADS = 256;
+}
+
+// =========================================================================== BatchNorm statistics
+template <class T>
+__global__ __launch_bounds__(RED_THREADS) void bn_partial_kernel(const T* __restrict__ x, Seq sx, int rows, int C, int rows_per_chunk, float* __restrict__ partial)
+{
+    __shared__ float red[2][RED_THREADS * 8];
+    ColMap m(C, threadIdx.x, RED_THREADS);
+    const int r0 = blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    for (int cb = 0; cb < m.CV; cb += m.CVb) {
+        const int cx = cb + m.cx0;
+        float s1[8], s2[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; sh[e] = 0.f; }
+        const bool cv = m.active && cx < m.CV;
+        if (cv) {
+            Vec8<T>::load(x + sx.row(0) * C + cx * 8, sh);      // shift = first row: tames E[x^2]-E[x]^2 cancellation
+            for (int r = r0 + m.ry; r < r1; r += m.RY) {
+                float v[8]; Vec8<T>::load(x + sx.row(r) * C + cx * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float d = v[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][threadIdx.x * 8 + e] = s1[e]; red[1][threadIdx.x * 8 + e] = s2[e]; }
+        __syncthreads();
+        if (cv && m.ry == 0) {
+            for (int y = 1; y < m.RY; ++y)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s1[e] += red[0][(y * m.CVb + m.cx0) * 8 + e]; s2[e] += red[1][(y * m.CVb + m.cx0) * 8 + e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                partial[((long long)blockIdx.x * 2 + 0) * C + cx * 8 + e] = s1[e];
+                partial[((long long)blockIdx.x * 2 + 1) * C + cx * 8 + e] = s2[e];
+            }
+        }
+    }
+}
+
+template <class T>
+__global__ void bn_finalize_kernel(const T* __restrict__ x, Seq sx, const float* __restrict__ partial, int nchunks, int rows, int C,
+                                   float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps, int training)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (!training) { mean[c] = running_mean[c]; invstd[c] = rsqrtf(running_var[c] + eps); return; }
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) { s1 += partial[((long long)k * 2 + 0) * C + c]; s2 += partial[((long long)k * 2 + 1) * C + c]; }
+    const float n = (float)rows, sh = ldf(x + sx.row(0) * C + c);
+    const float d = s1 / n, mu = sh + d;
+    float var = s2 / n - d * d; var = var < 0.f ? 0.f : var;
+    mean[c] = mu; invstd[c] = rsqrtf(var + eps);
+    if (running_mean) {   // torch: running = (1-m)*running + m*stat, unbiased variance for the running estimate
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (rows > 1 ? n / (n - 1.f) : 1.f);
+    }
+}
+
+static int red_chunks(int rows) { int c = (rows + 63) / 64; if (c > 1024) c = 1024; if (c < 1) c = 1; return c; }
+
+extern "C" int64_t ss_bn_scratch_floats(int B, int T, int C) { return (int64_t)red_chunks(B * T) * 4 * C + 8 * (int64_t)C; }
+
+extern "C" int ss_bn_stats(int dtype, const void* x, int B, int T, int C, int pad, float* scratch, float* mean, float* invstd,
+                           float* running_mean, float* running_var, float momentum, float eps, int training, void* stream)
+{
+    SS_CHECK(x && mean && invstd, "ss_bn_stats: null pointer");
+    SS_CHECK(C % 8 == 0 && C > 0, "ss_bn_stats: C=%d must be a positive multiple of 8", C);
+    SS_CHECK(B > 0 && T > 0, "ss_bn_stats: empty batch");
+    SS_CHECK(training || (running_mean && running_var), "ss_bn_stats: eval mode needs running statistics");
+    const int rows = B * T, nch = red_chunks(rows), rpc = (rows + nch - 1) / nch;
+    Seq sx = {T, pad};
+    if (training) {
+        SS_CHECK(scratch, "ss_bn_stats: scratch missing");
+        if (dtype == SS_BF16) SS_LAUNCH(bn_partial_kernel<bf16_t>, dim3(nch), dim3(RED_THREADS), 0, stream, (const bf16_t*)x, sx, rows, C, rpc, scratch);
+        else SS_LAUNCH(bn_partial_kernel<float>, dim3(nch), dim3(RED_THREADS), 0, stream, (const float*)x, sx, rows, C, rpc, scratch);
+    }
+    if (dtype == SS_BF16) SS_LAUNCH(bn_finalize_kernel<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, stream, (const bf16_t*)x, sx, scratch, nch, rows, C, mean, invstd, running_mean, running_var, momentum, eps, training);
+    else SS_LAUNCH(bn_finalize_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)x, sx, scratch, nch, rows, C, mean, invstd, running_mean, running_var, momentum, eps, training);
+    SS_LAUNCH_CHECK("ss_bn_stats");
+    return 0;
+}
+
+// =========================================================================== BatchNorm apply (+residual, +ReLU)
+template <class T>
+__global__ void bn_apply_kernel(const T* __restrict__ xa, Seq sa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a, const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
+                                const T* __restrict__ xb, Seq sb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b, const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
+                                T* __restrict__ y, Seq sy, int B, int C, int relu)
+{
+    const int CV = C >> 3, TT = sy.T;
+    const long long rows_out = (long long)B * (TT + 2 * sy.pad), total = rows_out * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cx = (int)(i % CV); const long long ro = i / CV;
+        const int b = (int)(ro / (TT + 2 * sy.pad)), tp = (int)(ro - (long long)b * (TT + 2 * sy.pad)), t = tp - sy.pad;
+        float o[8];
+        if (t < 0 || t >= TT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;             // zero halo rows
+        } else {
+            const int r = b * TT + t;
+            float v[8]; Vec8<T>::load(xa + sa.row(r) * C + cx * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float s = gamma_a[c] * invstd_a[c]; o[e] = (v[e] - mean_a[c]) * s + beta_a[c]; }
+            if (xb) {
+                float u[8]; Vec8<T>::load(xb + sb.row(r) * C + cx * 8, u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float s = gamma_b[c] * invstd_b[c]; o[e] += (u[e] - mean_b[c]) * s + beta_b[c]; }
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
+            }
+        }
+        Vec8<T>::store(y + ro * C + cx * 8, o);
+    }
+}
+
+static dim3 ew_grid(long long total, int block) { long long g = (total + block - 1) / block; if (g > 8192) g = 8192; if (g < 1) g = 1; return dim3((unsigned)g); }
+
+extern "C" int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const float* invstd_a, const float* gamma_a, const float* beta_a, int pad_xa,
+                           const void* xb, const float* mean_b, const float* invstd_b, const float* gamma_b, const float* beta_b, int pad_xb,
+                           void* y, int pad_y, int B, int T, int C, int relu, void* stream)
+{
+    SS_CHECK(xa && mean_a && invstd_a && gamma_a && beta_a && y, "ss_bn_apply: null pointer");
+    SS_CHECK(!xb || (mean_b && invstd_b && gamma_b && beta_b), "ss_bn_apply: second branch incomplete");
+    SS_CHECK(C % 8 == 0 && C > 0 && B > 0 && T > 0, "ss_bn_apply: bad shape B=%d T=%d C=%d", B, T, C);
+    Seq sa = {T, pad_xa}, sb = {T, pad_xb}, sy = {T, pad_y};
+    const long long total = (long long)B * (T + 2 * pad_y) * (C / 8);
+    if (dtype == SS_BF16) SS_LAUNCH(bn_apply_kernel<bf16_t>, ew_grid(total, 256), dim3(256), 0, stream, (const bf16_t*)xa, sa, mean_a, invstd_a, gamma_a, beta_a, (const bf16_t*)xb, sb, mean_b, invstd_b, gamma_b, beta_b, (bf16_t*)y, sy, B, C, relu);
+    else SS_LAUNCH(bn_apply_kernel<float>, ew_grid(total, 256), dim3(256), 0, stream, (const float*)xa, sa, mean_a, invstd_a, gamma_a, beta_a, (const float*)xb, sb, mean_b, invstd_b, gamma_b, beta_b, (float*)y, sy, B, C, relu);
+    SS_LAUNCH_CHECK("ss_bn_apply");
+    return 0;
+}
+
+// =========================================================================== BatchNorm backward
+// g = dy * 1[y>0]  (ReLU of the fused output);  per branch: dgamma = sum g*xhat, dbeta = sum g,
+// dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).
+template <class T>
+__global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const T* __restrict__ dy, Seq sdy, const T* __restrict__ y, Seq sy,
+                                                                     const T* __restrict__ xa, Seq sa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a,
+                                                                     const T* __restrict__ xb, Seq sb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b,
+                                                                     int rows, int C, int rows_per_chunk, int relu, float* __restrict__ partial)
+{
+    __shared__ float red[3][RED_THREADS * 8];
+    ColMap m(C, threadIdx.x, RED_THREADS);
+    const int r0 = blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    for (int cb = 0; cb < m.CV; cb += m.CVb) {
+        const int cx = cb + m.cx0;
+        float sg[8], sga[8], sgb[8], ma[8], ia[8], mb[8], ib[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sg[e] = sga[e] = sgb[e] = 0.f; ma[e] = ia[e] = mb[e] = ib[e] = 0.f; }
+        const bool cv = m.active && cx < m.CV;
+        if (cv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ma[e] = mean_a[cx * 8 + e]; ia[e] = invstd_a[cx * 8 + e]; if (xb) { mb[e] = mean_b[cx * 8 + e]; ib[e] = invstd_b[cx * 8 + e]; } }
+            for (int r = r0 + m.ry; r < r1; r += m.RY) {
+                float g[8], v[8];
+                Vec8<T>::load(dy + sdy.row(r) * C + cx * 8, g);
+                if (relu) { float o[8]; Vec8<T>::load(y + sy.row(r) * C + cx * 8, o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
+                Vec8<T>::load(xa + sa.row(r) * C + cx * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sg[e] += g[e]; sga[e] += g[e] * (v[e] - ma[e]) * ia[e]; }
+                if (xb) { Vec8<T>::load(xb + sb.row(r) * C + cx * 8, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sgb[e] += g[e] * (v[e] - mb[e]) * ib[e]; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][threadIdx.x * 8 + e] = sg[e]; red[1][threadIdx.x * 8 + e] = sga[e]; red[2][threadIdx.x * 8 + e] = sgb[e]; }
+        __syncthreads();
+        if (cv && m.ry == 0) {
+            for (int yy = 1; yy < m.RY; ++yy)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int o = (yy * m.CVb + m.cx0) * 8 + e; sg[e] += red[0][o]; sga[e] += red[1][o]; sgb[e] += red[2][o]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                partial[((long long)blockIdx.x * 3 + 0) * C + cx * 8 + e] = sg[e];
+                partial[((long long)blockIdx.x * 3 + 1) * C + cx * 8 + e] = sga[e];
+                partial[((long long)blockIdx.x * 3 + 2) * C + cx * 8 + e] = sgb[e];
+            }
+        }
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunks, int rows, int C, float* __restrict__ coef /* [3][C] means */,
+                                       float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) { s0 += partial[((long long)k * 3 + 0) * C + c]; s1 += partial[((long long)k * 3 + 1) * C + c]; s2 += partial[((long long)k * 3 + 2) * C + c]; }
+    const float n = (float)rows;
+    coef[c] = s0 / n; coef[C + c] = s1 / n; coef[2 * C + c] = s2 / n;
+    if (dgamma_a) dgamma_a[c] += s1;
+    if (dbeta_a) dbeta_a[c] += s0;
+    if (dgamma_b) dgamma_b[c] += s2;
+    if (dbeta_b) dbeta_b[c] += s0;
+}
+
+template <class T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* __restrict__ y, Seq sy,
+                                    const T* __restrict__ xa, Seq sa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a, const float* __restrict__ gamma_a,
+                                    const T* __restrict__ xb, Seq sb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b, const float* __restrict__ gamma_b,
+                                    const float* __restrict__ coef, T* __restrict__ dxa, Seq sda, T* __restrict__ dxb, Seq sdb, int B, int C, int relu)
+{
+    const int CV = C >> 3, TT = sdy.T;
+    const int padmax = sda.pad > sdb.pad ? sda.pad : sdb.pad;
+    const long long total = (long long)B * (TT + 2 * padmax) * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int cx = (int)(i % CV); const long long ro = i / CV;
+        const int b = (int)(ro / (TT + 2 * padmax)), t = (int)(ro - (long long)b * (TT + 2 * padmax)) - padmax;
+        float oa[8], ob[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { oa[e] = 0.f; ob[e] = 0.f; }
+        const bool halo = t < 0 || t >= TT;
+        if (!halo) {
+            const int r = b * TT + t;
+            float g[8], v[8];
+            Vec8<T>::load(dy + sdy.row(r) * C + cx * 8, g);
+            if (relu) { float o[8]; Vec8<T>::load(y + sy.row(r) * C + cx * 8, o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
+            Vec8<T>::load(xa + sa.row(r) * C + cx * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float xh = (v[e] - mean_a[c]) * invstd_a[c]; oa[e] = gamma_a[c] * invstd_a[c] * (g[e] - coef[c] - xh * coef[C + c]); }
+            if (xb) { Vec8<T>::load(xb + sb.row(r) * C + cx * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float xh = (v[e] - mean_b[c]) * invstd_b[c]; ob[e] = gamma_b[c] * invstd_b[c] * (g[e] - coef[c] - xh * coef[2 * C + c]); } }
+        }
+        // halo rows (only for padded outputs) are written as zeros
+        const int ta = t + sda.pad, tb = t + sdb.pad;
+        if (dxa && ta >= 0 && ta < TT + 2 * sda.pad) Vec8<T>::store(dxa + ((long long)b * (TT + 2 * sda.pad) + ta) * C + cx * 8, oa);
+        if (dxb && tb >= 0 && tb < TT + 2 * sdb.pad) Vec8<T>::store(dxb + ((long long)b * (TT + 2 * sdb.pad) + tb) * C + cx * 8, ob);
+    }
+}
+
+extern "C" int ss_bn_backward(int dtype, const void* dy, int pad_dy, const void* y, int pad_y,
+                              const void* xa, int pad_xa, const float* mean_a, const float* invstd_a, const float* gamma_a,
+                              const void* xb, int pad_xb, const float* mean_b, const float* invstd_b, const float* gamma_b,
+                              void* dxa, int pad_dxa, void* dxb, int pad_dxb,
+                              float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
+                              float* scratch, int B, int T, int C, int relu, void* stream)
+{
+    SS_CHECK(dy && xa && mean_a && invstd_a && gamma_a && dxa && scratch, "ss_bn_backward: null pointer");
+    SS_CHECK(!relu || y, "ss_bn_backward: relu backward needs the saved output");
+    SS_CHECK(!xb || (mean_b && invstd_b && gamma_b && dxb), "ss_bn_backward: second branch incomplete");
+    SS_CHECK(C % 8 == 0 && C > 0 && B > 0 && T > 0, "ss_bn_backward: bad shape");
+    const int rows = B * T, nch = red_chunks(rows), rpc = (rows + nch - 1) / nch;
+    Seq sdy = {T, pad_dy}, sy = {T, pad_y}, sa = {T, pad_xa}, sb = {T, pad_xb}, sda = {T, pad_dxa}, sdb = {T, pad_dxb};
+    float* partial = scratch; float* coef = scratch + (long long)nch * 3 * C;
+    const int padmax = pad_dxa > pad_dxb ? pad_dxa : pad_dxb;
+    const long long total = (long long)B * (T + 2 * padmax) * (C / 8);
+#define SS_BNB(TT)                                                                                                                             \
+    SS_LAUNCH(bn_bwd_partial_kernel<TT>, dim3(nch), dim3(RED_THREADS), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, \
+              (const TT*)xb, sb, mean_b, invstd_b, rows, C, rpc, relu, partial);                                                                \
+    SS_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)partial, nch, rows, C, coef, dgamma_a, dbeta_a, dgamma_b, dbeta_b); \
+    SS_LAUNCH(bn_bwd_apply_kernel<TT>, ew_grid(total, 256), dim3(256), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, gamma_a, \
+              (const TT*)xb, sb, mean_b, invstd_b, gamma_b, (const float*)coef, (TT*)dxa, sda, (TT*)dxb, sdb, B, C, relu)
+    if (dtype == SS_BF16) { SS_BNB(bf16_t); } else { SS_BNB(float); }
+#undef SS_BNB
+    SS_LAUNCH_CHECK("ss_bn_backward");
+    return 0;
+}
+
+// =========================================================================== column sums (bias gradients)
+template <class T>
+__global__ __launch_bounds__(RED_THREADS) void colsum_kernel(const T* __restrict__ x, int rows, int C, long long ld, int rows_per_chunk, float* __restrict__ out)
+{
+    __shared__ float red[RED_THREADS * 8];
+    ColMap m(C, threadIdx.x, RED_THREADS);
+    const int r0 = blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    for (int cb = 0; cb < m.CV; cb += m.CVb) {
+        const int cx = cb + m.cx0;
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        const bool cv = m.active && cx < m.CV;
+        if (cv)
+            for (int r = r0 + m.ry; r < r1; r += m.RY) { float v[8]; Vec8<T>::load(x + (long long)r * ld + cx * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += v[e]; }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
+        __syncthreads();
+        if (cv && m.ry == 0) {
+            for (int yy = 1; yy < m.RY; ++yy)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += red[(yy * m.CVb + m.cx0) * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(out + cx * 8 + e, s[e]);
+        }
+    }
+}
+
+extern "C" int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, float* out_accum, void* stream)
+{
+    SS_CHECK(x && out_accum, "ss_colsum: null pointer");
+    SS_CHECK(C % 8 == 0 && C > 0 && rows >= 0 && ld % 8 == 0, "ss_colsum: C and ld must be multiples of 8");
+    if (rows == 0) return 0;
+    int nch = (rows + 255) / 256; if (nch > 512) nch = 512;
+    const int rpc = (rows + nch - 1) / nch;
+    if (dtype == SS_BF16) SS_LAUNCH(colsum_kernel<bf16_t>, dim3(nch), dim3(RED_THREADS), 0, stream, (const bf16_t*)x, rows, C, (long long)ld, rpc, out_accum);
+    else SS_LAUNCH(colsum_kernel<float>, dim3(nch), dim3(RED_THREADS), 0, stream, (const float*)x, rows, C, (long long)ld, rpc, out_accum);
+    SS_LAUNCH_CHECK("ss_colsum");
+    return 0;
+}
+
+// =========================================================================== residual + dropout + LayerNorm
+// One wave per row; a lane keeps NV 8-channel vectors of the row in registers (C <= 512*NV).
+template <class T, int NV>
+__global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ a_z, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int rows, int C, float eps,
+                                                                 unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id)
+{
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, CV = C >> 3;
+    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += gridDim.x * wpb) {
+        float z[NV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int cx = lane + 64 * i;
+            if (cx < CV) {
+                float xv[8], av[8];
+                Vec8<T>::load(x + (long long)r * C + cx * 8, xv);
+                Vec8<T>::load(a_z + (long long)r * C + cx * 8, av);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float br = av[e];
+                    if (thresh) br = dropout_keep(seed, stream_id, (unsigned long long)r * C + cx * 8 + e, thresh) ? br * keep_scale : 0.f;
+                    z[i][e] = rnd<T>(xv[e] + br);           // z is stored (and re-read by backward) in T
+                    s += z[i][e];
+                }
+                Vec8<T>::store(a_z + (long long)r * C + cx * 8, z[i]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[i][e] = 0.f;
+            }
+        }
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < CV)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = z[i][e] - mu; q += d * d; }
+        const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+        if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int cx = lane + 64 * i;
+            if (cx < CV) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (z[i][e] - mu) * rs * gamma[cx * 8 + e] + beta[cx * 8 + e];
+                Vec8<T>::store(y + (long long)r * C + cx * 8, o);
+            }
+        }
+    }
+}
+
+template <class T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, T* __restrict__ dres, T* __restrict__ dbranch, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int rows, int C, unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id)
+{
+    __shared__ float red[2][4][NV * 64 * 8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6, CV = C >> 3;
+    float dg[NV][8], db[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+    for (int r = blockIdx.x * wpb + w; r < rows; r += gridDim.x * wpb) {
+        const float mu = mean[r], rs = rstd[r];
+        float gy[NV][8], xh[NV][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int cx = lane + 64 * i;
+            if (cx < CV) {
+                float d[8], zz[8];
+                Vec8<T>::load(dy + (long long)r * C + cx * 8, d);
+                Vec8<T>::load(z + (long long)r * C + cx * 8, zz);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[i][e] = (zz[e] - mu) * rs;
+                    dg[i][e] += d[e] * xh[i][e]; db[i][e] += d[e];
+                    gy[i][e] = d[e] * gamma[cx * 8 + e];
+                    s1 += gy[i][e]; s2 += gy[i][e] * xh[i][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { gy[i][e] = 0.f; xh[i][e] = 0.f; }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int cx = lane + 64 * i;
+            if (cx < CV) {
+                float o[8], ob[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
+                    ob[e] = o[e];
+                    if (thresh) ob[e] = dropout_keep(seed, stream_id, (unsigned long long)r * C + cx * 8 + e, thresh) ? o[e] * keep_scale : 0.f;
+                }
+                Vec8<T>::store(dres + (long long)r * C + cx * 8, o);
+                if (dbranch) Vec8<T>::store(dbranch + (long long)r * C + cx * 8, ob);
+            }
+        }
+    }
+    // block-level reduction of the affine gradients, then one atomic per channel per block
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][w][(i * 64 + lane) * 8 + e] = dg[i][e]; red[1][w][(i * 64 + lane) * 8 + e] = db[i][e]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NV * 64 * 8; idx += blockDim.x) {
+        const int i = idx / 512, l = (idx / 8) & 63, e = idx & 7, cx = l + 64 * i;
+        if (cx < CV) {
+            float a = 0.f, b = 0.f;
+            for (int ww = 0; ww < wpb; ++ww) { a += red[0][ww][idx]; b += red[1][ww][idx]; }
+            atomicAdd(dgamma + cx * 8 + e, a); atomicAdd(dbeta + cx * 8 + e, b);
+        }
+    }
+}
+
+extern "C" int ss_add_dropout_layernorm_forward(int dtype, const void* x, void* branch_inout, const float* gamma, const float* beta, void* y,
+                                                float* mean, float* rstd, int rows, int C, float eps, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
+{
+    SS_CHECK(x && branch_inout && gamma && beta && y && mean && rstd, "ss_add_dropout_layernorm_forward: null pointer");
+    SS_CHECK(C % 8 == 0 && C > 0 && C <= 4096, "ss_add_dropout_layernorm_forward: C=%d must be a multiple of 8 and <= 4096", C);
+    SS_CHECK(dropout_p >= 0.f && dropout_p < 1.f, "dropout p out of range");
+    if (rows <= 0) return 0;
+    const unsigned th = dropout_threshold(dropout_p); const float ks = 1.f / (1.f - dropout_p);
+    int blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096;
+#define SS_LNF(TT, NV) SS_LAUNCH(SS_KERNEL(add_dropout_ln_fwd_kernel<TT, NV>), dim3(blocks), dim3(256), 0, stream, (const TT*)x, (TT*)branch_inout, gamma, beta, (TT*)y, mean, rstd, rows, C, eps, th, ks, (unsigned long long)seed, rng_stream)
+    if (dtype == SS_BF16) { if (C <= 1024) SS_LNF(bf16_t, 2); else SS_LNF(bf16_t, 8); }
+    else { if (C <= 1024) SS_LNF(float, 2); else SS_LNF(float, 8); }
+#undef SS_LNF
+    SS_LAUNCH_CHECK("ss_add_dropout_layernorm_forward");
+    return 0;
+}
+
+extern "C" int ss_layernorm_backward(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                     void* dres, void* dbranch, float* dgamma, float* dbeta, int rows, int C, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
+{
+    SS_CHECK(dy && z && mean && rstd && gamma && dres && dgamma && dbeta, "ss_layernorm_backward: null pointer");
+    SS_CHECK(C % 8 == 0 && C > 0 && C <= 4096, "ss_layernorm_backward: C=%d must be a multiple of 8 and <= 4096", C);
+    if (rows <= 0) return 0;
+    const unsigned th = dropout_threshold(dropout_p); const float ks = 1.f / (1.f - dropout_p);
+    int blocks = (rows + 15) / 16; if (blocks > 1024) blocks = 1024;
+#define SS_LNB(TT, NV) SS_LAUNCH(SS_KERNEL(ln_bwd_kernel<TT, NV>), dim3(blocks), dim3(256), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, dgamma, dbeta, rows, C, th, ks, (unsigned long long)seed, rng_stream)
+    if (dtype == SS_BF16) { if (C <= 1024) SS_LNB(bf16_t, 2); else SS_LNB(bf16_t, 8); }
+    else { if (C <= 1024) SS_LNB(float, 2); else SS_LNB(float, 8); }
+#undef SS_LNB
+    SS_LAUNCH_CHECK("ss_layernorm_backward");
+    return 0;
+}
+
+// =========================================================================== EMG input conditioning
+// out (B, T0+2, 8) in the compute dtype = left-shift-by-r of x_raw (B, T0, 8) f32, zero tail, zero halo rows;
+// optionally also writes the shifted f32 copy back (the reference mutates its input in place).
+template <class T>
+__global__ void emg_prepare_kernel(const float* __restrict__ x, T* __restrict__ out, float* __restrict__ shifted, int B, int T0, int Cin, int r)
+{
+    const long long total = (long long)B * (T0 + 2) * Cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cin); const long long ro = i / Cin;
+        const int b = (int)(ro / (T0 + 2)), t = (int)(ro - (long long)b * (T0 + 2)) - 1;
+        float v = 0.f;
+        if (t >= 0 && t < T0) {
+            v = t + r < T0 ? x[((long long)b * T0 + t + r) * Cin + c] : 0.f;
+            if (shifted) shifted[((long long)b * T0 + t) * Cin + c] = v;
+        }
+        stf(out + i, v);
+    }
+}
+
+extern "C" int ss_emg_prepare(int dtype, const float* x_raw, void* out_padded, float* shifted_copy, int B, int T0, int Cin, int shift, void* stream)
+{
+    SS_CHECK(x_raw && out_padded, "ss_emg_prepare: null pointer");
+    SS_CHECK(B > 0 && T0 > 0 && Cin > 0 && shift >= 0 && shift < T0, "ss_emg_prepare: bad shape/shift");
+    const long long total = (long long)B * (T0 + 2) * Cin;
+    if (dtype == SS_BF16) SS_LAUNCH(emg_prepare_kernel<bf16_t>, ew_grid(total, 256), dim3(256), 0, stream, x_raw, (bf16_t*)out_padded, shifted_copy, B, T0, Cin, shift);
+    else SS_LAUNCH(emg_prepare_kernel<float>, ew_grid(total, 256), dim3(256), 0, stream, x_raw, (float*)out_padded, shifted_copy, B, T0, Cin, shift);
+    SS_LAUNCH_CHECK("ss_emg_prepare");
+    return 0;
+}

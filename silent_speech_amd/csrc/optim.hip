@@ -1,0 +1,108 @@
+// optim.hip -- fused AdamW over the flat parameter arena (reference transduction_model.py:178,210:
+// torch.optim.AdamW, betas (.9,.999), eps 1e-8, decoupled weight decay FLAGS.l2) and small elementwise
+// helpers of the mel-target path (data_utils.py:51,57).  HBM-bound: 16 B read + 12 B written per parameter.
+#include "common.h"
+#include "silent_speech_hip.h"
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                             float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, float grad_scale)
+{
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * grad_scale;
+            float x = pp[e] * (1.f - lr * wd);
+            mm[e] = beta1 * mm[e] + (1.f - beta1) * gr;
+            vv[e] = beta2 * vv[e] + (1.f - beta2) * gr * gr;
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pp[e] = x - (lr / bc1) * (mm[e] / denom);
+        }
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+    }
+    // tail (n not a multiple of 4)
+    const long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float gr = g[i] * grad_scale;
+        float x = p[i] * (1.f - lr * wd);
+        float mm = beta1 * m[i] + (1.f - beta1) * gr, vv = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mm; v[i] = vv;
+        p[i] = x - (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+}
+
+extern "C" int ss_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int step, float grad_scale, void* stream)
+{
+    SS_CHECK(p && g && m && v, "ss_adamw_step: null pointer");
+    SS_CHECK(step >= 1, "ss_adamw_step: step is 1-based");
+    SS_CHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "ss_adamw_step: arenas must be 16-byte aligned");
+    if (n <= 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    long long blocks = ((n >> 2) + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    SS_LAUNCH(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    SS_LAUNCH_CHECK("ss_adamw_step");
+    return 0;
+}
+
+// ---------------------------------------------------------------- f32 -> compute-dtype cast of a flat range (weight shadow copies)
+template <class TO>
+__global__ void cast_kernel(const float* __restrict__ in, TO* __restrict__ out, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) stf(out + i, in[i]);
+}
+extern "C" int ss_cast_f32(const float* in, void* out, int out_dtype, int64_t n, void* stream)
+{
+    SS_CHECK(in && out, "ss_cast_f32: null pointer");
+    if (n <= 0) return 0;
+    long long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    if (out_dtype == SS_BF16) SS_LAUNCH(cast_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, in, (bf16_t*)out, (long long)n);
+    else SS_LAUNCH(cast_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, in, (float*)out, (long long)n);
+    SS_LAUNCH_CHECK("ss_cast_f32");
+    return 0;
+}
+
+// ---------------------------------------------------------------- mel targets: reflect padding and |STFT|
+// data_utils.py:51  F.pad(y, (p, p), mode='reflect')
+__global__ void reflect_pad_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int L, int pad, long long ld_out)
+{
+    const int Lp = L + 2 * pad;
+    const long long total = (long long)B * Lp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / Lp), t = (int)(i - (long long)b * Lp) - pad;
+        const int s = t < 0 ? -t : (t >= L ? 2 * (L - 1) - t : t);
+        out[(long long)b * ld_out + t + pad] = y[(long long)b * L + s];
+    }
+}
+extern "C" int ss_reflect_pad(const float* y, float* out, int B, int L, int pad, int64_t ld_out, void* stream)
+{
+    SS_CHECK(y && out, "ss_reflect_pad: null pointer");
+    SS_CHECK(B > 0 && L > pad && pad >= 0 && ld_out >= L + 2 * pad, "ss_reflect_pad: bad sizes (reflect needs pad < L)");
+    long long total = (long long)B * (L + 2 * pad), blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    SS_LAUNCH(reflect_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, out, B, L, pad, (long long)ld_out);
+    SS_LAUNCH_CHECK("ss_reflect_pad");
+    return 0;
+}
+
+// data_utils.py:56-57  sqrt(re^2 + im^2 + 1e-9); spec rows hold [re(0..nb-1) | im(0..nb-1)] with row stride ld_spec
+__global__ void stft_magnitude_kernel(const float* __restrict__ spec, long long ld_spec, int nb, float* __restrict__ mag, long long ld_mag, int rows)
+{
+    const long long total = (long long)rows * ld_mag;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / ld_mag), k = (int)(i - (long long)r * ld_mag);
+        float v = 0.f;
+        if (k < nb) { const float re = spec[(long long)r * ld_spec + k], im = spec[(long long)r * ld_spec + nb + k]; v = sqrtf(re * re + im * im + 1e-9f); }
+        mag[i] = v;
+    }
+}
+extern "C" int ss_stft_magnitude(const float* spec, int64_t ld_spec, int n_bins, float* mag, int64_t ld_mag, int rows, void* stream)
+{
+    SS_CHECK(spec && mag, "ss_stft_magnitude: null pointer");
+    SS_CHECK(ld_spec >= 2 * n_bins && ld_mag >= n_bins, "ss_stft_magnitude: bad leading dimensions");
+    if (rows <= 0) return 0;
+    long long total = (long long)rows * ld_mag, blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    SS_LAUNCH(stft_magnitude_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, spec, (long long)ld_spec, n_bins, mag, (long long)ld_mag, rows);
+    SS_LAUNCH_CHECK("ss_stft_magnitude");
+    return 0;
+}

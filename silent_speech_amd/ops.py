@@ -48,3 +48,120 @@ def permute3d(inp, out, dims, strides, valid1=None, valid2=None, scale=1.0, accu
                                  float(scale), int(accumulate), _lib.stream_of(out))
     _lib.check(rc, 'ss_permute3d')
     return out
+
+
+# ------------------------------------------------------------------ helpers
+def _L():
+    return _lib.lib()
+
+
+def _p(t):
+    return _lib.ptr(t)
+
+
+def _s(t):
+    return _lib.stream_of(t)
+
+
+def _dt(t):
+    return _lib.dtype_code(t.dtype)
+
+
+_epi_defaults = dict(log_clamp=0.0, c2=None, cmap2=None, col_stride2=0)
+
+
+def gemm_ex(A, B, C, M, N, K, amap, bmap, cmap, **kw):
+    """gemm() plus the rarely used epilogue extras: log_clamp, c2/cmap2/col_stride2."""
+    extras = {k: kw.pop(k) for k in list(kw) if k in _epi_defaults}
+    if not extras:
+        return gemm(A, B, C, M, N, K, amap, bmap, cmap, **kw)
+    return _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, extras, **kw)
+
+
+def _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, extras, a_mode=OP_KC, b_mode=OP_KC, bias=None, relu=False, gate=None,
+               gate_scale=1.0, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0, mode=0, split_k=1, col_perm=None):
+    epi = GemmEpilogue()
+    epi.bias = _p(bias).value if bias is not None else None
+    epi.gate = _p(gate).value if gate is not None else None
+    epi.gate_scale, epi.alpha, epi.relu, epi.dropout_p = gate_scale, alpha, int(bool(relu)), float(dropout_p)
+    epi.seed, epi.rng_stream, epi.mode = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_stream), int(mode)
+    if col_perm is not None:
+        epi.col_mod, epi.col_mul, epi.col_div_mul = col_perm
+    epi.log_clamp = float(extras.get('log_clamp', 0.0))
+    c2 = extras.get('c2')
+    if c2 is not None:
+        assert c2.dtype == C.dtype
+        epi.c2 = _p(c2).value
+        epi.cmap2 = extras['cmap2']
+        epi.col_stride2 = int(extras['col_stride2'])
+    rc = _L().ss_gemm(_dt(A), _dt(C), a_mode, b_mode, _p(A), _p(B), _p(C), M, N, K, ctypes.byref(amap), ctypes.byref(bmap),
+                      ctypes.byref(cmap), ctypes.byref(epi), split_k, _s(C))
+    _lib.check(rc, 'ss_gemm')
+    return C
+
+
+# ------------------------------------------------------------------ BatchNorm / LayerNorm / misc
+def bn_scratch(B, T, C, device):
+    return torch.empty(int(_L().ss_bn_scratch_floats(B, T, C)), dtype=torch.float32, device=device)
+
+
+def bn_stats(x, B, T, C, pad, scratch, running_mean, running_var, momentum=0.1, eps=1e-5, training=True):
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    rc = _L().ss_bn_stats(_dt(x), _p(x), B, T, C, pad, _p(scratch), _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+                          momentum, eps, int(training), _s(x))
+    _lib.check(rc, 'ss_bn_stats')
+    return mean, invstd
+
+
+def bn_apply(xa, sa, pad_xa, y, pad_y, B, T, C, relu, xb=None, sb=None, pad_xb=0):
+    """sa/sb = (mean, invstd, gamma, beta)."""
+    n4 = [None] * 4
+    b4 = sb if sb is not None else n4
+    rc = _L().ss_bn_apply(_dt(xa), _p(xa), _p(sa[0]), _p(sa[1]), _p(sa[2]), _p(sa[3]), pad_xa,
+                          _p(xb), _p(b4[0]), _p(b4[1]), _p(b4[2]), _p(b4[3]), pad_xb, _p(y), pad_y, B, T, C, int(relu), _s(xa))
+    _lib.check(rc, 'ss_bn_apply')
+    return y
+
+
+def bn_backward(dy, pad_dy, y, pad_y, xa, pad_xa, sa, dxa, pad_dxa, dgamma_a, dbeta_a, scratch, B, T, C, relu,
+                xb=None, pad_xb=0, sb=None, dxb=None, pad_dxb=0, dgamma_b=None, dbeta_b=None):
+    """sa/sb = (mean, invstd, gamma)."""
+    b3 = sb if sb is not None else [None] * 3
+    rc = _L().ss_bn_backward(_dt(dy), _p(dy), pad_dy, _p(y), pad_y, _p(xa), pad_xa, _p(sa[0]), _p(sa[1]), _p(sa[2]),
+                             _p(xb), pad_xb, _p(b3[0]), _p(b3[1]), _p(b3[2]), _p(dxa), pad_dxa, _p(dxb), pad_dxb,
+                             _p(dgamma_a), _p(dbeta_a), _p(dgamma_b), _p(dbeta_b), _p(scratch), B, T, C, int(relu), _s(dy))
+    _lib.check(rc, 'ss_bn_backward')
+
+
+def colsum(x, rows, C, ld, out_accum):
+    _lib.check(_L().ss_colsum(_dt(x), _p(x), rows, C, ld, _p(out_accum), _s(x)), 'ss_colsum')
+
+
+def add_dropout_layernorm(x, branch_inout, gamma, beta, y, rows, C, eps=1e-5, p=0.0, seed=0, rng_stream=0):
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rc = _L().ss_add_dropout_layernorm_forward(_dt(x), _p(x), _p(branch_inout), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd),
+                                               rows, C, eps, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(x))
+    _lib.check(rc, 'ss_add_dropout_layernorm_forward')
+    return mean, rstd
+
+
+def layernorm_backward(dy, z, mean, rstd, gamma, dres, dbranch, dgamma, dbeta, rows, C, p=0.0, seed=0, rng_stream=0):
+    rc = _L().ss_layernorm_backward(_dt(dy), _p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dbranch), _p(dgamma), _p(dbeta),
+                                    rows, C, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(dy))
+    _lib.check(rc, 'ss_layernorm_backward')
+
+
+def emg_prepare(x_raw, out_padded, shifted_copy, B, T0, Cin, shift):
+    rc = _L().ss_emg_prepare(_dt(out_padded), _p(x_raw), _p(out_padded), _p(shifted_copy), B, T0, Cin, shift, _s(x_raw))
+    _lib.check(rc, 'ss_emg_prepare')
+
+
+def adamw_step(p, g, m, v, n, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    rc = _L().ss_adamw_step(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, _s(p))
+    _lib.check(rc, 'ss_adamw_step')
+
+
+def cast_f32(src, dst, n):
+    _lib.check(_L().ss_cast_f32(_p(src), _p(dst), _dt(dst), n, _s(src)), 'ss_cast_f32')
