@@ -173,6 +173,25 @@ int ss_cast_f32(const float* in, void* out, int out_dtype, int64_t n, void* stre
 int ss_reflect_pad(const float* y, float* out, int B, int L, int pad, int64_t ld_out, void* stream);
 int ss_stft_magnitude(const float* spec, int64_t ld_spec, int n_bins, float* mag, int64_t ld_mag, int rows, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head self-attention with learned relative-position logits (transformer.py:87-112 and
+ * :162-297; closed form in csrc/attention.hip), fused: QK^T, Q.E^T (banded, |k-q| <= D-1, -1e8
+ * outside), softmax, dropout (transformer.py:109), P.V.  Operands (compute dtype):
+ *   qkv  [B*T][3*H*dp] (q|k|v, head, d) with the head dim zero-padded to dp (multiple of 32, <=128);
+ *   qkvT [B][3*H*dp][Tp] the same transposed per sequence (2nd output of the QKV ss_gemm);
+ *   E    [H][2D-1][dp];  ET [H][dp][MPt], MPt = roundup(2D-1, 32)  (ss_permute3d of the embeddings);
+ *   out  [B*T][H*dp];  lse [B][H][T] f32 (saved for backward).  scale = 1/sqrt(d_qkv) (unpadded).
+ * backward (transduction_model.py:209): dqkv [B*T][3*H*dp] = (dQ|dK|dV); dO/dOT like out / its
+ * transposed copy [B][H*dp][Tp]; Dscratch [B][H][T] f32.  The embeddings receive no gradient
+ * (transformer.py:214-218). */
+int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse,
+                                int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
+                                uint32_t rng_stream, void* stream);
+int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* out,
+                                 const float* lse, const void* dO, const void* dOT, float* Dscratch, void* dqkv,
+                                 int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
+                                 uint32_t rng_stream, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

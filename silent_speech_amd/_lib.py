@@ -40,6 +40,8 @@ SIGNATURES = {
     'ss_permute3d': [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _I, _P],
     'ss_dtw_align': [_P, _P, _I, _I, _I, _P, _P, _P],
     'ss_dtw_align_skewed': [_P, _I, _P, _P, _P],
+    'ss_relpos_attention_forward': [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_relpos_attention_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_bn_stats': [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P],
     'ss_bn_apply': [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'ss_bn_backward': [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

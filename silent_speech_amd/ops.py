@@ -165,3 +165,16 @@ def adamw_step(p, g, m, v, n, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight
 
 def cast_f32(src, dst, n):
     _lib.check(_L().ss_cast_f32(_p(src), _p(dst), _dt(dst), n, _s(src)), 'ss_cast_f32')
+
+
+# ------------------------------------------------------------------ attention
+def relpos_attention_forward(qkv, qkvT, E, out, lse, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0):
+    rc = _L().ss_relpos_attention_forward(_dt(qkv), _p(qkv), _p(qkvT), _p(E), _p(out), _p(lse), B, H, T, Tp, dp, D, scale, p,
+                                          int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
+    _lib.check(rc, 'ss_relpos_attention_forward')
+
+
+def relpos_attention_backward(qkv, qkvT, E, ET, out, lse, dO, dOT, dscratch, dqkv, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0):
+    rc = _L().ss_relpos_attention_backward(_dt(qkv), _p(qkv), _p(qkvT), _p(E), _p(ET), _p(out), _p(lse), _p(dO), _p(dOT), _p(dscratch),
+                                           _p(dqkv), B, H, T, Tp, dp, D, scale, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
+    _lib.check(rc, 'ss_relpos_attention_backward')

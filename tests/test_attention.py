@@ -1,0 +1,107 @@
+"""Fused relative-position attention (forward + backward) vs the closed-form fp32 torch restatement
+(oracle/model_ref.relpos_logits, itself pinned to the reference's pad/view skew by golden vectors)."""
+import math
+
+import pytest
+import torch
+
+from oracle import model_ref
+from silent_speech_amd import ops
+from tests.backend import dev, is_emu  # noqa: F401
+from tests.util import assert_close_robust
+
+
+def _reference(q, k, v, E, D, dh, drop=None):
+    """q,k,v: (B,H,T,dh) f32 leaf tensors; E: (H,2D-1,dh)."""
+    logits = torch.einsum('bhqa,bhka->bhqk', q, k) / math.sqrt(dh)
+    logits = logits + model_ref.relpos_logits(q, E[..., None], max_rel=D)
+    P = torch.softmax(logits, -1)
+    if drop is not None:
+        P = P * drop
+    return torch.einsum('bhqk,bhka->bhqa', P, v), torch.logsumexp(logits, -1)
+
+
+def _pack(x, dp):          # (B,H,T,dh) -> (B,T,H,dp) zero padded
+    B, H, T, dh = x.shape
+    o = torch.zeros(B, T, H, dp, dtype=x.dtype)
+    o[..., :dh] = x.permute(0, 2, 1, 3)
+    return o
+
+
+def _run(dev, dt, B, H, T, dh, D, seed, tol_f, tol_b):
+    dp = (dh + 31) // 32 * 32
+    Tp = (T + 7) // 8 * 8
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = [(torch.randn(B, H, T, dh, generator=g) * 0.8).to(dt).float().requires_grad_(True) for _ in range(3)]
+    E = (torch.randn(H, 2 * D - 1, dh, generator=g) * dh ** -0.5).to(dt).float()
+    dO = torch.randn(B, H, T, dh, generator=g).to(dt).float()
+    O_ref, lse_ref = _reference(q, k, v, E, D, dh)
+    O_ref.backward(dO)
+    # device operands
+    qkv = torch.cat([_pack(t.detach(), dp).reshape(B * T, H * dp) for t in (q, k, v)], 1).to(dt).contiguous()          # [B*T][3*H*dp]
+    qkvT = torch.zeros(B, 3 * H * dp, Tp, dtype=dt)
+    qkvT[:, :, :T] = qkv.view(B, T, 3 * H * dp).transpose(1, 2)
+    Ed = torch.zeros(H, 2 * D - 1, dp, dtype=dt); Ed[..., :dh] = E.to(dt)
+    MPt = (2 * D - 1 + 31) // 32 * 32
+    ETd = torch.zeros(H, dp, MPt, dtype=dt); ETd[:, :dh, :2 * D - 1] = E.transpose(1, 2).to(dt)
+    out = torch.zeros(B * T, H * dp, dtype=dt, device=dev)
+    lse = torch.zeros(B, H, T, device=dev)
+    qkv_d, qkvT_d, E_d, ET_d = qkv.to(dev), qkvT.to(dev), Ed.to(dev), ETd.to(dev)
+    scale = 1.0 / math.sqrt(dh)
+    ops.relpos_attention_forward(qkv_d, qkvT_d, E_d, out, lse, B, H, T, Tp, dp, D, scale)
+    O = out.view(B, T, H, dp)[..., :dh].permute(0, 2, 1, 3)
+    assert_close_robust(O, O_ref, tol_f, name='O', max_outlier_frac=0)
+    assert_close_robust(lse, lse_ref, 1e-5 if dt == torch.float32 else 2e-2, name='lse', max_outlier_frac=0)
+    if dp > dh:
+        assert float(out.view(B, T, H, dp)[..., dh:].float().abs().max()) == 0.0          # padded head dims stay zero
+    # backward
+    dOd = _pack(dO, dp).reshape(B * T, H * dp).to(dt).contiguous()
+    dOT = torch.zeros(B, H * dp, Tp, dtype=dt); dOT[:, :, :T] = dOd.view(B, T, H * dp).transpose(1, 2)
+    dqkv = torch.full((B * T, 3 * H * dp), 7.0, dtype=dt, device=dev)
+    dsc = torch.empty(B, H, T, device=dev)
+    ops.relpos_attention_backward(qkv_d, qkvT_d, E_d, ET_d, out, lse, dOd.to(dev), dOT.to(dev), dsc, dqkv, B, H, T, Tp, dp, D, scale)
+    dq, dk, dv = [dqkv.view(B, T, 3, H, dp)[:, :, i, :, :dh].permute(0, 2, 1, 3) for i in range(3)]
+    assert_close_robust(dv, v.grad, tol_b, name='dV', max_outlier_frac=0)
+    assert_close_robust(dk, k.grad, tol_b, name='dK', max_outlier_frac=0)
+    assert_close_robust(dq, q.grad, tol_b, name='dQ', max_outlier_frac=0)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_attention_small_band(dev, dt):
+    """T > D: banded; ragged T (not a multiple of 16 or 8); padded head dim."""
+    if is_emu(dev):
+        _run(dev, dt, B=1, H=2, T=37, dh=8, D=9, seed=1, tol_f=2e-5 if dt == torch.float32 else 2e-2, tol_b=5e-5 if dt == torch.float32 else 3e-2)
+    else:
+        _run(dev, dt, B=2, H=3, T=77, dh=24, D=21, seed=1, tol_f=2e-5 if dt == torch.float32 else 2e-2, tol_b=5e-5 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_attention_no_band(dev, dt):
+    """T <= D: no masking at all (transformer.py:256 branch not taken)."""
+    T = 20 if is_emu(dev) else 50
+    _run(dev, dt, B=1, H=1, T=T, dh=32, D=100 if not is_emu(dev) else 24, seed=2, tol_f=2e-5 if dt == torch.float32 else 2e-2, tol_b=5e-5 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('T', [200, 250, 100])
+def test_attention_model_shape(dt, T):
+    """The real configuration: d_qkv = 96, D = 100, T = 200 (training rows) / 250 / 100."""
+    from silent_speech_amd import _lib
+    _lib.load()
+    _run(torch.device('cuda'), dt, B=2, H=8, T=T, dh=96, D=100, seed=T, tol_f=3e-5 if dt == torch.float32 else 2e-2, tol_b=1e-4 if dt == torch.float32 else 3e-2)
+
+
+def test_attention_dropout_statistics(dev):
+    """P~ = P*keep/(1-p): with V = 1 every output equals sum_k P~ -> mean 1, and backward uses the same mask."""
+    B, H, T, dh, D, p = 1, 1, 32, 32, 8, 0.25
+    dp, Tp = 32, 32
+    qkv = torch.zeros(B * T, 3 * dp); qkv[:, 2 * dp:] = 1.0
+    qkvT = qkv.view(B, T, 3 * dp).transpose(1, 2).contiguous()
+    E = torch.zeros(H, 2 * D - 1, dp)
+    out = torch.zeros(B * T, dp, device=dev); lse = torch.zeros(B, H, T, device=dev)
+    ops.relpos_attention_forward(qkv.to(dev), qkvT.to(dev), E.to(dev), out, lse, B, H, T, Tp, dp, D, 1.0, p=p, seed=5, rng_stream=2)
+    o = out.cpu()[:, 0]
+    # band of 2D-1 = 15 uniform probabilities, each kept w.p. 0.75 and scaled by 1/0.75
+    assert abs(o.mean().item() - 1.0) < 0.15
+    assert o.std().item() > 0.01
