@@ -107,23 +107,33 @@ int ss_dtw_align_skewed(const int64_t* desc_dev, int n, void* workspace, int32_t
  * :32 relu(bn1(conv1)), :33 bn2(conv2), :36 res_norm(residual_path), :40 relu(x + res)).
  * Activations are (B, T + 2*pad, C), C contiguous, pad in {0,1}: padded buffers carry a zero row on
  * each side of every sequence (the conv halo); pad rows of outputs are written as zeros.
- * ss_bn_stats: training: per-channel batch mean / 1/sqrt(biased var + eps) over B*T, running stats
- * updated in place (momentum, unbiased variance) as torch does; eval: from the running stats.
+ * Training: per-channel batch mean / 1/sqrt(biased var + eps) over B*T, running stats updated in place
+ * (momentum, unbiased variance) as torch does; eval: from the running stats.
  * scratch: ss_bn_scratch_floats(B,T,C) floats. */
 int64_t ss_bn_scratch_floats(int B, int T, int C); /* [host] */
-int ss_bn_stats(int dtype, const void* x, int B, int T, int C, int pad, float* scratch, float* mean, float* invstd,
-                float* running_mean, float* running_var, float momentum, float eps, int training, void* stream);
+/* Two-phase statistics so that data-parallel ranks can all-reduce between the phases (the batch
+ * statistics of the reference span the WHOLE batch):  sums[3][C] = { sum(x-s), sum (x-s)^2, s } with
+ * s = shift (a [C] vector identical on all ranks, e.g. running_mean) or, if NULL, the first row. */
+int ss_bn_stats_sums(int dtype, const void* x, int B, int T, int C, int pad, float* scratch, const float* shift, float* sums, void* stream);
+int ss_bn_finalize(const float* sums, double n_total, int C, float* mean, float* invstd, float* running_mean, float* running_var,
+                   float momentum, float eps, int training, void* stream);
 /* y = act( bn_a(xa) [+ bn_b(xb)] ),  act = ReLU if relu */
 int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const float* invstd_a, const float* gamma_a, const float* beta_a, int pad_xa,
                 const void* xb, const float* mean_b, const float* invstd_b, const float* gamma_b, const float* beta_b, int pad_xb,
                 void* y, int pad_y, int B, int T, int C, int relu, void* stream);
-/* autograd backward of the above (transduction_model.py:209): dgamma/dbeta are ACCUMULATED (+=). */
-int ss_bn_backward(int dtype, const void* dy, int pad_dy, const void* y, int pad_y,
-                   const void* xa, int pad_xa, const float* mean_a, const float* invstd_a, const float* gamma_a,
-                   const void* xb, int pad_xb, const float* mean_b, const float* invstd_b, const float* gamma_b,
-                   void* dxa, int pad_dxa, void* dxb, int pad_dxb,
-                   float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
-                   float* scratch, int B, int T, int C, int relu, void* stream);
+/* autograd backward of the above (transduction_model.py:209), again in two phases:
+ * sums[3][C] = { sum g, sum g*xhat_a, sum g*xhat_b } with g = dy*1[y>0]; dgamma/dbeta are ACCUMULATED (+=);
+ * apply: dx = gamma*invstd*(g - sums0/n - xhat*sums{1,2}/n). */
+int ss_bn_backward_sums(int dtype, const void* dy, int pad_dy, const void* y, int pad_y,
+                        const void* xa, int pad_xa, const float* mean_a, const float* invstd_a,
+                        const void* xb, int pad_xb, const float* mean_b, const float* invstd_b,
+                        float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
+                        float* scratch, float* sums, int B, int T, int C, int relu, void* stream);
+int ss_bn_backward_apply(int dtype, const void* dy, int pad_dy, const void* y, int pad_y,
+                         const void* xa, int pad_xa, const float* mean_a, const float* invstd_a, const float* gamma_a,
+                         const void* xb, int pad_xb, const float* mean_b, const float* invstd_b, const float* gamma_b,
+                         const float* sums, double n_total, void* dxa, int pad_dxa, void* dxb, int pad_dxb,
+                         int B, int T, int C, int relu, void* stream);
 /* out[c] += sum_r x[r][c]  (bias gradients of nn.Linear / nn.Conv1d) */
 int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, float* out_accum, void* stream);
 

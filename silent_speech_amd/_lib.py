@@ -42,9 +42,11 @@ SIGNATURES = {
     'ss_dtw_align_skewed': [_P, _I, _P, _P, _P],
     'ss_relpos_attention_forward': [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_relpos_attention_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
-    'ss_bn_stats': [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P],
+    'ss_bn_stats_sums': [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    'ss_bn_finalize': [_P, ctypes.c_double, _I, _P, _P, _P, _P, _F, _F, _I, _P],
     'ss_bn_apply': [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    'ss_bn_backward': [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'ss_bn_backward_sums': [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'ss_bn_backward_apply': [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, ctypes.c_double, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'ss_colsum': [_I, _P, _I, _I, _L, _P, _P],
     'ss_add_dropout_layernorm_forward': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_layernorm_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _P],

@@ -1,0 +1,180 @@
+"""EMG -> mel transduction model on the MI355X -- drop-in for the reference's architecture.py.
+
+    Model(num_features, num_outs, num_aux_outs=None)          architecture.py:43
+    .forward(x_feat, x_raw, session_ids) -> pred | (pred, aux)  architecture.py:61-84
+
+Same parameter names / shapes / initialisation (so `state_dict()` round-trips with reference
+checkpoints), same train()/eval() semantics (random 0-7 sample shift augmentation drawn from Python's
+`random`, dropout, BatchNorm batch statistics + running-stat updates), `x_feat` and `session_ids`
+accepted and ignored exactly like the reference.  All compute runs in hand-written HIP kernels
+(engine.py sequences them); there is no eager / CPU fallback.
+
+Extras (keyword-only, defaults reproduce the reference): model_size / num_layers / dropout override the
+absl FLAGS the reference reads globally (architecture.py:47-54); compute_dtype selects bf16 MFMA
+(default, BASELINE config 2) or exact-f32 MFMA kernels.
+"""
+import random
+
+import torch
+from torch import nn
+
+from . import engine
+from .flags import FLAGS
+from .transformer import TransformerEncoder, TransformerEncoderLayer
+
+
+class ResBlock(nn.Module):
+    """architecture.py:14-27 (parameter container; forward is fused in engine.py)."""
+
+    def __init__(self, num_ins, num_outs, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv1d(num_ins, num_outs, 3, padding=1, stride=stride)
+        self.bn1 = nn.BatchNorm1d(num_outs)
+        self.conv2 = nn.Conv1d(num_outs, num_outs, 3, padding=1)
+        self.bn2 = nn.BatchNorm1d(num_outs)
+        if stride != 1 or num_ins != num_outs:
+            self.residual_path = nn.Conv1d(num_ins, num_outs, 1, stride=stride)
+            self.res_norm = nn.BatchNorm1d(num_outs)
+        else:
+            self.residual_path = None
+        self.stride = stride
+
+
+class _ModelFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward/backward are the HIP execution plans of
+    engine.py.  Parameter gradients are accumulated straight into the (flat) .grad buffers."""
+
+    @staticmethod
+    def forward(ctx, model, x_raw, shift_r, seed, anchor):
+        head, saved = engine.forward(model, x_raw, model.training, shift_r, seed)
+        ctx.model, ctx.saved = model, saved
+        return head
+
+    @staticmethod
+    def backward(ctx, dhead):
+        if ctx.saved is None:
+            raise RuntimeError('backward through a forward pass that ran in eval mode')
+        engine.backward(ctx.model, ctx.saved, dhead.contiguous())
+        ctx.saved = None
+        return None, None, None, None, None
+
+
+class Model(nn.Module):
+    def __init__(self, num_features, num_outs, num_aux_outs=None, *, model_size=None, num_layers=None, dropout=None,
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        model_size = FLAGS.model_size if model_size is None else model_size
+        num_layers = FLAGS.num_layers if num_layers is None else num_layers
+        dropout = FLAGS.dropout if dropout is None else dropout
+        if model_size % 8 != 0:
+            raise ValueError('model_size must be a multiple of 8 (nhead=8, 16-byte channel vectors)')
+        self.conv_blocks = nn.Sequential(ResBlock(8, model_size, 2), ResBlock(model_size, model_size, 2), ResBlock(model_size, model_size, 2))
+        self.w_raw_in = nn.Linear(model_size, model_size)
+        encoder_layer = TransformerEncoderLayer(d_model=model_size, nhead=8, relative_positional=True, relative_positional_distance=100,
+                                                dim_feedforward=3072, dropout=dropout)
+        self.transformer = TransformerEncoder(encoder_layer, num_layers)
+        self.w_out = nn.Linear(model_size, num_outs)
+        self.has_aux_out = num_aux_outs is not None
+        if self.has_aux_out:
+            self.w_aux = nn.Linear(model_size, num_aux_outs)
+        # ---- MI355X execution state (not part of the state_dict)
+        self.d_model, self.n_head, self.max_rel = model_size, 8, 100
+        self.d_qkv = model_size // 8
+        self.dp = (self.d_qkv + 31) // 32 * 32            # head dim zero-padded to the MFMA K granularity
+        self.dropout_p = float(dropout)
+        self.num_outs, self.num_aux_outs = num_outs, num_aux_outs
+        if compute_dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError('compute_dtype must be torch.bfloat16 or torch.float32')
+        self.compute_dtype = compute_dtype
+        self._weights_version = 0
+        self._bn_reduce_fn = None                         # set by the data-parallel wrapper (SyncBN-equivalent statistics)
+        self._seed_base, self._step = 0x5EED, 0
+        self.shift_rng = random                           # architecture.py:65 draws r = random.randrange(8)
+        self._anchor = None
+        self._flat = None
+
+    # ------------------------------------------------------------------ flat parameter / gradient arenas
+    def optimized_parameters(self):
+        """Every parameter except the relative-position embeddings, which never receive a gradient in the
+        reference (padded under no_grad, transformer.py:214-218) and are therefore never updated by AdamW."""
+        return [p for n, p in self.named_parameters() if 'relative_positional' not in n]
+
+    def flatten_parameters(self):
+        """Re-home all optimised parameters (and their .grad) in two contiguous f32 arenas: one fused AdamW
+        launch and one gradient all-reduce cover the whole model.  Views keep names/shapes intact."""
+        ps = self.optimized_parameters()
+        if not ps:
+            return
+        dev = ps[0].device
+        offs, n = [], 0
+        for p in ps:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4                 # 16-byte aligned slots
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(ps, offs):
+                flat[o:o + p.numel()].copy_(p.detach().reshape(-1).to(torch.float32))
+                p.data = flat[o:o + p.numel()].view(p.shape)
+                p.grad = gflat[o:o + p.numel()].view(p.shape)
+        self._flat, self._gflat, self._flat_n = flat, gflat, n
+        self._weights_version += 1
+
+    def flat_arenas(self):
+        if self._flat is None or self._flat.device != self.w_out.weight.device or self.w_out.weight.data_ptr() < self._flat.data_ptr() \
+                or self.w_out.weight.data_ptr() >= self._flat.data_ptr() + 4 * self._flat_n:
+            self.flatten_parameters()
+        for p in self.optimized_parameters():             # zero_grad(set_to_none=True) detached them: re-attach
+            if p.grad is None:
+                self._reattach_grads()
+                break
+        return self._flat, self._gflat, self._flat_n
+
+    def _reattach_grads(self):
+        self._gflat.zero_()
+        off = 0
+        for p in self.optimized_parameters():
+            p.grad = self._gflat[off:off + p.numel()].view(p.shape)
+            off += (p.numel() + 3) // 4 * 4
+
+    def mark_weights_updated(self):
+        """Called by optimisers that update the arena through the C ABI (no torch version bump)."""
+        self._weights_version += 1
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._weights_version += 1
+        return r
+
+    def set_seed(self, seed):
+        self._seed_base = int(seed)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x_feat, x_raw, session_ids):
+        # x shape is (batch, time, electrode); x_feat and session_ids are unused, as in the reference
+        if x_raw.dim() != 3 or x_raw.shape[2] != 8:
+            raise ValueError('x_raw must be (batch, time, 8)')
+        if x_raw.dtype != torch.float32:
+            raise TypeError('x_raw must be float32')
+        r = 0
+        if self.training:
+            r = self.shift_rng.randrange(8)               # architecture.py:65
+            if x_raw.is_cuda or True:
+                self.flat_arenas()
+        xr = x_raw if x_raw.is_contiguous() else x_raw.contiguous()
+        self._step += 1
+        seed = (self._seed_base * 0x9E3779B1 + self._step) & 0xFFFFFFFFFFFFFFFF
+        if self._anchor is None or self._anchor.device != xr.device:
+            self._anchor = torch.zeros(1, device=xr.device, requires_grad=True)
+        if self.training and torch.is_grad_enabled():
+            head = _ModelFn.apply(self, xr, r, seed, self._anchor)
+        else:
+            head, _ = engine.forward(self, xr, self.training, r, seed)
+        if xr is not x_raw and self.training and r > 0:
+            x_raw.copy_(xr)
+        B, T = x_raw.shape[0], x_raw.shape[1] // 8
+        n_out = self.num_outs
+        pred = head[:, :n_out].view(B, T, n_out)
+        if self.has_aux_out:
+            return pred, head[:, n_out:n_out + self.num_aux_outs].view(B, T, self.num_aux_outs)
+        return pred

@@ -28,7 +28,7 @@ constexpr int RED_THREADS = 256;
 
 // =========================================================================== BatchNorm statistics
 template <class T>
-__global__ __launch_bounds__(RED_THREADS) void bn_partial_kernel(const T* __restrict__ x, Seq sx, int rows, int C, int rows_per_chunk, float* __restrict__ partial)
+__global__ __launch_bounds__(RED_THREADS) void bn_partial_kernel(const T* __restrict__ x, Seq sx, int rows, int C, int rows_per_chunk, const float* __restrict__ shift, float* __restrict__ partial)
 {
     __shared__ float red[2][RED_THREADS * 8];
     ColMap m(C, threadIdx.x, RED_THREADS);
@@ -40,7 +40,10 @@ __global__ __launch_bounds__(RED_THREADS) void bn_partial_kernel(const T* __rest
         for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; sh[e] = 0.f; }
         const bool cv = m.active && cx < m.CV;
         if (cv) {
-            Vec8<T>::load(x + sx.row(0) * C + cx * 8, sh);      // shift = first row: tames E[x^2]-E[x]^2 cancellation
+            if (shift) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sh[e] = shift[cx * 8 + e];
+            } else Vec8<T>::load(x + sx.row(0) * C + cx * 8, sh);   // shift = first row: tames E[x^2]-E[x]^2 cancellation
             for (int r = r0 + m.ry; r < r1; r += m.RY) {
                 float v[8]; Vec8<T>::load(x + sx.row(r) * C + cx * 8, v);
 #pragma unroll
@@ -64,22 +67,29 @@ __global__ __launch_bounds__(RED_THREADS) void bn_partial_kernel(const T* __rest
     }
 }
 
+// sums[0][c] = sum(x - shift), sums[1][c] = sum (x - shift)^2, sums[2][c] = shift
 template <class T>
-__global__ void bn_finalize_kernel(const T* __restrict__ x, Seq sx, const float* __restrict__ partial, int nchunks, int rows, int C,
-                                   float* mean, float* invstd, float* running_mean, float* running_var, float momentum, float eps, int training)
+__global__ void bn_sums_kernel(const T* __restrict__ x, Seq sx, const float* __restrict__ partial, int nchunks, int C, const float* __restrict__ shift, float* __restrict__ sums)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) { s1 += partial[((long long)k * 2 + 0) * C + c]; s2 += partial[((long long)k * 2 + 1) * C + c]; }
+    sums[c] = s1; sums[C + c] = s2; sums[2 * C + c] = shift ? shift[c] : ldf(x + sx.row(0) * C + c);
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float n, int C, float* mean, float* invstd, float* running_mean, float* running_var,
+                                   float momentum, float eps, int training)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (!training) { mean[c] = running_mean[c]; invstd[c] = rsqrtf(running_var[c] + eps); return; }
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nchunks; ++k) { s1 += partial[((long long)k * 2 + 0) * C + c]; s2 += partial[((long long)k * 2 + 1) * C + c]; }
-    const float n = (float)rows, sh = ldf(x + sx.row(0) * C + c);
-    const float d = s1 / n, mu = sh + d;
-    float var = s2 / n - d * d; var = var < 0.f ? 0.f : var;
+    const float d = sums[c] / n, mu = sums[2 * C + c] + d;
+    float var = sums[C + c] / n - d * d; var = var < 0.f ? 0.f : var;
     mean[c] = mu; invstd[c] = rsqrtf(var + eps);
     if (running_mean) {   // torch: running = (1-m)*running + m*stat, unbiased variance for the running estimate
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (rows > 1 ? n / (n - 1.f) : 1.f);
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (n > 1.f ? n / (n - 1.f) : 1.f);
     }
 }
 
@@ -87,23 +97,31 @@ static int red_chunks(int rows) { int c = (rows + 63) / 64; if (c > 1024) c = 10
 
 extern "C" int64_t ss_bn_scratch_floats(int B, int T, int C) { return (int64_t)red_chunks(B * T) * 4 * C + 8 * (int64_t)C; }
 
-extern "C" int ss_bn_stats(int dtype, const void* x, int B, int T, int C, int pad, float* scratch, float* mean, float* invstd,
-                           float* running_mean, float* running_var, float momentum, float eps, int training, void* stream)
+extern "C" int ss_bn_stats_sums(int dtype, const void* x, int B, int T, int C, int pad, float* scratch, const float* shift, float* sums, void* stream)
 {
-    SS_CHECK(x && mean && invstd, "ss_bn_stats: null pointer");
-    SS_CHECK(C % 8 == 0 && C > 0, "ss_bn_stats: C=%d must be a positive multiple of 8", C);
-    SS_CHECK(B > 0 && T > 0, "ss_bn_stats: empty batch");
-    SS_CHECK(training || (running_mean && running_var), "ss_bn_stats: eval mode needs running statistics");
+    SS_CHECK(x && scratch && sums, "ss_bn_stats_sums: null pointer");
+    SS_CHECK(C % 8 == 0 && C > 0, "ss_bn_stats_sums: C=%d must be a positive multiple of 8", C);
+    SS_CHECK(B > 0 && T > 0, "ss_bn_stats_sums: empty batch");
     const int rows = B * T, nch = red_chunks(rows), rpc = (rows + nch - 1) / nch;
     Seq sx = {T, pad};
-    if (training) {
-        SS_CHECK(scratch, "ss_bn_stats: scratch missing");
-        if (dtype == SS_BF16) SS_LAUNCH(bn_partial_kernel<bf16_t>, dim3(nch), dim3(RED_THREADS), 0, stream, (const bf16_t*)x, sx, rows, C, rpc, scratch);
-        else SS_LAUNCH(bn_partial_kernel<float>, dim3(nch), dim3(RED_THREADS), 0, stream, (const float*)x, sx, rows, C, rpc, scratch);
+    if (dtype == SS_BF16) {
+        SS_LAUNCH(bn_partial_kernel<bf16_t>, dim3(nch), dim3(RED_THREADS), 0, stream, (const bf16_t*)x, sx, rows, C, rpc, shift, scratch);
+        SS_LAUNCH(bn_sums_kernel<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, stream, (const bf16_t*)x, sx, (const float*)scratch, nch, C, shift, sums);
+    } else {
+        SS_LAUNCH(bn_partial_kernel<float>, dim3(nch), dim3(RED_THREADS), 0, stream, (const float*)x, sx, rows, C, rpc, shift, scratch);
+        SS_LAUNCH(bn_sums_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)x, sx, (const float*)scratch, nch, C, shift, sums);
     }
-    if (dtype == SS_BF16) SS_LAUNCH(bn_finalize_kernel<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, stream, (const bf16_t*)x, sx, scratch, nch, rows, C, mean, invstd, running_mean, running_var, momentum, eps, training);
-    else SS_LAUNCH(bn_finalize_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)x, sx, scratch, nch, rows, C, mean, invstd, running_mean, running_var, momentum, eps, training);
-    SS_LAUNCH_CHECK("ss_bn_stats");
+    SS_LAUNCH_CHECK("ss_bn_stats_sums");
+    return 0;
+}
+
+extern "C" int ss_bn_finalize(const float* sums, double n_total, int C, float* mean, float* invstd, float* running_mean, float* running_var,
+                              float momentum, float eps, int training, void* stream)
+{
+    SS_CHECK(mean && invstd && C > 0, "ss_bn_finalize: null pointer");
+    SS_CHECK(training ? (sums != nullptr && n_total >= 1.0) : (running_mean && running_var), "ss_bn_finalize: missing sums (training) or running statistics (eval)");
+    SS_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, (float)n_total, C, mean, invstd, running_mean, running_var, momentum, eps, training);
+    SS_LAUNCH_CHECK("ss_bn_finalize");
     return 0;
 }
 
@@ -211,15 +229,14 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const T* __
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunks, int rows, int C, float* __restrict__ coef /* [3][C] means */,
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunks, int C, float* __restrict__ coef /* [3][C] sums */,
                                        float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int k = 0; k < nchunks; ++k) { s0 += partial[((long long)k * 3 + 0) * C + c]; s1 += partial[((long long)k * 3 + 1) * C + c]; s2 += partial[((long long)k * 3 + 2) * C + c]; }
-    const float n = (float)rows;
-    coef[c] = s0 / n; coef[C + c] = s1 / n; coef[2 * C + c] = s2 / n;
+    coef[c] = s0; coef[C + c] = s1; coef[2 * C + c] = s2;
     if (dgamma_a) dgamma_a[c] += s1;
     if (dbeta_a) dbeta_a[c] += s0;
     if (dgamma_b) dgamma_b[c] += s2;
@@ -230,7 +247,7 @@ template <class T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* __restrict__ y, Seq sy,
                                     const T* __restrict__ xa, Seq sa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a, const float* __restrict__ gamma_a,
                                     const T* __restrict__ xb, Seq sb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b, const float* __restrict__ gamma_b,
-                                    const float* __restrict__ coef, T* __restrict__ dxa, Seq sda, T* __restrict__ dxb, Seq sdb, int B, int C, int relu)
+                                    const float* __restrict__ coef, float inv_n, T* __restrict__ dxa, Seq sda, T* __restrict__ dxb, Seq sdb, int B, int C, int relu)
 {
     const int CV = C >> 3, TT = sdy.T;
     const int padmax = sda.pad > sdb.pad ? sda.pad : sdb.pad;
@@ -251,10 +268,10 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* 
                 for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
             Vec8<T>::load(xa + sa.row(r) * C + cx * 8, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float xh = (v[e] - mean_a[c]) * invstd_a[c]; oa[e] = gamma_a[c] * invstd_a[c] * (g[e] - coef[c] - xh * coef[C + c]); }
+            for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float xh = (v[e] - mean_a[c]) * invstd_a[c]; oa[e] = gamma_a[c] * invstd_a[c] * (g[e] - coef[c] * inv_n - xh * coef[C + c] * inv_n); }
             if (xb) { Vec8<T>::load(xb + sb.row(r) * C + cx * 8, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float xh = (v[e] - mean_b[c]) * invstd_b[c]; ob[e] = gamma_b[c] * invstd_b[c] * (g[e] - coef[c] - xh * coef[2 * C + c]); } }
+                for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float xh = (v[e] - mean_b[c]) * invstd_b[c]; ob[e] = gamma_b[c] * invstd_b[c] * (g[e] - coef[c] * inv_n - xh * coef[2 * C + c] * inv_n); } }
         }
         // halo rows (only for padded outputs) are written as zeros
         const int ta = t + sda.pad, tb = t + sdb.pad;
@@ -263,31 +280,48 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* 
     }
 }
 
-extern "C" int ss_bn_backward(int dtype, const void* dy, int pad_dy, const void* y, int pad_y,
-                              const void* xa, int pad_xa, const float* mean_a, const float* invstd_a, const float* gamma_a,
-                              const void* xb, int pad_xb, const float* mean_b, const float* invstd_b, const float* gamma_b,
-                              void* dxa, int pad_dxa, void* dxb, int pad_dxb,
-                              float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
-                              float* scratch, int B, int T, int C, int relu, void* stream)
+extern "C" int ss_bn_backward_sums(int dtype, const void* dy, int pad_dy, const void* y, int pad_y,
+                                   const void* xa, int pad_xa, const float* mean_a, const float* invstd_a,
+                                   const void* xb, int pad_xb, const float* mean_b, const float* invstd_b,
+                                   float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
+                                   float* scratch, float* sums, int B, int T, int C, int relu, void* stream)
 {
-    SS_CHECK(dy && xa && mean_a && invstd_a && gamma_a && dxa && scratch, "ss_bn_backward: null pointer");
-    SS_CHECK(!relu || y, "ss_bn_backward: relu backward needs the saved output");
-    SS_CHECK(!xb || (mean_b && invstd_b && gamma_b && dxb), "ss_bn_backward: second branch incomplete");
-    SS_CHECK(C % 8 == 0 && C > 0 && B > 0 && T > 0, "ss_bn_backward: bad shape");
+    SS_CHECK(dy && xa && mean_a && invstd_a && scratch && sums, "ss_bn_backward_sums: null pointer");
+    SS_CHECK(!relu || y, "ss_bn_backward_sums: relu backward needs the saved output");
+    SS_CHECK(!xb || (mean_b && invstd_b), "ss_bn_backward_sums: second branch incomplete");
+    SS_CHECK(C % 8 == 0 && C > 0 && B > 0 && T > 0, "ss_bn_backward_sums: bad shape");
     const int rows = B * T, nch = red_chunks(rows), rpc = (rows + nch - 1) / nch;
-    Seq sdy = {T, pad_dy}, sy = {T, pad_y}, sa = {T, pad_xa}, sb = {T, pad_xb}, sda = {T, pad_dxa}, sdb = {T, pad_dxb};
-    float* partial = scratch; float* coef = scratch + (long long)nch * 3 * C;
-    const int padmax = pad_dxa > pad_dxb ? pad_dxa : pad_dxb;
-    const long long total = (long long)B * (T + 2 * padmax) * (C / 8);
+    Seq sdy = {T, pad_dy}, sy = {T, pad_y}, sa = {T, pad_xa}, sb = {T, pad_xb};
 #define SS_BNB(TT)                                                                                                                             \
     SS_LAUNCH(bn_bwd_partial_kernel<TT>, dim3(nch), dim3(RED_THREADS), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, \
-              (const TT*)xb, sb, mean_b, invstd_b, rows, C, rpc, relu, partial);                                                                \
-    SS_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)partial, nch, rows, C, coef, dgamma_a, dbeta_a, dgamma_b, dbeta_b); \
-    SS_LAUNCH(bn_bwd_apply_kernel<TT>, ew_grid(total, 256), dim3(256), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, gamma_a, \
-              (const TT*)xb, sb, mean_b, invstd_b, gamma_b, (const float*)coef, (TT*)dxa, sda, (TT*)dxb, sdb, B, C, relu)
+              (const TT*)xb, sb, mean_b, invstd_b, rows, C, rpc, relu, scratch);                                                                \
+    SS_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)scratch, nch, C, sums, dgamma_a, dbeta_a, dgamma_b, dbeta_b)
     if (dtype == SS_BF16) { SS_BNB(bf16_t); } else { SS_BNB(float); }
 #undef SS_BNB
-    SS_LAUNCH_CHECK("ss_bn_backward");
+    SS_LAUNCH_CHECK("ss_bn_backward_sums");
+    return 0;
+}
+
+extern "C" int ss_bn_backward_apply(int dtype, const void* dy, int pad_dy, const void* y, int pad_y,
+                                    const void* xa, int pad_xa, const float* mean_a, const float* invstd_a, const float* gamma_a,
+                                    const void* xb, int pad_xb, const float* mean_b, const float* invstd_b, const float* gamma_b,
+                                    const float* sums, double n_total, void* dxa, int pad_dxa, void* dxb, int pad_dxb,
+                                    int B, int T, int C, int relu, void* stream)
+{
+    SS_CHECK(dy && xa && mean_a && invstd_a && gamma_a && dxa && sums, "ss_bn_backward_apply: null pointer");
+    SS_CHECK(!relu || y, "ss_bn_backward_apply: relu backward needs the saved output");
+    SS_CHECK(!xb || (mean_b && invstd_b && gamma_b && dxb), "ss_bn_backward_apply: second branch incomplete");
+    SS_CHECK(C % 8 == 0 && C > 0 && B > 0 && T > 0 && n_total >= 1.0, "ss_bn_backward_apply: bad shape");
+    Seq sdy = {T, pad_dy}, sy = {T, pad_y}, sa = {T, pad_xa}, sb = {T, pad_xb}, sda = {T, pad_dxa}, sdb = {T, pad_dxb};
+    const int padmax = pad_dxa > pad_dxb ? pad_dxa : pad_dxb;
+    const long long total = (long long)B * (T + 2 * padmax) * (C / 8);
+    const float inv_n = (float)(1.0 / n_total);
+#define SS_BNA(TT)                                                                                                                             \
+    SS_LAUNCH(bn_bwd_apply_kernel<TT>, ew_grid(total, 256), dim3(256), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, gamma_a, \
+              (const TT*)xb, sb, mean_b, invstd_b, gamma_b, sums, inv_n, (TT*)dxa, sda, (TT*)dxb, sdb, B, C, relu)
+    if (dtype == SS_BF16) { SS_BNA(bf16_t); } else { SS_BNA(float); }
+#undef SS_BNA
+    SS_LAUNCH_CHECK("ss_bn_backward_apply");
     return 0;
 }
 

@@ -1,0 +1,356 @@
+"""Execution plan of the transduction model on the MI355X: which C-ABI kernel runs when, on which
+buffers.  Pure orchestration -- every FLOP happens in libsilent_speech_hip.so (csrc/*.hip); torch is
+used for device memory, streams and autograd bookkeeping only.
+
+Forward follows reference architecture.py:61-84 (Model.forward), :29-40 (ResBlock.forward) and
+transformer.py:43-60,87-112; backward is the hand-derived reverse pass that
+loss.backward() (transduction_model.py:209) triggers in the reference through autograd.
+
+Canonical activation layout: (B, T, C) row-major == a flat [B*T][C] matrix (the reference's
+(B,C,T) / (T,B,C) transposes, architecture.py:70,72,77,79, are layout-only).  Convolution inputs live
+in (B, T+2, C) buffers with a zero halo row at both ends of every sequence, so a k=3 window is one
+contiguous 3C-wide row and conv == GEMM with an overlapping-row RowMap (csrc/gemm.hip).
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import OP_KC, OP_OC
+
+RM = ops.rowmap
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def _split_k(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    s = max(1, min(64, 1024 // max(tiles, 1)))
+    return max(1, min(s, K // 512 if K >= 512 else 1))
+
+
+class Prepared(object):
+    """GEMM-ready copies of the parameters in the compute dtype (bf16 or f32): layout changes for the
+    conv / attention tensors, plain casts for the nn.Linear ones.  Rebuilt when the parameters change."""
+
+    def __init__(self, model):
+        self.sig = None
+        self.build(model)
+
+    @staticmethod
+    def signature(model):
+        return (model._weights_version, tuple(p._version for p in model.parameters()), model.compute_dtype)
+
+    def build(self, model):
+        dt, dev = model.compute_dtype, model.w_out.weight.device
+        d = model.d_model
+        self.blocks = []
+        for blk in model.conv_blocks:
+            O, I, _ = blk.conv1.weight.shape
+            e = {}
+            w1, w2 = blk.conv1.weight.detach(), blk.conv2.weight.detach()
+            e['w1f'] = ops.permute3d(w1, torch.empty(O, 3 * I, dtype=dt, device=dev), (O, 3, I), (3 * I, 1, 3))
+            e['w2f'] = ops.permute3d(w2, torch.empty(O, 3 * O, dtype=dt, device=dev), (O, 3, O), (3 * O, 1, 3))
+            e['wr'] = ops.permute3d(blk.residual_path.weight.detach(), torch.empty(O, I, dtype=dt, device=dev), (O, 1, I), (I, 0, 1))
+            # input-gradient forms (flipped taps):  conv2 (stride 1)  Wb[i][j*O+o] = W[o][i][2-j]
+            e['w2b'] = ops.permute3d(w2.view(-1)[2:], torch.empty(O, 3 * O, dtype=dt, device=dev), (O, 3, O), (3, -1, 3 * O))
+            if I % 8 == 0:   # stride-2 conv1: even rows use tap 1, odd rows taps (2, 0); block 0 has no input gradient
+                e['w1b_even'] = ops.permute3d(w1.view(-1)[1:], torch.empty(I, O, dtype=dt, device=dev), (I, 1, O), (3, 0, 3 * I))
+                e['w1b_odd'] = ops.permute3d(w1.view(-1)[2:], torch.empty(I, 2 * O, dtype=dt, device=dev), (I, 2, O), (3, -2, 3 * I))
+            self.blocks.append(e)
+
+        def cast(w):
+            if dt == torch.float32:
+                return w.detach()
+            out = torch.empty(w.shape, dtype=dt, device=dev)
+            ops.cast_f32(w.detach(), out, w.numel())
+            return out
+
+        self.w_raw_in = cast(model.w_raw_in.weight)
+        H, dh, dp, D = model.n_head, model.d_qkv, model.dp, model.max_rel
+        MPt = _round_up(2 * D - 1, 32)
+        self.layers = []
+        for layer in model.transformer.layers:
+            a = layer.self_attn
+            e = {}
+            wqkv = torch.empty(3, H, dp, d, dtype=dt, device=dev)
+            for i, w in enumerate((a.w_q, a.w_k, a.w_v)):       # (H, d, dh) -> [h][a (padded)][f]
+                ops.permute3d(w.detach(), wqkv[i], (H, dp, d), (d * dh, 1, dh), valid1=dh)
+            e['wqkv'] = wqkv.view(3 * H * dp, d)
+            e['wo'] = ops.permute3d(a.w_o.detach(), torch.empty(d, H * dp, dtype=dt, device=dev), (d, H, dp), (1, dh * d, d), valid2=dh)
+            emb = a.relative_positional.embeddings.detach()    # (H, 2D-1, dh, 1)
+            e['E'] = ops.permute3d(emb, torch.empty(H, 2 * D - 1, dp, dtype=dt, device=dev), (H, 2 * D - 1, dp), ((2 * D - 1) * dh, dh, 1), valid2=dh)
+            e['ET'] = ops.permute3d(emb, torch.empty(H, dp, MPt, dtype=dt, device=dev), (H, dp, MPt), ((2 * D - 1) * dh, 1, dh), valid1=dh, valid2=2 * D - 1)
+            e['w1'] = cast(layer.linear1.weight)
+            e['w2'] = cast(layer.linear2.weight)
+            self.layers.append(e)
+        n_out = model.w_out.weight.shape[0]
+        n_aux = model.w_aux.weight.shape[0] if model.has_aux_out else 0
+        nh = _round_up(n_out + n_aux, 8)
+        wh = torch.zeros(nh, d, dtype=dt, device=dev)
+        bh = torch.zeros(nh, dtype=torch.float32, device=dev)
+        ops.cast_f32(model.w_out.weight.detach(), wh[:n_out], n_out * d)
+        bh[:n_out] = model.w_out.bias.detach()
+        if n_aux:
+            ops.cast_f32(model.w_aux.weight.detach(), wh[n_out:n_out + n_aux], n_aux * d)
+            bh[n_out:n_out + n_aux] = model.w_aux.bias.detach()
+        self.w_head, self.b_head, self.n_head_cols = wh, bh, nh
+        self.sig = self.signature(model)
+
+
+def prepared(model):
+    pr = getattr(model, '_prepared', None)
+    if pr is None or pr.sig != Prepared.signature(model):
+        pr = Prepared(model)
+        model._prepared = pr
+    return pr
+
+
+class Ctx(object):
+    pass
+
+
+def _bn(mod):
+    return mod.weight.detach(), mod.bias.detach()
+
+
+def forward(model, x_raw, training, shift_r, seed):
+    """x_raw (B, 8T, 8) f32 on the GPU -> head [B*T][n_head_cols] f32 and the saved context."""
+    pr = prepared(model)
+    dt, dev = model.compute_dtype, x_raw.device
+    B, T0, Cin0 = x_raw.shape
+    if T0 % 8 != 0:
+        raise ValueError('raw EMG length %d must be a multiple of 8 (three stride-2 convolutions)' % T0)
+    d = model.d_model
+    ctx = Ctx()
+    ctx.B, ctx.T0, ctx.training, ctx.seed = B, T0, training, seed
+    p_drop = model.dropout_p if training else 0.0
+    ctx.p_drop = p_drop
+    bn_reduce = model._bn_reduce_fn if training else None
+
+    xin = torch.empty(B, T0 + 2, Cin0, dtype=dt, device=dev)
+    shifted = torch.empty_like(x_raw) if (training and shift_r > 0) else None
+    ops.emg_prepare(x_raw, xin, shifted, B, T0, Cin0, shift_r if training else 0)
+    if shifted is not None:
+        x_raw.copy_(shifted)            # the reference mutates its input in place (architecture.py:67-68)
+
+    ctx.blocks = []
+    Tin, Cin = T0, Cin0
+    nblk = len(model.conv_blocks)
+    for i, (blk, w) in enumerate(zip(model.conv_blocks, pr.blocks)):
+        O = blk.conv1.weight.shape[0]
+        Tout = Tin // 2
+        rows = B * Tout
+        s = Ctx()
+        s.xin, s.Tin, s.Cin, s.Tout, s.O = xin, Tin, Cin, Tout, O
+        scratch = ops.bn_scratch(B, Tout, O, dev)
+        s.scratch = scratch
+        in_bs = (Tin + 2) * Cin
+        c1 = torch.empty(rows, O, dtype=dt, device=dev)
+        ops.gemm(xin, w['w1f'], c1, rows, O, 3 * Cin, RM(2 * Cin, Tout, in_bs), RM(3 * Cin), RM(O), bias=blk.conv1.bias.detach())
+        cr = torch.empty(rows, O, dtype=dt, device=dev)
+        ops.gemm(xin, w['wr'], cr, rows, O, Cin, RM(2 * Cin, Tout, in_bs, base=Cin), RM(Cin), RM(O), bias=blk.residual_path.bias.detach())
+        g1, b1 = _bn(blk.bn1)
+        sh1 = blk.bn1.running_mean if bn_reduce is not None else None
+        m1, i1 = ops.bn_stats(c1, B, Tout, O, 0, scratch, blk.bn1.running_mean, blk.bn1.running_var, training=training, shift=sh1, reduce_fn=bn_reduce)
+        h1 = torch.empty(B, Tout + 2, O, dtype=dt, device=dev)
+        ops.bn_apply(c1, (m1, i1, g1, b1), 0, h1, 1, B, Tout, O, True)
+        c2 = torch.empty(rows, O, dtype=dt, device=dev)
+        ops.gemm(h1, w['w2f'], c2, rows, O, 3 * O, RM(O, Tout, (Tout + 2) * O), RM(3 * O), RM(O), bias=blk.conv2.bias.detach())
+        g2, b2 = _bn(blk.bn2)
+        gr, br = _bn(blk.res_norm)
+        sh2 = blk.bn2.running_mean if bn_reduce is not None else None
+        shr = blk.res_norm.running_mean if bn_reduce is not None else None
+        m2, i2 = ops.bn_stats(c2, B, Tout, O, 0, scratch, blk.bn2.running_mean, blk.bn2.running_var, training=training, shift=sh2, reduce_fn=bn_reduce)
+        mr, ir = ops.bn_stats(cr, B, Tout, O, 0, scratch, blk.res_norm.running_mean, blk.res_norm.running_var, training=training, shift=shr, reduce_fn=bn_reduce)
+        last = i == nblk - 1
+        pad_y = 0 if last else 1
+        y = torch.empty(B, Tout + 2 * pad_y, O, dtype=dt, device=dev)
+        ops.bn_apply(c2, (m2, i2, g2, b2), 0, y, pad_y, B, Tout, O, True, xb=cr, sb=(mr, ir, gr, br), pad_xb=0)
+        if training:
+            for bnm in (blk.bn1, blk.bn2, blk.res_norm):
+                bnm.num_batches_tracked += 1
+        s.c1, s.cr, s.h1, s.c2, s.y, s.pad_y = c1, cr, h1, c2, y, pad_y
+        s.st1, s.st2, s.str_ = (m1, i1, g1), (m2, i2, g2), (mr, ir, gr)
+        ctx.blocks.append(s)
+        xin, Tin, Cin = y, Tout, O
+
+    T = Tin
+    M = B * T
+    ctx.T, ctx.M = T, M
+    conv_out = xin.view(M, d)
+    ctx.conv_out = conv_out
+    x = torch.empty(M, d, dtype=dt, device=dev)
+    ops.gemm(conv_out, pr.w_raw_in, x, M, d, d, RM(d), RM(d), RM(d), bias=model.w_raw_in.bias.detach())
+
+    H, dp, D = model.n_head, model.dp, model.max_rel
+    Tp = _round_up(T, 8)
+    scale = 1.0 / math.sqrt(model.d_qkv)
+    ctx.Tp, ctx.scale = Tp, scale
+    ctx.layers = []
+    for l, (layer, w) in enumerate(zip(model.transformer.layers, pr.layers)):
+        s = Ctx()
+        s.x = x
+        qkv = torch.empty(M, 3 * H * dp, dtype=dt, device=dev)
+        qkvT = torch.empty(B, 3 * H * dp, Tp, dtype=dt, device=dev)
+        ops.gemm_ex(x, w['wqkv'], qkv, M, 3 * H * dp, d, RM(d), RM(d), RM(3 * H * dp),
+                    c2=qkvT, cmap2=RM(1, T, 3 * H * dp * Tp), col_stride2=Tp)
+        o = torch.empty(M, H * dp, dtype=dt, device=dev)
+        lse = torch.empty(B, H, T, dtype=torch.float32, device=dev)
+        ops.relpos_attention_forward(qkv, qkvT, w['E'], o, lse, B, H, T, Tp, dp, D, scale, p=p_drop, seed=seed, rng_stream=4 * l)
+        a = torch.empty(M, d, dtype=dt, device=dev)
+        ops.gemm(o, w['wo'], a, M, d, H * dp, RM(H * dp), RM(H * dp), RM(d))
+        y1 = torch.empty(M, d, dtype=dt, device=dev)
+        mean1, rstd1 = ops.add_dropout_layernorm(x, a, layer.norm1.weight.detach(), layer.norm1.bias.detach(), y1, M, d,
+                                                 eps=layer.norm1.eps, p=p_drop, seed=seed, rng_stream=4 * l + 1)
+        ff = layer.linear1.weight.shape[0]
+        hid = torch.empty(M, ff, dtype=dt, device=dev)
+        ops.gemm(y1, w['w1'], hid, M, ff, d, RM(d), RM(d), RM(ff), bias=layer.linear1.bias.detach(), relu=True,
+                 dropout_p=p_drop, seed=seed, rng_stream=4 * l + 2)
+        f = torch.empty(M, d, dtype=dt, device=dev)
+        ops.gemm(hid, w['w2'], f, M, d, ff, RM(ff), RM(ff), RM(d), bias=layer.linear2.bias.detach())
+        y2 = torch.empty(M, d, dtype=dt, device=dev)
+        mean2, rstd2 = ops.add_dropout_layernorm(y1, f, layer.norm2.weight.detach(), layer.norm2.bias.detach(), y2, M, d,
+                                                 eps=layer.norm2.eps, p=p_drop, seed=seed, rng_stream=4 * l + 3)
+        s.qkv, s.qkvT, s.o, s.lse, s.z1, s.mean1, s.rstd1, s.y1 = qkv, qkvT, o, lse, a, mean1, rstd1, y1
+        s.hid, s.z2, s.mean2, s.rstd2 = hid, f, mean2, rstd2
+        ctx.layers.append(s)
+        x = y2
+    ctx.x_final = x
+    nh = pr.n_head_cols
+    head = torch.empty(M, nh, dtype=torch.float32, device=dev)
+    ops.gemm(x, pr.w_head, head, M, nh, d, RM(d), RM(d), RM(nh), bias=pr.b_head)
+    if not training:
+        ctx = None
+    return head, ctx
+
+
+def _grad(p):
+    """The (flat-arena backed) gradient buffer of a parameter; accumulated into, as autograd would."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _dw_direct(dy, x, grad, N, K, rows, amap, bmap):
+    """grad[N][K] += dy^T x  (both operands outer-contiguous, split-K with f32 atomics)."""
+    ops.gemm(dy, x, grad, N, K, rows, amap, bmap, RM(K), a_mode=OP_OC, b_mode=OP_OC, mode=2, split_k=_split_k(N, K, rows))
+
+
+def backward(model, ctx, dhead):
+    """Accumulates into .grad of every parameter (except the relative-position embeddings, which get
+    no gradient in the reference either, transformer.py:214-218).  dhead: [M][n_head_cols] f32."""
+    pr = prepared(model)
+    dt, dev = model.compute_dtype, dhead.device
+    B, T, M, d = ctx.B, ctx.T, ctx.M, model.d_model
+    H, dp, D, dh = model.n_head, model.dp, model.max_rel, model.d_qkv
+    Tp, p_drop, seed = ctx.Tp, ctx.p_drop, ctx.seed
+    keep_scale = 1.0 / (1.0 - p_drop)
+    bn_reduce = model._bn_reduce_fn
+    nh = pr.n_head_cols
+
+    # ---- heads (architecture.py:82)
+    dh_t = dhead if dt == torch.float32 else torch.empty(M, nh, dtype=dt, device=dev)
+    if dt != torch.float32:
+        ops.cast_f32(dhead, dh_t, M * nh)
+    n_out = model.w_out.weight.shape[0]
+    n_aux = model.w_aux.weight.shape[0] if model.has_aux_out else 0
+    tmp_w = torch.zeros(nh, d, dtype=torch.float32, device=dev)
+    tmp_b = torch.zeros(nh, dtype=torch.float32, device=dev)
+    _dw_direct(dh_t, ctx.x_final, tmp_w, nh, d, M, RM(nh), RM(d))
+    ops.colsum(dh_t, M, nh, nh, tmp_b)
+    _grad(model.w_out.weight).add_(tmp_w[:n_out]); _grad(model.w_out.bias).add_(tmp_b[:n_out])
+    if n_aux:
+        _grad(model.w_aux.weight).add_(tmp_w[n_out:n_out + n_aux]); _grad(model.w_aux.bias).add_(tmp_b[n_out:n_out + n_aux])
+    G = torch.empty(M, d, dtype=dt, device=dev)
+    ops.gemm(dh_t, pr.w_head, G, M, d, nh, RM(nh), RM(d), RM(d), b_mode=OP_OC)
+
+    # ---- encoder layers, last to first (transformer.py:54-59)
+    for l in range(len(ctx.layers) - 1, -1, -1):
+        layer, w, s = model.transformer.layers[l], pr.layers[l], ctx.layers[l]
+        a = layer.self_attn
+        ff = layer.linear1.weight.shape[0]
+        dF = torch.empty(M, d, dtype=dt, device=dev)
+        ops.layernorm_backward(G, s.z2, s.mean2, s.rstd2, layer.norm2.weight.detach(), G, dF, _grad(layer.norm2.weight), _grad(layer.norm2.bias),
+                               M, d, p=p_drop, seed=seed, rng_stream=4 * l + 3)
+        _dw_direct(dF, s.hid, _grad(layer.linear2.weight), d, ff, M, RM(d), RM(ff))
+        ops.colsum(dF, M, d, d, _grad(layer.linear2.bias))
+        dHid = torch.empty(M, ff, dtype=dt, device=dev)
+        ops.gemm(dF, w['w2'], dHid, M, ff, d, RM(d), RM(ff), RM(ff), b_mode=OP_OC, gate=s.hid, gate_scale=keep_scale)
+        _dw_direct(dHid, s.y1, _grad(layer.linear1.weight), ff, d, M, RM(ff), RM(d))
+        ops.colsum(dHid, M, ff, ff, _grad(layer.linear1.bias))
+        ops.gemm(dHid, w['w1'], G, M, d, ff, RM(ff), RM(d), RM(d), b_mode=OP_OC, mode=1)
+        del dHid
+        dA = dF      # reuse
+        ops.layernorm_backward(G, s.z1, s.mean1, s.rstd1, layer.norm1.weight.detach(), G, dA, _grad(layer.norm1.weight), _grad(layer.norm1.bias),
+                               M, d, p=p_drop, seed=seed, rng_stream=4 * l + 1)
+        # output projection  out[t,b,f] = sum_{h,a} o[b,h,t,a] w_o[h,a,f]   (transformer.py:111)
+        tmp = torch.zeros(d, H * dp, dtype=torch.float32, device=dev)
+        _dw_direct(dA, s.o, tmp, d, H * dp, M, RM(d), RM(H * dp))
+        ops.permute3d(tmp, _grad(a.w_o), (H, dh, d), (dp, 1, H * dp), accumulate=True)
+        dO = torch.empty(M, H * dp, dtype=dt, device=dev)
+        dOT = torch.empty(B, H * dp, Tp, dtype=dt, device=dev)
+        ops.gemm_ex(dA, w['wo'], dO, M, H * dp, d, RM(d), RM(H * dp), RM(H * dp), b_mode=OP_OC,
+                    c2=dOT, cmap2=RM(1, T, H * dp * Tp), col_stride2=Tp)
+        dqkv = torch.empty(M, 3 * H * dp, dtype=dt, device=dev)
+        dsc = torch.empty(B, H, T, dtype=torch.float32, device=dev)
+        ops.relpos_attention_backward(s.qkv, s.qkvT, w['E'], w['ET'], s.o, s.lse, dO, dOT, dsc, dqkv, B, H, T, Tp, dp, D, ctx.scale,
+                                      p=p_drop, seed=seed, rng_stream=4 * l)
+        tmp = torch.zeros(3 * H * dp, d, dtype=torch.float32, device=dev)
+        _dw_direct(dqkv, s.x, tmp, 3 * H * dp, d, M, RM(3 * H * dp), RM(d))
+        for i, wp in enumerate((a.w_q, a.w_k, a.w_v)):
+            ops.permute3d(tmp[i * H * dp:], _grad(wp), (H, d, dh), (dp * d, 1, d), accumulate=True)
+        ops.gemm(dqkv, w['wqkv'], G, M, d, 3 * H * dp, RM(3 * H * dp), RM(d), RM(d), b_mode=OP_OC, mode=1)
+        del dqkv, dO, dOT, dA, dF
+
+    # ---- w_raw_in (architecture.py:73)
+    _dw_direct(G, ctx.conv_out, _grad(model.w_raw_in.weight), d, d, M, RM(d), RM(d))
+    ops.colsum(G, M, d, d, _grad(model.w_raw_in.bias))
+    dy = torch.empty(M, d, dtype=dt, device=dev)
+    ops.gemm(G, pr.w_raw_in, dy, M, d, d, RM(d), RM(d), RM(d), b_mode=OP_OC)
+    del G
+
+    # ---- ResBlocks, last to first (architecture.py:29-40)
+    for i in range(len(ctx.blocks) - 1, -1, -1):
+        blk, w, s = model.conv_blocks[i], pr.blocks[i], ctx.blocks[i]
+        O, Cin, Tin, Tout = s.O, s.Cin, s.Tin, s.Tout
+        rows = B * Tout
+        pbs = (Tout + 2) * O                    # batch stride of a padded (B, Tout+2, O) buffer
+        dc2 = torch.empty(B, Tout + 2, O, dtype=dt, device=dev)
+        dcr = torch.empty(rows, O, dtype=dt, device=dev)
+        ops.bn_backward(dy, 0, s.y, s.pad_y, s.c2, 0, s.st2, dc2, 1, _grad(blk.bn2.weight), _grad(blk.bn2.bias), s.scratch, B, Tout, O, True,
+                        xb=s.cr, pad_xb=0, sb=s.str_, dxb=dcr, pad_dxb=0, dgamma_b=_grad(blk.res_norm.weight), dbeta_b=_grad(blk.res_norm.bias),
+                        reduce_fn=bn_reduce)
+        # conv2 (k3, stride 1): weight, bias, input gradients
+        tmp = torch.zeros(O, 3 * O, dtype=torch.float32, device=dev)
+        ops.gemm(dc2, s.h1, tmp, O, 3 * O, rows, RM(O, Tout, pbs, base=O), RM(O, Tout, pbs), RM(3 * O), a_mode=OP_OC, b_mode=OP_OC, mode=2,
+                 split_k=_split_k(O, 3 * O, rows))
+        ops.permute3d(tmp, _grad(blk.conv2.weight), (O, O, 3), (3 * O, 1, O), accumulate=True)
+        ops.colsum(dc2, B * (Tout + 2), O, O, _grad(blk.conv2.bias))
+        dh1 = torch.empty(rows, O, dtype=dt, device=dev)
+        ops.gemm(dc2, w['w2b'], dh1, rows, O, 3 * O, RM(O, Tout, pbs), RM(3 * O), RM(O))
+        dc1 = torch.empty(B, Tout + 2, O, dtype=dt, device=dev)
+        ops.bn_backward(dh1, 0, s.h1, 1, s.c1, 0, s.st1, dc1, 1, _grad(blk.bn1.weight), _grad(blk.bn1.bias), s.scratch, B, Tout, O, True,
+                        reduce_fn=bn_reduce)
+        del dh1, dc2
+        # conv1 (k3, stride 2) and the 1x1 stride-2 residual path
+        in_bs = (Tin + 2) * Cin
+        tmp = torch.zeros(O, 3 * Cin, dtype=torch.float32, device=dev)
+        ops.gemm(dc1, s.xin, tmp, O, 3 * Cin, rows, RM(O, Tout, pbs, base=O), RM(2 * Cin, Tout, in_bs), RM(3 * Cin), a_mode=OP_OC, b_mode=OP_OC,
+                 mode=2, split_k=_split_k(O, 3 * Cin, rows))
+        ops.permute3d(tmp, _grad(blk.conv1.weight), (O, Cin, 3), (3 * Cin, 1, Cin), accumulate=True)
+        ops.colsum(dc1, B * (Tout + 2), O, O, _grad(blk.conv1.bias))
+        ops.gemm(dcr, s.xin, _grad(blk.residual_path.weight), O, Cin, rows, RM(O), RM(2 * Cin, Tout, in_bs, base=Cin), RM(Cin), a_mode=OP_OC,
+                 b_mode=OP_OC, mode=2, split_k=_split_k(O, Cin, rows))
+        ops.colsum(dcr, rows, O, O, _grad(blk.residual_path.bias))
+        if i > 0:
+            dx = torch.empty(B * Tin, Cin, dtype=dt, device=dev)
+            out_even = RM(2 * Cin, Tout, Tin * Cin)
+            out_odd = RM(2 * Cin, Tout, Tin * Cin, base=Cin)
+            ops.gemm(dc1, w['w1b_even'], dx, rows, Cin, O, RM(O, Tout, pbs, base=O), RM(O), out_even)
+            ops.gemm(dcr, w['wr'], dx, rows, Cin, O, RM(O), RM(Cin), out_even, b_mode=OP_OC, mode=1)
+            ops.gemm(dc1, w['w1b_odd'], dx, rows, Cin, 2 * O, RM(O, Tout, pbs, base=O), RM(2 * O), out_odd)
+            dy = dx
+        del dc1, dcr

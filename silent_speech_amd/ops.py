@@ -105,12 +105,21 @@ def bn_scratch(B, T, C, device):
     return torch.empty(int(_L().ss_bn_scratch_floats(B, T, C)), dtype=torch.float32, device=device)
 
 
-def bn_stats(x, B, T, C, pad, scratch, running_mean, running_var, momentum=0.1, eps=1e-5, training=True):
+def bn_stats(x, B, T, C, pad, scratch, running_mean, running_var, momentum=0.1, eps=1e-5, training=True, shift=None,
+             reduce_fn=None):
+    """Training: batch statistics (+ running-stat update); eval: from the running statistics.
+    reduce_fn(sums, n) -> n_total: optional hook that all-reduces the [3][C] sums across data-parallel ranks
+    (then `shift` must be a vector shared by all ranks)."""
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-    rc = _L().ss_bn_stats(_dt(x), _p(x), B, T, C, pad, _p(scratch), _p(mean), _p(invstd), _p(running_mean), _p(running_var),
-                          momentum, eps, int(training), _s(x))
-    _lib.check(rc, 'ss_bn_stats')
+    n_total, sums = float(B * T), None
+    if training:
+        sums = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+        _lib.check(_L().ss_bn_stats_sums(_dt(x), _p(x), B, T, C, pad, _p(scratch), _p(shift), _p(sums), _s(x)), 'ss_bn_stats_sums')
+        if reduce_fn is not None:
+            n_total = reduce_fn(sums[:2 * C], n_total)
+    rc = _L().ss_bn_finalize(_p(sums), n_total, C, _p(mean), _p(invstd), _p(running_mean), _p(running_var), momentum, eps, int(training), _s(x))
+    _lib.check(rc, 'ss_bn_finalize')
     return mean, invstd
 
 
@@ -125,13 +134,21 @@ def bn_apply(xa, sa, pad_xa, y, pad_y, B, T, C, relu, xb=None, sb=None, pad_xb=0
 
 
 def bn_backward(dy, pad_dy, y, pad_y, xa, pad_xa, sa, dxa, pad_dxa, dgamma_a, dbeta_a, scratch, B, T, C, relu,
-                xb=None, pad_xb=0, sb=None, dxb=None, pad_dxb=0, dgamma_b=None, dbeta_b=None):
-    """sa/sb = (mean, invstd, gamma)."""
+                xb=None, pad_xb=0, sb=None, dxb=None, pad_dxb=0, dgamma_b=None, dbeta_b=None, reduce_fn=None):
+    """sa/sb = (mean, invstd, gamma).  reduce_fn as in bn_stats (all-reduces the [3][C] gradient sums)."""
     b3 = sb if sb is not None else [None] * 3
-    rc = _L().ss_bn_backward(_dt(dy), _p(dy), pad_dy, _p(y), pad_y, _p(xa), pad_xa, _p(sa[0]), _p(sa[1]), _p(sa[2]),
-                             _p(xb), pad_xb, _p(b3[0]), _p(b3[1]), _p(b3[2]), _p(dxa), pad_dxa, _p(dxb), pad_dxb,
-                             _p(dgamma_a), _p(dbeta_a), _p(dgamma_b), _p(dbeta_b), _p(scratch), B, T, C, int(relu), _s(dy))
-    _lib.check(rc, 'ss_bn_backward')
+    sums = torch.empty(3 * C, dtype=torch.float32, device=dy.device)
+    rc = _L().ss_bn_backward_sums(_dt(dy), _p(dy), pad_dy, _p(y), pad_y, _p(xa), pad_xa, _p(sa[0]), _p(sa[1]),
+                                  _p(xb), pad_xb, _p(b3[0]), _p(b3[1]), _p(dgamma_a), _p(dbeta_a), _p(dgamma_b), _p(dbeta_b),
+                                  _p(scratch), _p(sums), B, T, C, int(relu), _s(dy))
+    _lib.check(rc, 'ss_bn_backward_sums')
+    n_total = float(B * T)
+    if reduce_fn is not None:
+        n_total = reduce_fn(sums, n_total)
+    rc = _L().ss_bn_backward_apply(_dt(dy), _p(dy), pad_dy, _p(y), pad_y, _p(xa), pad_xa, _p(sa[0]), _p(sa[1]), _p(sa[2]),
+                                   _p(xb), pad_xb, _p(b3[0]), _p(b3[1]), _p(b3[2]), _p(sums), n_total, _p(dxa), pad_dxa, _p(dxb), pad_dxb,
+                                   B, T, C, int(relu), _s(dy))
+    _lib.check(rc, 'ss_bn_backward_apply')
 
 
 def colsum(x, rows, C, ld, out_accum):

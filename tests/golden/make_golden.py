@@ -266,6 +266,8 @@ if __name__ == '__main__':
     gen_model('model_d8_L1_train_r0', 8, 1, 2, 200, 0, True, 2)
     gen_model('model_d16_L2_train_r3', 16, 2, 3, 200, 3, True, 3)
     gen_model('model_d16_L2_train_r7_T120', 16, 2, 2, 120, 7, True, 4)
+    gen_model('model_d16_L1_train_r3_T40', 16, 1, 2, 40, 3, True, 5)       # tiny: also runs on the host emulator (B>=2: at B=1 the reference's overlapping in-place shift raises)
+    gen_model('model_d32_L1_train_r5_T200', 32, 1, 2, 200, 5, True, 6)     # d_qkv = 4, full 200-frame rows (banded attention)
     gen_dtw_loss()
     gen_mel()
     gen_adamw()

@@ -1,0 +1,106 @@
+"""Model (HIP execution plan) vs golden vectors captured from the reference: forward, every parameter
+gradient, BatchNorm running statistics, in-place shift of the input, state_dict compatibility."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from silent_speech_amd.architecture import Model
+from tests.backend import dev, is_emu  # noqa: F401
+from tests.util import assert_close_robust
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+class _FixedShift(object):
+    def __init__(self, r):
+        self.r = r
+
+    def randrange(self, n):
+        return self.r
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLD, name + '.npz'))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd/')}
+    return z, sd
+
+
+def _build(z, sd, dev, dt):
+    d = sd['w_raw_in.weight'].shape[0]
+    L = 0
+    while 'transformer.layers.%d.linear1.weight' % L in sd:
+        L += 1
+    m = Model(112, 80, 48, model_size=d, num_layers=L, dropout=0.0, compute_dtype=dt)
+    missing, unexpected = m.load_state_dict(sd, strict=True), None      # reference checkpoint loads strictly
+    m.to(dev)
+    m.shift_rng = _FixedShift(int(z['r']))
+    return m
+
+
+def _check(name, dev, dt):
+    z, sd = _load(name)
+    m = _build(z, sd, dev, dt)
+    training = bool(z['training'])
+    m.train(training)
+    x_raw = torch.from_numpy(z['x_raw']).clone().to(dev)
+    B, T0, _ = x_raw.shape
+    pred, aux = m(torch.zeros(B, T0 // 8, 112, device=dev), x_raw, torch.zeros(B, T0 // 8, dtype=torch.long, device=dev))
+    f32 = dt == torch.float32
+    ft = 2e-4 if f32 else 6e-2
+    assert_close_robust(pred, z['pred'], ft, name=name + ':pred', max_outlier_frac=0 if f32 else 1e-3)
+    assert_close_robust(aux, z['aux'], ft, name=name + ':aux', max_outlier_frac=0 if f32 else 1e-3)
+    l1 = float((pred.detach().float().cpu() - torch.from_numpy(z['pred'])).abs().mean())
+    if f32:
+        assert l1 < 1e-4, 'mel-L1 %g' % l1            # north_star: mel-L1 within 1e-4 of the reference (fp32 kernels)
+    if not training:
+        return l1
+    assert torch.equal(x_raw.cpu(), torch.from_numpy(z['x_raw_after']))         # in-place shift, architecture.py:67-68
+    loss = (pred * torch.from_numpy(z['wp']).to(dev)).sum() + (aux * torch.from_numpy(z['wa']).to(dev)).sum()
+    m.zero_grad(set_to_none=True)
+    loss.backward()
+    gt = 3e-3 if f32 else 1.5e-1
+    for n, p in m.named_parameters():
+        if 'relative_positional' in n:
+            assert ('nograd/' + n) in z.files and (p.grad is None or float(p.grad.abs().max()) == 0.0)
+            continue
+        want = z['grad/' + n]
+        if n.endswith('.bias') and ('conv1' in n or 'conv2' in n or 'residual_path' in n):
+            scale = 1e-3 if f32 else 0.5       # true gradient is 0 (bias feeds training-mode BatchNorm)
+            assert float(p.grad.abs().max()) < scale * max(1.0, float(np.abs(z['grad/' + n.replace('.bias', '.weight')]).max())), n
+            continue
+        assert_close_robust(p.grad, want, gt, name=name + ':' + n, min_outliers=40 if f32 else 200, max_outlier_frac=2e-3 if f32 else 2e-2)
+    for n, b in m.named_buffers():
+        if n.endswith('num_batches_tracked'):
+            assert int(b) == int(z['after/' + n]), n
+        else:
+            assert_close_robust(b, z['after/' + n], 1e-4 if f32 else 2e-2, name=name + ':' + n, max_outlier_frac=0)
+    return l1
+
+
+def test_model_tiny_fp32(dev):
+    _check('model_d16_L1_train_r3_T40', dev, torch.float32)
+
+
+def test_model_tiny_bf16(dev):
+    _check('model_d16_L1_train_r3_T40', dev, torch.bfloat16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['model_d8_L1_eval', 'model_d8_L1_train_r0', 'model_d16_L2_train_r3', 'model_d16_L2_train_r7_T120',
+                                  'model_d32_L1_train_r5_T200'])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_model_golden_gpu(name, dt):
+    from silent_speech_amd import _lib
+    _lib.load()
+    _check(name, torch.device('cuda'), dt)
+
+
+def test_state_dict_keys_match_reference(dev):
+    z, sd = _load('model_d16_L1_train_r3_T40')
+    m = Model(112, 80, 48, model_size=16, num_layers=1, dropout=0.0)
+    mine = m.state_dict()
+    assert set(mine.keys()) == set(sd.keys())
+    for k in sd:
+        assert tuple(mine[k].shape) == tuple(sd[k].shape), k
