@@ -12,31 +12,37 @@ def rowmap(row_stride, rows_per_batch=0, batch_stride=0, base=0):
     return RowMap(int(base), int(batch_stride), int(row_stride), int(rows_per_batch))
 
 
-def gemm(A, B, C, M, N, K, amap, bmap, cmap, a_mode=OP_KC, b_mode=OP_KC, bias=None, relu=False, gate=None,
-         gate_scale=1.0, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0, mode=0, split_k=1, col_perm=None):
+PROFILER = None     # bench.py installs a GemmProfiler here to time ss_gemm launches with HIP events on the launch stream
+
+
+class GemmProfiler(object):
+    """Brackets every ss_gemm launch with HIP events on the stream it is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []
+
+    def run(self, key, flops, fn, stream_tensor):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.append((key, flops, s, e))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, s, e in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += s.elapsed_time(e) * 1e-3
+        return {k: dict(launches=v[0], flops=v[1], seconds=v[2]) for k, v in agg.items()}
+
+
+def gemm(A, B, C, M, N, K, amap, bmap, cmap, **kw):
     """C[m][n] (+)= alpha * sum_k A(m,k)*B(n,k); see include/silent_speech_hip.h:ss_gemm."""
-    assert A.dtype == B.dtype
-    epi = GemmEpilogue()
-    epi.bias = _lib.ptr(bias).value if bias is not None else None
-    if bias is not None:
-        assert bias.dtype == torch.float32 and bias.numel() >= N
-    epi.gate = _lib.ptr(gate).value if gate is not None else None
-    if gate is not None:
-        assert gate.dtype == C.dtype
-    epi.gate_scale = gate_scale
-    epi.alpha = alpha
-    epi.relu = int(bool(relu))
-    epi.dropout_p = float(dropout_p)
-    epi.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    epi.rng_stream = int(rng_stream)
-    epi.mode = int(mode)
-    if col_perm is not None:
-        epi.col_mod, epi.col_mul, epi.col_div_mul = col_perm
-    rc = _lib.lib().ss_gemm(_lib.dtype_code(A.dtype), _lib.dtype_code(C.dtype), a_mode, b_mode, _lib.ptr(A), _lib.ptr(B),
-                            _lib.ptr(C), M, N, K, ctypes.byref(amap), ctypes.byref(bmap), ctypes.byref(cmap),
-                            ctypes.byref(epi), split_k, _lib.stream_of(C))
-    _lib.check(rc, 'ss_gemm')
-    return C
+    return _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, {}, **kw)
 
 
 def permute3d(inp, out, dims, strides, valid1=None, valid2=None, scale=1.0, accumulate=False):
@@ -94,9 +100,20 @@ def _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, extras, a_mode=OP_KC, b_mode=
         epi.c2 = _p(c2).value
         epi.cmap2 = extras['cmap2']
         epi.col_stride2 = int(extras['col_stride2'])
-    rc = _L().ss_gemm(_dt(A), _dt(C), a_mode, b_mode, _p(A), _p(B), _p(C), M, N, K, ctypes.byref(amap), ctypes.byref(bmap),
-                      ctypes.byref(cmap), ctypes.byref(epi), split_k, _s(C))
-    _lib.check(rc, 'ss_gemm')
+    assert A.dtype == B.dtype
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= N
+    if gate is not None:
+        assert gate.dtype == C.dtype
+
+    def launch():
+        rc = _L().ss_gemm(_dt(A), _dt(C), a_mode, b_mode, _p(A), _p(B), _p(C), M, N, K, ctypes.byref(amap), ctypes.byref(bmap),
+                          ctypes.byref(cmap), ctypes.byref(epi), split_k, _s(C))
+        _lib.check(rc, 'ss_gemm')
+    if PROFILER is not None and C.is_cuda:
+        PROFILER.run((str(A.dtype), str(C.dtype), a_mode, b_mode), 2.0 * M * N * K, launch, C)
+    else:
+        launch()
     return C
 
 

@@ -1,0 +1,31 @@
+"""Fused AdamW over the model's flat parameter arena (one HIP launch for all 53 M parameters) with the
+torch.optim.Optimizer interface the reference's training loop uses (transduction_model.py:178-189:
+param_groups[...]['lr'] writes, zero_grad(), step(); ReduceLROnPlateau works on it unchanged)."""
+import torch
+
+from . import ops
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.model = model
+        params = model.optimized_parameters()
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._m = self._v = None
+        self._t = 0
+
+    def zero_grad(self, set_to_none=False):
+        flat, gflat, n = self.model.flat_arenas()
+        gflat.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        flat, gflat, n = self.model.flat_arenas()
+        if self._m is None or self._m.device != flat.device or self._m.numel() != n:
+            self._m = torch.zeros_like(flat)
+            self._v = torch.zeros_like(flat)
+        g = self.param_groups[0]
+        self._t += 1
+        ops.adamw_step(flat, gflat, self._m, self._v, n, float(g['lr']), self._t, beta1=g['betas'][0], beta2=g['betas'][1], eps=g['eps'],
+                       weight_decay=g['weight_decay'], grad_scale=grad_scale)
+        self.model.mark_weights_updated()

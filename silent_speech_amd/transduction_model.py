@@ -1,0 +1,234 @@
+"""Drop-in for the hot-path entry points of the reference's transduction_model.py:
+
+    dtw_loss(predictions, phoneme_predictions, example, phoneme_eval=False, phoneme_confusion=None)   (:98-157)
+    test(model, testset, device)                                                                       (:33-55)
+    train_model(trainset, devset, device, save_sound_outputs=True)                                     (:159-227)
+
+dtw_loss keeps everything on the GPU: cost matrices are produced directly in the DTW kernel's strip
+layout, DTW + backtrace run on device, and loss/gradient touch only the aligned pairs -- no D2H copy
+of a T1 x T2 matrix and no per-utterance synchronisation (the reference blocks on both at :126).
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .align import _workspace_layout
+from .architecture import Model
+from .data_utils import combine_fixed_length, phoneme_inventory
+from .flags import FLAGS
+from .optim import FusedAdamW
+
+_L = _lib.lib
+_p = _lib.ptr
+
+
+class _LossPlan(object):
+    """Host-side index arithmetic for one batch (the packed-row <-> utterance bookkeeping that
+    decollate_tensor + zip do in the reference, transduction_model.py:101-111)."""
+
+    def __init__(self, example, rows_total, device):
+        lengths = [int(n) for n in example['lengths']]
+        silent = [bool(s) for s in example['silent']]
+        audio = example['audio_features']
+        phones = example['phonemes']
+        t2 = [int(a.shape[0]) for a in audio]
+        assert sum(lengths) <= rows_total                                           # data_utils.py:175
+        pred_off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        tgt_off = np.concatenate([[0], np.cumsum(t2)]).astype(np.int64)
+        self.total_length = int(sum(t2))
+        vo_pred, vo_tgt, si_tgt, si_base, si_res, desc = [], [], [], [], [], []
+        shapes, res_tot = [], 0
+        for u, (n1, n2, s) in enumerate(zip(lengths, t2, silent)):
+            assert audio[u].dim() == 2
+            if s:
+                shapes.append((n2, n1))
+                si_tgt.append(tgt_off[u] + np.arange(n2)); si_base.append(np.full(n2, pred_off[u])); si_res.append(res_tot + np.arange(n2))
+                desc.append([n2, n1, pred_off[u], tgt_off[u], 0, 0, 0, 0, res_tot, 0])
+                res_tot += n2
+            else:
+                assert n2 == n1, 'voiced utterance: audio features (%d) and predictions (%d) differ in length' % (n2, n1)   # :139
+                vo_pred.append(pred_off[u] + np.arange(n1)); vo_tgt.append(tgt_off[u] + np.arange(n1))
+        self.n_silent = len(shapes)
+        self.shapes = shapes
+        layout, ws_bytes = _workspace_layout(shapes) if shapes else ([], 0)
+        for row, (sk, dr, bd) in zip(desc, layout):
+            row[5], row[6], row[7] = sk, dr, bd
+        self.ws_bytes, self.res_total = ws_bytes, res_tot
+
+        def cat(xs):
+            return np.concatenate(xs).astype(np.int32) if xs else np.zeros(0, dtype=np.int32)
+        parts = [cat(vo_pred), cat(vo_tgt), cat(si_tgt), cat(si_base), cat(si_res)]
+        self.n_voiced, self.n_silent_frames = len(parts[0]), len(parts[2])
+        packed = torch.from_numpy(np.concatenate(parts)) if sum(len(x) for x in parts) else torch.zeros(1, dtype=torch.int32)
+        packed = packed.to(device, non_blocking=True)
+        o = np.cumsum([0] + [len(x) for x in parts])
+        self.vo_pred, self.vo_tgt, self.si_tgt, self.si_base, self.si_res = [packed[o[i]:o[i + 1]] for i in range(5)]
+        self.desc = torch.from_numpy(np.asarray(desc, dtype=np.int64).reshape(-1, 10)).to(device, non_blocking=True) if desc else None
+        self.Y = torch.cat([a.to(device=device, dtype=torch.float32, non_blocking=True) for a in audio], 0).contiguous()
+        self.phones = torch.cat([p.to(device=device, dtype=torch.int64, non_blocking=True) for p in phones], 0).contiguous()
+        self.lengths, self.silent, self.t2 = lengths, silent, t2
+        self.pred_off, self.tgt_off = pred_off, tgt_off
+
+
+class _DtwLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, head, plan, n_mel, n_ph, lam, inv_total):
+        dev = head.device
+        M, ld = head.shape
+        st = _lib.stream_of(head)
+        lse = torch.empty(M, dtype=torch.float32, device=dev)
+        amax = torch.empty(M, dtype=torch.int32, device=dev)
+        dhead = torch.zeros_like(head)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        correct = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(_L().ss_frame_lse(_p(head), ld, n_mel, n_ph, M, _p(lse), _p(amax), st), 'ss_frame_lse')
+        if plan.n_voiced:
+            _lib.check(_L().ss_voiced_loss(_p(head), ld, n_mel, n_ph, _p(lse), _p(amax), _p(plan.Y), _p(plan.phones), _p(plan.vo_pred), _p(plan.vo_tgt),
+                                           plan.n_voiced, lam, inv_total, _p(dhead), _p(loss), _p(correct), st), 'ss_voiced_loss')
+        results = None
+        if plan.n_silent:
+            ws = torch.empty(max(plan.ws_bytes, 256), dtype=torch.uint8, device=dev)
+            results = torch.empty(max(plan.res_total, 1), dtype=torch.int32, device=dev)
+            mx_n, mx_m = max(s[0] for s in plan.shapes), max(s[1] for s in plan.shapes)
+            _lib.check(_L().ss_silent_cost_skewed(_p(head), ld, n_mel, _p(lse), _p(plan.Y), _p(plan.phones), _p(plan.desc), plan.n_silent, mx_n, mx_m,
+                                                  lam, _p(ws), _p(results), st), 'ss_silent_cost_skewed')
+            _lib.check(_L().ss_dtw_align_skewed(_p(plan.desc), plan.n_silent, _p(ws), _p(results), st), 'ss_dtw_align_skewed')
+            _lib.check(_L().ss_silent_loss(_p(head), ld, n_mel, n_ph, _p(lse), _p(amax), _p(plan.Y), _p(plan.phones), _p(results), _p(plan.si_tgt),
+                                           _p(plan.si_base), _p(plan.si_res), plan.n_silent_frames, lam, inv_total, _p(dhead), _p(loss), _p(correct), st),
+                       'ss_silent_loss')
+        ctx.dhead = dhead
+        ctx.mark_non_differentiable(correct)
+        plan.results, plan.argmax = results, amax
+        return loss[0], correct
+
+    @staticmethod
+    def backward(ctx, gl, gc):
+        return ctx.dhead * gl, None, None, None, None, None
+
+
+def dtw_loss(predictions, phoneme_predictions, example, phoneme_eval=False, phoneme_confusion=None, *, phoneme_loss_weight=None,
+             total_length=None):
+    """Returns (loss, phoneme accuracy) like transduction_model.py:98-157.  The loss is a 0-dim tensor attached
+    to autograd; the accuracy is a Python float when phoneme_eval=True (needs a device sync, as the reference's
+    .item() calls do) and a 0-dim device tensor otherwise (the training loop discards it, :206).
+    total_length: override of the normaliser sum(T2) (data-parallel ranks pass the GLOBAL frame count)."""
+    lam = FLAGS.phoneme_loss_weight if phoneme_loss_weight is None else phoneme_loss_weight
+    B, T, n_mel = predictions.shape
+    n_ph = phoneme_predictions.shape[2]
+    if n_mel % 4:
+        raise ValueError('number of mel bins must be a multiple of 4')
+    M = B * T
+    ld = (n_mel + n_ph + 3) // 4 * 4
+    parts = [predictions.reshape(M, n_mel).float(), phoneme_predictions.reshape(M, n_ph).float()]
+    if ld > n_mel + n_ph:
+        parts.append(torch.zeros(M, ld - n_mel - n_ph, device=predictions.device))
+    head = torch.cat(parts, 1)
+    plan = _LossPlan(example, M, predictions.device)
+    total = plan.total_length if total_length is None else total_length
+    loss, correct = _DtwLossFn.apply(head, plan, n_mel, n_ph, float(lam), 1.0 / float(total))
+    if not phoneme_eval:
+        return loss, correct[0].float() / plan.total_length
+    # ---- evaluation extras: host-side confusion matrix (transduction_model.py:130-137,147-152)
+    acc = float(correct.item()) / plan.total_length
+    if phoneme_confusion is not None:
+        amax = plan.argmax.cpu().numpy()
+        res = plan.results.cpu().numpy() if plan.results is not None else None
+        ro = 0
+        for u, (n1, n2, s) in enumerate(zip(plan.lengths, plan.t2, plan.silent)):
+            tgt = example['phonemes'][u].cpu().numpy()
+            if s:
+                p = amax[plan.pred_off[u] + res[ro:ro + n2]]
+                ro += n2
+            else:
+                p = amax[plan.pred_off[u]:plan.pred_off[u] + n1]
+            np.add.at(phoneme_confusion, (p, tgt), 1)
+    return loss, acc
+
+
+def _pack_batch(batch, device, seq_len=200):
+    X = combine_fixed_length([t.to(device, non_blocking=True) for t in batch['emg']], seq_len)
+    X_raw = combine_fixed_length([t.to(device, non_blocking=True) for t in batch['raw_emg']], seq_len * 8)
+    sess = combine_fixed_length([t.to(device, non_blocking=True) for t in batch['session_ids']], seq_len)
+    return X, X_raw, sess
+
+
+def test(model, testset, device):
+    """transduction_model.py:33-55: eval-mode forward on batches of 32 utterances; returns
+    (mean loss, mean phoneme accuracy, confusion matrix)."""
+    model.eval()
+    dataloader = torch.utils.data.DataLoader(testset, batch_size=32, collate_fn=testset.collate_raw)
+    losses, accuracies = [], []
+    phoneme_confusion = np.zeros((len(phoneme_inventory), len(phoneme_inventory)))
+    with torch.no_grad():
+        for batch in dataloader:
+            X, X_raw, sess = _pack_batch(batch, device)
+            pred, phoneme_pred = model(X, X_raw, sess)
+            loss, phon_acc = dtw_loss(pred, phoneme_pred, batch, True, phoneme_confusion)
+            losses.append(loss.item())
+            accuracies.append(phon_acc)
+    model.train()
+    return np.mean(losses), np.mean(accuracies), phoneme_confusion
+
+
+def train_model(trainset, devset, device, save_sound_outputs=True, *, compute_dtype=torch.bfloat16, max_steps=None, data_parallel=None):
+    """transduction_model.py:159-227 on the MI355X.  trainset/devset follow the reference's EMGDataset protocol
+    (collate_raw, num_features, num_speech_features, size-aware batches -- see synthetic.SyntheticEMGDataset).
+    The vocoder / ASR tail (:175-176,218-225) is outside the hot path: save_sound_outputs is accepted for
+    signature compatibility and ignored with a warning."""
+    if save_sound_outputs:
+        logging.warning('save_sound_outputs: HiFi-GAN vocoding / DeepSpeech evaluation are outside the MI355X hot path; skipped')
+    n_epochs = FLAGS.epochs
+    training_subset = trainset if FLAGS.data_size_fraction >= 1 else trainset.subset(FLAGS.data_size_fraction)
+    dataloader = torch.utils.data.DataLoader(training_subset, collate_fn=devset.collate_raw, num_workers=0,
+                                             batch_sampler=training_subset.size_aware_sampler(256000))
+    n_phones = len(phoneme_inventory)
+    model = Model(devset.num_features, devset.num_speech_features, n_phones, compute_dtype=compute_dtype).to(device)
+    if FLAGS.start_training_from is not None:
+        model.load_state_dict(torch.load(FLAGS.start_training_from), strict=False)
+    if data_parallel is not None:
+        data_parallel.attach(model)
+    optim = FusedAdamW(model, weight_decay=FLAGS.l2)
+    lr_sched = torch.optim.lr_scheduler.ReduceLROnPlateau(optim, 'min', 0.5, patience=FLAGS.learning_rate_patience)
+
+    def set_lr(new_lr):
+        for param_group in optim.param_groups:
+            param_group['lr'] = new_lr
+
+    target_lr = FLAGS.learning_rate
+
+    def schedule_lr(iteration):
+        iteration = iteration + 1
+        if iteration <= FLAGS.learning_rate_warmup:
+            set_lr(iteration * target_lr / FLAGS.learning_rate_warmup)
+
+    batch_idx = 0
+    for epoch_idx in range(n_epochs):
+        losses = []
+        for batch in dataloader:
+            optim.zero_grad()
+            schedule_lr(batch_idx)
+            X, X_raw, sess = _pack_batch(batch, device)
+            pred, phoneme_pred = model(X, X_raw, sess)
+            total = data_parallel.global_total(batch) if data_parallel is not None else None
+            loss, _ = dtw_loss(pred, phoneme_pred, batch, total_length=total)
+            losses.append(loss.detach())
+            loss.backward()
+            if data_parallel is not None:
+                data_parallel.sync_gradients(model)
+            optim.step()
+            batch_idx += 1
+            if max_steps is not None and batch_idx >= max_steps:
+                break
+        train_loss = float(torch.stack(losses).mean()) if losses else float('nan')      # one sync per epoch instead of per step (:207)
+        val, phoneme_acc, _ = test(model, devset, device)
+        lr_sched.step(val)
+        logging.info(f'finished epoch {epoch_idx+1} - validation loss: {val:.4f} training loss: {train_loss:.4f} phoneme accuracy: {phoneme_acc*100:.2f}')
+        out_dir = FLAGS.output_directory
+        os.makedirs(out_dir, exist_ok=True)
+        torch.save(model.state_dict(), os.path.join(out_dir, 'model.pt'))                 # :217
+        if max_steps is not None and batch_idx >= max_steps:
+            break
+    return model

@@ -1,0 +1,110 @@
+"""dtw_loss (fused HIP loss path) and mel_spectrogram vs golden vectors from the reference / the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_ref, mel_ref
+from silent_speech_amd import data_utils, transduction_model as tm
+from tests.backend import dev, is_emu  # noqa: F401
+from tests.util import assert_close_robust
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _example(z, n, dev):
+    return dict(lengths=z['lengths'].tolist(), silent=z['silent'].tolist(),
+                audio_features=[torch.from_numpy(z['audio/%d' % i]).to(dev) for i in range(n)],
+                phonemes=[torch.from_numpy(z['phones/%d' % i]).to(dev) for i in range(n)])
+
+
+def test_dtw_loss_mixed_golden(dev):
+    """2 voiced + 2 silent utterances: loss, accuracy, gradients and eval-mode confusion matrix vs the reference."""
+    z = np.load(os.path.join(GOLD, 'dtw_loss_mixed.npz'))
+    pred = torch.from_numpy(z['pred']).to(dev).requires_grad_(True)
+    aux = torch.from_numpy(z['aux']).to(dev).requires_grad_(True)
+    ex = _example(z, 4, dev)
+    loss, acc = tm.dtw_loss(pred, aux, ex, phoneme_loss_weight=0.5)
+    assert abs(float(loss) - float(z['loss'])) < 2e-5 * abs(float(z['loss']))
+    assert abs(float(acc) - float(z['acc_eval'])) < 1e-6
+    loss.backward()
+    assert_close_robust(pred.grad, z['dpred'], 1e-4, name='dpred', max_outlier_frac=0)
+    assert_close_robust(aux.grad, z['daux'], 1e-4, name='daux', max_outlier_frac=0)
+    conf = np.zeros((48, 48))
+    with torch.no_grad():
+        le, ae = tm.dtw_loss(pred.detach(), aux.detach(), ex, True, conf, phoneme_loss_weight=0.5)
+    assert abs(float(le) - float(z['loss_eval'])) < 2e-5 * abs(float(z['loss_eval']))
+    assert abs(ae - float(z['acc_eval'])) < 1e-9
+    assert np.array_equal(conf, z['confusion'])
+
+
+def test_dtw_loss_voiced_golden(dev):
+    z = np.load(os.path.join(GOLD, 'dtw_loss_voiced.npz'))
+    pred = torch.from_numpy(z['pred']).to(dev).requires_grad_(True)
+    aux = torch.from_numpy(z['aux']).to(dev).requires_grad_(True)
+    ex = dict(lengths=[200], silent=[False], audio_features=[torch.from_numpy(z['audio']).to(dev)], phonemes=[torch.from_numpy(z['phones']).to(dev)])
+    loss, acc = tm.dtw_loss(pred, aux, ex, phoneme_loss_weight=0.5)
+    assert abs(float(loss) - float(z['loss'])) < 2e-5 * abs(float(z['loss']))
+    loss.backward()
+    assert_close_robust(pred.grad, z['dpred'], 1e-4, name='dpred', max_outlier_frac=0)
+    assert_close_robust(aux.grad, z['daux'], 1e-4, name='daux', max_outlier_frac=0)
+
+
+def test_dtw_loss_voiced_length_mismatch_asserts(dev):
+    pred = torch.zeros(1, 50, 80, device=dev); aux = torch.zeros(1, 50, 48, device=dev)
+    ex = dict(lengths=[40], silent=[False], audio_features=[torch.zeros(39, 80)], phonemes=[torch.zeros(39, dtype=torch.long)])
+    with pytest.raises(AssertionError):
+        tm.dtw_loss(pred, aux, ex)
+
+
+@pytest.mark.gpu
+def test_dtw_loss_vs_oracle_realistic_sizes():
+    """Mixed batch with ~600-frame silent utterances: the alignment is computed by the HIP DTW on device."""
+    from silent_speech_amd import _lib
+    _lib.load()
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(11)
+    lengths, silent = [420, 610, 333, 505], [True, False, True, False]
+    t2 = [480, 610, 300, 505]
+    rows = (sum(lengths) + 199) // 200
+    pred = torch.randn(rows, 200, 80, generator=g); aux = torch.randn(rows, 200, 48, generator=g)
+    audio = [torch.randn(n, 80, generator=g) * 0.7 for n in t2]
+    phones = [torch.randint(0, 48, (n,), generator=g) for n in t2]
+    ex = dict(lengths=lengths, silent=silent, audio_features=audio, phonemes=phones)
+    pr, ar = pred.clone().requires_grad_(True), aux.clone().requires_grad_(True)
+    lref, accref = loss_ref.dtw_loss_ref(pr, ar, ex)
+    lref.backward()
+    pd, ad = pred.to(dev).requires_grad_(True), aux.to(dev).requires_grad_(True)
+    loss, acc = tm.dtw_loss(pd, ad, ex, phoneme_loss_weight=0.5)
+    assert abs(float(loss) - float(lref)) < 2e-5 * abs(float(lref))
+    assert abs(float(acc) - accref) < 1e-6
+    loss.backward()
+    assert_close_robust(pd.grad, pr.grad, 1e-4, name='dpred', max_outlier_frac=0)
+    assert_close_robust(ad.grad, ar.grad, 1e-4, name='daux', max_outlier_frac=0)
+
+
+def test_mel_spectrogram_golden(dev):
+    """STFT-as-GEMM + mel + log vs the reference's torch.stft path (basis injected identically)."""
+    z = np.load(os.path.join(GOLD, 'mel.npz'))
+    y = torch.from_numpy(z['y'])
+    if is_emu(dev):
+        y = y[:1, :256 * 6]                       # emulator: 1 clip, 5 frames
+        want = mel_ref.mel_spectrogram_ref(y.numpy(), basis=z['basis'])
+    else:
+        want = z['mel']
+    got = data_utils.mel_spectrogram(y.to(dev), 1024, 80, 22050, 256, 1024, 0, 8000, center=False)
+    assert tuple(got.shape) == tuple(want.shape)
+    d = (got.cpu().numpy() - want)
+    assert float(np.abs(d).mean()) < 1e-4, float(np.abs(d).mean())          # north_star: mel-L1 within 1e-4
+    assert float(np.abs(d).max()) < 2e-2
+    assert np.array_equal(data_utils.slaney_mel_filterbank(22050, 1024, 80, 0, 8000), z['basis'])
+
+
+def test_pack_roundtrip_golden():
+    z = np.load(os.path.join(GOLD, 'pack.npz'))
+    ts = [torch.from_numpy(z['t/%d' % i]) for i in range(4)]
+    packed = data_utils.combine_fixed_length(ts, 16)
+    assert np.array_equal(packed.numpy(), z['packed'])
+    for a, b in zip(ts, data_utils.decollate_tensor(packed, [t.shape[0] for t in ts])):
+        assert torch.equal(a, b)
