@@ -34,7 +34,9 @@ def cpu_baseline(batch_cpu, rows_limit, steps):
     import subprocess
     subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
     from oracle import loss_ref, model_ref
-    torch.set_num_threads(os.cpu_count())
+    # 32 threads is the fastest setting on the GPU node's 2x64-core host for this small-batch fp32 step (probed:
+    # 16 thr 0.41 s, 32 thr 0.34 s, 64 thr 0.76 s, 128 thr 1.70 s, 256 thr >100 s per fwd+bwd of 762 frames)
+    torch.set_num_threads(min(32, os.cpu_count()))
     n, frames = 0, 0
     while n < len(batch_cpu['lengths']) and (frames + batch_cpu['lengths'][n] + 199) // 200 <= rows_limit:
         frames += batch_cpu['lengths'][n]

@@ -135,7 +135,8 @@ int ss_bn_backward_apply(int dtype, const void* dy, int pad_dy, const void* y, i
                          const float* sums, double n_total, void* dxa, int pad_dxa, void* dxb, int pad_dxb,
                          int B, int T, int C, int relu, void* stream);
 /* out[c] += sum_r x[r][c]  (bias gradients of nn.Linear / nn.Conv1d) */
-int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, float* out_accum, void* stream);
+int64_t ss_colsum_scratch_floats(int rows, int C); /* [host] */
+int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, float* scratch, float* out_accum, void* stream);
 
 /* Post-norm residual block of the encoder layer (transformer.py:55-56, 58-59):
  *   z = x + dropout(branch);  y = LayerNorm(z) * gamma + beta        (eps 1e-5)

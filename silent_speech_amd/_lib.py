@@ -47,7 +47,7 @@ SIGNATURES = {
     'ss_bn_apply': [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'ss_bn_backward_sums': [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'ss_bn_backward_apply': [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, ctypes.c_double, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    'ss_colsum': [_I, _P, _I, _I, _L, _P, _P],
+    'ss_colsum': [_I, _P, _I, _I, _L, _P, _P, _P],
     'ss_add_dropout_layernorm_forward': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_layernorm_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _P],
     'ss_emg_prepare': [_I, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -62,7 +62,8 @@ SIGNATURES = {
 }
 _LP = ctypes.POINTER(ctypes.c_int64)
 _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int64),
-               'ss_bn_scratch_floats': ([_I, _I, _I], ctypes.c_int64)}
+               'ss_bn_scratch_floats': ([_I, _I, _I], ctypes.c_int64),
+               'ss_colsum_scratch_floats': ([_I, _I], ctypes.c_int64)}
 _RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}
 
 _lib = None

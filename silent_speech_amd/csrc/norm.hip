@@ -24,6 +24,29 @@ struct ColMap {
     }
 };
 constexpr int RED_THREADS = 256;
+
+// sum over the per-chunk partials of NQ per-channel quantities: 256 threads = 32 channels x 8 chunk lanes
+template <int NQ>
+__device__ __forceinline__ bool chunk_reduce(const float* __restrict__ partial, int nchunks, int C, float (&out)[NQ], int& c_out)
+{
+    __shared__ float red[NQ][8][32];
+    const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    float acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+    if (c < C)
+        for (int k = ln; k < nchunks; k += 8)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] += partial[((long long)k * NQ + q) * C + c];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) red[q][ln][cl] = acc[q];
+    __syncthreads();
+    c_out = c;
+    if (ln != 0 || c >= C) return false;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { float t = 0.f; for (int y = 0; y < 8; ++y) t += red[q][y][cl]; out[q] = t; }
+    return true;
+}
 }
 
 // =========================================================================== BatchNorm statistics
@@ -69,13 +92,11 @@ __global__ __launch_bounds__(RED_THREADS) void bn_partial_kernel(const T* __rest
 
 // sums[0][c] = sum(x - shift), sums[1][c] = sum (x - shift)^2, sums[2][c] = shift
 template <class T>
-__global__ void bn_sums_kernel(const T* __restrict__ x, Seq sx, const float* __restrict__ partial, int nchunks, int C, const float* __restrict__ shift, float* __restrict__ sums)
+__global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, Seq sx, const float* __restrict__ partial, int nchunks, int C, const float* __restrict__ shift, float* __restrict__ sums)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nchunks; ++k) { s1 += partial[((long long)k * 2 + 0) * C + c]; s2 += partial[((long long)k * 2 + 1) * C + c]; }
-    sums[c] = s1; sums[C + c] = s2; sums[2 * C + c] = shift ? shift[c] : ldf(x + sx.row(0) * C + c);
+    float t[2]; int c;
+    if (!chunk_reduce<2>(partial, nchunks, C, t, c)) return;
+    sums[c] = t[0]; sums[C + c] = t[1]; sums[2 * C + c] = shift ? shift[c] : ldf(x + sx.row(0) * C + c);
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, float n, int C, float* mean, float* invstd, float* running_mean, float* running_var,
@@ -106,10 +127,10 @@ extern "C" int ss_bn_stats_sums(int dtype, const void* x, int B, int T, int C, i
     Seq sx = {T, pad};
     if (dtype == SS_BF16) {
         SS_LAUNCH(bn_partial_kernel<bf16_t>, dim3(nch), dim3(RED_THREADS), 0, stream, (const bf16_t*)x, sx, rows, C, rpc, shift, scratch);
-        SS_LAUNCH(bn_sums_kernel<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, stream, (const bf16_t*)x, sx, (const float*)scratch, nch, C, shift, sums);
+        SS_LAUNCH(bn_sums_kernel<bf16_t>, dim3((C + 31) / 32), dim3(256), 0, stream, (const bf16_t*)x, sx, (const float*)scratch, nch, C, shift, sums);
     } else {
         SS_LAUNCH(bn_partial_kernel<float>, dim3(nch), dim3(RED_THREADS), 0, stream, (const float*)x, sx, rows, C, rpc, shift, scratch);
-        SS_LAUNCH(bn_sums_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)x, sx, (const float*)scratch, nch, C, shift, sums);
+        SS_LAUNCH(bn_sums_kernel<float>, dim3((C + 31) / 32), dim3(256), 0, stream, (const float*)x, sx, (const float*)scratch, nch, C, shift, sums);
     }
     SS_LAUNCH_CHECK("ss_bn_stats_sums");
     return 0;
@@ -229,18 +250,16 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const T* __
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunks, int C, float* __restrict__ coef /* [3][C] sums */,
-                                       float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nchunks, int C, float* __restrict__ coef /* [3][C] sums */,
+                                                              float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nchunks; ++k) { s0 += partial[((long long)k * 3 + 0) * C + c]; s1 += partial[((long long)k * 3 + 1) * C + c]; s2 += partial[((long long)k * 3 + 2) * C + c]; }
-    coef[c] = s0; coef[C + c] = s1; coef[2 * C + c] = s2;
-    if (dgamma_a) dgamma_a[c] += s1;
-    if (dbeta_a) dbeta_a[c] += s0;
-    if (dgamma_b) dgamma_b[c] += s2;
-    if (dbeta_b) dbeta_b[c] += s0;
+    float t[3]; int c;
+    if (!chunk_reduce<3>(partial, nchunks, C, t, c)) return;
+    coef[c] = t[0]; coef[C + c] = t[1]; coef[2 * C + c] = t[2];
+    if (dgamma_a) dgamma_a[c] += t[1];
+    if (dbeta_a) dbeta_a[c] += t[0];
+    if (dgamma_b) dgamma_b[c] += t[2];
+    if (dbeta_b) dbeta_b[c] += t[0];
 }
 
 template <class T>
@@ -295,7 +314,7 @@ extern "C" int ss_bn_backward_sums(int dtype, const void* dy, int pad_dy, const 
 #define SS_BNB(TT)                                                                                                                             \
     SS_LAUNCH(bn_bwd_partial_kernel<TT>, dim3(nch), dim3(RED_THREADS), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, \
               (const TT*)xb, sb, mean_b, invstd_b, rows, C, rpc, relu, scratch);                                                                \
-    SS_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)scratch, nch, C, sums, dgamma_a, dbeta_a, dgamma_b, dbeta_b)
+    SS_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, (const float*)scratch, nch, C, sums, dgamma_a, dbeta_a, dgamma_b, dbeta_b)
     if (dtype == SS_BF16) { SS_BNB(bf16_t); } else { SS_BNB(float); }
 #undef SS_BNB
     SS_LAUNCH_CHECK("ss_bn_backward_sums");
@@ -327,7 +346,7 @@ extern "C" int ss_bn_backward_apply(int dtype, const void* dy, int pad_dy, const
 
 // =========================================================================== column sums (bias gradients)
 template <class T>
-__global__ __launch_bounds__(RED_THREADS) void colsum_kernel(const T* __restrict__ x, int rows, int C, long long ld, int rows_per_chunk, float* __restrict__ out)
+__global__ __launch_bounds__(RED_THREADS) void colsum_partial_kernel(const T* __restrict__ x, int rows, int C, long long ld, int rows_per_chunk, float* __restrict__ partial)
 {
     __shared__ float red[RED_THREADS * 8];
     ColMap m(C, threadIdx.x, RED_THREADS);
@@ -351,20 +370,30 @@ __global__ __launch_bounds__(RED_THREADS) void colsum_kernel(const T* __restrict
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s[e] += red[(yy * m.CVb + m.cx0) * 8 + e];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(out + cx * 8 + e, s[e]);
+            for (int e = 0; e < 8; ++e) partial[(long long)blockIdx.x * C + cx * 8 + e] = s[e];
         }
     }
 }
 
-extern "C" int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, float* out_accum, void* stream)
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nchunks, int C, float* __restrict__ out)
 {
-    SS_CHECK(x && out_accum, "ss_colsum: null pointer");
+    float t[1]; int c;
+    if (!chunk_reduce<1>(partial, nchunks, C, t, c)) return;
+    out[c] += t[0];
+}
+
+static int colsum_chunks(int rows) { int c = (rows + 31) / 32; if (c > 2048) c = 2048; if (c < 1) c = 1; return c; }
+extern "C" int64_t ss_colsum_scratch_floats(int rows, int C) { return (int64_t)colsum_chunks(rows) * C; }
+
+extern "C" int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, float* scratch, float* out_accum, void* stream)
+{
+    SS_CHECK(x && out_accum && scratch, "ss_colsum: null pointer");
     SS_CHECK(C % 8 == 0 && C > 0 && rows >= 0 && ld % 8 == 0, "ss_colsum: C and ld must be multiples of 8");
     if (rows == 0) return 0;
-    int nch = (rows + 255) / 256; if (nch > 512) nch = 512;
-    const int rpc = (rows + nch - 1) / nch;
-    if (dtype == SS_BF16) SS_LAUNCH(colsum_kernel<bf16_t>, dim3(nch), dim3(RED_THREADS), 0, stream, (const bf16_t*)x, rows, C, (long long)ld, rpc, out_accum);
-    else SS_LAUNCH(colsum_kernel<float>, dim3(nch), dim3(RED_THREADS), 0, stream, (const float*)x, rows, C, (long long)ld, rpc, out_accum);
+    const int nch = colsum_chunks(rows), rpc = (rows + nch - 1) / nch;
+    if (dtype == SS_BF16) SS_LAUNCH(colsum_partial_kernel<bf16_t>, dim3(nch), dim3(RED_THREADS), 0, stream, (const bf16_t*)x, rows, C, (long long)ld, rpc, scratch);
+    else SS_LAUNCH(colsum_partial_kernel<float>, dim3(nch), dim3(RED_THREADS), 0, stream, (const float*)x, rows, C, (long long)ld, rpc, scratch);
+    SS_LAUNCH(colsum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, (const float*)scratch, nch, C, out_accum);
     SS_LAUNCH_CHECK("ss_colsum");
     return 0;
 }

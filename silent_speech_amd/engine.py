@@ -328,7 +328,7 @@ def backward(model, ctx, dhead):
         ops.gemm(dc2, s.h1, tmp, O, 3 * O, rows, RM(O, Tout, pbs, base=O), RM(O, Tout, pbs), RM(3 * O), a_mode=OP_OC, b_mode=OP_OC, mode=2,
                  split_k=_split_k(O, 3 * O, rows))
         ops.permute3d(tmp, _grad(blk.conv2.weight), (O, O, 3), (3 * O, 1, O), accumulate=True)
-        ops.colsum(dc2, B * (Tout + 2), O, O, _grad(blk.conv2.bias))
+        _grad(blk.conv2.bias)   # d/d(bias) of a conv feeding training-mode BatchNorm is identically 0 (BN removes the mean)
         dh1 = torch.empty(rows, O, dtype=dt, device=dev)
         ops.gemm(dc2, w['w2b'], dh1, rows, O, 3 * O, RM(O, Tout, pbs), RM(3 * O), RM(O))
         dc1 = torch.empty(B, Tout + 2, O, dtype=dt, device=dev)
@@ -341,10 +341,10 @@ def backward(model, ctx, dhead):
         ops.gemm(dc1, s.xin, tmp, O, 3 * Cin, rows, RM(O, Tout, pbs, base=O), RM(2 * Cin, Tout, in_bs), RM(3 * Cin), a_mode=OP_OC, b_mode=OP_OC,
                  mode=2, split_k=_split_k(O, 3 * Cin, rows))
         ops.permute3d(tmp, _grad(blk.conv1.weight), (O, Cin, 3), (3 * Cin, 1, Cin), accumulate=True)
-        ops.colsum(dc1, B * (Tout + 2), O, O, _grad(blk.conv1.bias))
+        _grad(blk.conv1.bias)
         ops.gemm(dcr, s.xin, _grad(blk.residual_path.weight), O, Cin, rows, RM(O), RM(2 * Cin, Tout, in_bs, base=Cin), RM(Cin), a_mode=OP_OC,
                  b_mode=OP_OC, mode=2, split_k=_split_k(O, Cin, rows))
-        ops.colsum(dcr, rows, O, O, _grad(blk.residual_path.bias))
+        _grad(blk.residual_path.bias)
         if i > 0:
             dx = torch.empty(B * Tin, Cin, dtype=dt, device=dev)
             out_even = RM(2 * Cin, Tout, Tin * Cin)

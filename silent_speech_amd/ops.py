@@ -169,7 +169,8 @@ def bn_backward(dy, pad_dy, y, pad_y, xa, pad_xa, sa, dxa, pad_dxa, dgamma_a, db
 
 
 def colsum(x, rows, C, ld, out_accum):
-    _lib.check(_L().ss_colsum(_dt(x), _p(x), rows, C, ld, _p(out_accum), _s(x)), 'ss_colsum')
+    scratch = torch.empty(int(_L().ss_colsum_scratch_floats(rows, C)), dtype=torch.float32, device=x.device)
+    _lib.check(_L().ss_colsum(_dt(x), _p(x), rows, C, ld, _p(scratch), _p(out_accum), _s(x)), 'ss_colsum')
 
 
 def add_dropout_layernorm(x, branch_inout, gamma, beta, y, rows, C, eps=1e-5, p=0.0, seed=0, rng_stream=0):

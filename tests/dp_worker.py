@@ -1,0 +1,90 @@
+"""Worker for tests/test_distributed.py: one data-parallel rank (gloo, CPU tensors, host-emulator kernels)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, ROOT)
+
+
+class _R(object):
+    @staticmethod
+    def randrange(n):
+        return 2
+
+
+def make_batch(seed_list):
+    from silent_speech_amd.synthetic import make_utterance, SyntheticEMGDataset
+    items = []
+    for sd, T, silent in seed_list:
+        it = make_utterance(np.random.default_rng(sd), T, silent)
+        items.append(it)
+    return SyntheticEMGDataset.collate_raw(items)
+
+
+UTTS = [(1, 40, False), (2, 80, True), (3, 80, False), (4, 40, True)]      # whole rows of 40 frames -> per-rank rows == global rows
+
+
+def run_step(model, batch, dp, seq_len=40):
+    from silent_speech_amd.data_utils import combine_fixed_length
+    from silent_speech_amd.transduction_model import dtw_loss
+    X_raw = combine_fixed_length(batch['raw_emg'], seq_len * 8)
+    X = combine_fixed_length(batch['emg'], seq_len)
+    sess = combine_fixed_length(batch['session_ids'], seq_len)
+    if dp is not None:
+        dp.begin_step(X_raw.shape[0] * seq_len)
+    pred, aux = model(X, X_raw, sess)
+    total = dp.global_total(batch) if dp is not None else None
+    loss, _ = dtw_loss(pred, aux, batch, phoneme_loss_weight=0.5, total_length=total)
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    if dp is not None:
+        dp.sync_gradients(model)
+    return loss
+
+
+def build_model():
+    from silent_speech_amd.architecture import Model
+    torch.manual_seed(123)
+    m = Model(112, 80, 48, model_size=16, num_layers=1, dropout=0.0, compute_dtype=torch.float32)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1 and 'bias' not in n:
+                p.add_(torch.randn(p.shape) * 0.1)
+    m.shift_rng = _R
+    m.train()
+    return m
+
+
+def main():
+    out = sys.argv[1]
+    from silent_speech_amd import _lib
+    _lib.use_library_for_testing(os.path.join(ROOT, 'silent_speech_amd', 'lib', 'libsilent_speech_emu.so'))
+    from silent_speech_amd.distributed import DataParallel
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % os.environ['MASTER_PORT'], rank=rank, world_size=world)
+    model = build_model()
+    dp = None
+    if world > 1:
+        dp = DataParallel()
+        dp.attach(model)
+        batch = make_batch(UTTS[rank::world])
+    else:
+        batch = make_batch(UTTS[0::2] + UTTS[1::2])
+    loss = run_step(model, batch, dp)
+    _, gflat, n = model.flat_arenas()
+    res = {'loss': float(loss), 'grads': gflat.clone(), 'rm': model.conv_blocks[0].bn1.running_mean.clone(), 'rv': model.conv_blocks[2].bn2.running_var.clone()}
+    if rank == 0:
+        torch.save(res, out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,77 @@
+"""The C-ABI library loads and exports every symbol include/silent_speech_hip.h declares (no compute calls);
+the product path refuses to run without the gfx950 library / on CPU tensors."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+HIP_SO = os.path.join(ROOT, 'silent_speech_amd', 'lib', 'libsilent_speech_hip.so')
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'silent_speech_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ss_[a-z0-9_]+)\s*\(', src)))
+
+
+@pytest.fixture(scope='module')
+def hip_lib():
+    if not os.path.exists(HIP_SO):
+        subprocess.check_call(['make', '-s', '-j8', '-C', os.path.join(ROOT, 'silent_speech_amd', 'csrc'), 'hip'])
+    return ctypes.CDLL(HIP_SO)
+
+
+def test_every_declared_symbol_is_exported(hip_lib):
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(hip_lib, n), 'include/silent_speech_hip.h declares %s but the library does not export it' % n
+
+
+def test_ctypes_table_covers_the_header():
+    from silent_speech_amd import _lib
+    bound = set(_lib.SIGNATURES) | set(_lib._HOST_FUNCS) | set(_lib._RESTYPES)
+    assert set(_declared()) == bound
+
+
+def test_library_is_gfx950_and_reports_errors(hip_lib):
+    hip_lib.ss_target_arch.restype = ctypes.c_char_p
+    assert hip_lib.ss_target_arch() == b'gfx950'
+    out = subprocess.check_output(['/opt/rocm/lib/llvm/bin/llvm-readelf', '-S', HIP_SO]).decode() if os.path.exists('/opt/rocm/lib/llvm/bin/llvm-readelf') else '.hip_fatbin'
+    assert '.hip_fatbin' in out          # carries device code (not a host-only stub)
+    hip_lib.ss_last_error.restype = ctypes.c_char_p
+    rc = hip_lib.ss_dtw_align(None, None, 1, 4, 4, None, None, None)     # argument validation happens before any launch
+    assert rc != 0 and b'null pointer' in hip_lib.ss_last_error()
+
+
+def test_product_path_has_no_cpu_fallback():
+    from silent_speech_amd import _lib, align
+    import numpy as np
+    _lib.load()                       # the gfx950 library
+    assert not _lib.is_emulator()
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(Exception):
+        align.align_from_distances(np.ones((4, 4), dtype=np.float32), device=torch.device('cpu'))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _lib.ptr(torch.zeros(4))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from silent_speech_amd import _lib
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _lib.load(str(tmp_path / 'libsilent_speech_hip.so'))
+    _lib.load()
+
+
+def test_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'silent_speech_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith('.py') or f.endswith('.hip') or f.endswith('.h'):
+                txt = open(os.path.join(dp, f)).read()
+                assert 'import oracle' not in txt and 'from oracle' not in txt, os.path.join(dp, f)

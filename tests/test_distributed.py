@@ -1,0 +1,41 @@
+"""Data-parallel contract, checked without GPUs: 2 gloo ranks (CPU tensors, host-emulator kernels), each with
+half of the utterances, must reproduce the single-process step on the concatenated batch: same BatchNorm batch
+statistics (all-reduced sums), same loss normaliser (global frame count), summed gradients equal."""
+import os
+import socket
+import subprocess
+import sys
+
+import torch
+
+from tests.backend import _ensure_emu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_two_rank_step_equals_single_process(tmp_path):
+    _ensure_emu()
+    worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    single = str(tmp_path / 'single.pt')
+    p0 = subprocess.Popen([sys.executable, worker, single], env=dict(env, WORLD_SIZE='1', RANK='0'))
+    port = str(_free_port())
+    multi = str(tmp_path / 'multi.pt')
+    procs = [subprocess.Popen([sys.executable, worker, multi], env=dict(env, WORLD_SIZE='2', RANK=str(r), MASTER_PORT=port, MASTER_ADDR='127.0.0.1'))
+             for r in range(2)]
+    for p in [p0] + procs:
+        assert p.wait(timeout=600) == 0
+    a, b = torch.load(single), torch.load(multi)
+    # loss: each rank reports sum(local losses)/global frames; the single-process loss is the sum over ranks
+    assert abs(b['loss']) < abs(a['loss'])
+    ga, gb = a['grads'], b['grads']
+    assert ga.shape == gb.shape
+    err = float((ga - gb).abs().max()) / (float(ga.abs().max()) + 1e-12)
+    assert err < 2e-4, err
+    assert torch.allclose(a['rm'], b['rm'], rtol=1e-4, atol=1e-6)
+    assert torch.allclose(a['rv'], b['rv'], rtol=1e-4, atol=1e-6)
