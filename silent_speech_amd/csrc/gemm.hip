@@ -41,20 +41,27 @@ struct GemmEpi {
     void* c2;                // optional second copy of the result at rowmap2(row) + col*col_stride2 (transposed layouts)
     RowMap cmap2;
     long long col_stride2;
+    int fast;                // 1: LDS-staged, 16-byte coalesced output path (host decides)
+    int c2_pack;             // 1: the 4 rows a lane holds are consecutive, aligned elements of c2 -> one packed store
 };
 
 template <class T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPC = 4; static constexpr int BK = 32; };
 template <> struct Elem<bf16_t> { static constexpr int EPC = 8; static constexpr int BK = 64; };
 
-__device__ __forceinline__ unsigned swz(int row, int chunk) { return (unsigned)row * ROWB + (unsigned)((chunk ^ (row & 7)) << 4); }
+// 16-byte chunk c of tile row r lives at chunk position c ^ s(r), s(r) = (r & 7) ^ (2 * ((r >> 3) & 3)):
+//  * MFMA fragment reads (16 consecutive rows, two adjacent chunks per 16-lane service group) stay conflict-free
+//    (bit 0 of s equals bit 0 of r, so a q=0 lane and a q=1 lane can never meet on one slot);
+//  * the transposing (OC) stores write rows 8k+o / 4k+o at fixed o: the (r >> 3) term spreads them over 4 / 8 chunk
+//    positions instead of one (was a 16-way bank conflict).
+__device__ __forceinline__ unsigned swz(int row, int chunk) { return (unsigned)row * ROWB + (unsigned)((chunk ^ (row & 7) ^ (((row >> 3) & 3) << 1)) << 4); }
 
 // ---------------------------------------------------------------- staging: KC (copy) mode
 template <class T>
 struct StageKC {
+    typedef u32x4 Regs[4];
     long long off[4];
     const T* p;
-    u32x4 reg[4];
     int c, r0;
     __device__ __forceinline__ void init(const T* p_, const RowMap& map, int outer0, int outer_size, int tid) {
         p = p_; c = tid & 7; r0 = tid >> 3;
@@ -65,7 +72,7 @@ struct StageKC {
         }
     }
     __device__ __forceinline__ void seek(int) {}
-    __device__ __forceinline__ void load(int k0, int kend) {
+    __device__ __forceinline__ void load(int k0, int kend, Regs& reg) {
         int kk = k0 + c * Elem<T>::EPC;
         bool kv = kk < kend;
 #pragma unroll
@@ -74,7 +81,7 @@ struct StageKC {
             reg[i] = (kv && off[i] >= 0) ? *(const u32x4*)(p + off[i] + kk) : z;
         }
     }
-    __device__ __forceinline__ void store(unsigned char* tile) {
+    __device__ __forceinline__ void store(unsigned char* tile, const Regs& reg) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { int r = r0 + 32 * i; *(u32x4*)(tile + swz(r, c)) = reg[i]; }
     }
@@ -84,15 +91,15 @@ struct StageKC {
 template <class T> struct StageOC;
 template <>
 struct StageOC<bf16_t> {   // thread: 8 outer x 4 reduction
+    typedef u32x4 Regs[4];
     const bf16_t* p; RowMap map; int ob, rb, bb, tt; bool ov;
-    u32x4 in[4];
     __device__ __forceinline__ void init(const bf16_t* p_, const RowMap& map_, int outer0, int outer_size, int tid) {
         map = map_; ob = (tid & 15) * 8; rb = (tid >> 4) * 4;
         ov = outer0 + ob < outer_size;     // outer_size % 8 == 0 (checked on the host)
         p = p_ + outer0 + ob;
     }
     __device__ __forceinline__ void seek(int k_begin) { int r = k_begin + rb; bb = r / map.rows_per_batch; tt = r - bb * map.rows_per_batch; }
-    __device__ __forceinline__ void load(int k0, int kend) {
+    __device__ __forceinline__ void load(int k0, int kend, Regs& in) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int t = tt + j, b = bb;
@@ -104,7 +111,7 @@ struct StageOC<bf16_t> {   // thread: 8 outer x 4 reduction
         tt += Elem<bf16_t>::BK;
         while (tt >= map.rows_per_batch) { tt -= map.rows_per_batch; ++bb; }
     }
-    __device__ __forceinline__ void store(unsigned char* tile) {
+    __device__ __forceinline__ void store(unsigned char* tile, const Regs& in) {
         int q = rb >> 2;                    // 8-byte slot index within the row (0..15)
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -119,15 +126,15 @@ struct StageOC<bf16_t> {   // thread: 8 outer x 4 reduction
 };
 template <>
 struct StageOC<float> {    // thread: 4 outer x 4 reduction
+    typedef f32x4 Regs[4];
     const float* p; RowMap map; int ob, rb, bb, tt; bool ov;
-    f32x4 in[4];
     __device__ __forceinline__ void init(const float* p_, const RowMap& map_, int outer0, int outer_size, int tid) {
         map = map_; ob = (tid & 31) * 4; rb = (tid >> 5) * 4;
         ov = outer0 + ob < outer_size;     // outer_size % 4 == 0
         p = p_ + outer0 + ob;
     }
     __device__ __forceinline__ void seek(int k_begin) { int r = k_begin + rb; bb = r / map.rows_per_batch; tt = r - bb * map.rows_per_batch; }
-    __device__ __forceinline__ void load(int k0, int kend) {
+    __device__ __forceinline__ void load(int k0, int kend, Regs& in) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int t = tt + j, b = bb;
@@ -139,7 +146,7 @@ struct StageOC<float> {    // thread: 4 outer x 4 reduction
         tt += Elem<float>::BK;
         while (tt >= map.rows_per_batch) { tt -= map.rows_per_batch; ++bb; }
     }
-    __device__ __forceinline__ void store(unsigned char* tile) {
+    __device__ __forceinline__ void store(unsigned char* tile, const Regs& in) {
         int chunk = rb >> 2;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -222,8 +229,73 @@ __device__ __forceinline__ void epilogue_tile(const f32x4& a, TO* __restrict__ C
     }
 }
 
+// ---- fast epilogue, phase 1: elementwise part in registers, result into the LDS C tile (and the packed c2 copy)
+template <class TO>
+__device__ __forceinline__ void epilogue_stage(const f32x4& a, TO* __restrict__ ct, int ldc, int lrow0, int lcol, const GemmEpi& epi, int row0, int col, int M, int N)
+{
+    float v[4];
+    const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        float x = a[reg] * epi.alpha + bias;
+        if (epi.relu) x = fmaxf(x, 0.f);
+        if (epi.drop_thresh) x = dropout_keep(epi.seed, epi.stream, (unsigned long long)(row0 + reg) * (unsigned)N + col, epi.drop_thresh) ? x * epi.drop_scale : 0.f;
+        if (epi.log_clamp > 0.f) x = logf(fmaxf(x, epi.log_clamp));
+        v[reg] = x;
+        stf(ct + (lrow0 + reg) * ldc + lcol, x);
+    }
+    if (epi.c2 && col < N) {
+        TO* c2 = (TO*)epi.c2 + (long long)col * epi.col_stride2;
+        if (epi.c2_pack && row0 + 3 < M) {
+            TO* p = c2 + rowmap_off(epi.cmap2, row0);
+            if (sizeof(TO) == 2) { u32x2 w; w[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); w[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16); *(u32x2*)p = w; }
+            else { f32x4 w = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = w; }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) if (row0 + reg < M) stf(c2 + rowmap_off(epi.cmap2, row0 + reg), v[reg]);
+        }
+    }
+}
+
+// ---- fast epilogue, phase 2: 16-byte row-contiguous stores from the LDS C tile
+template <class TO> struct OutVec;
+template <> struct OutVec<bf16_t> { static constexpr int N = 8; };
+template <> struct OutVec<float> { static constexpr int N = 4; };
+__device__ __forceinline__ void outvec_load(const bf16_t* p, float (&v)[8]) { Vec8<bf16_t>::load(p, v); }
+__device__ __forceinline__ void outvec_store(bf16_t* p, const float (&v)[8]) { Vec8<bf16_t>::store(p, v); }
+__device__ __forceinline__ void outvec_load(const float* p, float (&v)[4]) { f32x4 a = *(const f32x4*)p; v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
+__device__ __forceinline__ void outvec_store(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = a; }
+
+template <class TO>
+__device__ __forceinline__ void epilogue_flush(const TO* __restrict__ ct, int ldc, TO* __restrict__ C, const GemmEpi& epi, int row_base, int nrows, int n0, int M, int N, int tid)
+{
+    constexpr int EV = OutVec<TO>::N;
+    constexpr int CPR = BN / EV;                       // 16-byte chunks per tile row
+    const int total = nrows * CPR;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int r = idx / CPR, ch = idx - r * CPR;
+        const int row = row_base + r, col = n0 + ch * EV;
+        if (row < M && col < N) {
+            float v[EV];
+            outvec_load(ct + r * ldc + ch * EV, v);
+            const long long off = rowmap_off(epi.cmap, row) + col;
+            if (epi.gate) {
+                float g[EV]; outvec_load((const TO*)epi.gate + off, g);
+#pragma unroll
+                for (int e = 0; e < EV; ++e) v[e] = g[e] > 0.f ? v[e] * epi.gate_scale : 0.f;
+            }
+            if (epi.mode == 1) {
+                float o[EV]; outvec_load(C + off, o);
+#pragma unroll
+                for (int e = 0; e < EV; ++e) v[e] += o[e];
+            }
+            outvec_store(C + off, v);
+        }
+    }
+}
+
 template <class T, class TO, int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C,
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C,
                                                    int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi,
                                                    int k_chunk, int tiles_m, int tiles_n)
 {
@@ -254,23 +326,77 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
 
+    // Software pipeline, global->register prefetch TWO K-tiles ahead (two register sets), LDS double buffer, one
+    // barrier per K-tile: at step s the MFMAs read LDS[s&1] while tile s+1 (already in registers) is written to
+    // LDS[(s+1)&1] afterwards and the loads of tile s+2 are in flight the whole time.
+    typedef typename StagerSel<T, AMODE>::type SA;
+    typedef typename StagerSel<T, BMODE>::type SB;
     const int nsteps = (k_end - k_begin + BK - 1) / BK;
-    if (nsteps > 0) {
-        sa.load(k_begin, k_end); sb.load(k_begin, k_end);
-        sa.store(lds[0][0]); sb.store(lds[0][1]);
-    }
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const int cur = s & 1;
-        const bool more = s + 1 < nsteps;
-        if (more) { int k0 = k_begin + (s + 1) * BK; sa.load(k0, k_end); sb.load(k0, k_end); }
-        TileMma<T>::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
-        if (more) { sa.store(lds[cur ^ 1][0]); sb.store(lds[cur ^ 1][1]); }
+    if (sizeof(T) == 2) {
+        typename SA::Regs ra0, ra1;
+        typename SB::Regs rb0, rb1;
+        if (nsteps > 0) {
+            sa.load(k_begin, k_end, ra0); sb.load(k_begin, k_end, rb0);
+            if (nsteps > 1) { sa.load(k_begin + BK, k_end, ra1); sb.load(k_begin + BK, k_end, rb1); }
+            sa.store(lds[0][0], ra0); sb.store(lds[0][1], rb0);
+        }
         __syncthreads();
+        for (int s = 0; s < nsteps; s += 2) {
+            if (s + 2 < nsteps) { const int k0 = k_begin + (s + 2) * BK; sa.load(k0, k_end, ra0); sb.load(k0, k_end, rb0); }
+            TileMma<T>::run(lds[0][0], lds[0][1], wm, wn, lane, acc);
+            if (s + 1 < nsteps) { sa.store(lds[1][0], ra1); sb.store(lds[1][1], rb1); }
+            __syncthreads();
+            if (s + 1 >= nsteps) break;
+            if (s + 3 < nsteps) { const int k0 = k_begin + (s + 3) * BK; sa.load(k0, k_end, ra1); sb.load(k0, k_end, rb1); }
+            TileMma<T>::run(lds[1][0], lds[1][1], wm, wn, lane, acc);
+            if (s + 2 < nsteps) { sa.store(lds[0][0], ra0); sb.store(lds[0][1], rb0); }
+            __syncthreads();
+        }
+    } else {        // f32: the fragments alone take 64 VGPRs -> one register set (prefetch one K-tile ahead)
+        typename SA::Regs ra;
+        typename SB::Regs rb;
+        if (nsteps > 0) { sa.load(k_begin, k_end, ra); sb.load(k_begin, k_end, rb); sa.store(lds[0][0], ra); sb.store(lds[0][1], rb); }
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const int cur = s & 1;
+            const bool more = s + 1 < nsteps;
+            if (more) { const int k0 = k_begin + (s + 1) * BK; sa.load(k0, k_end, ra); sb.load(k0, k_end, rb); }
+            TileMma<T>::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
+            if (more) { sa.store(lds[cur ^ 1][0], ra); sb.store(lds[cur ^ 1][1], rb); }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane holds rows (lane>>4)*4+reg, column lane&15 of each 16x16 tile
     const int cq = lane >> 4, cr = lane & 15;
+    if (epi.fast) {
+        // C tile through LDS (the staging buffers are free after the loop's final barrier) -> 16-byte coalesced stores
+        TO* ct = (TO*)&lds[0][0][0];
+        constexpr int LDC = BN + 16 / (int)sizeof(TO);
+        constexpr int NPASS = sizeof(TO) == 4 ? 2 : 1;       // an f32 128x128 tile does not fit 64 KiB: two 64-row passes
+#define SS_EPS(I, J) epilogue_stage<TO>(acc[I][J], ct, LDC, lr + I * 16 + cq * 4, wn * 64 + J * 16 + cr, epi, m0 + wm * 64 + I * 16 + cq * 4, n0 + wn * 64 + J * 16 + cr, M, N)
+#define SS_EPS_ROW(I) SS_EPS(I, 0); SS_EPS(I, 1); SS_EPS(I, 2); SS_EPS(I, 3)
+#define SS_EPS_ALL SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3)
+        if (NPASS == 1) {
+            const int lr = wm * 64;
+            SS_EPS_ALL;
+            __syncthreads();
+            epilogue_flush<TO>(ct, LDC, C, epi, m0, BM, n0, M, N, tid);
+        } else {
+            const int lr = 0;
+            if (wm == 0) { SS_EPS_ALL; }
+            __syncthreads();
+            epilogue_flush<TO>(ct, LDC, C, epi, m0, BM / 2, n0, M, N, tid);
+            __syncthreads();
+            if (wm == 1) { SS_EPS_ALL; }
+            __syncthreads();
+            epilogue_flush<TO>(ct, LDC, C, epi, m0 + BM / 2, BM / 2, n0, M, N, tid);
+        }
+#undef SS_EPS_ALL
+#undef SS_EPS_ROW
+#undef SS_EPS
+        return;
+    }
 #define SS_EPI(I, J) epilogue_tile<TO>(acc[I][J], C, epi, m0 + wm * 64 + I * 16 + cq * 4, n0 + wn * 64 + J * 16 + cr, M, N)
 #define SS_EPI_ROW(I) SS_EPI(I, 0); SS_EPI(I, 1); SS_EPI(I, 2); SS_EPI(I, 3)
     SS_EPI_ROW(0); SS_EPI_ROW(1); SS_EPI_ROW(2); SS_EPI_ROW(3);
@@ -350,6 +476,19 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
         SS_CHECK(split_k <= 1, "ss_gemm: split_k > 1 needs mode 2 (atomic accumulate)");
     }
     RowMap am = to_rowmap(amap), bm = to_rowmap(bmap);
+    {
+        const int ev = dtype_out == SS_BF16 ? 8 : 4;
+        const RowMap& cm = epi.cmap;
+        epi.fast = epi.mode != 2 && epi.col_mod == 0 && N % ev == 0 && cm.base % ev == 0 && cm.batch_stride % ev == 0 && cm.row_stride % ev == 0 &&
+                   ((uintptr_t)C) % 16 == 0 && (!epi.gate || ((uintptr_t)epi.gate) % 16 == 0);
+        if (epi.c2) {
+            const int pk = 4;      // rows per lane
+            const size_t osz = dtype_out == SS_BF16 ? 2 : 4;
+            const RowMap& c2m = epi.cmap2;
+            epi.c2_pack = c2m.row_stride == 1 && c2m.rows_per_batch % pk == 0 && c2m.base % pk == 0 && c2m.batch_stride % pk == 0 && epi.col_stride2 % pk == 0 &&
+                          ((uintptr_t)epi.c2) % (pk * osz) == 0;
+        }
+    }
     if (dtype_in == SS_BF16 && dtype_out == SS_BF16) return launch_gemm<bf16_t, bf16_t>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
     if (dtype_in == SS_BF16 && dtype_out == SS_F32) return launch_gemm<bf16_t, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
     return launch_gemm<float, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
