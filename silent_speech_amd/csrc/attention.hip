@@ -26,6 +26,18 @@
 
 namespace {
 
+// LDS hand-off inside ONE wave (each wave owns its tiles): LDS operations of a wave are served in order, so only
+// the compiler must be kept from reordering; no workgroup barrier -> the 4 waves of a block run independently.
+__device__ __forceinline__ void wave_lds_sync() {
+#if defined(SS_EMU)
+    hipemu::sync_wave();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 struct AttnP {
     const void* qkv; const void* qkvT; const void* E; const void* ET;
     void* out; float* lse;
@@ -70,7 +82,27 @@ __device__ __forceinline__ void row_frags(Frag<T> (&f)[DPK], const T* rowp, bool
 #pragma unroll
     for (int kk = 0; kk < DPK; ++kk) { if (valid) frag_load(f[kk], rowp + kk * 32 + (lane >> 4) * 8); else frag_zero(f[kk]); }
 }
+__device__ __forceinline__ void frag_select(Frag<bf16_t>& f, bool keep) { bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; f.v = keep ? f.v : z; }
+__device__ __forceinline__ void frag_select(Frag<float>& f, bool keep) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; f.lo = keep ? f.lo : z; f.hi = keep ? f.hi : z; }
+// branch-free variant: always loads (row clamped into [0, nrows)), zeroes by select -> no control flow, so the
+// compiler can hoist the loads of later key blocks above the MFMAs of earlier ones (memory-level parallelism)
+template <class T, int DPK>
+__device__ __forceinline__ void row_frags_nb(Frag<T> (&f)[DPK], const T* base, long long stride, int row, int nrows, int lane) {
+    const bool ok = row >= 0 && row < nrows;
+    const int r = row < 0 ? 0 : (row >= nrows ? nrows - 1 : row);
+    const T* rowp = base + (long long)r * stride + (lane >> 4) * 8;
+#pragma unroll
+    for (int kk = 0; kk < DPK; ++kk) { frag_load(f[kk], rowp + kk * 32); frag_select(f[kk], ok); }
+}
 // 8 consecutive time steps t0..t0+7 of one row of a [..][Tp] transposed copy, zero beyond T
+// branch-free variant (t0 is a multiple of 8, Tp a multiple of 8 and >= Tlen)
+template <class T>
+__device__ __forceinline__ void time_frag_nb(Frag<T>& f, const T* rowp, int t0, int Tlen, int Tp) {
+    const int tc = t0 > Tp - 8 ? Tp - 8 : t0;
+    frag_load(f, rowp + tc);
+    int n = Tlen - t0; n = n < 0 ? 0 : (n > 8 ? 8 : n);
+    frag_keep(f, tc == t0 ? n : 0);
+}
 template <class T>
 __device__ __forceinline__ void time_frag(Frag<T>& f, const T* rowp, int t0, int Tlen) {
     if (t0 >= Tlen || t0 < 0) { frag_zero(f); return; }
@@ -148,25 +180,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p)
 
     float lg[NB_MAX][4];
     f32x4 rprev;
-    { Frag<T> ef[DPK]; const int m = m_org + c; row_frags<T, DPK>(ef, E + (long long)m * dp, m >= 0 && m <= 2 * D - 2, lane); rprev = dot_frags<T, DPK>(qf, ef); }
+    { Frag<T> ef[DPK]; row_frags_nb<T, DPK>(ef, E, dp, m_org + c, 2 * D - 1, lane); rprev = dot_frags<T, DPK>(qf, ef); }
+    // All NB_MAX key blocks are computed unconditionally and branch-free (blocks beyond the band are masked to -inf):
+    // with no control flow between them the scheduler overlaps the fragment loads of later blocks with the MFMAs,
+    // shuffles and softmax prologue of earlier ones.
 #pragma unroll
     for (int j = 0; j < NB_MAX; ++j) {
-        if (j < nb) {
-            const int k0 = kstart + 16 * j;
-            Frag<T> kf[DPK], ef[DPK];
-            row_frags<T, DPK>(kf, K + (long long)(k0 + c) * ldq, k0 + c < Tn, lane);
-            const int m = m_org + 16 * (j + 1) + c;
-            row_frags<T, DPK>(ef, E + (long long)m * dp, m >= 0 && m <= 2 * D - 2, lane);
-            const f32x4 s = dot_frags<T, DPK>(qf, kf);
-            const f32x4 rn = dot_frags<T, DPK>(qf, ef);
-            float pos[4];
-            skew_gather(rprev, rn, lane, pos);
-            finish_logits(s, pos, q0, k0, lane, Tn, D, p.scale, lg[j]);
-            rprev = rn;
-        } else {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) lg[j][reg] = -INFINITY;
-        }
+        const int k0 = kstart + 16 * j;
+        Frag<T> kf[DPK], ef[DPK];
+        row_frags_nb<T, DPK>(kf, K, ldq, k0 + c, Tn, lane);
+        row_frags_nb<T, DPK>(ef, E, dp, m_org + 16 * (j + 1) + c, 2 * D - 1, lane);
+        const f32x4 s = dot_frags<T, DPK>(qf, kf);
+        const f32x4 rn = dot_frags<T, DPK>(qf, ef);
+        float pos[4];
+        skew_gather(rprev, rn, lane, pos);
+        finish_logits(s, pos, q0, k0, lane, j < nb ? Tn : 0, D, p.scale, lg[j]);
+        rprev = rn;
     }
     // ---- softmax over the band (row = g*4+reg lives on the 16 lanes of group g)
     float mx[4], sm[4];
@@ -185,36 +214,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) { const int q = q0 + g * 4 + reg; if (q < Tn) p.lse[((long long)b * H + h) * Tn + q] = mx[reg] + logf(sm[reg]); }
     }
-    // ---- P~ (normalised, dropped-out) -> LDS in A-operand order
-    const int nchunk = (nb + 1) / 2;
+    // ---- P~ (normalised, dropped-out) -> LDS in A-operand order (all NB_MAX blocks: zeros beyond the band)
 #pragma unroll
     for (int j = 0; j < NB_MAX; ++j) {
-        if (j < 2 * nchunk) {
+        bool kp[4] = {true, true, true, true};
+        if (p.drop_thresh)   // probability (q, k) <-> Philox block ((bh*T + q/4)*T + k), word q & 3
+            dropout_keep4(p.seed, p.stream, (((unsigned long long)b * H + h) * Tn + ((q0 >> 2) + g)) * Tn + (kstart + 16 * j + c), p.drop_thresh, kp);
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                float pv = 0.f;
-                if (j < nb) {
-                    pv = lg[j][reg] / sm[reg];
-                    if (p.drop_thresh) {
-                        const int q = q0 + g * 4 + reg, k = kstart + 16 * j + c;
-                        const unsigned long long idx = (((unsigned long long)b * H + h) * Tn + q) * Tn + k;
-                        pv = dropout_keep(p.seed, p.stream, idx, p.drop_thresh) ? pv * p.drop_scale : 0.f;
-                    }
-                }
-                stf(&ptile[w][g * 4 + reg][16 * j + c], pv);
-            }
+        for (int reg = 0; reg < 4; ++reg) {
+            float pv = sm[reg] > 0.f ? lg[j][reg] / sm[reg] : 0.f;
+            if (p.drop_thresh) pv = kp[reg] ? pv * p.drop_scale : 0.f;
+            stf(&ptile[w][g * 4 + reg][16 * j + c], pv);
         }
     }
-    __syncthreads();
-    // ---- O = P~ V  (B operand straight from the transposed copy of V)
+    wave_lds_sync();
+    // ---- O = P~ V  (B operand straight from the transposed copy of V); unconditional over the whole tile width
     f32x4 o[2 * DPK];
 #pragma unroll
     for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; o[n] = z; }
-    for (int kc = 0; kc < nchunk; ++kc) {
+#pragma unroll
+    for (int kc = 0; kc < NB_MAX / 2; ++kc) {
         Frag<T> pa; frag_load(pa, &ptile[w][c][kc * 32 + g * 8]);
 #pragma unroll
         for (int n = 0; n < 2 * DPK; ++n) {
-            Frag<T> vb; time_frag(vb, VT + (long long)(n * 16 + c) * p.Tp, kstart + kc * 32 + g * 8, Tn);
+            Frag<T> vb; time_frag_nb(vb, VT + (long long)(n * 16 + c) * p.Tp, kstart + kc * 32 + g * 8, Tn, p.Tp);
             o[n] = mma32(pa, vb, o[n]);
         }
     }
@@ -249,15 +272,13 @@ __device__ __forceinline__ void prob_ds(const float (&lgt)[4], const f32x4& dpv,
                                         const AttnP& p, int b, int h, int q0, int k0, int lane, float (&pd)[4], float (&ds)[4])
 {
     const int c = lane & 15, g = lane >> 4;
+    bool kp[4] = {true, true, true, true};
+    if (p.drop_thresh) dropout_keep4(p.seed, p.stream, (((unsigned long long)b * p.H + h) * p.T + ((q0 >> 2) + g)) * p.T + (k0 + c), p.drop_thresh, kp);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         float pr = (rowok[reg] && lgt[reg] != -INFINITY) ? expf(lgt[reg] - lse[reg]) : 0.f;
         float keep = 1.f;
-        if (p.drop_thresh) {
-            const int q = q0 + g * 4 + reg, k = k0 + c;
-            const unsigned long long idx = (((unsigned long long)b * p.H + h) * p.T + q) * p.T + k;
-            keep = dropout_keep(p.seed, p.stream, idx, p.drop_thresh) ? p.drop_scale : 0.f;
-        }
+        if (p.drop_thresh) keep = kp[reg] ? p.drop_scale : 0.f;
         pd[reg] = pr * keep;
         ds[reg] = pr * (dpv[reg] * keep - dv[reg]);
     }
@@ -304,27 +325,25 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p)
         const long long si = ((long long)b * H + h) * Tn + (rowok[reg] ? q : 0);
         lse[reg] = p.lse[si]; dv[reg] = p.Dv[si];
     }
-    __syncthreads();
+    wave_lds_sync();
     f32x4 rprev;
-    { Frag<T> ef[DPK]; const int m = m_org + c; row_frags<T, DPK>(ef, E + (long long)m * dp, m >= 0 && m <= 2 * D - 2, lane); rprev = dot_frags<T, DPK>(qf, ef); }
-    for (int j = 0; j < 2 * nchunk; ++j) {
+    { Frag<T> ef[DPK]; row_frags_nb<T, DPK>(ef, E, dp, m_org + c, 2 * D - 1, lane); rprev = dot_frags<T, DPK>(qf, ef); }
+    // all NB_MAX key blocks, unconditional and branch-free (see attn_fwd_kernel); dS of blocks beyond the band is 0
+#pragma unroll
+    for (int j = 0; j < NB_MAX; ++j) {
         const int k0 = kstart + 16 * j;
-        float ds[4] = {0.f, 0.f, 0.f, 0.f};
-        if (j < nb) {
-            Frag<T> kf[DPK], ef[DPK], vf[DPK];
-            row_frags<T, DPK>(kf, K + (long long)(k0 + c) * ldq, k0 + c < Tn, lane);
-            row_frags<T, DPK>(vf, V + (long long)(k0 + c) * ldq, k0 + c < Tn, lane);
-            const int m = m_org + 16 * (j + 1) + c;
-            row_frags<T, DPK>(ef, E + (long long)m * dp, m >= 0 && m <= 2 * D - 2, lane);
-            const f32x4 s = dot_frags<T, DPK>(qf, kf);
-            const f32x4 rn = dot_frags<T, DPK>(qf, ef);
-            const f32x4 dpv = dot_frags<T, DPK>(dof, vf);
-            float pos[4], lgt[4], pd[4];
-            skew_gather(rprev, rn, lane, pos);
-            finish_logits(s, pos, q0, k0, lane, Tn, D, p.scale, lgt);
-            prob_ds(lgt, dpv, lse, dv, rowok, p, b, h, q0, k0, lane, pd, ds);
-            rprev = rn;
-        }
+        float ds[4], pd[4], pos[4], lgt[4];
+        Frag<T> kf[DPK], ef[DPK], vf[DPK];
+        row_frags_nb<T, DPK>(kf, K, ldq, k0 + c, Tn, lane);
+        row_frags_nb<T, DPK>(vf, V, ldq, k0 + c, Tn, lane);
+        row_frags_nb<T, DPK>(ef, E, dp, m_org + 16 * (j + 1) + c, 2 * D - 1, lane);
+        const f32x4 s = dot_frags<T, DPK>(qf, kf);
+        const f32x4 rn = dot_frags<T, DPK>(qf, ef);
+        const f32x4 dpv = dot_frags<T, DPK>(dof, vf);
+        skew_gather(rprev, rn, lane, pos);
+        finish_logits(s, pos, q0, k0, lane, j < nb ? Tn : 0, D, p.scale, lgt);
+        prob_ds(lgt, dpv, lse, dv, rowok, p, b, h, q0, k0, lane, pd, ds);
+        rprev = rn;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int ql = g * 4 + reg;
@@ -333,21 +352,25 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p)
             if (j < nb && m >= 0 && m <= 2 * D - 2) stf(tileB + ql * ldb + m, ds[reg]);
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     f32x4 acc[2 * DPK];
 #pragma unroll
     for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[n] = z; }
-    for (int kc = 0; kc < nchunk; ++kc) {                                   // content term: dS . K
+#pragma unroll
+    for (int kc = 0; kc < NB_MAX / 2; ++kc) {                               // content term: dS . K
         Frag<T> a; frag_load(a, tileA + c * PT_LD + kc * 32 + g * 8);
 #pragma unroll
-        for (int n = 0; n < 2 * DPK; ++n) { Frag<T> kb; time_frag(kb, KT + (long long)(n * 16 + c) * p.Tp, kstart + kc * 32 + g * 8, Tn); acc[n] = mma32(a, kb, acc[n]); }
+        for (int n = 0; n < 2 * DPK; ++n) { Frag<T> kb; time_frag_nb(kb, KT + (long long)(n * 16 + c) * p.Tp, kstart + kc * 32 + g * 8, Tn, p.Tp); acc[n] = mma32(a, kb, acc[n]); }
     }
 #pragma unroll
     for (int n = 0; n < 2 * DPK; ++n) acc[n] = acc[n] * p.scale;
-    for (int mc = 0; mc < MPt / 32; ++mc) {                                 // positional term: dR . E (unscaled Q)
-        Frag<T> a; frag_load(a, tileB + c * ldb + mc * 32 + g * 8);
 #pragma unroll
-        for (int n = 0; n < 2 * DPK; ++n) { Frag<T> eb; frag_load(eb, ET + (long long)(n * 16 + c) * MPt + mc * 32 + g * 8); acc[n] = mma32(a, eb, acc[n]); }
+    for (int mc = 0; mc < 7; ++mc) {                                        // positional term: dR . E (unscaled Q); MPt <= 224
+        const bool on = mc * 32 < MPt;
+        const int mo = on ? mc * 32 : 0;
+        Frag<T> a; frag_load(a, tileB + c * ldb + mo + g * 8); frag_select(a, on);
+#pragma unroll
+        for (int n = 0; n < 2 * DPK; ++n) { Frag<T> eb; frag_load(eb, ET + (long long)(n * 16 + c) * MPt + mo + g * 8); acc[n] = mma32(a, eb, acc[n]); }
     }
     if (tile_ok) {
         T* dQ = (T*)p.dqkv + (long long)b * Tn * ldq + h * dp;
@@ -390,62 +413,52 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p)
 #pragma unroll
     for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; dk[n] = z; dvv[n] = z; }
 
-    // all four waves run the same number of rounds (barriers are workgroup-wide)
-    int rounds = 0;
-#pragma unroll
-    for (int ww = 0; ww < 4; ++ww) {
-        const int kk0 = (blockIdx.x * 4 + ww) * 16;
-        if (kk0 < Tn) {
-            int a = kk0 - (D - 1); a = a < 0 ? 0 : a; a &= ~31;
-            int e = kk0 + 16 + (D - 1); e = e > Tn ? Tn : e;
-            const int np = ((e - a + 15) / 16 + 1) / 2;
-            rounds = np > rounds ? np : rounds;
-        }
-    }
-    for (int pr = 0; pr < rounds; ++pr) {
+    // Each wave owns its P~^T / dS^T tiles, so the hand-off is wave-local (no workgroup barrier, waves run independently).
+    // Both 16-query halves of a 32-query step are branch-free: loads clamped, contributions of out-of-band / out-of-range
+    // queries are exact zeros, so the scheduler can overlap the second half's loads with the first half's MFMAs.
+    for (int pr = 0; pr < npair; ++pr) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int jq = 2 * pr + half, qb0 = qstart + 16 * jq;
-            float pd[4] = {0.f, 0.f, 0.f, 0.f}, ds[4] = {0.f, 0.f, 0.f, 0.f};
-            if (pr < npair && jq < nqb) {
-                Frag<T> qf[DPK], dof[DPK], e0[DPK], e1[DPK];
-                int qr = qb0 + c; const bool qok = qr < Tn; qr = qok ? qr : Tn - 1;
-                row_frags<T, DPK>(qf, Q + (long long)qr * ldq, qok, lane);
-                row_frags<T, DPK>(dof, dO + (long long)qr * (H * dp), qok, lane);
-                const int m0 = k0 - qb0 - 15 + (D - 1);
-                row_frags<T, DPK>(e0, E + (long long)(m0 + c) * dp, m0 + c >= 0 && m0 + c <= 2 * D - 2, lane);
-                row_frags<T, DPK>(e1, E + (long long)(m0 + 16 + c) * dp, m0 + 16 + c >= 0 && m0 + 16 + c <= 2 * D - 2, lane);
-                const f32x4 s = dot_frags<T, DPK>(qf, kf);
-                const f32x4 rlo = dot_frags<T, DPK>(qf, e0), rhi = dot_frags<T, DPK>(qf, e1);
-                const f32x4 dpv = dot_frags<T, DPK>(dof, vf);
-                float pos[4], lgt[4], lse[4], dv[4]; bool rowok[4];
-                skew_gather(rlo, rhi, lane, pos);
-                finish_logits(s, pos, qb0, k0, lane, Tn, D, p.scale, lgt);
+            float pd[4], ds[4], pos[4], lgt[4], lse[4], dv[4]; bool rowok[4];
+            Frag<T> qf[DPK], dof[DPK], e0[DPK], e1[DPK];
+            row_frags_nb<T, DPK>(qf, Q, ldq, qb0 + c, Tn, lane);
+            row_frags_nb<T, DPK>(dof, dO, (long long)H * dp, qb0 + c, Tn, lane);
+            const int m0 = k0 - qb0 - 15 + (D - 1);
+            row_frags_nb<T, DPK>(e0, E, dp, m0 + c, 2 * D - 1, lane);
+            row_frags_nb<T, DPK>(e1, E, dp, m0 + 16 + c, 2 * D - 1, lane);
+            const f32x4 s = dot_frags<T, DPK>(qf, kf);
+            const f32x4 rlo = dot_frags<T, DPK>(qf, e0), rhi = dot_frags<T, DPK>(qf, e1);
+            const f32x4 dpv = dot_frags<T, DPK>(dof, vf);
+            skew_gather(rlo, rhi, lane, pos);
+            finish_logits(s, pos, qb0, k0, lane, Tn, D, p.scale, lgt);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int q = qb0 + g * 4 + reg; rowok[reg] = q < Tn;
-                    const long long si = ((long long)b * H + h) * Tn + (rowok[reg] ? q : 0);
-                    lse[reg] = p.lse[si]; dv[reg] = p.Dv[si];
-                }
-                prob_ds(lgt, dpv, lse, dv, rowok, p, b, h, qb0, k0, lane, pd, ds);
+            for (int reg = 0; reg < 4; ++reg) {
+                const int q = qb0 + g * 4 + reg; rowok[reg] = q < Tn && jq < nqb;
+                const long long si = ((long long)b * H + h) * Tn + (q < Tn ? q : Tn - 1);
+                lse[reg] = p.lse[si]; dv[reg] = p.Dv[si];
             }
+            prob_ds(lgt, dpv, lse, dv, rowok, p, b, h, qb0, k0, lane, pd, ds);
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) { stf(&tP[w][c][half * 16 + g * 4 + reg], pd[reg]); stf(&tS[w][c][half * 16 + g * 4 + reg], ds[reg]); }
+            for (int reg = 0; reg < 4; ++reg) {
+                const bool ok = rowok[reg];
+                stf(&tP[w][c][half * 16 + g * 4 + reg], ok ? pd[reg] : 0.f); stf(&tS[w][c][half * 16 + g * 4 + reg], ok ? ds[reg] : 0.f);
+            }
         }
-        __syncthreads();
-        if (pr < npair) {
+        wave_lds_sync();
+        {
             Frag<T> pa, sa; frag_load(pa, &tP[w][c][g * 8]); frag_load(sa, &tS[w][c][g * 8]);
             const int t0 = qstart + 32 * pr + g * 8;
 #pragma unroll
             for (int n = 0; n < 2 * DPK; ++n) {
                 Frag<T> db, qb;
-                time_frag(db, dOT + (long long)(n * 16 + c) * p.Tp, t0, Tn);
-                time_frag(qb, QT + (long long)(n * 16 + c) * p.Tp, t0, Tn);
+                time_frag_nb(db, dOT + (long long)(n * 16 + c) * p.Tp, t0, Tn, p.Tp);
+                time_frag_nb(qb, QT + (long long)(n * 16 + c) * p.Tp, t0, Tn, p.Tp);
                 dvv[n] = mma32(pa, db, dvv[n]);
                 dk[n] = mma32(sa, qb, dk[n]);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     if (tile_ok) {
         T* dK = (T*)p.dqkv + (long long)b * Tn * ldq + H * dp + h * dp;

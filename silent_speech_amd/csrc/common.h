@@ -134,6 +134,12 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned s
     Philox4 r = philox4x32(seed, idx >> 2, stream);
     return r.v[idx & 3] >= thresh;
 }
+// four keep-decisions from ONE Philox block: group index g4 (any bijective group numbering shared by forward/backward)
+__device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned stream, unsigned long long g4, unsigned thresh, bool (&keep)[4]) {
+    Philox4 r = philox4x32(seed, g4, stream);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) keep[i] = r.v[i] >= thresh;
+}
 static inline unsigned dropout_threshold(float p) {
     double t = (double)p * 4294967296.0;
     if (t <= 0) return 0u;

@@ -416,10 +416,20 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __rest
                 float xv[8], av[8];
                 Vec8<T>::load(x + (long long)r * C + cx * 8, xv);
                 Vec8<T>::load(a_z + (long long)r * C + cx * 8, av);
+                bool kp[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kp[e] = true;
+                if (thresh) {                               // element r*C + c  <->  Philox block (r*C + c) >> 2, word c & 3
+                    bool k0[4], k1[4];
+                    dropout_keep4(seed, stream_id, ((unsigned long long)r * C + cx * 8) >> 2, thresh, k0);
+                    dropout_keep4(seed, stream_id, (((unsigned long long)r * C + cx * 8) >> 2) + 1, thresh, k1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { kp[e] = k0[e]; kp[4 + e] = k1[e]; }
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float br = av[e];
-                    if (thresh) br = dropout_keep(seed, stream_id, (unsigned long long)r * C + cx * 8 + e, thresh) ? br * keep_scale : 0.f;
+                    if (thresh) br = kp[e] ? br * keep_scale : 0.f;
                     z[i][e] = rnd<T>(xv[e] + br);           // z is stored (and re-read by backward) in T
                     s += z[i][e];
                 }
@@ -492,11 +502,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             const int cx = lane + 64 * i;
             if (cx < CV) {
                 float o[8], ob[8];
+                bool kp[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kp[e] = true;
+                if (thresh && dbranch) {
+                    bool k0[4], k1[4];
+                    dropout_keep4(seed, stream_id, ((unsigned long long)r * C + cx * 8) >> 2, thresh, k0);
+                    dropout_keep4(seed, stream_id, (((unsigned long long)r * C + cx * 8) >> 2) + 1, thresh, k1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { kp[e] = k0[e]; kp[4 + e] = k1[e]; }
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
-                    ob[e] = o[e];
-                    if (thresh) ob[e] = dropout_keep(seed, stream_id, (unsigned long long)r * C + cx * 8 + e, thresh) ? o[e] * keep_scale : 0.f;
+                    ob[e] = (thresh && !kp[e]) ? 0.f : (thresh ? o[e] * keep_scale : o[e]);
                 }
                 Vec8<T>::store(dres + (long long)r * C + cx * 8, o);
                 if (dbranch) Vec8<T>::store(dbranch + (long long)r * C + cx * 8, ob);

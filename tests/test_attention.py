@@ -105,3 +105,40 @@ def test_attention_dropout_statistics(dev):
     # band of 2D-1 = 15 uniform probabilities, each kept w.p. 0.75 and scaled by 1/0.75
     assert abs(o.mean().item() - 1.0) < 0.15
     assert o.std().item() > 0.01
+
+
+@pytest.mark.parametrize('dt', [torch.float32])
+def test_attention_backward_uses_the_forward_dropout_mask(dev, dt):
+    """Recover the kept set from a forward pass with V = I (O reveals P~), then check the kernel backward against
+    autograd of the closed form with exactly that mask (all three kernels regenerate the same Philox stream)."""
+    B, H, T, dh, D, p = 1, 2, 32, 32, 9, 0.3
+    dp, Tp = 32, 32
+    g = torch.Generator().manual_seed(21)
+    q, k = [(torch.randn(B, H, T, dh, generator=g) * 0.5).requires_grad_(True) for _ in range(2)]
+    v = torch.eye(T).expand(B, H, T, T).clone().requires_grad_(True)                    # dh == T
+    E = torch.randn(H, 2 * D - 1, dh, generator=g) * dh ** -0.5
+    scale = 1.0 / math.sqrt(dh)
+    qkv = torch.cat([_pack(t.detach(), dp).reshape(B * T, H * dp) for t in (q, k, v)], 1).contiguous()
+    qkvT = qkv.view(B, T, 3 * H * dp).transpose(1, 2).contiguous()
+    Ed = E.clone(); MPt = (2 * D - 1 + 31) // 32 * 32
+    ETd = torch.zeros(H, dp, MPt); ETd[:, :, :2 * D - 1] = E.transpose(1, 2)
+    out = torch.zeros(B * T, H * dp, device=dev); lse = torch.zeros(B, H, T, device=dev)
+    qkv_d, qkvT_d, E_d, ET_d = qkv.to(dev), qkvT.to(dev), Ed.to(dev), ETd.to(dev)
+    ops.relpos_attention_forward(qkv_d, qkvT_d, E_d, out, lse, B, H, T, Tp, dp, D, scale, p=p, seed=99, rng_stream=4)
+    Pd = out.cpu().view(B, T, H, dp).permute(0, 2, 1, 3)                                # (B,H,q,k) = P~
+    band = (torch.arange(T)[None, :] - torch.arange(T)[:, None]).abs() <= D - 1
+    keep = (Pd != 0).float()
+    frac = keep[..., band].mean().item()
+    assert abs(frac - (1 - p)) < 0.08, frac
+    O_ref, _ = _reference(q, k, v, E, D, dh, drop=keep / (1 - p))
+    assert_close_robust(Pd, O_ref, 2e-5, name='P~', max_outlier_frac=0)
+    dO = torch.randn(B, H, T, dh, generator=g)
+    O_ref.backward(dO)
+    dOd = _pack(dO, dp).reshape(B * T, H * dp).contiguous()
+    dOT = dOd.view(B, T, H * dp).transpose(1, 2).contiguous()
+    dqkv = torch.zeros(B * T, 3 * H * dp, device=dev); dsc = torch.empty(B, H, T, device=dev)
+    ops.relpos_attention_backward(qkv_d, qkvT_d, E_d, ET_d, out, lse, dOd.to(dev), dOT.to(dev), dsc, dqkv, B, H, T, Tp, dp, D, scale, p=p, seed=99, rng_stream=4)
+    dq, dk, dv = [dqkv.view(B, T, 3, H, dp)[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+    assert_close_robust(dv, v.grad, 5e-5, name='dV', max_outlier_frac=0)
+    assert_close_robust(dk, k.grad, 5e-5, name='dK', max_outlier_frac=0)
+    assert_close_robust(dq, q.grad, 5e-5, name='dQ', max_outlier_frac=0)

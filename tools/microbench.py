@@ -68,6 +68,46 @@ def bench_dtw():
     return out
 
 
+def bench_attn():
+    import math
+    dev = torch.device('cuda')
+    B, H, T, dh, D = 110, 8, 200, 96, 100
+    dp, Tp = 96, 200
+    out = []
+    for dt in (torch.bfloat16,):
+        qkv = (torch.randn(B * T, 3 * H * dp, device=dev) * 0.5).to(dt)
+        qkvT = qkv.view(B, T, 3 * H * dp).transpose(1, 2).contiguous()
+        E = (torch.randn(H, 2 * D - 1, dp, device=dev) * 0.1).to(dt)
+        ET = torch.zeros(H, dp, 224, device=dev, dtype=dt); ET[:, :, :199] = E.transpose(1, 2)
+        o = torch.empty(B * T, H * dp, device=dev, dtype=dt); lse = torch.empty(B, H, T, device=dev)
+        dO = torch.randn(B * T, H * dp, device=dev).to(dt); dOT = dO.view(B, T, H * dp).transpose(1, 2).contiguous()
+        dqkv = torch.empty_like(qkv); dsc = torch.empty(B, H, T, device=dev)
+        sc = 1 / math.sqrt(dh)
+        for p in (0.0, 0.2):
+            tf = timeit(lambda: ops.relpos_attention_forward(qkv, qkvT, E, o, lse, B, H, T, Tp, dp, D, sc, p=p, seed=1, rng_stream=0))
+            tb = timeit(lambda: ops.relpos_attention_backward(qkv, qkvT, E, ET, o, lse, dO, dOT, dsc, dqkv, B, H, T, Tp, dp, D, sc, p=p, seed=1, rng_stream=0))
+            useful = B * H * (2.0 * T * T * dh * 2 + 2.0 * T * 199 * dh)      # QK^T + PV + positional term, forward
+            out.append(dict(kernel='attention', dtype=str(dt), p=p, fwd_us=tf * 1e6, bwd_us=tb * 1e6, fwd_useful_tflops=useful / tf / 1e12))
+            print(out[-1], flush=True)
+    return out
+
+
+def bench_ln():
+    dev = torch.device('cuda')
+    rows, C = 22000, 768
+    out = []
+    x = torch.randn(rows, C, device=dev).to(torch.bfloat16); a = torch.randn(rows, C, device=dev).to(torch.bfloat16)
+    y = torch.empty_like(x); g = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
+    for p in (0.0, 0.2):
+        t = timeit(lambda: ops.add_dropout_layernorm(x, a, g, b, y, rows, C, p=p, seed=3, rng_stream=1))
+        mean, rstd = ops.add_dropout_layernorm(x, a, g, b, y, rows, C, p=p, seed=3, rng_stream=1)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev); dbr = torch.empty_like(x); dy = torch.randn(rows, C, device=dev).to(torch.bfloat16)
+        tb = timeit(lambda: ops.layernorm_backward(dy, a, mean, rstd, g, dy, dbr, dg, db, rows, C, p=p, seed=3, rng_stream=1))
+        out.append(dict(kernel='layernorm', p=p, fwd_us=t * 1e6, fwd_GBps=rows * C * 2 * 4 / t / 1e9, bwd_us=tb * 1e6, bwd_GBps=rows * C * 2 * 4 / tb / 1e9))
+        print(out[-1], flush=True)
+    return out
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['gemm', 'dtw']
     res = []
@@ -75,6 +115,10 @@ if __name__ == '__main__':
         res += bench_gemm()
     if 'dtw' in which:
         res += bench_dtw()
+    if 'attn' in which:
+        res += bench_attn()
+    if 'ln' in which:
+        res += bench_ln()
     import os
     os.makedirs('gpurun_out', exist_ok=True)
     with open('gpurun_out/microbench_%d.json' % int(time.time()), 'w') as f:
