@@ -12,6 +12,7 @@ in (B, T+2, C) buffers with a zero halo row at both ends of every sequence, so a
 contiguous 3C-wide row and conv == GEMM with an overlapping-row RowMap (csrc/gemm.hip).
 """
 import math
+import os
 
 import torch
 
@@ -234,6 +235,41 @@ def _grad(p):
     return p.grad
 
 
+class _SideStream(object):
+    """Weight-gradient GEMMs (dW = dY^T X), bias column sums and gradient re-layouts do not feed the backward chain,
+    so they run on a second HIP stream: their workgroups fill the CUs that the dependent chain (dX GEMMs, attention,
+    norm kernels) leaves idle in its tail rounds (e.g. a 22 k x 768 GEMM is 1032 tiles = 2.02 rounds of 512 slots).
+    Inputs are kept alive (and never written again on the main stream) until join()."""
+
+    def __init__(self, model, dev):
+        self.enabled = dev.type == 'cuda' and os.environ.get('SS_AMD_SIDE_STREAM', '1') != '0'
+        self.keep = []
+        if self.enabled:
+            st = getattr(model, '_side_stream', None)
+            if st is None or st.device != dev:
+                st = torch.cuda.Stream(device=dev)
+                model._side_stream = st
+            self.stream = st
+
+    def run(self, fn, *keep):
+        if not self.enabled:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            fn()
+        self.keep.extend(keep)
+
+    def join(self):
+        if self.enabled:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            torch.cuda.current_stream().wait_event(ev)
+        self.keep = []
+
+
 def _dw_direct(dy, x, grad, N, K, rows, amap, bmap):
     """grad[N][K] += dy^T x  (both operands outer-contiguous, split-K with f32 atomics)."""
     ops.gemm(dy, x, grad, N, K, rows, amap, bmap, RM(K), a_mode=OP_OC, b_mode=OP_OC, mode=2, split_k=_split_k(N, K, rows))
@@ -257,13 +293,19 @@ def backward(model, ctx, dhead):
         ops.cast_f32(dhead, dh_t, M * nh)
     n_out = model.w_out.weight.shape[0]
     n_aux = model.w_aux.weight.shape[0] if model.has_aux_out else 0
-    tmp_w = torch.zeros(nh, d, dtype=torch.float32, device=dev)
-    tmp_b = torch.zeros(nh, dtype=torch.float32, device=dev)
-    _dw_direct(dh_t, ctx.x_final, tmp_w, nh, d, M, RM(nh), RM(d))
-    ops.colsum(dh_t, M, nh, nh, tmp_b)
-    _grad(model.w_out.weight).add_(tmp_w[:n_out]); _grad(model.w_out.bias).add_(tmp_b[:n_out])
-    if n_aux:
-        _grad(model.w_aux.weight).add_(tmp_w[n_out:n_out + n_aux]); _grad(model.w_aux.bias).add_(tmp_b[n_out:n_out + n_aux])
+    side = _SideStream(model, dev)
+    for p_ in model.optimized_parameters():
+        _grad(p_)
+
+    def head_grads():
+        tmp_w = torch.zeros(nh, d, dtype=torch.float32, device=dev)
+        tmp_b = torch.zeros(nh, dtype=torch.float32, device=dev)
+        _dw_direct(dh_t, ctx.x_final, tmp_w, nh, d, M, RM(nh), RM(d))
+        ops.colsum(dh_t, M, nh, nh, tmp_b)
+        model.w_out.weight.grad.add_(tmp_w[:n_out]); model.w_out.bias.grad.add_(tmp_b[:n_out])
+        if n_aux:
+            model.w_aux.weight.grad.add_(tmp_w[n_out:n_out + n_aux]); model.w_aux.bias.grad.add_(tmp_b[n_out:n_out + n_aux])
+    side.run(head_grads, dh_t, dhead)
     G = torch.empty(M, d, dtype=dt, device=dev)
     ops.gemm(dh_t, pr.w_head, G, M, d, nh, RM(nh), RM(d), RM(d), b_mode=OP_OC)
 
@@ -275,21 +317,28 @@ def backward(model, ctx, dhead):
         dF = torch.empty(M, d, dtype=dt, device=dev)
         ops.layernorm_backward(G, s.z2, s.mean2, s.rstd2, layer.norm2.weight.detach(), G, dF, _grad(layer.norm2.weight), _grad(layer.norm2.bias),
                                M, d, p=p_drop, seed=seed, rng_stream=4 * l + 3)
-        _dw_direct(dF, s.hid, _grad(layer.linear2.weight), d, ff, M, RM(d), RM(ff))
-        ops.colsum(dF, M, d, d, _grad(layer.linear2.bias))
+        def ffn2_grads(dF=dF, s=s, layer=layer):
+            _dw_direct(dF, s.hid, layer.linear2.weight.grad, d, ff, M, RM(d), RM(ff))
+            ops.colsum(dF, M, d, d, layer.linear2.bias.grad)
+        side.run(ffn2_grads, dF)
         dHid = torch.empty(M, ff, dtype=dt, device=dev)
         ops.gemm(dF, w['w2'], dHid, M, ff, d, RM(d), RM(ff), RM(ff), b_mode=OP_OC, gate=s.hid, gate_scale=keep_scale)
-        _dw_direct(dHid, s.y1, _grad(layer.linear1.weight), ff, d, M, RM(ff), RM(d))
-        ops.colsum(dHid, M, ff, ff, _grad(layer.linear1.bias))
+
+        def ffn1_grads(dHid=dHid, s=s, layer=layer):
+            _dw_direct(dHid, s.y1, layer.linear1.weight.grad, ff, d, M, RM(ff), RM(d))
+            ops.colsum(dHid, M, ff, ff, layer.linear1.bias.grad)
+        side.run(ffn1_grads, dHid)
         ops.gemm(dHid, w['w1'], G, M, d, ff, RM(ff), RM(d), RM(d), b_mode=OP_OC, mode=1)
         del dHid
-        dA = dF      # reuse
+        dA = torch.empty(M, d, dtype=dt, device=dev)
         ops.layernorm_backward(G, s.z1, s.mean1, s.rstd1, layer.norm1.weight.detach(), G, dA, _grad(layer.norm1.weight), _grad(layer.norm1.bias),
                                M, d, p=p_drop, seed=seed, rng_stream=4 * l + 1)
         # output projection  out[t,b,f] = sum_{h,a} o[b,h,t,a] w_o[h,a,f]   (transformer.py:111)
-        tmp = torch.zeros(d, H * dp, dtype=torch.float32, device=dev)
-        _dw_direct(dA, s.o, tmp, d, H * dp, M, RM(d), RM(H * dp))
-        ops.permute3d(tmp, _grad(a.w_o), (H, dh, d), (dp, 1, H * dp), accumulate=True)
+        def wo_grads(dA=dA, s=s, a=a):
+            tmp = torch.zeros(d, H * dp, dtype=torch.float32, device=dev)
+            _dw_direct(dA, s.o, tmp, d, H * dp, M, RM(d), RM(H * dp))
+            ops.permute3d(tmp, a.w_o.grad, (H, dh, d), (dp, 1, H * dp), accumulate=True)
+        side.run(wo_grads, dA)
         dO = torch.empty(M, H * dp, dtype=dt, device=dev)
         dOT = torch.empty(B, H * dp, Tp, dtype=dt, device=dev)
         ops.gemm_ex(dA, w['wo'], dO, M, H * dp, d, RM(d), RM(H * dp), RM(H * dp), b_mode=OP_OC,
@@ -298,16 +347,20 @@ def backward(model, ctx, dhead):
         dsc = torch.empty(B, H, T, dtype=torch.float32, device=dev)
         ops.relpos_attention_backward(s.qkv, s.qkvT, w['E'], w['ET'], s.o, s.lse, dO, dOT, dsc, dqkv, B, H, T, Tp, dp, D, ctx.scale,
                                       p=p_drop, seed=seed, rng_stream=4 * l)
-        tmp = torch.zeros(3 * H * dp, d, dtype=torch.float32, device=dev)
-        _dw_direct(dqkv, s.x, tmp, 3 * H * dp, d, M, RM(3 * H * dp), RM(d))
-        for i, wp in enumerate((a.w_q, a.w_k, a.w_v)):
-            ops.permute3d(tmp[i * H * dp:], _grad(wp), (H, d, dh), (dp * d, 1, d), accumulate=True)
+        def wqkv_grads(dqkv=dqkv, s=s, a=a):
+            tmp = torch.zeros(3 * H * dp, d, dtype=torch.float32, device=dev)
+            _dw_direct(dqkv, s.x, tmp, 3 * H * dp, d, M, RM(3 * H * dp), RM(d))
+            for i, wp in enumerate((a.w_q, a.w_k, a.w_v)):
+                ops.permute3d(tmp[i * H * dp:], wp.grad, (H, d, dh), (dp * d, 1, d), accumulate=True)
+        side.run(wqkv_grads, dqkv)
         ops.gemm(dqkv, w['wqkv'], G, M, d, 3 * H * dp, RM(3 * H * dp), RM(d), RM(d), b_mode=OP_OC, mode=1)
         del dqkv, dO, dOT, dA, dF
 
     # ---- w_raw_in (architecture.py:73)
-    _dw_direct(G, ctx.conv_out, _grad(model.w_raw_in.weight), d, d, M, RM(d), RM(d))
-    ops.colsum(G, M, d, d, _grad(model.w_raw_in.bias))
+    def raw_in_grads(G=G):
+        _dw_direct(G, ctx.conv_out, model.w_raw_in.weight.grad, d, d, M, RM(d), RM(d))
+        ops.colsum(G, M, d, d, model.w_raw_in.bias.grad)
+    side.run(raw_in_grads, G)
     dy = torch.empty(M, d, dtype=dt, device=dev)
     ops.gemm(G, pr.w_raw_in, dy, M, d, d, RM(d), RM(d), RM(d), b_mode=OP_OC)
     del G
@@ -324,11 +377,13 @@ def backward(model, ctx, dhead):
                         xb=s.cr, pad_xb=0, sb=s.str_, dxb=dcr, pad_dxb=0, dgamma_b=_grad(blk.res_norm.weight), dbeta_b=_grad(blk.res_norm.bias),
                         reduce_fn=bn_reduce)
         # conv2 (k3, stride 1): weight, bias, input gradients
-        tmp = torch.zeros(O, 3 * O, dtype=torch.float32, device=dev)
-        ops.gemm(dc2, s.h1, tmp, O, 3 * O, rows, RM(O, Tout, pbs, base=O), RM(O, Tout, pbs), RM(3 * O), a_mode=OP_OC, b_mode=OP_OC, mode=2,
-                 split_k=_split_k(O, 3 * O, rows))
-        ops.permute3d(tmp, _grad(blk.conv2.weight), (O, O, 3), (3 * O, 1, O), accumulate=True)
-        _grad(blk.conv2.bias)   # d/d(bias) of a conv feeding training-mode BatchNorm is identically 0 (BN removes the mean)
+        def conv2_grads(dc2=dc2, s=s, blk=blk, O=O, Tout=Tout, pbs=pbs, rows=rows):
+            tmp = torch.zeros(O, 3 * O, dtype=torch.float32, device=dev)
+            ops.gemm(dc2, s.h1, tmp, O, 3 * O, rows, RM(O, Tout, pbs, base=O), RM(O, Tout, pbs), RM(3 * O), a_mode=OP_OC, b_mode=OP_OC, mode=2,
+                     split_k=_split_k(O, 3 * O, rows))
+            ops.permute3d(tmp, blk.conv2.weight.grad, (O, O, 3), (3 * O, 1, O), accumulate=True)
+        side.run(conv2_grads, dc2)
+        # d/d(bias) of a conv feeding training-mode BatchNorm is identically 0 (BN removes the mean): nothing to add
         dh1 = torch.empty(rows, O, dtype=dt, device=dev)
         ops.gemm(dc2, w['w2b'], dh1, rows, O, 3 * O, RM(O, Tout, pbs), RM(3 * O), RM(O))
         dc1 = torch.empty(B, Tout + 2, O, dtype=dt, device=dev)
@@ -337,14 +392,14 @@ def backward(model, ctx, dhead):
         del dh1, dc2
         # conv1 (k3, stride 2) and the 1x1 stride-2 residual path
         in_bs = (Tin + 2) * Cin
-        tmp = torch.zeros(O, 3 * Cin, dtype=torch.float32, device=dev)
-        ops.gemm(dc1, s.xin, tmp, O, 3 * Cin, rows, RM(O, Tout, pbs, base=O), RM(2 * Cin, Tout, in_bs), RM(3 * Cin), a_mode=OP_OC, b_mode=OP_OC,
-                 mode=2, split_k=_split_k(O, 3 * Cin, rows))
-        ops.permute3d(tmp, _grad(blk.conv1.weight), (O, Cin, 3), (3 * Cin, 1, Cin), accumulate=True)
-        _grad(blk.conv1.bias)
-        ops.gemm(dcr, s.xin, _grad(blk.residual_path.weight), O, Cin, rows, RM(O), RM(2 * Cin, Tout, in_bs, base=Cin), RM(Cin), a_mode=OP_OC,
-                 b_mode=OP_OC, mode=2, split_k=_split_k(O, Cin, rows))
-        _grad(blk.residual_path.bias)
+        def conv1_grads(dc1=dc1, dcr=dcr, s=s, blk=blk, O=O, Cin=Cin, Tout=Tout, pbs=pbs, rows=rows, in_bs=in_bs):
+            tmp = torch.zeros(O, 3 * Cin, dtype=torch.float32, device=dev)
+            ops.gemm(dc1, s.xin, tmp, O, 3 * Cin, rows, RM(O, Tout, pbs, base=O), RM(2 * Cin, Tout, in_bs), RM(3 * Cin), a_mode=OP_OC, b_mode=OP_OC,
+                     mode=2, split_k=_split_k(O, 3 * Cin, rows))
+            ops.permute3d(tmp, blk.conv1.weight.grad, (O, Cin, 3), (3 * Cin, 1, Cin), accumulate=True)
+            ops.gemm(dcr, s.xin, blk.residual_path.weight.grad, O, Cin, rows, RM(O), RM(2 * Cin, Tout, in_bs, base=Cin), RM(Cin), a_mode=OP_OC,
+                     b_mode=OP_OC, mode=2, split_k=_split_k(O, Cin, rows))
+        side.run(conv1_grads, dc1, dcr)
         if i > 0:
             dx = torch.empty(B * Tin, Cin, dtype=dt, device=dev)
             out_even = RM(2 * Cin, Tout, Tin * Cin)
@@ -354,3 +409,4 @@ def backward(model, ctx, dhead):
             ops.gemm(dc1, w['w1b_odd'], dx, rows, Cin, 2 * O, RM(O, Tout, pbs, base=O), RM(2 * O), out_odd)
             dy = dx
         del dc1, dcr
+    side.join()
