@@ -299,120 +299,151 @@ __device__ __forceinline__ void epilogue_flush(const TO* __restrict__ ct, int ld
     }
 }
 
+// Work item `it` (tile x K-slice) of a persistent block.  Items are taken G at a time; inside each batch of G the
+// XCD-aware bijective remap keeps consecutive tile ids (which share an A row panel) on one XCD's L2.
+__device__ __forceinline__ void item_coord(int it, int G, int nitems, int ntiles, int tiles_n, int k_chunk, int K, int& m0, int& n0, int& k_begin, int& k_end)
+{
+    const int chunk0 = it / G * G, pos = it - chunk0;
+    int R = nitems - chunk0; R = R > G ? G : R;
+    const int xcd = pos & 7, q = R >> 3, r = R & 7;
+    const int idx = chunk0 + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pos >> 3);
+    const int z = idx / ntiles, tile = idx - z * ntiles;
+    const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
+    m0 = mt * BM; n0 = nt * BN;
+    k_begin = z * k_chunk; k_end = min(K, k_begin + k_chunk);
+}
+
+// PERSISTENT kernel: gridDim.x = min(#items, 2 blocks x #CUs); each block walks items it, it+G, ...  The global loads of
+// the NEXT item's first K-tiles are issued before the current item's epilogue, so the C-tile store burst, the next
+// tile's cold loads and the launch ramp overlap instead of serialising once per "round" of tiles.
 template <class T, class TO, int AMODE, int BMODE>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C,
-                                                   int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi,
-                                                   int k_chunk, int tiles_m, int tiles_n)
+                                                      int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi,
+                                                      int k_chunk, int tiles_m, int tiles_n, int nitems)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BM * ROWB];
     constexpr int BK = Elem<T>::BK;
+    constexpr bool D2 = false;               // second register set (prefetch 2 K-tiles ahead): measured no gain, and with the
+                                             // cross-item prefetch live during the epilogue it spills -> one set
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware bijective remap: consecutive tile ids (sharing an A row panel) stay on one XCD's L2.
-    int nwg = tiles_m * tiles_n, bid = blockIdx.x;
-    {
-        int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int mt = bid / tiles_n, nt = bid - mt * tiles_n;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int k_begin = blockIdx.z * k_chunk;
-    const int k_end = min(K, k_begin + k_chunk);
-
-    typename StagerSel<T, AMODE>::type sa;
-    typename StagerSel<T, BMODE>::type sb;
-    sa.init(A, amap, m0, M, tid);
-    sb.init(B, bmap, n0, N, tid);
-    sa.seek(k_begin); sb.seek(k_begin);
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
-
-    // Software pipeline, global->register prefetch TWO K-tiles ahead (two register sets), LDS double buffer, one
-    // barrier per K-tile: at step s the MFMAs read LDS[s&1] while tile s+1 (already in registers) is written to
-    // LDS[(s+1)&1] afterwards and the loads of tile s+2 are in flight the whole time.
+    const int G = gridDim.x, ntiles = tiles_m * tiles_n;
     typedef typename StagerSel<T, AMODE>::type SA;
     typedef typename StagerSel<T, BMODE>::type SB;
-    const int nsteps = (k_end - k_begin + BK - 1) / BK;
-    if (sizeof(T) == 2) {
-        typename SA::Regs ra0, ra1;
-        typename SB::Regs rb0, rb1;
-        if (nsteps > 0) {
-            sa.load(k_begin, k_end, ra0); sb.load(k_begin, k_end, rb0);
-            if (nsteps > 1) { sa.load(k_begin + BK, k_end, ra1); sb.load(k_begin + BK, k_end, rb1); }
-            sa.store(lds[0][0], ra0); sb.store(lds[0][1], rb0);
-        }
-        __syncthreads();
-        for (int s = 0; s < nsteps; s += 2) {
-            if (s + 2 < nsteps) { const int k0 = k_begin + (s + 2) * BK; sa.load(k0, k_end, ra0); sb.load(k0, k_end, rb0); }
-            TileMma<T>::run(lds[0][0], lds[0][1], wm, wn, lane, acc);
-            if (s + 1 < nsteps) { sa.store(lds[1][0], ra1); sb.store(lds[1][1], rb1); }
-            __syncthreads();
-            if (s + 1 >= nsteps) break;
-            if (s + 3 < nsteps) { const int k0 = k_begin + (s + 3) * BK; sa.load(k0, k_end, ra1); sb.load(k0, k_end, rb1); }
-            TileMma<T>::run(lds[1][0], lds[1][1], wm, wn, lane, acc);
-            if (s + 2 < nsteps) { sa.store(lds[0][0], ra0); sb.store(lds[0][1], rb0); }
-            __syncthreads();
-        }
-    } else {        // f32: the fragments alone take 64 VGPRs -> one register set (prefetch one K-tile ahead)
-        typename SA::Regs ra;
-        typename SB::Regs rb;
-        if (nsteps > 0) { sa.load(k_begin, k_end, ra); sb.load(k_begin, k_end, rb); sa.store(lds[0][0], ra); sb.store(lds[0][1], rb); }
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            const int cur = s & 1;
-            const bool more = s + 1 < nsteps;
-            if (more) { const int k0 = k_begin + (s + 1) * BK; sa.load(k0, k_end, ra); sb.load(k0, k_end, rb); }
-            TileMma<T>::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
-            if (more) { sa.store(lds[cur ^ 1][0], ra); sb.store(lds[cur ^ 1][1], rb); }
-            __syncthreads();
-        }
-    }
+    SA sa; SB sb;
+    typename SA::Regs ra0, ra1;
+    typename SB::Regs rb0, rb1;
+    int it = blockIdx.x, m0, n0, k_begin, k_end, nsteps;
 
-    // ---- epilogue: lane holds rows (lane>>4)*4+reg, column lane&15 of each 16x16 tile
-    const int cq = lane >> 4, cr = lane & 15;
-    if (epi.fast) {
-        // C tile through LDS (the staging buffers are free after the loop's final barrier) -> 16-byte coalesced stores
-        TO* ct = (TO*)&lds[0][0][0];
-        constexpr int LDC = BN + 16 / (int)sizeof(TO);
-        constexpr int NPASS = sizeof(TO) == 4 ? 2 : 1;       // an f32 128x128 tile does not fit 64 KiB: two 64-row passes
-#define SS_EPS(I, J) epilogue_stage<TO>(acc[I][J], ct, LDC, lr + I * 16 + cq * 4, wn * 64 + J * 16 + cr, epi, m0 + wm * 64 + I * 16 + cq * 4, n0 + wn * 64 + J * 16 + cr, M, N)
+#define SS_SETUP()                                                                                             \
+    do {                                                                                                        \
+        item_coord(it, G, nitems, ntiles, tiles_n, k_chunk, K, m0, n0, k_begin, k_end);                          \
+        sa.init(A, amap, m0, M, tid); sb.init(B, bmap, n0, N, tid);                                              \
+        sa.seek(k_begin); sb.seek(k_begin);                                                                      \
+        nsteps = (k_end - k_begin + BK - 1) / BK;                                                                \
+        if (nsteps > 0) {                                                                                        \
+            sa.load(k_begin, k_end, ra0); sb.load(k_begin, k_end, rb0);                                          \
+            if (D2 && nsteps > 1) { sa.load(k_begin + BK, k_end, ra1); sb.load(k_begin + BK, k_end, rb1); }      \
+        }                                                                                                        \
+    } while (0)
+
+    SS_SETUP();
+    for (;;) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+        if (nsteps > 0) { sa.store(lds[0][0], ra0); sb.store(lds[0][1], rb0); }
+        __syncthreads();
+        // Software pipeline: at step s the MFMAs read LDS[s&1]; tile s+1 (already in registers) is written to
+        // LDS[(s+1)&1] afterwards; the loads of tile s+2 (bf16) are in flight the whole time; one barrier per K-tile.
+        if (D2) {
+            for (int s = 0; s < nsteps; s += 2) {
+                if (s + 2 < nsteps) { const int k0 = k_begin + (s + 2) * BK; sa.load(k0, k_end, ra0); sb.load(k0, k_end, rb0); }
+                TileMma<T>::run(lds[0][0], lds[0][1], wm, wn, lane, acc);
+                if (s + 1 < nsteps) { sa.store(lds[1][0], ra1); sb.store(lds[1][1], rb1); }
+                __syncthreads();
+                if (s + 1 >= nsteps) break;
+                if (s + 3 < nsteps) { const int k0 = k_begin + (s + 3) * BK; sa.load(k0, k_end, ra1); sb.load(k0, k_end, rb1); }
+                TileMma<T>::run(lds[1][0], lds[1][1], wm, wn, lane, acc);
+                if (s + 2 < nsteps) { sa.store(lds[0][0], ra0); sb.store(lds[0][1], rb0); }
+                __syncthreads();
+            }
+        } else {
+            for (int s = 0; s < nsteps; ++s) {
+                const int cur = s & 1;
+                const bool more = s + 1 < nsteps;
+                if (more) { const int k0 = k_begin + (s + 1) * BK; sa.load(k0, k_end, ra0); sb.load(k0, k_end, rb0); }
+                TileMma<T>::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
+                if (more) { sa.store(lds[cur ^ 1][0], ra0); sb.store(lds[cur ^ 1][1], rb0); }
+                __syncthreads();
+            }
+        }
+        // ---- next item: its first global loads fly during this item's epilogue
+        const int cm0 = m0, cn0 = n0;
+        const bool has_next = it + G < nitems;
+        if (has_next) { it += G; SS_SETUP(); }
+
+        // ---- epilogue: lane holds rows (lane>>4)*4+reg, column lane&15 of each 16x16 tile
+        const int cq = lane >> 4, cr = lane & 15;
+        if (epi.fast) {
+            // C tile through LDS (the staging buffers are free after the loop's final barrier) -> 16-byte coalesced stores
+            TO* ct = (TO*)&lds[0][0][0];
+            constexpr int LDC = BN + 16 / (int)sizeof(TO);
+            constexpr int NPASS = sizeof(TO) == 4 ? 2 : 1;   // an f32 128x128 tile does not fit 64 KiB: two 64-row passes
+#define SS_EPS(I, J) epilogue_stage<TO>(acc[I][J], ct, LDC, lr + I * 16 + cq * 4, wn * 64 + J * 16 + cr, epi, cm0 + wm * 64 + I * 16 + cq * 4, cn0 + wn * 64 + J * 16 + cr, M, N)
 #define SS_EPS_ROW(I) SS_EPS(I, 0); SS_EPS(I, 1); SS_EPS(I, 2); SS_EPS(I, 3)
 #define SS_EPS_ALL SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3)
-        if (NPASS == 1) {
-            const int lr = wm * 64;
-            SS_EPS_ALL;
-            __syncthreads();
-            epilogue_flush<TO>(ct, LDC, C, epi, m0, BM, n0, M, N, tid);
-        } else {
-            const int lr = 0;
-            if (wm == 0) { SS_EPS_ALL; }
-            __syncthreads();
-            epilogue_flush<TO>(ct, LDC, C, epi, m0, BM / 2, n0, M, N, tid);
-            __syncthreads();
-            if (wm == 1) { SS_EPS_ALL; }
-            __syncthreads();
-            epilogue_flush<TO>(ct, LDC, C, epi, m0 + BM / 2, BM / 2, n0, M, N, tid);
-        }
+            if (NPASS == 1) {
+                const int lr = wm * 64;
+                SS_EPS_ALL;
+                __syncthreads();
+                epilogue_flush<TO>(ct, LDC, C, epi, cm0, BM, cn0, M, N, tid);
+            } else {
+                const int lr = 0;
+                if (wm == 0) { SS_EPS_ALL; }
+                __syncthreads();
+                epilogue_flush<TO>(ct, LDC, C, epi, cm0, BM / 2, cn0, M, N, tid);
+                __syncthreads();
+                if (wm == 1) { SS_EPS_ALL; }
+                __syncthreads();
+                epilogue_flush<TO>(ct, LDC, C, epi, cm0 + BM / 2, BM / 2, cn0, M, N, tid);
+            }
 #undef SS_EPS_ALL
 #undef SS_EPS_ROW
 #undef SS_EPS
-        return;
-    }
-#define SS_EPI(I, J) epilogue_tile<TO>(acc[I][J], C, epi, m0 + wm * 64 + I * 16 + cq * 4, n0 + wn * 64 + J * 16 + cr, M, N)
+        } else {
+#define SS_EPI(I, J) epilogue_tile<TO>(acc[I][J], C, epi, cm0 + wm * 64 + I * 16 + cq * 4, cn0 + wn * 64 + J * 16 + cr, M, N)
 #define SS_EPI_ROW(I) SS_EPI(I, 0); SS_EPI(I, 1); SS_EPI(I, 2); SS_EPI(I, 3)
-    SS_EPI_ROW(0); SS_EPI_ROW(1); SS_EPI_ROW(2); SS_EPI_ROW(3);
+            SS_EPI_ROW(0); SS_EPI_ROW(1); SS_EPI_ROW(2); SS_EPI_ROW(3);
 #undef SS_EPI_ROW
 #undef SS_EPI
+        }
+        if (!has_next) break;
+        __syncthreads();      // the C tile in LDS is fully flushed before the next item restages
+    }
+#undef SS_SETUP
 }
 
 // ---------------------------------------------------------------- host launcher
 static RowMap to_rowmap(const ss_rowmap* m) {
     RowMap r; r.base = m->base; r.batch_stride = m->batch_stride; r.row_stride = m->row_stride; r.rows_per_batch = m->rows_per_batch > 0 ? m->rows_per_batch : 0x7fffffff;
     return r;
+}
+
+// resident block slots: 2 blocks (64 KiB LDS, <=256 registers) per CU
+static int gemm_slots() {
+#if defined(SS_EMU)
+    return 3;            // tiny on purpose: the emulator tests exercise the multi-item path of the persistent loop
+#else
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 2 * cus;
+    }
+    return slots;
+#endif
 }
 
 template <class T, class TO>
@@ -426,9 +457,11 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     int per = (ksteps + split_k - 1) / split_k;
     int k_chunk = per * BK;
     split_k = (ksteps + per - 1) / per;
-    dim3 grid(tiles_m * tiles_n, 1, split_k), block(256);
+    const int nitems = tiles_m * tiles_n * split_k;
+    const int slots = gemm_slots();
+    dim3 grid(nitems < slots ? nitems : slots), block(256);
 #define SS_GEMM_CASE(AM, BMD)                                                                                     \
-    SS_LAUNCH(SS_KERNEL(gemm_kernel<T, TO, AM, BMD>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n)
+    SS_LAUNCH(SS_KERNEL(gemm_kernel<T, TO, AM, BMD>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems)
     if (a_mode == OP_KC && b_mode == OP_KC) SS_GEMM_CASE(OP_KC, OP_KC);
     else if (a_mode == OP_KC && b_mode == OP_OC) SS_GEMM_CASE(OP_KC, OP_OC);
     else if (a_mode == OP_OC && b_mode == OP_OC) SS_GEMM_CASE(OP_OC, OP_OC);
