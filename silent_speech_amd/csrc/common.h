@@ -42,10 +42,14 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {   // round-to-nearest-even, NaN-preserving
+#if defined(SS_EMU)
     unsigned u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
+#else
+    return __builtin_bit_cast(bf16_t, (__bf16)f);      // gfx950: v_cvt_pk_bf16_f32 (hardware RNE), no branches
+#endif
 }
 template <class T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
@@ -160,6 +164,7 @@ struct RowMap {
     int rows_per_batch;
 };
 __device__ __host__ __forceinline__ long long rowmap_off(const RowMap& m, int i) {
+    if (m.rows_per_batch == 0x7fffffff) return m.base + (long long)i * m.row_stride;      // plain matrix: no division
     int b = i / m.rows_per_batch, t = i - b * m.rows_per_batch;
     return m.base + (long long)b * m.batch_stride + (long long)t * m.row_stride;
 }

@@ -20,6 +20,8 @@
 //   bf16: v_mfma_f32_16x16x32_bf16 (f32 accumulate);  f32: v_mfma_f32_16x16x4_f32 (exact f32 fma chain).
 #include "common.h"
 #include "silent_speech_hip.h"
+#include <stdlib.h>
+#include <math.h>
 
 enum { OP_KC = 0, OP_OC = 1 };
 constexpr int BM = 128, BN = 128, ROWB = 128;   // ROWB: bytes of K per tile row
@@ -43,6 +45,8 @@ struct GemmEpi {
     long long col_stride2;
     int fast;                // 1: LDS-staged, 16-byte coalesced output path (host decides)
     int c2_pack;             // 1: the 4 rows a lane holds are consecutive, aligned elements of c2 -> one packed store
+    int general;             // 1: dropout or log-clamp in the epilogue
+    int debug;               // tuning experiments only (SS_GEMM_DEBUG): 1 skip flush stores, 2 skip stage, 4 skip MFMA
 };
 
 template <class T> struct Elem;
@@ -233,19 +237,23 @@ __device__ __forceinline__ void epilogue_tile(const f32x4& a, TO* __restrict__ C
 }
 
 // ---- fast epilogue, phase 1: elementwise part in registers, result into the LDS C tile (and the packed c2 copy)
-template <class TO>
+// GENERAL = false: alpha/bias/ReLU only (the common case; the compiler would otherwise if-convert the uniform
+// dropout / log-clamp branches into per-element selects and evaluate Philox and v_log for every element).
+template <class TO, bool GENERAL>
 __device__ __forceinline__ void epilogue_stage(const f32x4& a, TO* __restrict__ ct, int ldc, int lrow0, int lcol, const GemmEpi& epi, int row0, int col, int M, int N)
 {
     float v[4];
     const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
+    const float lo = epi.relu ? 0.f : -INFINITY;
     bool kp[4] = {true, true, true, true};
-    if (epi.drop_thresh) dropout_keep4(epi.seed, epi.stream, (unsigned long long)(row0 >> 2) * (unsigned)N + col, epi.drop_thresh, kp);
+    if (GENERAL) { if (epi.drop_thresh) dropout_keep4(epi.seed, epi.stream, (unsigned long long)(row0 >> 2) * (unsigned)N + col, epi.drop_thresh, kp); }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-        float x = a[reg] * epi.alpha + bias;
-        if (epi.relu) x = fmaxf(x, 0.f);
-        if (epi.drop_thresh) x = kp[reg] ? x * epi.drop_scale : 0.f;
-        if (epi.log_clamp > 0.f) x = logf(fmaxf(x, epi.log_clamp));
+        float x = fmaxf(a[reg] * epi.alpha + bias, lo);
+        if (GENERAL) {
+            if (epi.drop_thresh) x = kp[reg] ? x * epi.drop_scale : 0.f;
+            if (epi.log_clamp > 0.f) x = logf(fmaxf(x, epi.log_clamp));
+        }
         v[reg] = x;
         stf(ct + (lrow0 + reg) * ldc + lcol, x);
     }
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
                 const int cur = s & 1;
                 const bool more = s + 1 < nsteps;
                 if (more) { const int k0 = k_begin + (s + 1) * BK; sa.load(k0, k_end, ra0); sb.load(k0, k_end, rb0); }
-                TileMma<T>::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
+                if (!(epi.debug & 4)) TileMma<T>::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
                 if (more) { sa.store(lds[cur ^ 1][0], ra0); sb.store(lds[cur ^ 1][1], rb0); }
                 __syncthreads();
             }
@@ -391,16 +399,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
             TO* ct = (TO*)&lds[0][0][0];
             constexpr int LDC = BN + 16 / (int)sizeof(TO);
             constexpr int NPASS = sizeof(TO) == 4 ? 2 : 1;   // an f32 128x128 tile does not fit 64 KiB: two 64-row passes
-#define SS_EPS(I, J) epilogue_stage<TO>(acc[I][J], ct, LDC, lr + I * 16 + cq * 4, wn * 64 + J * 16 + cr, epi, cm0 + wm * 64 + I * 16 + cq * 4, cn0 + wn * 64 + J * 16 + cr, M, N)
+#define SS_EPS(I, J) epilogue_stage<TO, GEN>(acc[I][J], ct, LDC, lr + I * 16 + cq * 4, wn * 64 + J * 16 + cr, epi, cm0 + wm * 64 + I * 16 + cq * 4, cn0 + wn * 64 + J * 16 + cr, M, N)
 #define SS_EPS_ROW(I) SS_EPS(I, 0); SS_EPS(I, 1); SS_EPS(I, 2); SS_EPS(I, 3)
 #define SS_EPS_ALL SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3)
             if (NPASS == 1) {
                 const int lr = wm * 64;
-                SS_EPS_ALL;
+                if (!(epi.debug & 2)) {
+                    if (epi.general) { constexpr bool GEN = true; SS_EPS_ALL; } else { constexpr bool GEN = false; SS_EPS_ALL; }
+                }
                 __syncthreads();
-                epilogue_flush<TO>(ct, LDC, C, epi, cm0, BM, cn0, M, N, tid);
+                if (!(epi.debug & 1)) epilogue_flush<TO>(ct, LDC, C, epi, cm0, BM, cn0, M, N, tid);
             } else {
                 const int lr = 0;
+                constexpr bool GEN = true;
                 if (wm == 0) { SS_EPS_ALL; }
                 __syncthreads();
                 epilogue_flush<TO>(ct, LDC, C, epi, cm0, BM / 2, cn0, M, N, tid);
@@ -514,9 +525,11 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
         SS_CHECK(split_k <= 1, "ss_gemm: split_k > 1 needs mode 2 (atomic accumulate)");
     }
     RowMap am = to_rowmap(amap), bm = to_rowmap(bmap);
+    { const char* dbg = getenv("SS_GEMM_DEBUG"); epi.debug = dbg ? atoi(dbg) : 0; }
     {
         const int ev = dtype_out == SS_BF16 ? 8 : 4;
         const RowMap& cm = epi.cmap;
+        epi.general = epi.drop_thresh != 0 || epi.log_clamp > 0.f;
         epi.fast = epi.mode != 2 && epi.col_mod == 0 && N % ev == 0 && cm.base % ev == 0 && cm.batch_stride % ev == 0 && cm.row_stride % ev == 0 &&
                    ((uintptr_t)C) % 16 == 0 && (!epi.gate || ((uintptr_t)epi.gate) % 16 == 0);
         if (epi.c2) {

@@ -30,6 +30,12 @@ def run(M, N, K, am=OP_KC, bm=OP_KC, split=1, out_dt=None, tag=''):
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * split
     print('%-10s M=%6d N=%5d K=%6d split=%2d tiles=%5d  %8.1f us  %7.1f TF' % (tag, M, N, K, split, tiles, t * 1e6, 2.0 * M * N * K / t / 1e12), flush=True)
 
+if os.environ.get('SS_GEMM_DEBUG') is not None or os.environ.get('SHORT'):
+    print('debug', os.environ.get('SS_GEMM_DEBUG'))
+    for K in (64, 768):
+        run(22016, 768, K, tag='Ksweep')
+    run(88064, 768, 24, tag='conv0')
+    sys.exit(0)
 print('--- K sweep (M=22016, N=768)')
 for K in (64, 256, 768, 1536, 3072, 6144):
     run(22016, 768, K, tag='Ksweep')
