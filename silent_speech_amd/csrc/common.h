@@ -116,6 +116,16 @@ __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
 #endif
 }
 
+// LDS transpose read (ds_read_b64_tr_b16): see tools/emu/hipemu.h for the lane map (verified on gfx950)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_ptr) {
+#if defined(SS_EMU)
+    return hipemu::ds_read_tr16_b64((const short*)lds_ptr);
+#else
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_ptr);
+#endif
+}
+
 // ------------------------------------------------------------------ Philox4x32-10 (dropout RNG)
 struct Philox4 { unsigned v[4]; };
 __device__ __forceinline__ Philox4 philox4x32(unsigned long long seed, unsigned long long ctr, unsigned stream) {

@@ -160,6 +160,69 @@ struct StageOC<float> {    // thread: 4 outer x 4 reduction
     }
 };
 
+// ---------------------------------------------------------------- staging: TR mode (bf16, BOTH operands outer-contiguous: dW = dY^T X)
+// The tile is copied UNtransposed ([reduction k][outer m], 16-byte chunks, like KC) and the transposition happens in the
+// LDS read: ds_read_b64_tr_b16 hands lane (c, q) the 4 k-values of outer row c (tools/emu/hipemu.h has the lane map).
+// Row pitch 288 B (= 256 B + 32 B pad): the 16 lanes of a group read 4 k-rows x 32 B on disjoint banks, and the two groups
+// served together (q, q+1) read adjacent k-quads.  k inside a 32-deep MFMA step is enumerated as h*16 + q*4 + j for
+// BOTH operands (any common permutation of k leaves the contraction unchanged).
+constexpr int TR_ROWB = 288;
+constexpr int TR_TILE = 64 * TR_ROWB;
+struct StageTR {
+    typedef u32x4 Regs[4];
+    const bf16_t* p; RowMap map; int c, r0; bool ov; int bb[4], tt[4];
+    __device__ __forceinline__ void init(const bf16_t* p_, const RowMap& map_, int outer0, int outer_size, int tid) {
+        map = map_; c = tid & 15; r0 = tid >> 4;
+        ov = outer0 + c * 8 < outer_size;          // outer_size % 8 == 0 (checked on the host)
+        p = p_ + outer0 + c * 8;
+    }
+    __device__ __forceinline__ void seek(int k_begin) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = k_begin + r0 + 16 * i;
+            if (map.rows_per_batch == 0x7fffffff) { bb[i] = 0; tt[i] = r; } else { bb[i] = r / map.rows_per_batch; tt[i] = r - bb[i] * map.rows_per_batch; }
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int kend, Regs& reg) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            const bool v = ov && (k0 + r0 + 16 * i < kend);
+            reg[i] = v ? *(const u32x4*)(p + map.base + (long long)bb[i] * map.batch_stride + (long long)tt[i] * map.row_stride) : z;
+            tt[i] += 64;
+            while (tt[i] >= map.rows_per_batch) { tt[i] -= map.rows_per_batch; ++bb[i]; }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* tile, const Regs& reg) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4*)(tile + (r0 + 16 * i) * TR_ROWB + c * 16) = reg[i];
+    }
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int sub, int kk, int c, int q) {
+    const unsigned char* a0 = tile + (kk * 32 + q * 4 + (c >> 2)) * TR_ROWB + sub * 32 + (c & 3) * 8;
+    const s16x4 lo = lds_read_tr16(a0), hi = lds_read_tr16(a0 + 16 * TR_ROWB);
+    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+struct TileMmaTR {
+    static __device__ __forceinline__ void run(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+        const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = tr_frag(As, wm * 4 + i, kk, c, q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = tr_frag(Bs, wn * 4 + j, kk, c, q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+        }
+    }
+};
+
 template <class T, int MODE> struct StagerSel { typedef StageKC<T> type; };
 template <class T> struct StagerSel<T, OP_OC> { typedef StageOC<T> type; };
 
@@ -307,6 +370,11 @@ __device__ __forceinline__ void epilogue_flush(const TO* __restrict__ ct, int ld
     }
 }
 
+template <bool TR, class S> struct TrSel { typedef S type; };
+template <class S> struct TrSel<true, S> { typedef StageTR type; };
+template <bool TR, class T> struct MmaSel { typedef TileMma<T> type; };
+template <class T> struct MmaSel<true, T> { typedef TileMmaTR type; };
+
 // Work item `it` (tile x K-slice) of a persistent block.  Items are taken G at a time; inside each batch of G the
 // XCD-aware bijective remap keeps consecutive tile ids (which share an A row panel) on one XCD's L2.
 __device__ __forceinline__ void item_coord(int it, int G, int nitems, int ntiles, int tiles_n, int k_chunk, int K, int& m0, int& n0, int& k_begin, int& k_end)
@@ -329,14 +397,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
                                                       int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi,
                                                       int k_chunk, int tiles_m, int tiles_n, int nitems)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BM * ROWB];
+    constexpr bool TR = sizeof(T) == 2 && AMODE == OP_OC && BMODE == OP_OC;     // LDS-transpose-read variant (dW GEMMs)
+    constexpr int STAGE = TR ? TR_TILE : BM * ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][STAGE];
     constexpr int BK = Elem<T>::BK;
     constexpr bool D2 = false;               // second register set (prefetch 2 K-tiles ahead): measured no gain, and with the
                                              // cross-item prefetch live during the epilogue it spills -> one set
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int G = gridDim.x, ntiles = tiles_m * tiles_n;
-    typedef typename StagerSel<T, AMODE>::type SA;
-    typedef typename StagerSel<T, BMODE>::type SB;
+    typedef typename TrSel<TR, typename StagerSel<T, AMODE>::type>::type SA;
+    typedef typename TrSel<TR, typename StagerSel<T, BMODE>::type>::type SB;
+    typedef typename MmaSel<TR, T>::type MMA;
     SA sa; SB sb;
     typename SA::Regs ra0, ra1;
     typename SB::Regs rb0, rb1;
@@ -368,12 +439,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
         if (D2) {
             for (int s = 0; s < nsteps; s += 2) {
                 if (s + 2 < nsteps) { const int k0 = k_begin + (s + 2) * BK; sa.load(k0, k_end, ra0); sb.load(k0, k_end, rb0); }
-                TileMma<T>::run(lds[0][0], lds[0][1], wm, wn, lane, acc);
+                MMA::run(lds[0][0], lds[0][1], wm, wn, lane, acc);
                 if (s + 1 < nsteps) { sa.store(lds[1][0], ra1); sb.store(lds[1][1], rb1); }
                 __syncthreads();
                 if (s + 1 >= nsteps) break;
                 if (s + 3 < nsteps) { const int k0 = k_begin + (s + 3) * BK; sa.load(k0, k_end, ra1); sb.load(k0, k_end, rb1); }
-                TileMma<T>::run(lds[1][0], lds[1][1], wm, wn, lane, acc);
+                MMA::run(lds[1][0], lds[1][1], wm, wn, lane, acc);
                 if (s + 2 < nsteps) { sa.store(lds[0][0], ra0); sb.store(lds[0][1], rb0); }
                 __syncthreads();
             }
@@ -382,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
                 const int cur = s & 1;
                 const bool more = s + 1 < nsteps;
                 if (more) { const int k0 = k_begin + (s + 1) * BK; sa.load(k0, k_end, ra0); sb.load(k0, k_end, rb0); }
-                if (!(epi.debug & 4)) TileMma<T>::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
+                if (!(epi.debug & 4)) MMA::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
                 if (more) { sa.store(lds[cur ^ 1][0], ra0); sb.store(lds[cur ^ 1][1], rb0); }
                 __syncthreads();
             }

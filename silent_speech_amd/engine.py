@@ -55,6 +55,7 @@ class Prepared(object):
             e['w1f'] = ops.permute3d(w1, torch.empty(O, 3 * I, dtype=dt, device=dev), (O, 3, I), (3 * I, 1, 3))
             e['w2f'] = ops.permute3d(w2, torch.empty(O, 3 * O, dtype=dt, device=dev), (O, 3, O), (3 * O, 1, 3))
             e['wr'] = ops.permute3d(blk.residual_path.weight.detach(), torch.empty(O, I, dtype=dt, device=dev), (O, 1, I), (I, 0, 1))
+            e['wrT'] = ops.permute3d(e['wr'], torch.empty(I, O, dtype=dt, device=dev), (I, 1, O), (1, 0, I))
             # input-gradient forms (flipped taps):  conv2 (stride 1)  Wb[i][j*O+o] = W[o][i][2-j]
             e['w2b'] = ops.permute3d(w2.view(-1)[2:], torch.empty(O, 3 * O, dtype=dt, device=dev), (O, 3, O), (3, -1, 3 * O))
             if I % 8 == 0:   # stride-2 conv1: even rows use tap 1, odd rows taps (2, 0); block 0 has no input gradient
@@ -69,7 +70,12 @@ class Prepared(object):
             ops.cast_f32(w.detach(), out, w.numel())
             return out
 
+        def castT(w):     # [N][K] -> [K][N]: lets every input-gradient GEMM (dX = dY . W) run in the fast KC x KC form
+            n, k = w.shape
+            return ops.permute3d(w.detach(), torch.empty(k, n, dtype=dt, device=dev), (k, 1, n), (1, 0, k))
+
         self.w_raw_in = cast(model.w_raw_in.weight)
+        self.w_raw_in_T = castT(model.w_raw_in.weight)
         H, dh, dp, D = model.n_head, model.d_qkv, model.dp, model.max_rel
         MPt = _round_up(2 * D - 1, 32)
         self.layers = []
@@ -80,12 +86,16 @@ class Prepared(object):
             for i, w in enumerate((a.w_q, a.w_k, a.w_v)):       # (H, d, dh) -> [h][a (padded)][f]
                 ops.permute3d(w.detach(), wqkv[i], (H, dp, d), (d * dh, 1, dh), valid1=dh)
             e['wqkv'] = wqkv.view(3 * H * dp, d)
+            e['wqkvT'] = ops.permute3d(e['wqkv'], torch.empty(d, 3 * H * dp, dtype=dt, device=dev), (d, 1, 3 * H * dp), (1, 0, d))
             e['wo'] = ops.permute3d(a.w_o.detach(), torch.empty(d, H * dp, dtype=dt, device=dev), (d, H, dp), (1, dh * d, d), valid2=dh)
+            e['woT'] = ops.permute3d(e['wo'], torch.empty(H * dp, d, dtype=dt, device=dev), (H * dp, 1, d), (1, 0, H * dp))
             emb = a.relative_positional.embeddings.detach()    # (H, 2D-1, dh, 1)
             e['E'] = ops.permute3d(emb, torch.empty(H, 2 * D - 1, dp, dtype=dt, device=dev), (H, 2 * D - 1, dp), ((2 * D - 1) * dh, dh, 1), valid2=dh)
             e['ET'] = ops.permute3d(emb, torch.empty(H, dp, MPt, dtype=dt, device=dev), (H, dp, MPt), ((2 * D - 1) * dh, 1, dh), valid1=dh, valid2=2 * D - 1)
             e['w1'] = cast(layer.linear1.weight)
             e['w2'] = cast(layer.linear2.weight)
+            e['w1T'] = castT(layer.linear1.weight)
+            e['w2T'] = castT(layer.linear2.weight)
             self.layers.append(e)
         n_out = model.w_out.weight.shape[0]
         n_aux = model.w_aux.weight.shape[0] if model.has_aux_out else 0
@@ -98,6 +108,7 @@ class Prepared(object):
             ops.cast_f32(model.w_aux.weight.detach(), wh[n_out:n_out + n_aux], n_aux * d)
             bh[n_out:n_out + n_aux] = model.w_aux.bias.detach()
         self.w_head, self.b_head, self.n_head_cols = wh, bh, nh
+        self.w_head_T = ops.permute3d(wh, torch.empty(d, nh, dtype=dt, device=dev), (d, 1, nh), (1, 0, d))
         self.sig = self.signature(model)
 
 
@@ -307,7 +318,7 @@ def backward(model, ctx, dhead):
             model.w_aux.weight.grad.add_(tmp_w[n_out:n_out + n_aux]); model.w_aux.bias.grad.add_(tmp_b[n_out:n_out + n_aux])
     side.run(head_grads, dh_t, dhead)
     G = torch.empty(M, d, dtype=dt, device=dev)
-    ops.gemm(dh_t, pr.w_head, G, M, d, nh, RM(nh), RM(d), RM(d), b_mode=OP_OC)
+    ops.gemm(dh_t, pr.w_head_T, G, M, d, nh, RM(nh), RM(nh), RM(d))
 
     # ---- encoder layers, last to first (transformer.py:54-59)
     for l in range(len(ctx.layers) - 1, -1, -1):
@@ -322,13 +333,13 @@ def backward(model, ctx, dhead):
             ops.colsum(dF, M, d, d, layer.linear2.bias.grad)
         side.run(ffn2_grads, dF)
         dHid = torch.empty(M, ff, dtype=dt, device=dev)
-        ops.gemm(dF, w['w2'], dHid, M, ff, d, RM(d), RM(ff), RM(ff), b_mode=OP_OC, gate=s.hid, gate_scale=keep_scale)
+        ops.gemm(dF, w['w2T'], dHid, M, ff, d, RM(d), RM(d), RM(ff), gate=s.hid, gate_scale=keep_scale)
 
         def ffn1_grads(dHid=dHid, s=s, layer=layer):
             _dw_direct(dHid, s.y1, layer.linear1.weight.grad, ff, d, M, RM(ff), RM(d))
             ops.colsum(dHid, M, ff, ff, layer.linear1.bias.grad)
         side.run(ffn1_grads, dHid)
-        ops.gemm(dHid, w['w1'], G, M, d, ff, RM(ff), RM(d), RM(d), b_mode=OP_OC, mode=1)
+        ops.gemm(dHid, w['w1T'], G, M, d, ff, RM(ff), RM(ff), RM(d), mode=1)
         del dHid
         dA = torch.empty(M, d, dtype=dt, device=dev)
         ops.layernorm_backward(G, s.z1, s.mean1, s.rstd1, layer.norm1.weight.detach(), G, dA, _grad(layer.norm1.weight), _grad(layer.norm1.bias),
@@ -341,7 +352,7 @@ def backward(model, ctx, dhead):
         side.run(wo_grads, dA)
         dO = torch.empty(M, H * dp, dtype=dt, device=dev)
         dOT = torch.empty(B, H * dp, Tp, dtype=dt, device=dev)
-        ops.gemm_ex(dA, w['wo'], dO, M, H * dp, d, RM(d), RM(H * dp), RM(H * dp), b_mode=OP_OC,
+        ops.gemm_ex(dA, w['woT'], dO, M, H * dp, d, RM(d), RM(d), RM(H * dp),
                     c2=dOT, cmap2=RM(1, T, H * dp * Tp), col_stride2=Tp)
         dqkv = torch.empty(M, 3 * H * dp, dtype=dt, device=dev)
         dsc = torch.empty(B, H, T, dtype=torch.float32, device=dev)
@@ -353,7 +364,7 @@ def backward(model, ctx, dhead):
             for i, wp in enumerate((a.w_q, a.w_k, a.w_v)):
                 ops.permute3d(tmp[i * H * dp:], wp.grad, (H, d, dh), (dp * d, 1, d), accumulate=True)
         side.run(wqkv_grads, dqkv)
-        ops.gemm(dqkv, w['wqkv'], G, M, d, 3 * H * dp, RM(3 * H * dp), RM(d), RM(d), b_mode=OP_OC, mode=1)
+        ops.gemm(dqkv, w['wqkvT'], G, M, d, 3 * H * dp, RM(3 * H * dp), RM(3 * H * dp), RM(d), mode=1)
         del dqkv, dO, dOT, dA, dF
 
     # ---- w_raw_in (architecture.py:73)
@@ -362,7 +373,7 @@ def backward(model, ctx, dhead):
         ops.colsum(G, M, d, d, model.w_raw_in.bias.grad)
     side.run(raw_in_grads, G)
     dy = torch.empty(M, d, dtype=dt, device=dev)
-    ops.gemm(G, pr.w_raw_in, dy, M, d, d, RM(d), RM(d), RM(d), b_mode=OP_OC)
+    ops.gemm(G, pr.w_raw_in_T, dy, M, d, d, RM(d), RM(d), RM(d))
     del G
 
     # ---- ResBlocks, last to first (architecture.py:29-40)
@@ -405,7 +416,7 @@ def backward(model, ctx, dhead):
             out_even = RM(2 * Cin, Tout, Tin * Cin)
             out_odd = RM(2 * Cin, Tout, Tin * Cin, base=Cin)
             ops.gemm(dc1, w['w1b_even'], dx, rows, Cin, O, RM(O, Tout, pbs, base=O), RM(O), out_even)
-            ops.gemm(dcr, w['wr'], dx, rows, Cin, O, RM(O), RM(Cin), out_even, b_mode=OP_OC, mode=1)
+            ops.gemm(dcr, w['wrT'], dx, rows, Cin, O, RM(O), RM(O), out_even, mode=1)
             ops.gemm(dc1, w['w1b_odd'], dx, rows, Cin, 2 * O, RM(O, Tout, pbs, base=O), RM(2 * O), out_odd)
             dy = dx
         del dc1, dcr

@@ -306,6 +306,26 @@ inline v4f mfma_16x16x4_f32(float a, float b, v4f c) {
     sync_wave();
     return d;
 }
+// ds_read_b64_tr_b16 (gfx950), verified on hardware (tools/probes/tr_probe.hip): inside each 16-lane group, lane i
+// supplies the address of 4 contiguous 16-bit elements; lane c receives, for j = 0..3, element (c % 4) of the
+// 4 elements addressed by lane (4*j + c/4)  -- i.e. column c of the 4 x 16 block whose row j is the 16 elements
+// addressed by lanes 4j..4j+3.
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+inline v4s_t ds_read_tr16_b64(const short* p) {
+    State& s = S();
+    int me = s.cur, lane = me & 63, base = me - lane, grp = lane & ~15, c = lane & 15;
+    uint64_t raw; memcpy(&raw, p, 8);
+    s.xch[me] = raw;
+    sync_wave();
+    v4s_t r;
+    for (int j = 0; j < 4; ++j) {
+        uint64_t q = s.xch[base + grp + 4 * j + (c >> 2)];
+        short e[4]; memcpy(e, &q, 8);
+        r[j] = e[c & 3];
+    }
+    sync_wave();
+    return r;
+}
 }  // namespace hipemu
 
 #define SS_DYN_SMEM(name) char* name = hipemu::S().dyn_smem
