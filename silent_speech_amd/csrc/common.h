@@ -116,6 +116,25 @@ __device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
 #endif
 }
 
+// direct global -> LDS copy (global_load_lds_dwordx4): lane l writes its 16 bytes at lds_wave_base + 16*l; the base must be
+// wave-uniform (it travels in M0).  Completion is tracked by vmcnt (a following __syncthreads() drains it).
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+#if defined(SS_EMU)
+    hipemu::global_load_lds16(gptr, lds_wave_base);
+#else
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gptr, (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+#endif
+}
+// barrier that does NOT drain outstanding global->LDS copies (only LDS accesses of this wave are waited for)
+__device__ __forceinline__ void barrier_keep_vm() {
+#if defined(SS_EMU)
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
+}
+
 // LDS transpose read (ds_read_b64_tr_b16): see tools/emu/hipemu.h for the lane map (verified on gfx950)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_ptr) {

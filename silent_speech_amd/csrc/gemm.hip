@@ -507,6 +507,100 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
 #undef SS_SETUP
 }
 
+// ================================================================ KC x KC kernel with direct global->LDS staging
+// Same tile / MFMA / LDS image as gemm_kernel, but the K-tiles are copied by global_load_lds_dwordx4: no VGPR round trip and
+// no ds_write instructions (the LDS-store path was the largest per-K-tile cost of the register-staged version).  The image
+// must be lane-linear (dest = wave base + 16*lane), so the XOR swizzle is applied to the per-lane SOURCE chunk instead.
+// Rows / columns beyond M / N are clamped to a valid row (their results are never stored); K must be a multiple of the
+// K-tile (host-checked), so no zero fill is ever needed.  One barrier per K-tile; the copy of tile s+1 overlaps the MFMAs
+// of tile s.  Persistent over items; the next item's first tile is requested before the epilogue and lands in the stage
+// the epilogue does not use.
+template <class T>
+struct StageG {
+    const T* src[4];      // per-lane source (row clamped, chunk pre-swizzled), advanced by BK per K-tile
+    int wrow;             // first tile row written by this wave in each of the 4 pieces: 8*wave (+32*i)
+    __device__ __forceinline__ void init(const T* p, const RowMap& map, int outer0, int outer_size, int k_begin, int tid) {
+        const int lr = (tid & 63) >> 3, cpos = tid & 7, wave = tid >> 6;
+        wrow = wave * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wrow + lr + 32 * i;
+            int o = outer0 + r; o = o < outer_size ? o : outer_size - 1;
+            const int chunk = cpos ^ (r & 7) ^ (((r >> 3) & 3) << 1);              // inverse of swz(): same involution
+            src[i] = p + rowmap_off(map, o) + k_begin + chunk * Elem<T>::EPC;
+        }
+    }
+    __device__ __forceinline__ void issue(unsigned char* tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { glds16(src[i], tile + (wrow + 32 * i) * ROWB); src[i] += Elem<T>::BK; }
+    }
+};
+
+template <class T, class TO>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C,
+                                                           int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi,
+                                                           int k_chunk, int tiles_m, int tiles_n, int nitems)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BM * ROWB];
+    constexpr int BK = Elem<T>::BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int G = gridDim.x, ntiles = tiles_m * tiles_n;
+    StageG<T> sa, sb;
+    int it = blockIdx.x, m0, n0, k_begin, k_end, cur = 0;
+    item_coord(it, G, nitems, ntiles, tiles_n, k_chunk, K, m0, n0, k_begin, k_end);
+    sa.init(A, amap, m0, M, k_begin, tid); sb.init(B, bmap, n0, N, k_begin, tid);
+    sa.issue(lds[cur][0]); sb.issue(lds[cur][1]);
+    for (;;) {
+        const int nsteps = (k_end - k_begin) / BK;           // >= 1, exact
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+        for (int s = 0; s < nsteps; ++s) {
+            __syncthreads();                                  // tile s has landed in stage `cur`; stage cur^1 is free
+            if (s + 1 < nsteps) { sa.issue(lds[cur ^ 1][0]); sb.issue(lds[cur ^ 1][1]); }
+            if (!(epi.debug & 4)) TileMma<T>::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
+            cur ^= 1;
+        }
+        // `cur` now names the stage NOT read by the last K-tile: the next item's first tile goes there
+        const int cm0 = m0, cn0 = n0;
+        const bool has_next = it + G < nitems;
+        if (has_next) {
+            it += G;
+            item_coord(it, G, nitems, ntiles, tiles_n, k_chunk, K, m0, n0, k_begin, k_end);
+            sa.init(A, amap, m0, M, k_begin, tid); sb.init(B, bmap, n0, N, k_begin, tid);
+            sa.issue(lds[cur][0]); sb.issue(lds[cur][1]);
+        }
+        barrier_keep_vm();                                    // every wave is done reading stage cur^1 -> it becomes the C tile
+        // ---- epilogue through the free stage (32 KiB): R rows per pass
+        TO* ct = (TO*)&lds[cur ^ 1][0][0];
+        constexpr int LDC = BN + 16 / (int)sizeof(TO);
+        constexpr int R = sizeof(TO) == 2 ? 64 : 32;
+        const int cq = lane >> 4, cr = lane & 15;
+#define SS_EPS(I, J) epilogue_stage<TO, GEN>(acc[I][J], ct, LDC, (I & (R / 16 - 1)) * 16 + cq * 4, wn * 64 + J * 16 + cr, epi, cm0 + wm * 64 + I * 16 + cq * 4, cn0 + wn * 64 + J * 16 + cr, M, N)
+#define SS_EPS_ROW(I) SS_EPS(I, 0); SS_EPS(I, 1); SS_EPS(I, 2); SS_EPS(I, 3)
+#pragma unroll
+        for (int pass = 0; pass < BM / R; ++pass) {
+            if (epi.general) {
+                constexpr bool GEN = true;
+                if (R == 64) { if (wm == pass) { SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3); } }
+                else if (wm == pass / 2) { if (pass & 1) { SS_EPS_ROW(2); SS_EPS_ROW(3); } else { SS_EPS_ROW(0); SS_EPS_ROW(1); } }
+            } else {
+                constexpr bool GEN = false;
+                if (R == 64) { if (wm == pass) { SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3); } }
+                else if (wm == pass / 2) { if (pass & 1) { SS_EPS_ROW(2); SS_EPS_ROW(3); } else { SS_EPS_ROW(0); SS_EPS_ROW(1); } }
+            }
+            barrier_keep_vm();
+            if (!(epi.debug & 1)) epilogue_flush<TO>(ct, LDC, C, epi, cm0 + pass * R, R, cn0, M, N, tid);
+            if (pass + 1 < BM / R) barrier_keep_vm();
+        }
+#undef SS_EPS_ROW
+#undef SS_EPS
+        if (!has_next) break;
+    }
+}
+
 // ---------------------------------------------------------------- host launcher
 static RowMap to_rowmap(const ss_rowmap* m) {
     RowMap r; r.base = m->base; r.batch_stride = m->batch_stride; r.row_stride = m->row_stride; r.rows_per_batch = m->rows_per_batch > 0 ? m->rows_per_batch : 0x7fffffff;
@@ -542,6 +636,11 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     const int nitems = tiles_m * tiles_n * split_k;
     const int slots = gemm_slots();
     dim3 grid(nitems < slots ? nitems : slots), block(256);
+    if (a_mode == OP_KC && b_mode == OP_KC && epi.fast && K % BK == 0 && k_chunk % BK == 0 && !(epi.debug & 8)) {
+        SS_LAUNCH(SS_KERNEL(gemm_glds_kernel<T, TO>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems);
+        SS_LAUNCH_CHECK("ss_gemm(glds)");
+        return 0;
+    }
 #define SS_GEMM_CASE(AM, BMD)                                                                                     \
     SS_LAUNCH(SS_KERNEL(gemm_kernel<T, TO, AM, BMD>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems)
     if (a_mode == OP_KC && b_mode == OP_KC) SS_GEMM_CASE(OP_KC, OP_KC);

@@ -102,3 +102,31 @@ def test_gemm_rejects_bad_arguments(dev):
     a = torch.zeros(8, 6, device=dev); c = torch.zeros(8, 8, device=dev)
     with pytest.raises(RuntimeError, match='multiple of'):
         ops.gemm(a, a, c, 8, 8, 6, ops.rowmap(6), ops.rowmap(6), ops.rowmap(8))
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_gemm_direct_to_lds_path(dev, dt):
+    """K a multiple of the K-tile -> global_load_lds staging kernel; several items per persistent block, ragged M/N
+    (clamped rows), bias+ReLU, gate and accumulate, overlapping conv rows."""
+    big = not is_emu(dev)
+    M, N, K = (1000, 328, 512) if big else (300, 200, 192)
+    g = torch.Generator().manual_seed(17)
+    a = torch.randn(M, K, generator=g).to(dt); b = torch.randn(N, K, generator=g).to(dt)
+    bias = torch.randn(N, generator=g)
+    C = torch.zeros(M, N, dtype=dt, device=dev)
+    ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), bias=bias.to(dev), relu=True)
+    assert_close_robust(C, torch.relu(a.float() @ b.float().t() + bias), _tol(dt), name='glds', max_outlier_frac=0)
+    gate = (torch.randn(M, N, generator=g) > 0).to(dt); base = torch.randn(M, N, generator=g).to(dt)
+    C2 = base.clone().to(dev)
+    ops.gemm(a.to(dev), b.to(dev), C2, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), gate=gate.to(dev), gate_scale=1.25, mode=1)
+    assert_close_robust(C2, base.float() + (a.float() @ b.float().t()) * gate.float() * 1.25, _tol(dt), name='glds gate/acc', max_outlier_frac=0)
+    # k=3 conv with C_in = 64 (K = 192): overlapping rows through the direct-to-LDS path
+    Bn, T, Ci, Co = 2, 40, 64, 48
+    x = torch.randn(Bn, T, Ci, generator=g).to(dt); w = (torch.randn(Co, Ci, 3, generator=g) * 0.2).to(dt)
+    want = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.float(), None, stride=2, padding=1).transpose(1, 2)
+    To = want.shape[1]
+    xpad = torch.zeros(Bn, T + 2, Ci, dtype=dt); xpad[:, 1:-1] = x
+    wg = w.permute(0, 2, 1).reshape(Co, 3 * Ci).contiguous()
+    y = torch.zeros(Bn, To, Co, dtype=dt, device=dev)
+    ops.gemm(xpad.to(dev), wg.to(dev), y, Bn * To, Co, 3 * Ci, ops.rowmap(2 * Ci, rows_per_batch=To, batch_stride=(T + 2) * Ci), ops.rowmap(3 * Ci), ops.rowmap(Co))
+    assert_close_robust(y, want, _tol(dt), name='glds conv', max_outlier_frac=0)

@@ -306,6 +306,12 @@ inline v4f mfma_16x16x4_f32(float a, float b, v4f c) {
     sync_wave();
     return d;
 }
+// global_load_lds_dwordx4: every lane copies 16 bytes from its own global address to  lds_base (wave-uniform) + lane*16
+inline void global_load_lds16(const void* gptr, void* lds_wave_base) {
+    State& s = S();
+    memcpy((char*)lds_wave_base + (s.cur & 63) * 16, gptr, 16);
+}
+
 // ds_read_b64_tr_b16 (gfx950), verified on hardware (tools/probes/tr_probe.hip): inside each 16-lane group, lane i
 // supplies the address of 4 contiguous 16-bit elements; lane c receives, for j = 0..3, element (c % 4) of the
 // 4 elements addressed by lane (4*j + c/4)  -- i.e. column c of the 4 x 16 block whose row j is the 16 elements
