@@ -145,33 +145,21 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_ptr) {
 #endif
 }
 
-// ------------------------------------------------------------------ Philox4x32-10 (dropout RNG)
-struct Philox4 { unsigned v[4]; };
-__device__ __forceinline__ Philox4 philox4x32(unsigned long long seed, unsigned long long ctr, unsigned stream) {
-    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = stream, c3 = 0x5eed5eedu;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    Philox4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
-    return o;
+// ------------------------------------------------------------------ dropout RNG
+// Four keep-decisions for dropout group g4 (any bijective group numbering shared by forward and backward).
+// Dropout only needs decorrelated, reproducible Bernoulli draws, not Philox-grade streams: two rounds of a 32-bit
+// multiply-xorshift finaliser per 2 draws (2 v_mul_lo per hash) cost ~1/7 of Philox4x32-10 (40 quarter-rate multiplies),
+// which was the largest item of the FFN epilogue.  16-bit uniforms -> the keep probability is exact to 2^-16.
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
 }
-// keep-decision for element `idx` of dropout site `stream`: true with probability 1-p.
-// One Philox block serves 4 consecutive elements (idx>>2), lane idx&3.
-__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned stream, unsigned long long idx, unsigned thresh /* p * 2^32 */) {
-    Philox4 r = philox4x32(seed, idx >> 2, stream);
-    return r.v[idx & 3] >= thresh;
-}
-// four keep-decisions from ONE Philox block: group index g4 (any bijective group numbering shared by forward/backward)
 __device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned stream, unsigned long long g4, unsigned thresh, bool (&keep)[4]) {
-    Philox4 r = philox4x32(seed, g4, stream);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) keep[i] = r.v[i] >= thresh;
+    const unsigned lo = (unsigned)g4, hi = (unsigned)(g4 >> 32);
+    const unsigned key = (unsigned)seed ^ ((unsigned)(seed >> 32) * 0x9E3779B9u) ^ (stream * 0x85EBCA6Bu) ^ (hi * 0xC2B2AE35u);
+    const unsigned a = mix32(lo * 2u + key), b = mix32(lo * 2u + 1u + (key ^ 0x68E31DA4u));
+    const unsigned t16 = thresh >> 16;
+    keep[0] = (a & 0xffffu) >= t16; keep[1] = (a >> 16) >= t16; keep[2] = (b & 0xffffu) >= t16; keep[3] = (b >> 16) >= t16;
 }
 static inline unsigned dropout_threshold(float p) {
     double t = (double)p * 4294967296.0;

@@ -46,6 +46,7 @@ struct GemmEpi {
     int fast;                // 1: LDS-staged, 16-byte coalesced output path (host decides)
     int c2_pack;             // 1: the 4 rows a lane holds are consecutive, aligned elements of c2 -> one packed store
     int general;             // 1: dropout or log-clamp in the epilogue
+    int c2_lds;              // 1: the transposed copy can leave through LDS as 16-byte stores (bf16, 8-row aligned sequences)
     int debug;               // tuning experiments only (SS_GEMM_DEBUG): 1 skip flush stores, 2 skip stage, 4 skip MFMA
 };
 
@@ -302,8 +303,9 @@ __device__ __forceinline__ void epilogue_tile(const f32x4& a, TO* __restrict__ C
 // ---- fast epilogue, phase 1: elementwise part in registers, result into the LDS C tile (and the packed c2 copy)
 // GENERAL = false: alpha/bias/ReLU only (the common case; the compiler would otherwise if-convert the uniform
 // dropout / log-clamp branches into per-element selects and evaluate Philox and v_log for every element).
-template <class TO, bool GENERAL>
-__device__ __forceinline__ void epilogue_stage(const f32x4& a, TO* __restrict__ ct, int ldc, int lrow0, int lcol, const GemmEpi& epi, int row0, int col, int M, int N)
+template <class TO, bool GENERAL, bool C2L = false>
+__device__ __forceinline__ void epilogue_stage(const f32x4& a, TO* __restrict__ ct, int ldc, int lrow0, int lcol, const GemmEpi& epi, int row0, int col, int M, int N,
+                                               TO* __restrict__ tt = nullptr, int ldt = 0)
 {
     float v[4];
     const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
@@ -320,7 +322,10 @@ __device__ __forceinline__ void epilogue_stage(const f32x4& a, TO* __restrict__ 
         v[reg] = x;
         stf(ct + (lrow0 + reg) * ldc + lcol, x);
     }
-    if (epi.c2 && col < N) {
+    if (C2L) {     // transposed copy goes through LDS too: [col][row], 4 consecutive rows = one 8-byte store (bf16)
+        u32x2 w; w[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); w[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *(u32x2*)(tt + lcol * ldt + lrow0) = w;
+    } else if (epi.c2 && col < N) {
         TO* c2 = (TO*)epi.c2 + (long long)col * epi.col_stride2;
         if (epi.c2_pack && row0 + 3 < M) {
             TO* p = c2 + rowmap_off(epi.cmap2, row0);
@@ -576,27 +581,54 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const T* __restrict__
         // ---- epilogue through the free stage (32 KiB): R rows per pass
         TO* ct = (TO*)&lds[cur ^ 1][0][0];
         constexpr int LDC = BN + 16 / (int)sizeof(TO);
-        constexpr int R = sizeof(TO) == 2 ? 64 : 32;
         const int cq = lane >> 4, cr = lane & 15;
+        if (sizeof(TO) == 2 && epi.c2_lds) {
+            // QKV / dO projections: the result AND its per-sequence transposed copy ([b][col][t], read by the attention
+            // kernels) leave through LDS as 16-byte stores: 32-row passes, C piece [32][136] + transposed piece [128][40].
+            constexpr int LDT = 40;
+            TO* tt = ct + 32 * LDC;
+#define SS_EPS(I, J) epilogue_stage<TO, false, true>(acc[I][J], ct, LDC, (I & 1) * 16 + cq * 4, wn * 64 + J * 16 + cr, epi, cm0 + wm * 64 + I * 16 + cq * 4, cn0 + wn * 64 + J * 16 + cr, M, N, tt, LDT)
+#define SS_EPS_ROW(I) SS_EPS(I, 0); SS_EPS(I, 1); SS_EPS(I, 2); SS_EPS(I, 3)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                if (wm == pass / 2) { if (pass & 1) { SS_EPS_ROW(2); SS_EPS_ROW(3); } else { SS_EPS_ROW(0); SS_EPS_ROW(1); } }
+                barrier_keep_vm();
+                epilogue_flush<TO>(ct, LDC, C, epi, cm0 + pass * 32, 32, cn0, M, N, tid);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = tid + 256 * i, col = idx >> 2, ch = idx & 3;
+                    const int row0 = cm0 + pass * 32 + ch * 8;
+                    if (cn0 + col < N && row0 < M) {
+                        const u32x4 v = *(const u32x4*)(tt + col * LDT + ch * 8);
+                        *(u32x4*)((TO*)epi.c2 + (long long)(cn0 + col) * epi.col_stride2 + rowmap_off(epi.cmap2, row0)) = v;
+                    }
+                }
+                if (pass < 3) barrier_keep_vm();
+            }
+#undef SS_EPS_ROW
+#undef SS_EPS
+        } else {
+            constexpr int R = sizeof(TO) == 2 ? 64 : 32;
 #define SS_EPS(I, J) epilogue_stage<TO, GEN>(acc[I][J], ct, LDC, (I & (R / 16 - 1)) * 16 + cq * 4, wn * 64 + J * 16 + cr, epi, cm0 + wm * 64 + I * 16 + cq * 4, cn0 + wn * 64 + J * 16 + cr, M, N)
 #define SS_EPS_ROW(I) SS_EPS(I, 0); SS_EPS(I, 1); SS_EPS(I, 2); SS_EPS(I, 3)
 #pragma unroll
-        for (int pass = 0; pass < BM / R; ++pass) {
-            if (epi.general) {
-                constexpr bool GEN = true;
-                if (R == 64) { if (wm == pass) { SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3); } }
-                else if (wm == pass / 2) { if (pass & 1) { SS_EPS_ROW(2); SS_EPS_ROW(3); } else { SS_EPS_ROW(0); SS_EPS_ROW(1); } }
-            } else {
-                constexpr bool GEN = false;
-                if (R == 64) { if (wm == pass) { SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3); } }
-                else if (wm == pass / 2) { if (pass & 1) { SS_EPS_ROW(2); SS_EPS_ROW(3); } else { SS_EPS_ROW(0); SS_EPS_ROW(1); } }
+            for (int pass = 0; pass < BM / R; ++pass) {
+                if (epi.general) {
+                    constexpr bool GEN = true;
+                    if (R == 64) { if (wm == pass) { SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3); } }
+                    else if (wm == pass / 2) { if (pass & 1) { SS_EPS_ROW(2); SS_EPS_ROW(3); } else { SS_EPS_ROW(0); SS_EPS_ROW(1); } }
+                } else {
+                    constexpr bool GEN = false;
+                    if (R == 64) { if (wm == pass) { SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3); } }
+                    else if (wm == pass / 2) { if (pass & 1) { SS_EPS_ROW(2); SS_EPS_ROW(3); } else { SS_EPS_ROW(0); SS_EPS_ROW(1); } }
+                }
+                barrier_keep_vm();
+                if (!(epi.debug & 1)) epilogue_flush<TO>(ct, LDC, C, epi, cm0 + pass * R, R, cn0, M, N, tid);
+                if (pass + 1 < BM / R) barrier_keep_vm();
             }
-            barrier_keep_vm();
-            if (!(epi.debug & 1)) epilogue_flush<TO>(ct, LDC, C, epi, cm0 + pass * R, R, cn0, M, N, tid);
-            if (pass + 1 < BM / R) barrier_keep_vm();
-        }
 #undef SS_EPS_ROW
 #undef SS_EPS
+        }
         if (!has_next) break;
     }
 }
@@ -706,6 +738,8 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
             const int pk = 4;      // rows per lane
             const size_t osz = dtype_out == SS_BF16 ? 2 : 4;
             const RowMap& c2m = epi.cmap2;
+            epi.c2_lds = dtype_out == SS_BF16 && !epi.general && c2m.row_stride == 1 && c2m.rows_per_batch % 8 == 0 && M % 8 == 0 && c2m.base % 8 == 0 &&
+                         c2m.batch_stride % 8 == 0 && epi.col_stride2 % 8 == 0 && ((uintptr_t)epi.c2) % 16 == 0;
             epi.c2_pack = c2m.row_stride == 1 && c2m.rows_per_batch % pk == 0 && c2m.base % pk == 0 && c2m.batch_stride % pk == 0 && epi.col_stride2 % pk == 0 &&
                           ((uintptr_t)epi.c2) % (pk * osz) == 0;
         }

@@ -130,3 +130,17 @@ def test_gemm_direct_to_lds_path(dev, dt):
     y = torch.zeros(Bn, To, Co, dtype=dt, device=dev)
     ops.gemm(xpad.to(dev), wg.to(dev), y, Bn * To, Co, 3 * Ci, ops.rowmap(2 * Ci, rows_per_batch=To, batch_stride=(T + 2) * Ci), ops.rowmap(3 * Ci), ops.rowmap(Co))
     assert_close_robust(y, want, _tol(dt), name='glds conv', max_outlier_frac=0)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_gemm_transposed_second_output(dev, dt):
+    """The QKV / dO projections also emit a per-sequence transposed copy [b][col][t] (read by the attention kernels)."""
+    Bn, T, N, K = (4, 40, 136, 128) if is_emu(dev) else (6, 200, 328, 256)
+    M, Tp = Bn * T, T
+    g = torch.Generator().manual_seed(23)
+    a = torch.randn(M, K, generator=g).to(dt); b = torch.randn(N, K, generator=g).to(dt)
+    want = a.float() @ b.float().t()
+    C = torch.zeros(M, N, dtype=dt, device=dev); C2 = torch.zeros(Bn, N, Tp, dtype=dt, device=dev)
+    ops.gemm_ex(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), c2=C2, cmap2=ops.rowmap(1, T, N * Tp), col_stride2=Tp)
+    assert_close_robust(C, want, _tol(dt), name='C', max_outlier_frac=0)
+    assert torch.equal(C2.cpu(), C.cpu().view(Bn, T, N).transpose(1, 2).contiguous())
