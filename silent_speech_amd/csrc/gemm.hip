@@ -303,7 +303,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x4& a, TO* __restrict__ C
 // ---- fast epilogue, phase 1: elementwise part in registers, result into the LDS C tile (and the packed c2 copy)
 // GENERAL = false: alpha/bias/ReLU only (the common case; the compiler would otherwise if-convert the uniform
 // dropout / log-clamp branches into per-element selects and evaluate Philox and v_log for every element).
-template <class TO, bool GENERAL, bool C2L = false>
+template <class TO, int GENERAL, bool C2L = false>     // GENERAL: 0 alpha/bias/ReLU, 1 + dropout, 2 + log-clamp
 __device__ __forceinline__ void epilogue_stage(const f32x4& a, TO* __restrict__ ct, int ldc, int lrow0, int lcol, const GemmEpi& epi, int row0, int col, int M, int N,
                                                TO* __restrict__ tt = nullptr, int ldt = 0)
 {
@@ -311,14 +311,12 @@ __device__ __forceinline__ void epilogue_stage(const f32x4& a, TO* __restrict__ 
     const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
     const float lo = epi.relu ? 0.f : -INFINITY;
     bool kp[4] = {true, true, true, true};
-    if (GENERAL) { if (epi.drop_thresh) dropout_keep4(epi.seed, epi.stream, (unsigned long long)(row0 >> 2) * (unsigned)N + col, epi.drop_thresh, kp); }
+    if (GENERAL == 1) dropout_keep4(epi.seed, epi.stream, (unsigned long long)(row0 >> 2) * (unsigned)N + col, epi.drop_thresh, kp);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         float x = fmaxf(a[reg] * epi.alpha + bias, lo);
-        if (GENERAL) {
-            if (epi.drop_thresh) x = kp[reg] ? x * epi.drop_scale : 0.f;
-            if (epi.log_clamp > 0.f) x = logf(fmaxf(x, epi.log_clamp));
-        }
+        if (GENERAL == 1) x = kp[reg] ? x * epi.drop_scale : 0.f;
+        if (GENERAL == 2) x = logf(fmaxf(x, epi.log_clamp));
         v[reg] = x;
         stf(ct + (lrow0 + reg) * ldc + lcol, x);
     }
@@ -481,18 +479,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
             if (NPASS == 1) {
                 const int lr = wm * 64;
                 if (!(epi.debug & 2)) {
-                    if (epi.general) { constexpr bool GEN = true; SS_EPS_ALL; } else { constexpr bool GEN = false; SS_EPS_ALL; }
+                    if (epi.general == 1) { constexpr int GEN = 1; SS_EPS_ALL; } else if (epi.general == 2) { constexpr int GEN = 2; SS_EPS_ALL; } else { constexpr int GEN = 0; SS_EPS_ALL; }
                 }
                 __syncthreads();
                 if (!(epi.debug & 1)) epilogue_flush<TO>(ct, LDC, C, epi, cm0, BM, cn0, M, N, tid);
             } else {
                 const int lr = 0;
-                constexpr bool GEN = true;
-                if (wm == 0) { SS_EPS_ALL; }
+                if (wm == 0) { if (epi.general == 1) { constexpr int GEN = 1; SS_EPS_ALL; } else if (epi.general == 2) { constexpr int GEN = 2; SS_EPS_ALL; } else { constexpr int GEN = 0; SS_EPS_ALL; } }
                 __syncthreads();
                 epilogue_flush<TO>(ct, LDC, C, epi, cm0, BM / 2, cn0, M, N, tid);
                 __syncthreads();
-                if (wm == 1) { SS_EPS_ALL; }
+                if (wm == 1) { if (epi.general == 1) { constexpr int GEN = 1; SS_EPS_ALL; } else if (epi.general == 2) { constexpr int GEN = 2; SS_EPS_ALL; } else { constexpr int GEN = 0; SS_EPS_ALL; } }
                 __syncthreads();
                 epilogue_flush<TO>(ct, LDC, C, epi, cm0 + BM / 2, BM / 2, cn0, M, N, tid);
             }
@@ -587,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const T* __restrict__
             // kernels) leave through LDS as 16-byte stores: 32-row passes, C piece [32][136] + transposed piece [128][40].
             constexpr int LDT = 40;
             TO* tt = ct + 32 * LDC;
-#define SS_EPS(I, J) epilogue_stage<TO, false, true>(acc[I][J], ct, LDC, (I & 1) * 16 + cq * 4, wn * 64 + J * 16 + cr, epi, cm0 + wm * 64 + I * 16 + cq * 4, cn0 + wn * 64 + J * 16 + cr, M, N, tt, LDT)
+#define SS_EPS(I, J) epilogue_stage<TO, 0, true>(acc[I][J], ct, LDC, (I & 1) * 16 + cq * 4, wn * 64 + J * 16 + cr, epi, cm0 + wm * 64 + I * 16 + cq * 4, cn0 + wn * 64 + J * 16 + cr, M, N, tt, LDT)
 #define SS_EPS_ROW(I) SS_EPS(I, 0); SS_EPS(I, 1); SS_EPS(I, 2); SS_EPS(I, 3)
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
@@ -613,15 +610,11 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const T* __restrict__
 #define SS_EPS_ROW(I) SS_EPS(I, 0); SS_EPS(I, 1); SS_EPS(I, 2); SS_EPS(I, 3)
 #pragma unroll
             for (int pass = 0; pass < BM / R; ++pass) {
-                if (epi.general) {
-                    constexpr bool GEN = true;
-                    if (R == 64) { if (wm == pass) { SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3); } }
-                    else if (wm == pass / 2) { if (pass & 1) { SS_EPS_ROW(2); SS_EPS_ROW(3); } else { SS_EPS_ROW(0); SS_EPS_ROW(1); } }
-                } else {
-                    constexpr bool GEN = false;
-                    if (R == 64) { if (wm == pass) { SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3); } }
-                    else if (wm == pass / 2) { if (pass & 1) { SS_EPS_ROW(2); SS_EPS_ROW(3); } else { SS_EPS_ROW(0); SS_EPS_ROW(1); } }
-                }
+#define SS_EPS_PASS                                                                                                                  \
+                if (R == 64) { if (wm == pass) { SS_EPS_ROW(0); SS_EPS_ROW(1); SS_EPS_ROW(2); SS_EPS_ROW(3); } }                              \
+                else if (wm == pass / 2) { if (pass & 1) { SS_EPS_ROW(2); SS_EPS_ROW(3); } else { SS_EPS_ROW(0); SS_EPS_ROW(1); } }
+                if (epi.general == 1) { constexpr int GEN = 1; SS_EPS_PASS } else if (epi.general == 2) { constexpr int GEN = 2; SS_EPS_PASS } else { constexpr int GEN = 0; SS_EPS_PASS }
+#undef SS_EPS_PASS
                 barrier_keep_vm();
                 if (!(epi.debug & 1)) epilogue_flush<TO>(ct, LDC, C, epi, cm0 + pass * R, R, cn0, M, N, tid);
                 if (pass + 1 < BM / R) barrier_keep_vm();
@@ -731,8 +724,8 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
     {
         const int ev = dtype_out == SS_BF16 ? 8 : 4;
         const RowMap& cm = epi.cmap;
-        epi.general = epi.drop_thresh != 0 || epi.log_clamp > 0.f;
-        epi.fast = epi.mode != 2 && epi.col_mod == 0 && N % ev == 0 && cm.base % ev == 0 && cm.batch_stride % ev == 0 && cm.row_stride % ev == 0 &&
+        epi.general = epi.drop_thresh != 0 ? 1 : (epi.log_clamp > 0.f ? 2 : 0);
+        epi.fast = !(epi.drop_thresh != 0 && epi.log_clamp > 0.f) && epi.mode != 2 && epi.col_mod == 0 && N % ev == 0 && cm.base % ev == 0 && cm.batch_stride % ev == 0 && cm.row_stride % ev == 0 &&
                    ((uintptr_t)C) % 16 == 0 && (!epi.gate || ((uintptr_t)epi.gate) % 16 == 0);
         if (epi.c2) {
             const int pk = 4;      // rows per lane
