@@ -666,6 +666,8 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
         SS_LAUNCH_CHECK("ss_gemm(glds)");
         return 0;
     }
+    // (measured: a global_load_lds + XOR-swizzled ds_read_b64_tr_b16 variant of the OC x OC kernel is ~7 % SLOWER than the
+    //  register-staged, 288-byte-pitch one below -- the transpose read's banking is not fixed by address swizzles.)
 #define SS_GEMM_CASE(AM, BMD)                                                                                     \
     SS_LAUNCH(SS_KERNEL(gemm_kernel<T, TO, AM, BMD>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems)
     if (a_mode == OP_KC && b_mode == OP_KC) SS_GEMM_CASE(OP_KC, OP_KC);
