@@ -38,11 +38,21 @@ __device__ __forceinline__ void wave_lds_sync() {
 #endif
 }
 
+// XCD-aware block order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (each with a private L2).
+// The tiles of one (batch, head) re-read the same Q/K/V/dO rows, so consecutive logical ids are mapped onto ONE XCD
+// (bijective chunked remap) and their re-reads hit that XCD's L2 instead of HBM.
+__device__ __forceinline__ void attn_block_coord(int gx, int H, int& bx, int& h, int& b) {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    bx = id % gx; const int t = id / gx; h = t % H; b = t / H;
+}
+
 struct AttnP {
     const void* qkv; const void* qkvT; const void* E; const void* ET;
     void* out; float* lse;
     const void* dO; const void* dOT; const float* Dv; void* dqkv;
-    int B, H, T, Tp, dp, D, MPt;
+    int B, H, T, Tp, dp, D, MPt, gx;
     float scale;
     unsigned drop_thresh; float drop_scale; unsigned long long seed; unsigned stream;
 };
@@ -161,7 +171,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p)
 {
     __shared__ __attribute__((aligned(16))) T ptile[4][16][PT_LD];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = (blockIdx.x * 4 + w) * 16;
+    int bxi, h, b; attn_block_coord(p.gx, p.H, bxi, h, b);
+    const int q0 = (bxi * 4 + w) * 16;
     const int Tn = p.T, D = p.D, dp = p.dp, H = p.H;
     const long long ldq = 3LL * H * dp;
     const T* Q = (const T*)p.qkv + (long long)b * Tn * ldq + h * dp;
@@ -290,7 +301,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p)
 {
     SS_DYN_SMEM(smem_raw);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = (blockIdx.x * (blockDim.x >> 6) + w) * 16;
+    int bxi, h, b; attn_block_coord(p.gx, p.H, bxi, h, b);
+    const int q0 = (bxi * (blockDim.x >> 6) + w) * 16;
     const int Tn = p.T, D = p.D, dp = p.dp, H = p.H, MPt = p.MPt;
     const int ldb = MPt + 8;
     T* tileA = (T*)smem_raw + (long long)w * 16 * (PT_LD + ldb);      // [16][PT_LD]  dS by key
@@ -388,7 +400,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p)
     __shared__ __attribute__((aligned(16))) T tP[4][16][40];     // [key][32 queries (+pad)]  P~^T
     __shared__ __attribute__((aligned(16))) T tS[4][16][40];     //                           dS^T
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, k0 = (blockIdx.x * 4 + w) * 16;
+    int bxi, h, b; attn_block_coord(p.gx, p.H, bxi, h, b);
+    const int k0 = (bxi * 4 + w) * 16;
     const int Tn = p.T, D = p.D, dp = p.dp, H = p.H;
     const long long ldq = 3LL * H * dp;
     const T* Q = (const T*)p.qkv + (long long)b * Tn * ldq + h * dp;
@@ -516,7 +529,8 @@ extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const voi
     SS_CHECK(qkv && qkvT && E && out && lse, "ss_relpos_attention_forward: null pointer");
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
     p.qkv = qkv; p.qkvT = qkvT; p.E = E; p.out = out; p.lse = lse;
-    dim3 grid(((T + 15) / 16 + 3) / 4, H, B);
+    p.gx = ((T + 15) / 16 + 3) / 4;
+    dim3 grid(p.gx * H * B);
     SS_ATTN_DISPATCH(attn_fwd_kernel, grid, 256, 0);
     SS_LAUNCH_CHECK("ss_relpos_attention_forward");
     return 0;
@@ -535,12 +549,14 @@ extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const vo
         if (dtype == SS_BF16) SS_LAUNCH(attn_dsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dO, (const bf16_t*)out, Dscratch, B, H, T, dp);
         else SS_LAUNCH(attn_dsum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)dO, (const float*)out, Dscratch, B, H, T, dp);
     }
-    dim3 grid(((T + 15) / 16 + 3) / 4, H, B);
     const size_t esz = dtype == SS_BF16 ? 2 : 4;
     const int nwq = dtype == SS_BF16 ? 4 : 2;                         // keep the dynamic LDS request under 64 KiB
     const size_t smem_q = (size_t)nwq * 16 * (size_t)(PT_LD + p.MPt + 8) * esz;
-    dim3 gridq(((T + 15) / 16 + nwq - 1) / nwq, H, B);
+    p.gx = ((T + 15) / 16 + nwq - 1) / nwq;
+    dim3 gridq(p.gx * H * B);
     SS_ATTN_DISPATCH(attn_bwd_q_kernel, gridq, nwq * 64, smem_q);
+    p.gx = ((T + 15) / 16 + 3) / 4;
+    dim3 grid(p.gx * H * B);
     SS_ATTN_DISPATCH(attn_bwd_kv_kernel, grid, 256, 0);
     SS_LAUNCH_CHECK("ss_relpos_attention_backward");
     return 0;
