@@ -188,7 +188,21 @@ def main():
             d = summ[key]
             peak = PEAK_BF16_TFLOPS if 'bfloat16' in key[0] else PEAK_F32_TFLOPS
             ach = d['flops'] / d['seconds'] / 1e12
-            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+            traffic, traffic_src = None, None
+            try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py)
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+                ctype = {'torch.bfloat16': 'unsigned short', 'torch.float32': 'float'}
+                names = ['gemm_glds_kernel<%s, %s>' % (ctype[key[0]], ctype[key[1]])] if key[2] == 0 and key[3] == 0 else []
+                names.append('gemm_kernel<%s, %s, %d, %d>' % (ctype[key[0]], ctype[key[1]], key[2], key[3]))
+                for nm in names:
+                    hit = [v for k, v in pmc.items() if nm in k]
+                    if hit:
+                        traffic, traffic_src = hit[0]['hbm_bytes_per_launch'], 'profiles/r01_pmc_traffic.json: ' + nm
+                        break
+            except Exception:
+                pass
+            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
+                               'traffic_source': traffic_src,
                                'kernel': 'gemm_kernel<%s,%s,a_mode=%d,b_mode=%d>' % key, 'launches_per_step': d['launches'] / args.steps,
                                'avg_launch_us': d['seconds'] / d['launches'] * 1e6, 'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                                'all_gemm_variants': {str(k): {'tflops': v['flops'] / v['seconds'] / 1e12, 'ms_per_step': v['seconds'] / args.steps * 1e3,
