@@ -49,9 +49,9 @@ typedef struct ss_gemm_epilogue {
     float gate_scale;
     float alpha;            /* scale applied to the accumulator first                                 */
     int32_t relu;           /* F.relu  (architecture.py:32; transformer.py:57)                        */
-    float dropout_p;        /* nn.Dropout in training mode (transformer.py:57), Philox4x32-10         */
+    float dropout_p;        /* nn.Dropout in training mode (transformer.py:57); counter-based hash RNG  */
     uint64_t seed;
-    uint32_t rng_stream;    /* dropout site id; element index = row*N + col                           */
+    uint32_t rng_stream;    /* dropout site id; 4 consecutive rows of one column share one RNG draw group */
     int32_t mode;           /* 0 store, 1 C += v, 2 atomicAdd(C, v) (f32 out; required for split_k>1) */
     int32_t col_mod, col_mul, col_div_mul; /* optional output column permutation
                                col -> (col % col_mod)*col_mul + (col / col_mod)*col_div_mul           */
@@ -75,6 +75,10 @@ typedef struct ss_gemm_epilogue {
 int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, const void* B, void* C,
             int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap,
             const ss_gemm_epilogue* epilogue, int split_k, void* stream);
+
+/* Persistent-grid size of ss_gemm for the calling thread: 2 (default) or 1 workgroup per CU.  The weight-gradient GEMMs that
+ * run on a side stream use 1 so that the dependent chain on the main stream can co-reside on every CU.  Returns the old value. */
+int ss_gemm_set_blocks_per_cu(int n); /* [host] */
 
 /* out[a][b][c] (contiguous, dims d0 x d1 x d2) (+)= scale * in[a*s0 + b*s1 + c*s2] for b < valid1 and
  * c < valid2, else 0 (zero padding).  Converts between the reference's parameter layouts (state_dict:

@@ -633,6 +633,9 @@ static RowMap to_rowmap(const ss_rowmap* m) {
 }
 
 // resident block slots: 2 blocks (64 KiB LDS, <=256 registers) per CU
+static thread_local int g_blocks_per_cu = 2;
+extern "C" int ss_gemm_set_blocks_per_cu(int n) { int old = g_blocks_per_cu; if (n >= 1 && n <= 2) g_blocks_per_cu = n; return old; }
+
 static int gemm_slots() {
 #if defined(SS_EMU)
     return 3;            // tiny on purpose: the emulator tests exercise the multi-item path of the persistent loop
@@ -641,9 +644,9 @@ static int gemm_slots() {
     if (!slots) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        slots = 2 * cus;
+        slots = cus;
     }
-    return slots;
+    return slots * g_blocks_per_cu;
 #endif
 }
 

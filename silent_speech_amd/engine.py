@@ -255,6 +255,7 @@ class _SideStream(object):
     def __init__(self, model, dev):
         self.enabled = dev.type == 'cuda' and os.environ.get('SS_AMD_SIDE_STREAM', '1') != '0'
         self.keep = []
+        self.blocks_per_cu = int(os.environ.get('SS_AMD_SIDE_BLOCKS', '2'))
         if self.enabled:
             st = getattr(model, '_side_stream', None)
             if st is None or st.device != dev:
@@ -269,8 +270,13 @@ class _SideStream(object):
         ev = torch.cuda.Event()
         ev.record()
         self.stream.wait_event(ev)
-        with torch.cuda.stream(self.stream):
-            fn()
+        from . import _lib
+        old = _lib.lib().ss_gemm_set_blocks_per_cu(self.blocks_per_cu)     # leave room on every CU for the main-stream kernels
+        try:
+            with torch.cuda.stream(self.stream):
+                fn()
+        finally:
+            _lib.lib().ss_gemm_set_blocks_per_cu(old)
         self.keep.extend(keep)
 
     def join(self):
