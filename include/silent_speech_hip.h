@@ -89,6 +89,13 @@ int ss_permute3d(const void* in, int in_dtype, void* out, int out_dtype, int d0,
                  int64_t s0, int64_t s1, int64_t s2, int valid1, int valid2, float scale, int accumulate,
                  void* stream);
 
+/* The same for a whole table of jobs in one launch (per-step weight re-layout, gradient un-layout).
+ * jobs_dev: device array of
+ *   struct { const void* in; void* out; int64 s0,s1,s2 (input strides), o0,o1 (output strides of dims 0,1; dim 2 contiguous);
+ *            int32 d0,d1,d2, valid1,valid2, in_dtype,out_dtype, accumulate; float scale; int32 first_block, nblocks, pad; }
+ * job_of_block_dev[b] = job index of workgroup b (workgroups first_block .. first_block+nblocks-1 grid-stride over the job). */
+int ss_permute3d_batch(const void* jobs_dev, const int32_t* job_of_block_dev, int total_blocks, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * DTW alignment (align.py:5-14 time_warp + align.py:16-34 align_from_distances; call site
  * transduction_model.py:126,131 and :88).  Batched: one workgroup per matrix.

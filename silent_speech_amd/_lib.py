@@ -30,6 +30,14 @@ class GemmEpilogue(ctypes.Structure):
                 ('log_clamp', ctypes.c_float), ('c2', ctypes.c_void_p), ('cmap2', RowMap), ('col_stride2', ctypes.c_int64)]
 
 
+class PermuteJob(ctypes.Structure):
+    _fields_ = [('inp', ctypes.c_void_p), ('out', ctypes.c_void_p), ('s0', ctypes.c_int64), ('s1', ctypes.c_int64), ('s2', ctypes.c_int64),
+                ('o0', ctypes.c_int64), ('o1', ctypes.c_int64), ('d0', ctypes.c_int32), ('d1', ctypes.c_int32), ('d2', ctypes.c_int32),
+                ('valid1', ctypes.c_int32), ('valid2', ctypes.c_int32), ('in_dtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32),
+                ('accumulate', ctypes.c_int32), ('scale', ctypes.c_float), ('first_block', ctypes.c_int32), ('nblocks', ctypes.c_int32),
+                ('pad_', ctypes.c_int32)]
+
+
 _P, _I, _F, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 _U64, _U32 = ctypes.c_uint64, ctypes.c_uint32
 
@@ -38,6 +46,7 @@ SIGNATURES = {
     'ss_gemm': [_I, _I, _I, _I, _P, _P, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap),
                 ctypes.POINTER(RowMap), ctypes.POINTER(GemmEpilogue), _I, _P],
     'ss_permute3d': [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _I, _P],
+    'ss_permute3d_batch': [_P, _P, _I, _P],
     'ss_dtw_align': [_P, _P, _I, _I, _I, _P, _P, _P],
     'ss_dtw_align_skewed': [_P, _I, _P, _P, _P],
     'ss_relpos_attention_forward': [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],

@@ -114,7 +114,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float n, int 
     }
 }
 
-static int red_chunks(int rows) { int c = (rows + 63) / 64; if (c > 1024) c = 1024; if (c < 1) c = 1; return c; }
+static int red_chunks(int rows) { int c = (rows + 63) / 64; if (c > 512) c = 512; if (c < 1) c = 1; return c; }
 
 extern "C" int64_t ss_bn_scratch_floats(int B, int T, int C) { return (int64_t)red_chunks(B * T) * 4 * C + 8 * (int64_t)C; }
 
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     out[c] += t[0];
 }
 
-static int colsum_chunks(int rows) { int c = (rows + 31) / 32; if (c > 2048) c = 2048; if (c < 1) c = 1; return c; }
+static int colsum_chunks(int rows) { int c = (rows + 63) / 64; if (c > 512) c = 512; if (c < 1) c = 1; return c; }
 extern "C" int64_t ss_colsum_scratch_floats(int rows, int C) { return (int64_t)colsum_chunks(rows) * C; }
 
 extern "C" int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, float* scratch, float* out_accum, void* stream)

@@ -58,3 +58,46 @@ extern "C" int ss_permute3d(const void* in, int in_dtype, void* out, int out_dty
     SS_LAUNCH_CHECK("ss_permute3d");
     return 0;
 }
+
+// ---------------------------------------------------------------- ss_permute3d_batch
+// Many ss_permute3d jobs in ONE launch (the per-step weight re-layout / gradient un-layout is ~130 small tensors).
+struct PermuteJob {       // mirrored by ctypes in silent_speech_amd/_lib.py
+    const void* in; void* out;
+    long long s0, s1, s2, o0, o1;        // input strides; output element (a,b,c) lives at a*o0 + b*o1 + c
+    int d0, d1, d2, valid1, valid2, in_dtype, out_dtype, accumulate;
+    float scale; int first_block, nblocks, pad_;
+};
+
+template <class TI, class TO>
+__device__ __forceinline__ void permute_job(const PermuteJob& j, int lb, int nthreads, int tid)
+{
+    const long long total = (long long)j.d0 * j.d1 * j.d2;
+    const TI* in = (const TI*)j.in; TO* out = (TO*)j.out;
+    for (long long i = (long long)lb * nthreads + tid; i < total; i += (long long)j.nblocks * nthreads) {
+        const int c = (int)(i % j.d2); const long long t = i / j.d2; const int b = (int)(t % j.d1); const int a = (int)(t / j.d1);
+        float v = (b < j.valid1 && c < j.valid2) ? ldf(in + a * j.s0 + b * j.s1 + c * j.s2) * j.scale : 0.f;
+        TO* o = out + a * j.o0 + b * j.o1 + c;
+        if (j.accumulate) v += ldf(o);
+        stf(o, v);
+    }
+}
+
+__global__ void permute3d_batch_kernel(const PermuteJob* __restrict__ jobs, const int* __restrict__ job_of_block)
+{
+    const PermuteJob j = jobs[job_of_block[blockIdx.x]];
+    const int lb = blockIdx.x - j.first_block;
+    if (j.in_dtype == SS_F32 && j.out_dtype == SS_F32) permute_job<float, float>(j, lb, blockDim.x, threadIdx.x);
+    else if (j.in_dtype == SS_F32) permute_job<float, bf16_t>(j, lb, blockDim.x, threadIdx.x);
+    else if (j.out_dtype == SS_F32) permute_job<bf16_t, float>(j, lb, blockDim.x, threadIdx.x);
+    else permute_job<bf16_t, bf16_t>(j, lb, blockDim.x, threadIdx.x);
+}
+
+extern "C" int ss_permute3d_batch(const void* jobs_dev, const int32_t* job_of_block_dev, int total_blocks, void* stream)
+{
+    SS_CHECK(total_blocks >= 0, "ss_permute3d_batch: negative block count");
+    if (total_blocks == 0) return 0;
+    SS_CHECK(jobs_dev && job_of_block_dev, "ss_permute3d_batch: null pointer");
+    SS_LAUNCH(permute3d_batch_kernel, dim3(total_blocks), dim3(256), 0, stream, (const PermuteJob*)jobs_dev, (const int*)job_of_block_dev);
+    SS_LAUNCH_CHECK("ss_permute3d_batch");
+    return 0;
+}

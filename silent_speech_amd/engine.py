@@ -33,90 +33,107 @@ def _split_k(M, N, K):
 
 
 class Prepared(object):
-    """GEMM-ready copies of the parameters in the compute dtype (bf16 or f32): layout changes for the
-    conv / attention tensors, plain casts for the nn.Linear ones.  Rebuilt when the parameters change."""
+    """GEMM-ready copies of the parameters in the compute dtype (bf16 or f32): layout changes for the conv / attention
+    tensors, casts and transposed copies (so that dX = dY.W is K-contiguous as well) for the nn.Linear ones.
+    The buffers are persistent; after every optimiser step they are refreshed by TWO batched launches
+    (ss_permute3d_batch): stage 1 reads the parameter arena, stage 2 derives transposes from stage-1 outputs."""
 
     def __init__(self, model):
-        self.sig = None
         self.build(model)
 
     @staticmethod
-    def signature(model):
-        return (model._weights_version, tuple(p._version for p in model.parameters()), model.compute_dtype)
+    def layout_signature(model):
+        return (tuple(p.data_ptr() for p in model.parameters()), model.compute_dtype, str(model.w_out.weight.device))
+
+    @staticmethod
+    def version_signature(model):
+        return (model._weights_version, tuple(p._version for p in model.parameters()))
 
     def build(self, model):
         dt, dev = model.compute_dtype, model.w_out.weight.device
         d = model.d_model
+        b1, b2 = ops.PermuteBatch(), ops.PermuteBatch()
+        self.b1, self.b2, self.dev = b1, b2, dev
+
+        def new(*shape, dtype=dt, zero=False):
+            return (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=dev)
+
+        def cast(w):                 # plain [N][K] weight in the compute dtype
+            w = w.detach()
+            if dt == torch.float32:
+                return w
+            return b1.add(w, new(*w.shape), (1, w.shape[0], w.shape[1]), (0, w.shape[1], 1))
+
+        def transposed(src, n, k):   # [n][k] -> [k][n]
+            return b2.add(src, new(k, n), (k, 1, n), (1, 0, k))
+
         self.blocks = []
         for blk in model.conv_blocks:
             O, I, _ = blk.conv1.weight.shape
             e = {}
             w1, w2 = blk.conv1.weight.detach(), blk.conv2.weight.detach()
-            e['w1f'] = ops.permute3d(w1, torch.empty(O, 3 * I, dtype=dt, device=dev), (O, 3, I), (3 * I, 1, 3))
-            e['w2f'] = ops.permute3d(w2, torch.empty(O, 3 * O, dtype=dt, device=dev), (O, 3, O), (3 * O, 1, 3))
-            e['wr'] = ops.permute3d(blk.residual_path.weight.detach(), torch.empty(O, I, dtype=dt, device=dev), (O, 1, I), (I, 0, 1))
-            e['wrT'] = ops.permute3d(e['wr'], torch.empty(I, O, dtype=dt, device=dev), (I, 1, O), (1, 0, I))
+            e['w1f'] = b1.add(w1, new(O, 3 * I), (O, 3, I), (3 * I, 1, 3))
+            e['w2f'] = b1.add(w2, new(O, 3 * O), (O, 3, O), (3 * O, 1, 3))
+            e['wr'] = b1.add(blk.residual_path.weight.detach(), new(O, I), (O, 1, I), (I, 0, 1))
+            e['wrT'] = transposed(e['wr'], O, I)
             # input-gradient forms (flipped taps):  conv2 (stride 1)  Wb[i][j*O+o] = W[o][i][2-j]
-            e['w2b'] = ops.permute3d(w2.view(-1)[2:], torch.empty(O, 3 * O, dtype=dt, device=dev), (O, 3, O), (3, -1, 3 * O))
-            if I % 8 == 0:   # stride-2 conv1: even rows use tap 1, odd rows taps (2, 0); block 0 has no input gradient
-                e['w1b_even'] = ops.permute3d(w1.view(-1)[1:], torch.empty(I, O, dtype=dt, device=dev), (I, 1, O), (3, 0, 3 * I))
-                e['w1b_odd'] = ops.permute3d(w1.view(-1)[2:], torch.empty(I, 2 * O, dtype=dt, device=dev), (I, 2, O), (3, -2, 3 * I))
+            e['w2b'] = b1.add(w2.view(-1)[2:], new(O, 3 * O), (O, 3, O), (3, -1, 3 * O))
+            if I % 8 == 0:   # stride-2 conv1: even rows use tap 1, odd rows taps (2, 0)
+                e['w1b_even'] = b1.add(w1.view(-1)[1:], new(I, O), (I, 1, O), (3, 0, 3 * I))
+                e['w1b_odd'] = b1.add(w1.view(-1)[2:], new(I, 2 * O), (I, 2, O), (3, -2, 3 * I))
             self.blocks.append(e)
 
-        def cast(w):
-            if dt == torch.float32:
-                return w.detach()
-            out = torch.empty(w.shape, dtype=dt, device=dev)
-            ops.cast_f32(w.detach(), out, w.numel())
-            return out
-
-        def castT(w):     # [N][K] -> [K][N]: lets every input-gradient GEMM (dX = dY . W) run in the fast KC x KC form
-            n, k = w.shape
-            return ops.permute3d(w.detach(), torch.empty(k, n, dtype=dt, device=dev), (k, 1, n), (1, 0, k))
-
         self.w_raw_in = cast(model.w_raw_in.weight)
-        self.w_raw_in_T = castT(model.w_raw_in.weight)
+        self.w_raw_in_T = transposed(self.w_raw_in, d, d)
         H, dh, dp, D = model.n_head, model.d_qkv, model.dp, model.max_rel
         MPt = _round_up(2 * D - 1, 32)
         self.layers = []
         for layer in model.transformer.layers:
             a = layer.self_attn
             e = {}
-            wqkv = torch.empty(3, H, dp, d, dtype=dt, device=dev)
+            wqkv = new(3, H, dp, d)
             for i, w in enumerate((a.w_q, a.w_k, a.w_v)):       # (H, d, dh) -> [h][a (padded)][f]
-                ops.permute3d(w.detach(), wqkv[i], (H, dp, d), (d * dh, 1, dh), valid1=dh)
+                b1.add(w.detach(), wqkv[i], (H, dp, d), (d * dh, 1, dh), valid1=dh)
             e['wqkv'] = wqkv.view(3 * H * dp, d)
-            e['wqkvT'] = ops.permute3d(e['wqkv'], torch.empty(d, 3 * H * dp, dtype=dt, device=dev), (d, 1, 3 * H * dp), (1, 0, d))
-            e['wo'] = ops.permute3d(a.w_o.detach(), torch.empty(d, H * dp, dtype=dt, device=dev), (d, H, dp), (1, dh * d, d), valid2=dh)
-            e['woT'] = ops.permute3d(e['wo'], torch.empty(H * dp, d, dtype=dt, device=dev), (H * dp, 1, d), (1, 0, H * dp))
+            e['wqkvT'] = transposed(e['wqkv'], 3 * H * dp, d)
+            e['wo'] = b1.add(a.w_o.detach(), new(d, H * dp), (d, H, dp), (1, dh * d, d), valid2=dh)
+            e['woT'] = transposed(e['wo'], d, H * dp)
             emb = a.relative_positional.embeddings.detach()    # (H, 2D-1, dh, 1)
-            e['E'] = ops.permute3d(emb, torch.empty(H, 2 * D - 1, dp, dtype=dt, device=dev), (H, 2 * D - 1, dp), ((2 * D - 1) * dh, dh, 1), valid2=dh)
-            e['ET'] = ops.permute3d(emb, torch.empty(H, dp, MPt, dtype=dt, device=dev), (H, dp, MPt), ((2 * D - 1) * dh, 1, dh), valid1=dh, valid2=2 * D - 1)
+            e['E'] = b1.add(emb, new(H, 2 * D - 1, dp), (H, 2 * D - 1, dp), ((2 * D - 1) * dh, dh, 1), valid2=dh)
+            e['ET'] = b1.add(emb, new(H, dp, MPt), (H, dp, MPt), ((2 * D - 1) * dh, 1, dh), valid1=dh, valid2=2 * D - 1)
             e['w1'] = cast(layer.linear1.weight)
             e['w2'] = cast(layer.linear2.weight)
-            e['w1T'] = castT(layer.linear1.weight)
-            e['w2T'] = castT(layer.linear2.weight)
+            e['w1T'] = transposed(e['w1'], layer.linear1.weight.shape[0], d)
+            e['w2T'] = transposed(e['w2'], d, layer.linear2.weight.shape[1])
             self.layers.append(e)
         n_out = model.w_out.weight.shape[0]
         n_aux = model.w_aux.weight.shape[0] if model.has_aux_out else 0
         nh = _round_up(n_out + n_aux, 8)
-        wh = torch.zeros(nh, d, dtype=dt, device=dev)
-        bh = torch.zeros(nh, dtype=torch.float32, device=dev)
-        ops.cast_f32(model.w_out.weight.detach(), wh[:n_out], n_out * d)
-        bh[:n_out] = model.w_out.bias.detach()
+        wh = new(nh, d, zero=True)
+        bh = new(nh, dtype=torch.float32, zero=True)
+        b1.add(model.w_out.weight.detach(), wh[:n_out], (1, n_out, d), (0, d, 1))
+        b1.add(model.w_out.bias.detach(), bh[:n_out], (1, 1, n_out), (0, 0, 1))
         if n_aux:
-            ops.cast_f32(model.w_aux.weight.detach(), wh[n_out:n_out + n_aux], n_aux * d)
-            bh[n_out:n_out + n_aux] = model.w_aux.bias.detach()
+            b1.add(model.w_aux.weight.detach(), wh[n_out:n_out + n_aux], (1, n_aux, d), (0, d, 1))
+            b1.add(model.w_aux.bias.detach(), bh[n_out:n_out + n_aux], (1, 1, n_aux), (0, 0, 1))
         self.w_head, self.b_head, self.n_head_cols = wh, bh, nh
-        self.w_head_T = ops.permute3d(wh, torch.empty(d, nh, dtype=dt, device=dev), (d, 1, nh), (1, 0, d))
-        self.sig = self.signature(model)
+        self.w_head_T = transposed(wh, nh, d)
+        self.layout_sig = self.layout_signature(model)
+        self.refresh(model)
+
+    def refresh(self, model):
+        self.b1.run(self.dev)
+        self.b2.run(self.dev)
+        self.version_sig = self.version_signature(model)
 
 
 def prepared(model):
     pr = getattr(model, '_prepared', None)
-    if pr is None or pr.sig != Prepared.signature(model):
+    if pr is None or pr.layout_sig != Prepared.layout_signature(model):
         pr = Prepared(model)
         model._prepared = pr
+    elif pr.version_sig != Prepared.version_signature(model):
+        pr.refresh(model)
     return pr
 
 
@@ -246,6 +263,61 @@ def _grad(p):
     return p.grad
 
 
+class GradUnpack(object):
+    """f32 staging buffers for the weight gradients whose GEMM layout differs from the parameter layout (conv (O,I,k),
+    per-head attention projections, fused heads) + ONE batched launch that accumulates them into the .grad arena."""
+
+    def __init__(self, model, dev):
+        d, H, dh, dp = model.d_model, model.n_head, model.d_qkv, model.dp
+        pr = prepared(model)
+        nh = pr.n_head_cols
+        sizes = [('head_w', nh * d), ('head_b', nh)]
+        for l in range(len(model.transformer.layers)):
+            sizes += [('wo%d' % l, d * H * dp), ('wqkv%d' % l, 3 * H * dp * d)]
+        for i, blk in enumerate(model.conv_blocks):
+            O, I, _ = blk.conv1.weight.shape
+            sizes += [('c2_%d' % i, O * 3 * O), ('c1_%d' % i, O * 3 * I)]
+        total = sum((n + 3) // 4 * 4 for _, n in sizes)
+        self.arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.buf, off = {}, 0
+        for k, n in sizes:
+            self.buf[k] = self.arena[off:off + n]
+            off += (n + 3) // 4 * 4
+        ub = ops.PermuteBatch()
+        n_out = model.w_out.weight.shape[0]
+        n_aux = model.w_aux.weight.shape[0] if model.has_aux_out else 0
+        hw, hb = self.buf['head_w'].view(nh, d), self.buf['head_b']
+        ub.add(hw[:n_out], model.w_out.weight.grad, (1, n_out, d), (0, d, 1), accumulate=True)
+        ub.add(hb[:n_out], model.w_out.bias.grad, (1, 1, n_out), (0, 0, 1), accumulate=True)
+        if n_aux:
+            ub.add(hw[n_out:n_out + n_aux], model.w_aux.weight.grad, (1, n_aux, d), (0, d, 1), accumulate=True)
+            ub.add(hb[n_out:n_out + n_aux], model.w_aux.bias.grad, (1, 1, n_aux), (0, 0, 1), accumulate=True)
+        for l, layer in enumerate(model.transformer.layers):
+            a = layer.self_attn
+            ub.add(self.buf['wo%d' % l], a.w_o.grad, (H, dh, d), (dp, 1, H * dp), accumulate=True)
+            for i, wp in enumerate((a.w_q, a.w_k, a.w_v)):
+                ub.add(self.buf['wqkv%d' % l][i * H * dp * d:], wp.grad, (H, d, dh), (dp * d, 1, d), accumulate=True)
+        for i, blk in enumerate(model.conv_blocks):
+            O, I, _ = blk.conv1.weight.shape
+            ub.add(self.buf['c2_%d' % i], blk.conv2.weight.grad, (O, O, 3), (3 * O, 1, O), accumulate=True)
+            ub.add(self.buf['c1_%d' % i], blk.conv1.weight.grad, (O, I, 3), (3 * I, 1, I), accumulate=True)
+        self.batch = ub
+        self.sig = self.signature(model)
+
+    @staticmethod
+    def signature(model):
+        return (model._gflat.data_ptr() if getattr(model, '_gflat', None) is not None else 0,
+                tuple(p.grad.data_ptr() for p in model.optimized_parameters()), str(model.w_out.weight.device))
+
+
+def grad_unpack(model, dev):
+    gu = getattr(model, '_grad_unpack', None)
+    if gu is None or gu.sig != GradUnpack.signature(model):
+        gu = GradUnpack(model, dev)
+        model._grad_unpack = gu
+    return gu
+
+
 class _SideStream(object):
     """Weight-gradient GEMMs (dW = dY^T X), bias column sums and gradient re-layouts do not feed the backward chain,
     so they run on a second HIP stream: their workgroups fill the CUs that the dependent chain (dX GEMMs, attention,
@@ -313,15 +385,12 @@ def backward(model, ctx, dhead):
     side = _SideStream(model, dev)
     for p_ in model.optimized_parameters():
         _grad(p_)
+    gu = grad_unpack(model, dev)
+    gu.arena.zero_()                 # staging buffers of the re-laid-out weight gradients (one memset, main stream)
 
     def head_grads():
-        tmp_w = torch.zeros(nh, d, dtype=torch.float32, device=dev)
-        tmp_b = torch.zeros(nh, dtype=torch.float32, device=dev)
-        _dw_direct(dh_t, ctx.x_final, tmp_w, nh, d, M, RM(nh), RM(d))
-        ops.colsum(dh_t, M, nh, nh, tmp_b)
-        model.w_out.weight.grad.add_(tmp_w[:n_out]); model.w_out.bias.grad.add_(tmp_b[:n_out])
-        if n_aux:
-            model.w_aux.weight.grad.add_(tmp_w[n_out:n_out + n_aux]); model.w_aux.bias.grad.add_(tmp_b[n_out:n_out + n_aux])
+        _dw_direct(dh_t, ctx.x_final, gu.buf['head_w'], nh, d, M, RM(nh), RM(d))
+        ops.colsum(dh_t, M, nh, nh, gu.buf['head_b'])
     side.run(head_grads, dh_t, dhead)
     G = torch.empty(M, d, dtype=dt, device=dev)
     ops.gemm(dh_t, pr.w_head_T, G, M, d, nh, RM(nh), RM(nh), RM(d))
@@ -351,10 +420,8 @@ def backward(model, ctx, dhead):
         ops.layernorm_backward(G, s.z1, s.mean1, s.rstd1, layer.norm1.weight.detach(), G, dA, _grad(layer.norm1.weight), _grad(layer.norm1.bias),
                                M, d, p=p_drop, seed=seed, rng_stream=4 * l + 1)
         # output projection  out[t,b,f] = sum_{h,a} o[b,h,t,a] w_o[h,a,f]   (transformer.py:111)
-        def wo_grads(dA=dA, s=s, a=a):
-            tmp = torch.zeros(d, H * dp, dtype=torch.float32, device=dev)
-            _dw_direct(dA, s.o, tmp, d, H * dp, M, RM(d), RM(H * dp))
-            ops.permute3d(tmp, a.w_o.grad, (H, dh, d), (dp, 1, H * dp), accumulate=True)
+        def wo_grads(dA=dA, s=s, l=l):
+            _dw_direct(dA, s.o, gu.buf['wo%d' % l], d, H * dp, M, RM(d), RM(H * dp))
         side.run(wo_grads, dA)
         dO = torch.empty(M, H * dp, dtype=dt, device=dev)
         dOT = torch.empty(B, H * dp, Tp, dtype=dt, device=dev)
@@ -364,11 +431,8 @@ def backward(model, ctx, dhead):
         dsc = torch.empty(B, H, T, dtype=torch.float32, device=dev)
         ops.relpos_attention_backward(s.qkv, s.qkvT, w['E'], w['ET'], s.o, s.lse, dO, dOT, dsc, dqkv, B, H, T, Tp, dp, D, ctx.scale,
                                       p=p_drop, seed=seed, rng_stream=4 * l)
-        def wqkv_grads(dqkv=dqkv, s=s, a=a):
-            tmp = torch.zeros(3 * H * dp, d, dtype=torch.float32, device=dev)
-            _dw_direct(dqkv, s.x, tmp, 3 * H * dp, d, M, RM(3 * H * dp), RM(d))
-            for i, wp in enumerate((a.w_q, a.w_k, a.w_v)):
-                ops.permute3d(tmp[i * H * dp:], wp.grad, (H, d, dh), (dp * d, 1, d), accumulate=True)
+        def wqkv_grads(dqkv=dqkv, s=s, l=l):
+            _dw_direct(dqkv, s.x, gu.buf['wqkv%d' % l], 3 * H * dp, d, M, RM(3 * H * dp), RM(d))
         side.run(wqkv_grads, dqkv)
         ops.gemm(dqkv, w['wqkvT'], G, M, d, 3 * H * dp, RM(3 * H * dp), RM(3 * H * dp), RM(d), mode=1)
         del dqkv, dO, dOT, dA, dF
@@ -394,11 +458,10 @@ def backward(model, ctx, dhead):
                         xb=s.cr, pad_xb=0, sb=s.str_, dxb=dcr, pad_dxb=0, dgamma_b=_grad(blk.res_norm.weight), dbeta_b=_grad(blk.res_norm.bias),
                         reduce_fn=bn_reduce)
         # conv2 (k3, stride 1): weight, bias, input gradients
-        def conv2_grads(dc2=dc2, s=s, blk=blk, O=O, Tout=Tout, pbs=pbs, rows=rows):
-            tmp = torch.zeros(O, 3 * O, dtype=torch.float32, device=dev)
+        def conv2_grads(dc2=dc2, s=s, blk=blk, O=O, Tout=Tout, pbs=pbs, rows=rows, i=i):
+            tmp = gu.buf['c2_%d' % i]
             ops.gemm(dc2, s.h1, tmp, O, 3 * O, rows, RM(O, Tout, pbs, base=O), RM(O, Tout, pbs), RM(3 * O), a_mode=OP_OC, b_mode=OP_OC, mode=2,
                      split_k=_split_k(O, 3 * O, rows))
-            ops.permute3d(tmp, blk.conv2.weight.grad, (O, O, 3), (3 * O, 1, O), accumulate=True)
         side.run(conv2_grads, dc2)
         # d/d(bias) of a conv feeding training-mode BatchNorm is identically 0 (BN removes the mean): nothing to add
         dh1 = torch.empty(rows, O, dtype=dt, device=dev)
@@ -409,11 +472,10 @@ def backward(model, ctx, dhead):
         del dh1, dc2
         # conv1 (k3, stride 2) and the 1x1 stride-2 residual path
         in_bs = (Tin + 2) * Cin
-        def conv1_grads(dc1=dc1, dcr=dcr, s=s, blk=blk, O=O, Cin=Cin, Tout=Tout, pbs=pbs, rows=rows, in_bs=in_bs):
-            tmp = torch.zeros(O, 3 * Cin, dtype=torch.float32, device=dev)
+        def conv1_grads(dc1=dc1, dcr=dcr, s=s, blk=blk, O=O, Cin=Cin, Tout=Tout, pbs=pbs, rows=rows, in_bs=in_bs, i=i):
+            tmp = gu.buf['c1_%d' % i]
             ops.gemm(dc1, s.xin, tmp, O, 3 * Cin, rows, RM(O, Tout, pbs, base=O), RM(2 * Cin, Tout, in_bs), RM(3 * Cin), a_mode=OP_OC, b_mode=OP_OC,
                      mode=2, split_k=_split_k(O, 3 * Cin, rows))
-            ops.permute3d(tmp, blk.conv1.weight.grad, (O, Cin, 3), (3 * Cin, 1, Cin), accumulate=True)
             ops.gemm(dcr, s.xin, blk.residual_path.weight.grad, O, Cin, rows, RM(O), RM(2 * Cin, Tout, in_bs, base=Cin), RM(Cin), a_mode=OP_OC,
                      b_mode=OP_OC, mode=2, split_k=_split_k(O, Cin, rows))
         side.run(conv1_grads, dc1, dcr)
@@ -426,4 +488,5 @@ def backward(model, ctx, dhead):
             ops.gemm(dc1, w['w1b_odd'], dx, rows, Cin, 2 * O, RM(O, Tout, pbs, base=O), RM(2 * O), out_odd)
             dy = dx
         del dc1, dcr
+    side.run(lambda: gu.batch.run(dev))       # all re-laid-out weight gradients -> .grad arena, one launch
     side.join()

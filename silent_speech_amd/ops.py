@@ -213,3 +213,50 @@ def relpos_attention_backward(qkv, qkvT, E, ET, out, lse, dO, dOT, dscratch, dqk
     rc = _L().ss_relpos_attention_backward(_dt(qkv), _p(qkv), _p(qkvT), _p(E), _p(ET), _p(out), _p(lse), _p(dO), _p(dOT), _p(dscratch),
                                            _p(dqkv), B, H, T, Tp, dp, D, scale, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
     _lib.check(rc, 'ss_relpos_attention_backward')
+
+
+class PermuteBatch(object):
+    """A table of ss_permute3d jobs executed by ONE kernel launch.  Tensors are referenced by address: they must stay
+    alive and in place while the batch is in use (parameter arenas / persistent prepared buffers do)."""
+
+    def __init__(self):
+        self.jobs, self.keep, self._dev = [], [], None
+
+    def add(self, inp, out, dims, strides, valid1=None, valid2=None, scale=1.0, accumulate=False, out_strides=None):
+        d0, d1, d2 = dims
+        if out_strides is None:
+            assert out.is_contiguous() and out.numel() >= d0 * d1 * d2
+            out_strides = (d1 * d2, d2)
+        j = _lib.PermuteJob()
+        j.inp, j.out = _p(inp).value, _p(out).value
+        j.s0, j.s1, j.s2 = [int(x) for x in strides]
+        j.o0, j.o1 = int(out_strides[0]), int(out_strides[1])
+        j.d0, j.d1, j.d2 = d0, d1, d2
+        j.valid1 = d1 if valid1 is None else valid1
+        j.valid2 = d2 if valid2 is None else valid2
+        j.in_dtype, j.out_dtype, j.accumulate, j.scale = _dt(inp), _dt(out), int(accumulate), float(scale)
+        total = d0 * d1 * d2
+        j.nblocks = max(1, min(64, (total + 2047) // 2048))
+        self.jobs.append(j)
+        self.keep.append((inp, out))
+        self._dev = None
+        return out
+
+    def _finalize(self, device):
+        import numpy as np
+        first, job_of_block = 0, []
+        for i, j in enumerate(self.jobs):
+            j.first_block = first
+            first += j.nblocks
+            job_of_block += [i] * j.nblocks
+        arr = (_lib.PermuteJob * len(self.jobs))(*self.jobs)
+        raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8).clone()
+        self._dev = (raw.to(device), torch.tensor(job_of_block, dtype=torch.int32).to(device), first)
+
+    def run(self, device):
+        if not self.jobs:
+            return
+        if self._dev is None or self._dev[0].device != device:
+            self._finalize(device)
+        jobs, jb, total = self._dev
+        _lib.check(_L().ss_permute3d_batch(_p(jobs), _p(jb), total, _s(jobs)), 'ss_permute3d_batch')
