@@ -262,19 +262,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p)
 }
 
 // =========================================================================== backward helpers
-// D[b,h,q] = sum_d dO . O
+// D[b,h,q] = sum_d dO . O : one wave per frame row (all heads), 16-byte chunks, per-head segment sums through LDS
 template <class T>
-__global__ void attn_dsum_kernel(const T* __restrict__ dO, const T* __restrict__ O, float* __restrict__ Dv, int B, int H, int Tn, int dp)
+__global__ __launch_bounds__(256) void attn_dsum_kernel(const T* __restrict__ dO, const T* __restrict__ O, float* __restrict__ Dv, int B, int H, int Tn, int dp)
 {
-    const long long total = (long long)B * H * Tn;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(i % Tn); const long long bh = i / Tn; const int h = (int)(bh % H), b = (int)(bh / H);
-        const long long off = ((long long)b * Tn + q) * (H * dp) + h * dp;
-        float s = 0.f;
-        for (int d = 0; d < dp; d += 8) { float a[8], o[8]; Vec8<T>::load(dO + off + d, a); Vec8<T>::load(O + off + d, o);
+    __shared__ float part[4][128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int cph = dp >> 3, nchunk = H * cph;            // chunks per head, per row (<= 128: H*dp <= 1024)
+    const long long rows = (long long)B * Tn;
+    for (long long r = (long long)blockIdx.x * wpb + w; r < rows; r += (long long)gridDim.x * wpb) {
+        for (int c = lane; c < nchunk; c += 64) {
+            float a[8], o[8]; Vec8<T>::load(dO + r * (H * dp) + c * 8, a); Vec8<T>::load(O + r * (H * dp) + c * 8, o);
+            float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += a[e] * o[e]; }
-        Dv[i] = s;
+            for (int e = 0; e < 8; ++e) s += a[e] * o[e];
+            part[w][c] = s;
+        }
+        wave_lds_sync();
+        if (lane < H) {
+            float s = 0.f;
+            for (int c = 0; c < cph; ++c) s += part[w][lane * cph + c];
+            const int b = (int)(r / Tn), q = (int)(r - (long long)b * Tn);
+            Dv[((long long)b * H + lane) * Tn + q] = s;
+        }
+        wave_lds_sync();
     }
 }
 
@@ -492,6 +503,7 @@ static int attn_check(const char* what, int dtype, int B, int H, int T, int Tp, 
     SS_CHECK(dtype == SS_F32 || dtype == SS_BF16, "%s: bad dtype", what);
     SS_CHECK(B > 0 && H > 0 && T > 0, "%s: empty problem", what);
     SS_CHECK(dp % 32 == 0 && dp >= 32 && dp <= 128, "%s: padded head dim %d must be 32, 64, 96 or 128", what, dp);
+    SS_CHECK(H <= 64 && H * dp <= 1024, "%s: H=%d heads x padded dim %d exceeds 1024 columns", what, H, dp);
     SS_CHECK(D >= 1 && D <= 100, "%s: relative_positional_distance %d not in [1,100]", what, D);
     SS_CHECK(Tp >= T && Tp % 8 == 0, "%s: Tp=%d must be a multiple of 8 and >= T", what, Tp);
     SS_CHECK(dropout_p >= 0.f && dropout_p < 1.f, "%s: dropout p out of range", what);
@@ -545,7 +557,7 @@ extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const vo
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
     p.qkv = qkv; p.qkvT = qkvT; p.E = E; p.ET = ET; p.out = (void*)out; p.lse = (float*)lse; p.dO = dO; p.dOT = dOT; p.Dv = Dscratch; p.dqkv = dqkv;
     {
-        long long total = (long long)B * H * T, blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+        long long blocks = ((long long)B * T + 3) / 4; if (blocks > 8192) blocks = 8192;
         if (dtype == SS_BF16) SS_LAUNCH(attn_dsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dO, (const bf16_t*)out, Dscratch, B, H, T, dp);
         else SS_LAUNCH(attn_dsum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)dO, (const float*)out, Dscratch, B, H, T, dp);
     }
