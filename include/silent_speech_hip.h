@@ -184,6 +184,16 @@ int ss_silent_loss(const float* head, int64_t ld, int n_mel, int n_phone, const 
                    const int32_t* res_idx, int nframes, float lam, float inv_total, float* dhead, float* loss_accum,
                    int32_t* correct_accum, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * CTC loss of the recognition trainer ("next" row N1): replaces F.log_softmax + pad_sequence(decollate_tensor(...))
+ * + F.ctc_loss(..., blank, reduction='mean') of recognition_model.py:96-101 on the PACKED (rows, ld) f32 logits.
+ * lse = per-frame log-sum-exp over the V classes (ss_frame_lse with col0=0).  desc (device, int64 x5 per utterance,
+ * sorted by frame0): first packed frame, T, first target index, S, offset (floats) of the utterance's T*(2S+1)
+ * block in alpha_ws / beta_ws.  Writes nll[n_utt], loss[0] = mean_u nll_u / max(S_u, 1) and the complete
+ * d loss / d logits (all `rows` x ld entries; zero outside the utterances). */
+int ss_ctc_loss(const float* logits, int64_t ld, int V, int blank, const float* lse, const int64_t* desc_dev, int n_utt, int max_target_len,
+                int64_t rows, const int32_t* targets, float* alpha_ws, float* beta_ws, float* nll, float* dlogits, float* loss, void* stream);
+
 /* AdamW over a flat f32 arena (transduction_model.py:178,210).  step is 1-based. */
 int ss_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float grad_scale, void* stream);

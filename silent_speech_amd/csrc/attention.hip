@@ -26,18 +26,6 @@
 
 namespace {
 
-// LDS hand-off inside ONE wave (each wave owns its tiles): LDS operations of a wave are served in order, so only
-// the compiler must be kept from reordering; no workgroup barrier -> the 4 waves of a block run independently.
-__device__ __forceinline__ void wave_lds_sync() {
-#if defined(SS_EMU)
-    hipemu::sync_wave();
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-}
-
 // XCD-aware block order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (each with a private L2).
 // The tiles of one (batch, head) re-read the same Q/K/V/dO rows, so consecutive logical ids are mapped onto ONE XCD
 // (bijective chunked remap) and their re-reads hit that XCD's L2 instead of HBM.

@@ -99,6 +99,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// LDS hand-off inside ONE wave (each wave owns its tiles): LDS operations of a wave are served in order, so only
+// the compiler must be kept from reordering; no workgroup barrier -> the 4 waves of a block run independently.
+__device__ __forceinline__ void wave_lds_sync() {
+#if defined(SS_EMU)
+    hipemu::sync_wave();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 // ------------------------------------------------------------------ MFMA wrappers
 __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
 #if defined(SS_EMU)

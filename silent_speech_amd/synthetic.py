@@ -31,6 +31,11 @@ class SyntheticEMGDataset(torch.utils.data.Dataset):
     num_speech_features = 80
     num_sessions = 1
 
+    @property
+    def text_transform(self):
+        from .recognition_model import TextTransform
+        return TextTransform()
+
     def __init__(self, n_utterances=64, seed=0, min_frames=200, max_frames=860, silent_fraction=0.25):
         rng = np.random.default_rng(seed)
         self.items = [make_utterance(rng, int(rng.integers(min_frames, max_frames + 1)), rng.random() < silent_fraction) for _ in range(n_utterances)]

@@ -253,12 +253,110 @@ def gen_adamw():
     save('adamw', p=torch.stack(hist), g=torch.stack(grads))
 
 
+def gen_ctc():
+    """The loss lines of the recognition trainer, recognition_model.py:96-101, on packed rows of 50 frames."""
+    import torch.nn.functional as F
+    from torch import nn
+    g = torch.Generator().manual_seed(12)
+    V, blank = 38, 37
+
+    def run(tag, lengths, tlens, row, repeat_heavy=False):
+        total = sum(lengths)
+        B = (total + row - 1) // row
+        logits = (2.0 * torch.randn(B, row, V, generator=g)).requires_grad_(True)
+        hi = 3 if repeat_heavy else blank
+        text_int = [torch.randint(0, hi, (n,), generator=g) for n in tlens]
+        pred = F.log_softmax(logits, 2)
+        pred = nn.utils.rnn.pad_sequence(ref_data.decollate_tensor(pred, lengths), batch_first=False)
+        y = nn.utils.rnn.pad_sequence(text_int, batch_first=True)
+        loss = F.ctc_loss(pred, y, lengths, tlens, blank=blank)
+        loss.backward()
+        nll = F.ctc_loss(pred.detach(), y, lengths, tlens, blank=blank, reduction='none')
+        arrs = dict(logits=logits, loss=loss, dlogits=logits.grad, nll=nll, lengths=np.array(lengths), tlens=np.array(tlens), blank=np.int64(blank))
+        for i, t in enumerate(text_int):
+            arrs['text/%d' % i] = t
+        save(tag, **arrs)
+
+    run('ctc_mixed', [37, 64, 50, 49], [5, 12, 0, 20], 50)
+    run('ctc_repeats', [30, 41, 9], [9, 14, 3], 40, repeat_heavy=True)          # many equal neighbours: the s-2 transition is mostly closed
+    run('ctc_long', [333, 267], [150, 40], 200)                                 # 301 extended states: two states per thread
+    run('ctc_infeasible', [4, 22], [5, 4], 13, repeat_heavy=True)               # utterance 0 cannot be aligned: loss = inf (zero_infinity=False)
+
+
+def gen_recog():
+    """Two accumulated batches + one AdamW step of the recognition trainer's inner loop (recognition_model.py:86-108)
+    on a tiny Model(112, 38) with 40-frame rows."""
+    import torch.nn.functional as F
+    from torch import nn
+    row, r, n_chars = 40, 3, 37
+    FLAGS.model_size, FLAGS.num_layers, FLAGS.dropout = 16, 1, 0.0
+    torch.manual_seed(21)
+    m = ref_arch.Model(112, n_chars + 1)
+    for layer in m.transformer.layers:
+        layer.self_attn.batch_first = False
+    g = torch.Generator().manual_seed(22)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if 'relative_positional' not in n:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05 * (p.abs().mean() + 0.1))
+    arrs = {'sd/' + k: v.clone() for k, v in m.state_dict().items()}
+    m.train()
+
+    class _R(object):
+        @staticmethod
+        def randrange(n):
+            return r
+    ref_arch.random = _R
+    optim = torch.optim.AdamW(m.parameters(), lr=3e-4, weight_decay=0.0)
+    optim.zero_grad()
+    batches = [([23, 40, 17], [4, 9, 3]), ([31, 30], [7, 0])]
+    for b, (lengths, tlens) in enumerate(batches):
+        lr = (b + 1) * 3e-4 / 1000                                           # schedule_lr, :79-82
+        for pg in optim.param_groups:
+            pg['lr'] = lr
+        raw = [50.0 * torch.tanh(torch.randn(8 * n, 8, generator=g) * 5.0 / 50.0) for n in lengths]
+        text = [torch.randint(0, n_chars, (n,), generator=g) for n in tlens]
+        X_raw = ref_data.combine_fixed_length(raw, row * 8)
+        rows = X_raw.shape[0]
+        pred = m(torch.zeros(rows, row, 112), X_raw, torch.zeros(rows, row, dtype=torch.long))
+        arrs['pred/%d' % b] = pred
+        pred = F.log_softmax(pred, 2)
+        pred = nn.utils.rnn.pad_sequence(ref_data.decollate_tensor(pred, lengths), batch_first=False)
+        y = nn.utils.rnn.pad_sequence(text, batch_first=True)
+        loss = F.ctc_loss(pred, y, lengths, tlens, blank=n_chars)
+        loss.backward()
+        arrs['loss/%d' % b] = loss
+        arrs['lengths/%d' % b] = np.array(lengths)
+        for i, (x, t) in enumerate(zip(raw, text)):
+            arrs['raw/%d/%d' % (b, i)] = x
+            arrs['text/%d/%d' % (b, i)] = t
+        if b == 0:
+            for n, p in m.named_parameters():
+                if p.grad is not None:
+                    arrs['grad0/' + n] = p.grad.clone()
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            arrs['grad/' + n] = p.grad.clone()
+    optim.step()
+    import random as _random
+    ref_arch.random = _random
+    for k, v in m.state_dict().items():
+        arrs['after/' + k] = v
+    arrs['r'] = np.int64(r)
+    arrs['lr'] = np.float64(lr)
+    save('recog_d16_L1_T40', **arrs)
+
+
 if __name__ == '__main__':
     random.seed(0)
     # architecture.py:67 copies x_raw[:, r:] onto x_raw[:, :-r] IN PLACE (overlapping views); with a
     # multi-threaded copy that is racy (observed: 24 samples shifted twice at a chunk boundary).
     # One thread gives the intended, deterministic left shift -- the semantics the build implements.
     torch.set_num_threads(1)
+    if len(sys.argv) > 1:                       # regenerate only the named groups, e.g. `make_golden.py ctc`
+        for name in sys.argv[1:]:
+            globals()['gen_' + name]()
+        sys.exit(0)
     gen_dtw()
     gen_pack()
     gen_mha()
@@ -271,3 +369,5 @@ if __name__ == '__main__':
     gen_dtw_loss()
     gen_mel()
     gen_adamw()
+    gen_ctc()
+    gen_recog()

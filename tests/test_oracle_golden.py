@@ -179,3 +179,23 @@ def test_adamw_three_steps():
         lr = adamw_ref.warmup_lr(it)
         p, m, v = adamw_ref.adamw_step_ref(p, torch.from_numpy(z['g'][it]), m, v, it + 1, lr)
         assert torch.allclose(p, torch.from_numpy(z['p'][it + 1]), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('tag', ['ctc_mixed', 'ctc_repeats', 'ctc_infeasible'])
+def test_ctc_oracle_matches_reference(tag):
+    """oracle/ctc_ref.py against the reference's loss lines (recognition_model.py:96-101) run on torch CPU."""
+    from oracle.ctc_ref import ctc_loss_packed
+    z = np.load(os.path.join(GOLD, tag + '.npz'))
+    lengths = [int(n) for n in z['lengths']]
+    targets = [z['text/%d' % i] for i in range(len(lengths))]
+    loss, d, nll = ctc_loss_packed(z['logits'], lengths, targets, int(z['blank']))
+    fin = np.isfinite(z['nll'])
+    assert np.array_equal(np.isfinite(nll), fin)
+    np.testing.assert_allclose(nll[fin], z['nll'][fin], rtol=2e-6)
+    if fin.all():
+        np.testing.assert_allclose(loss, float(z['loss']), rtol=2e-6)
+    else:
+        assert not np.isfinite(loss) and not np.isfinite(float(z['loss']))
+    nan = np.isnan(z['dlogits'])
+    assert np.array_equal(np.isnan(d), nan)
+    np.testing.assert_allclose(d[~nan], z['dlogits'][~nan], rtol=1e-4, atol=2e-7)

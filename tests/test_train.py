@@ -1,0 +1,63 @@
+"""End-to-end runs of the two trainer entry points on a tiny synthetic dataset (MI355X only): a few optimiser steps,
+one validation pass, checkpoint written with the reference's state_dict keys."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from silent_speech_amd import _lib
+from silent_speech_amd.flags import FLAGS
+from silent_speech_amd.synthetic import SyntheticEMGDataset
+
+
+@pytest.fixture
+def tiny_flags(tmp_path):
+    keep = dict(FLAGS._over)
+    FLAGS.model_size, FLAGS.num_layers, FLAGS.epochs = 64, 1, 1
+    FLAGS.output_directory = str(tmp_path)
+    yield tmp_path
+    FLAGS._over.clear()
+    FLAGS._over.update(keep)
+
+
+@pytest.mark.gpu
+def test_transduction_train_model_runs(tiny_flags):
+    from silent_speech_amd import transduction_model as tm
+    _lib.load()
+    train = SyntheticEMGDataset(24, seed=1, min_frames=40, max_frames=120)
+    devset = SyntheticEMGDataset(6, seed=2, min_frames=40, max_frames=120)
+    model = tm.train_model(train, devset, 'cuda', save_sound_outputs=False, max_steps=3)
+    sd = torch.load(os.path.join(str(tiny_flags), 'model.pt'))
+    assert set(sd.keys()) == set(model.state_dict().keys())
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
+    loss, acc, conf = tm.test(model, devset, 'cuda')
+    assert np.isfinite(loss) and 0.0 <= acc <= 1.0 and conf.sum() == sum(int(it['audio_features'].shape[0]) for it in devset.items)
+
+
+@pytest.mark.gpu
+def test_recognition_train_model_runs_and_learns(tiny_flags):
+    from silent_speech_amd import recognition_model as rm
+    _lib.load()
+    FLAGS.learning_rate, FLAGS.learning_rate_warmup = 2e-3, 4
+    train = SyntheticEMGDataset(8, seed=3, min_frames=40, max_frames=80)
+    model = rm.train_model(train, train, 'cuda', n_epochs=1, max_steps=2)
+    sd = torch.load(os.path.join(str(tiny_flags), 'model.pt'))
+    assert 'w_out.weight' in sd and sd['w_out.weight'].shape[0] == 38 and 'w_aux.weight' not in sd
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
+    # the CTC loss of a fixed batch must go down under the trainer's own update rule
+    batch = train.collate_raw(train.items[:4])
+    from silent_speech_amd.optim import FusedAdamW
+    from silent_speech_amd.transduction_model import _pack_batch
+    opt = FusedAdamW(model, lr=2e-3, weight_decay=0.0)
+    losses = []
+    for it in range(12):
+        opt.zero_grad()
+        X, X_raw, sess = _pack_batch(batch, 'cuda')
+        loss = rm.ctc_loss(model(X, X_raw, sess), batch, blank=37)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
+    wer = rm.test(model, train, 'cuda')
+    assert 0.0 <= wer
