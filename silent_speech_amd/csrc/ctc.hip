@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
             float g = 0.f;
             if (c < V) {
                 const float lp = logits[r * ld + c] - L, occ = bins[c];
-                g = expf(lp) - expf(logf(occ) + m + nl - lp);      // an utterance with no valid alignment gives NaN, as ATen does
+                g = expf(lp) - (occ > 0.f ? expf(logf(occ) + m + nl - lp) : 0.f);
+                if (nl == INFINITY) g = NAN;                        // no valid alignment: ATen's exp(-inf + inf - lp), stated explicitly
             }
             d[c] = g * sc;
         }

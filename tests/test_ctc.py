@@ -57,7 +57,7 @@ def test_ctc_random_vs_oracle(dev):
     loss, plan = rm.ctc_loss(x, dict(lengths=lengths, text_int=[torch.from_numpy(t) for t in text]), blank=blank, return_plan=True)
     (2.0 * loss).backward()
     np.testing.assert_allclose(plan.nll.cpu().numpy(), want_nll, rtol=1e-5)
-    assert abs(float(loss) - want_loss) < 1e-5 * abs(want_loss)
+    assert abs(float(loss.detach()) - want_loss) < 1e-5 * abs(want_loss)
     np.testing.assert_allclose(x.grad.cpu().numpy(), 2.0 * want_d, rtol=2e-3, atol=1e-6)
 
 
