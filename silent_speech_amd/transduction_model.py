@@ -109,13 +109,8 @@ class _DtwLossFn(torch.autograd.Function):
         return ctx.dhead * gl, None, None, None, None, None
 
 
-def dtw_loss(predictions, phoneme_predictions, example, phoneme_eval=False, phoneme_confusion=None, *, phoneme_loss_weight=None,
-             total_length=None):
-    """Returns (loss, phoneme accuracy) like transduction_model.py:98-157.  The loss is a 0-dim tensor attached
-    to autograd; the accuracy is a Python float when phoneme_eval=True (needs a device sync, as the reference's
-    .item() calls do) and a 0-dim device tensor otherwise (the training loop discards it, :206).
-    total_length: override of the normaliser sum(T2) (data-parallel ranks pass the GLOBAL frame count)."""
-    lam = FLAGS.phoneme_loss_weight if phoneme_loss_weight is None else phoneme_loss_weight
+def _dtw_loss_plan(predictions, phoneme_predictions, example, lam, total_length=None):
+    """Shared by dtw_loss and get_aligned_prediction: builds the fused head, runs the loss kernels, returns (loss, correct, plan)."""
     B, T, n_mel = predictions.shape
     n_ph = phoneme_predictions.shape[2]
     if n_mel % 4:
@@ -129,6 +124,17 @@ def dtw_loss(predictions, phoneme_predictions, example, phoneme_eval=False, phon
     plan = _LossPlan(example, M, predictions.device)
     total = plan.total_length if total_length is None else total_length
     loss, correct = _DtwLossFn.apply(head, plan, n_mel, n_ph, float(lam), 1.0 / float(total))
+    return loss, correct, plan
+
+
+def dtw_loss(predictions, phoneme_predictions, example, phoneme_eval=False, phoneme_confusion=None, *, phoneme_loss_weight=None,
+             total_length=None):
+    """Returns (loss, phoneme accuracy) like transduction_model.py:98-157.  The loss is a 0-dim tensor attached
+    to autograd; the accuracy is a Python float when phoneme_eval=True (needs a device sync, as the reference's
+    .item() calls do) and a 0-dim device tensor otherwise (the training loop discards it, :206).
+    total_length: override of the normaliser sum(T2) (data-parallel ranks pass the GLOBAL frame count)."""
+    lam = FLAGS.phoneme_loss_weight if phoneme_loss_weight is None else phoneme_loss_weight
+    loss, correct, plan = _dtw_loss_plan(predictions, phoneme_predictions, example, lam, total_length)
     if not phoneme_eval:
         return loss, correct[0].float() / plan.total_length
     # ---- evaluation extras: host-side confusion matrix (transduction_model.py:130-137,147-152)
@@ -146,6 +152,62 @@ def dtw_loss(predictions, phoneme_predictions, example, phoneme_eval=False, phon
                 p = amax[plan.pred_off[u]:plan.pred_off[u] + n1]
             np.add.at(phoneme_confusion, (p, tgt), 1)
     return loss, acc
+
+
+class EnsembleModel(torch.nn.Module):
+    """evaluate.py:22-34: averages the mel predictions and phoneme logits of several models."""
+
+    def __init__(self, models):
+        super().__init__()
+        self.models = torch.nn.ModuleList(models)
+
+    def forward(self, x, x_raw, sess):
+        ys, ps = [], []
+        for model in self.models:
+            y, p = model(x, x_raw, sess)
+            ys.append(y)
+            ps.append(p)
+        return torch.stack(ys, 0).mean(0), torch.stack(ps, 0).mean(0)
+
+
+def predict_utterance(model, datapoint, device):
+    """The model half of save_output (transduction_model.py:57-66): eval-mode forward of ONE whole utterance
+    (un-chunked: T is the utterance length, the banded attention kernel skips everything beyond +-99 frames).
+    Returns the (T, n_mel) prediction on the device; vocoding (:68-72) is outside the hot path."""
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        sess = datapoint['session_ids'].to(device=device).unsqueeze(0)
+        X = datapoint['emg'].to(dtype=torch.float32, device=device).unsqueeze(0)
+        X_raw = datapoint['raw_emg'].to(dtype=torch.float32, device=device).unsqueeze(0)
+        pred, _ = model(X, X_raw, sess)
+    model.train(was_training)
+    return pred.squeeze(0)
+
+
+def get_aligned_prediction(model, datapoint, device, audio_normalizer):
+    """transduction_model.py:75-96.  Silent utterances are aligned to the parallel voiced audio features by DTW on the
+    plain Euclidean cost (no phoneme term): cost matrix, DTW and backtrace all stay on the device (the reference
+    copies the T1 x T2 cdist matrix to the host, :87-88); only the T2 indices are used to gather."""
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        silent = datapoint['silent']
+        sess = datapoint['session_ids'].to(device).unsqueeze(0)
+        X = datapoint['emg'].to(device).unsqueeze(0)
+        X_raw = datapoint['raw_emg'].to(device).unsqueeze(0)
+        y = datapoint['parallel_voiced_audio_features' if silent else 'audio_features'].to(device)
+        pred, aux = model(X, X_raw, sess)                       # (1, seq, dim)
+        if silent:
+            ex = dict(lengths=[pred.shape[1]], silent=[True], audio_features=[y],
+                      phonemes=[torch.zeros(y.shape[0], dtype=torch.int64, device=y.device)])
+            _, _, plan = _dtw_loss_plan(pred, aux, ex, 0.0)     # lambda = 0: cost = ||pred_q - y_k||_2 exactly (torch.cdist, :87)
+            pred_aligned = pred.squeeze(0)[plan.results[:y.shape[0]].long()]
+        else:
+            pred_aligned = pred.squeeze(0)
+        pred_aligned = audio_normalizer.inverse(pred_aligned.cpu())
+    model.train(was_training)
+    return pred_aligned
 
 
 def _pack_batch(batch, device, seq_len=200):
