@@ -485,6 +485,479 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p)
     }
 }
 
+// =========================================================================== resident (whole sequence in LDS) kernels, bf16
+// The training rows are T = 200 frames: the K/V (or Q/dO) rows of one (sequence, head) and the head's 2D-1 embedding rows
+// fit in the 160 KB LDS of a CU.  The per-tile kernels above re-fetch those operands from L2 for every 16-row tile
+// (1.7 GB of L2->CU traffic per forward launch at the reference batch: they are L2-bandwidth bound); here ONE workgroup of
+// 8 waves owns a (sequence, head), stages the operands once (coalesced 16-byte copies, rows padded by 16 B so that every
+// fragment read is bank-conflict free) and its waves pull 16-row tiles from an LDS counter, heaviest (band-centre) first.
+// Contractions over the time axis take their B operand straight from the row-major tiles with ds_read_b64_tr_b16, so no
+// transposed copies are staged; only key blocks that intersect the +-(D-1) band are computed.
+namespace {
+constexpr int RES_NB = 13, RES_W = 8, RT_LD = 40;      // <= 13 key blocks (T <= 208), 8 waves, chunk-tile row length
+typedef bf16_t RT;
+
+__device__ __forceinline__ bf16x8 lds16(const unsigned char* p) { return *(const bf16x8*)p; }
+__device__ __forceinline__ bf16x8 bzero8() { bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
+// A operand in the k-order of the transposing reads: lane group g holds contraction elements {4g..4g+3, 16+4g..16+4g+3}
+__device__ __forceinline__ bf16x8 lds_a_tr(const RT* row, int g) {
+    const s16x4 lo = *(const s16x4*)(row + 4 * g), hi = *(const s16x4*)(row + 16 + 4 * g);
+    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+// B operand B[k][n] = tile[row0 + k][col0 + n] (k = 32 contraction rows, n = 16 columns) of a row-major LDS tile
+__device__ __forceinline__ bf16x8 lds_b_tr(const unsigned char* tile, int pitch, int row0, int colbyte0, int c, int g) {
+    const unsigned char* a0 = tile + (row0 + g * 4 + (c >> 2)) * pitch + colbyte0 + (c & 3) * 8;
+    const s16x4 lo = lds_read_tr16(a0), hi = lds_read_tr16(a0 + 16 * pitch);
+    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+template <int DPK>
+__device__ __forceinline__ void lds_row_frags(bf16x8 (&f)[DPK], const unsigned char* tile, int pitch, int row, int g) {
+#pragma unroll
+    for (int kk = 0; kk < DPK; ++kk) f[kk] = lds16(tile + row * pitch + kk * 64 + g * 16);
+}
+// rows of the embedding table with per-lane clamp + select (standard, non-transposing reads)
+template <int DPK>
+__device__ __forceinline__ void lds_e_frags(bf16x8 (&f)[DPK], const unsigned char* Es, int pitch, int m, int nrows, int g) {
+    const bool ok = m >= 0 && m < nrows;
+    const int r = m < 0 ? 0 : (m >= nrows ? nrows - 1 : m);
+#pragma unroll
+    for (int kk = 0; kk < DPK; ++kk) { const bf16x8 v = lds16(Es + r * pitch + kk * 64 + g * 16); f[kk] = ok ? v : bzero8(); }
+}
+template <int DPK>
+__device__ __forceinline__ f32x4 dot8(const bf16x8 (&a)[DPK], const bf16x8 (&b)[DPK]) {
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < DPK; ++kk) c = mfma_bf16_16x16x32(a[kk], b[kk], c);
+    return c;
+}
+template <int DPK>
+__device__ __forceinline__ void glb_row_frags(bf16x8 (&f)[DPK], const RT* rowp, bool valid, int g) {
+#pragma unroll
+    for (int kk = 0; kk < DPK; ++kk) f[kk] = valid ? *(const bf16x8*)(rowp + kk * 32 + g * 8) : bzero8();
+}
+// cooperative copy of `rows` rows of dp elements (row stride ld) into an LDS tile; rows >= valid are zero-filled.
+// Loads are issued 8 deep per thread before the first LDS store so that the copy is bandwidth- not latency-bound.
+template <int DPK>
+__device__ __forceinline__ void stage_rows(unsigned char* dst, int pitch, const RT* src, long long ld, int valid, int rows, int tid, int nthr) {
+    constexpr int CPR = DPK * 4, U = 8;
+    const int total = rows * CPR;
+    for (int base = tid; base < total; base += nthr * U) {
+        u32x4 v[U]; int off[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * nthr, r = i / CPR, ch = i - r * CPR;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            v[u] = z; off[u] = i < total ? r * pitch + ch * 16 : -1;
+            if (i < total && r < valid) v[u] = *(const u32x4*)(src + (long long)r * ld + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (off[u] >= 0) *(u32x4*)(dst + off[u]) = v[u];
+    }
+}
+// accumulator tile (16 rows x DPK*32 columns, f32, scaled) -> global rows of `ld` elements through a 16 x 32 LDS slab:
+// 3 wave-wide 16-byte stores per tile instead of 96 two-byte ones (which also kept vmcnt busy ahead of the next tile's loads)
+template <int DPK>
+__device__ __forceinline__ void store_tile_rows(RT* tile, const f32x4 (&acc)[2 * DPK], float scale, RT* dst, long long ld, int row0, int nrows, int lane) {
+    const int c = lane & 15, g = lane >> 4, r = lane >> 2, ch = lane & 3;
+#pragma unroll
+    for (int sl = 0; sl < DPK; ++sl) {
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) tile[(g * 4 + reg) * RT_LD + nn * 16 + c] = f2bf(acc[2 * sl + nn][reg] * scale);
+        wave_lds_sync();
+        const u32x4 v = *(const u32x4*)(tile + r * RT_LD + ch * 8);
+        if (row0 + r < nrows) *(u32x4*)(dst + (long long)(row0 + r) * ld + sl * 32 + ch * 8) = v;
+        wave_lds_sync();
+    }
+}
+// tile index of the i-th work item: centre of the sequence (full band, most key blocks) first
+__device__ __forceinline__ int res_tile_of(int i, int nb) { const int mid = nb >> 1; return (i & 1) ? mid - ((i + 1) >> 1) : mid + (i >> 1); }
+__device__ __forceinline__ int res_next(int* ctr, int lane) {
+    int i = 0; if (lane == 0) i = atomicAdd(ctr, 1);
+#if defined(SS_EMU)
+    return __shfl(i, 0);
+#else
+    return __builtin_amdgcn_readfirstlane(i);        // scalar: the tile index drives uniform branches and LDS base addresses
+#endif
+}
+}  // namespace
+
+// ---- branch-free band bookkeeping.  Key blocks are indexed RELATIVE to the first in-band block jlo of the tile
+// (block i <-> keys 16*(jlo+i) ..), a tile body handles a compile-time count NBLK of them (blocks i >= nblk are masked),
+// so one tile is one basic block and the scheduler overlaps the LDS reads / MFMAs / shuffles of neighbouring blocks.
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f, MASKED2 = -1e8f * 1.4426950408889634f;
+constexpr int RES_PL = 32;                                  // zero rows below / above the staged embedding table
+
+// log2-domain logits of block (q0, k0): (s*scale + pos)*log2(e) inside the band and the sequence, -1e8*log2(e) elsewhere
+// (transformer.py:256-261; keys >= T get the same treatment: exp2 makes both exactly 0 against any real logit)
+__device__ __forceinline__ void res_logits(const f32x4& s, const float (&pos)[4], const int (&bandA)[4], int off, bool key_ok, unsigned span, float scale2, float (&out)[4]) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const bool in = (unsigned)(off + bandA[reg]) <= span && key_ok;        // 0 <= (k - q) + D-1 <= 2D-2
+        out[reg] = in ? fmaf(s[reg], scale2, pos[reg] * LOG2E) : MASKED2;      // select AFTER the fma: masked blocks may have read LDS garbage
+    }
+}
+template <int DPK>
+__device__ __forceinline__ void lds_e_pad(bf16x8 (&f)[DPK], const unsigned char* Es, int pitch, int row, int last, int g) {
+    row = row > last ? last : row;                                             // rows past the table are zero pad
+#pragma unroll
+    for (int kk = 0; kk < DPK; ++kk) f[kk] = lds16(Es + row * pitch + kk * 64 + g * 16);
+}
+
+template <int DPK, int NBLK, bool DROP>
+__device__ __forceinline__ void fwd_res_tile(const AttnP& p, const unsigned char* Ks, const unsigned char* Es, const unsigned char* VTs, RT* Pt,
+                                             const bf16x8 (&qf)[DPK], int b, int h, int q0, int jlo, int nblk, int lane, int PVT, int ER, f32x4 (&o)[2 * DPK])
+{
+    constexpr int PK = DPK * 64 + 16, PTL = 20;
+    const int c = lane & 15, g = lane >> 4, Tn = p.T, D = p.D, H = p.H;
+    const float scale2 = p.scale * LOG2E;
+    const int m_org = -q0 - 15 + (D - 1) + RES_PL;
+    int bandA[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) bandA[reg] = c - (g * 4 + reg) + (D - 1);
+    float lg[NBLK][4];
+    f32x4 rprev;
+    { bf16x8 ef[DPK]; lds_e_pad<DPK>(ef, Es, PK, m_org + 16 * jlo + c, ER - 1, g); rprev = dot8<DPK>(qf, ef); }
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) {
+        const int k0 = 16 * (jlo + i);
+        bf16x8 kf[DPK], ef[DPK];
+        lds_row_frags<DPK>(kf, Ks, PK, k0 + c, g);
+        lds_e_pad<DPK>(ef, Es, PK, m_org + k0 + 16 + c, ER - 1, g);
+        const f32x4 s = dot8<DPK>(qf, kf);
+        const f32x4 rn = dot8<DPK>(qf, ef);
+        float pos[4];
+        skew_gather(rprev, rn, lane, pos);
+        res_logits(s, pos, bandA, k0 - q0, i < nblk && k0 + c < Tn, 2u * (unsigned)(D - 1), scale2, lg[i]);
+        rprev = rn;
+    }
+    float inv[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        float m = lg[0][reg];
+#pragma unroll
+        for (int i = 1; i < NBLK; ++i) m = fmaxf(m, lg[i][reg]);
+        m = group16_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) { const float e = fast_exp2(lg[i][reg] - m); lg[i][reg] = e; sum += e; }
+        sum = group16_sum(sum);
+        inv[reg] = fast_rcp(sum) * (DROP ? p.drop_scale : 1.f);
+        if (c == 0) { const int q = q0 + g * 4 + reg; if (q < Tn) p.lse[((long long)b * H + h) * Tn + q] = m * LN2 + logf(sum); }
+    }
+#pragma unroll
+    for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; o[n] = z; }
+    // O = P~ V per 32-key chunk: P~^T goes to LDS as [key][query] (one 8-byte store per block: this lane's 4 rows are adjacent),
+    // the A operand comes back through a transposing read, V^T fragments are read in the same k order
+#pragma unroll
+    for (int kc = 0; kc < (NBLK + 1) / 2; ++kc) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int i = 2 * kc + half;
+            float pv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (i < NBLK) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) pv[reg] = lg[i < NBLK ? i : 0][reg] * inv[reg];
+                if (DROP) {
+                    bool kp[4];
+                    dropout_keep4(p.seed, p.stream, (((unsigned long long)b * H + h) * Tn + ((q0 >> 2) + g)) * Tn + (16 * (jlo + i) + c), p.drop_thresh, kp);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) pv[reg] = kp[reg] ? pv[reg] : 0.f;
+                }
+            }
+            u32x2 pk = {pack_bf16(pv[0], pv[1]), pack_bf16(pv[2], pv[3])};
+            *(u32x2*)(Pt + (16 * half + c) * PTL + g * 4) = pk;
+        }
+        wave_lds_sync();
+        const bf16x8 pa = lds_b_tr((const unsigned char*)Pt, PTL * 2, 0, 0, c, g);
+        int vcol = 16 * jlo + kc * 32; vcol = 2 * kc < nblk ? vcol : 0;          // chunks past the band hold P = 0: keep their reads on staged (finite) data
+#pragma unroll
+        for (int n = 0; n < 2 * DPK; ++n) {
+            const unsigned char* vp = VTs + (n * 16 + c) * PVT + (vcol + g * 4) * 2;
+            const s16x4 lo = *(const s16x4*)vp, hi = *(const s16x4*)(vp + 32);
+            const bf16x8 vb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[n] = mfma_bf16_16x16x32(pa, vb, o[n]);
+        }
+        wave_lds_sync();
+    }
+}
+
+template <int DPK, bool DROP>
+__global__ __launch_bounds__(RES_W * 64) void attn_fwd_res_kernel(AttnP p)
+{
+    SS_DYN_SMEM(smem);
+    constexpr int dp = DPK * 32, PK = dp * 2 + 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int H = p.H, h = blockIdx.x % H, b = blockIdx.x / H;
+    const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1, ER = NE + 2 * RES_PL;
+    const int WV = ((nb + 2) >> 1) * 32, PVT = WV * 2 + 16;            // a chunk starting at an odd block may end 16 keys past Tr
+    unsigned char* Ks = (unsigned char*)smem;
+    unsigned char* Es = Ks + Tr * PK;                                   // row m + RES_PL holds embedding m
+    unsigned char* VTs = Es + ER * PK;
+    RT* Pt = (RT*)(VTs + dp * PVT) + w * 16 * RT_LD;
+    int* ctr = (int*)(VTs + dp * PVT + RES_W * 16 * RT_LD * 2);
+    const long long ldq = 3LL * H * dp;
+    const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
+    {
+        stage_rows<DPK>(Ks, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W * 64);
+        stage_rows<DPK>(Es, PK, (const RT*)p.E, dp, 0, RES_PL, tid, RES_W * 64);
+        stage_rows<DPK>(Es + RES_PL * PK, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE + RES_PL, tid, RES_W * 64);
+        const RT* VT = (const RT*)p.qkvT + ((long long)b * 3 * H * dp + 2 * H * dp + h * dp) * p.Tp;
+        const int cpr = WV >> 3, total = dp * cpr;
+        for (int base = tid; base < total; base += RES_W * 64 * 8) {
+            bf16x8 v[8]; int off[8], t0s[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * RES_W * 64, r = i / cpr, t0 = (i - r * cpr) * 8;
+                v[u] = bzero8(); off[u] = i < total ? r * PVT + t0 * 2 : -1; t0s[u] = t0;
+                if (i < total && t0 < Tn) v[u] = *(const bf16x8*)(VT + (long long)r * p.Tp + t0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (off[u] < 0) continue;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (t0s[u] + e >= Tn) v[u][e] = 0;
+                *(bf16x8*)(VTs + off[u]) = v[u];
+            }
+        }
+        if (tid == 0) *ctr = 0;
+    }
+    __syncthreads();
+    int it = res_next(ctr, lane);
+    bf16x8 qf[DPK], qn[DPK];
+    if (it < nb) { int qr = res_tile_of(it, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1; glb_row_frags<DPK>(qf, Q + (long long)qr * ldq, true, g); }
+    while (it < nb) {
+        const int q0 = res_tile_of(it, nb) * 16;
+        int jlo = q0 - (D - 1); jlo = jlo < 0 ? 0 : jlo >> 4;
+        int jhi = (q0 + 15 + D - 1) >> 4; jhi = jhi > nb - 1 ? nb - 1 : jhi;
+        const int nblk = jhi - jlo + 1;
+        // next tile's Q rows are requested now: loads issued before this tile's stores never wait for them
+        const int itn = res_next(ctr, lane);
+        if (itn < nb) { int qr = res_tile_of(itn, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1; glb_row_frags<DPK>(qn, Q + (long long)qr * ldq, true, g); }
+        f32x4 o[2 * DPK];
+        if (nblk <= 4) fwd_res_tile<DPK, 4, DROP>(p, Ks, Es, VTs, Pt, qf, b, h, q0, jlo, nblk, lane, PVT, ER, o);
+        else if (nblk <= 10) fwd_res_tile<DPK, 10, DROP>(p, Ks, Es, VTs, Pt, qf, b, h, q0, jlo, nblk, lane, PVT, ER, o);
+        else fwd_res_tile<DPK, RES_NB, DROP>(p, Ks, Es, VTs, Pt, qf, b, h, q0, jlo, nblk, lane, PVT, ER, o);
+        store_tile_rows<DPK>(Pt, o, 1.f, (RT*)p.out + (long long)b * Tn * (H * dp) + h * dp, (long long)H * dp, q0, Tn, lane);
+        it = itn;
+#pragma unroll
+        for (int kk = 0; kk < DPK; ++kk) qf[kk] = qn[kk];
+    }
+}
+
+// query-major backward (dQ) on resident K, V rows and a zero-padded embedding table (PL rows below, PH above)
+template <int DPK>
+__global__ __launch_bounds__(RES_W * 64) void attn_bwd_q_res_kernel(AttnP p)
+{
+    SS_DYN_SMEM(smem);
+    constexpr int dp = DPK * 32, PK = dp * 2 + 16, PL = 48, PH = 48;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int H = p.H, h = blockIdx.x % H, b = blockIdx.x / H;
+    const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1, ER = NE + PL + PH;
+    unsigned char* Ks = (unsigned char*)smem;
+    unsigned char* Vs = Ks + Tr * PK;
+    unsigned char* Es = Vs + Tr * PK;                                  // row m + PL holds embedding m
+    RT* tA = (RT*)(Es + ER * PK) + w * 16 * RT_LD;
+    int* ctr = (int*)(Es + ER * PK + RES_W * 16 * RT_LD * 2);
+    const long long ldq = 3LL * H * dp;
+    const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
+    const RT* dO = (const RT*)p.dO + (long long)b * Tn * (H * dp) + h * dp;
+    {
+        stage_rows<DPK>(Ks, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W * 64);
+        stage_rows<DPK>(Vs, PK, Q + 2 * H * dp, ldq, Tn, Tr, tid, RES_W * 64);
+        stage_rows<DPK>(Es, PK, (const RT*)p.E, dp, 0, PL, tid, RES_W * 64);
+        stage_rows<DPK>(Es + PL * PK, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE + PH, tid, RES_W * 64);
+        if (tid == 0) *ctr = 0;
+    }
+    __syncthreads();
+    for (;;) {
+        const int it = res_next(ctr, lane);
+        if (it >= nb) break;
+        const int q0 = res_tile_of(it, nb) * 16;
+        int jlo = q0 - (D - 1); jlo = jlo < 0 ? 0 : jlo >> 4;
+        int jhi = (q0 + 15 + D - 1) >> 4; jhi = jhi > nb - 1 ? nb - 1 : jhi;
+        const int m_org = -q0 - 15 + (D - 1);
+        bf16x8 qf[DPK], dof[DPK];
+        { int qr = q0 + c; qr = qr < Tn ? qr : Tn - 1;
+          glb_row_frags<DPK>(qf, Q + (long long)qr * ldq, true, g);
+          glb_row_frags<DPK>(dof, dO + (long long)qr * (H * dp), true, g); }
+        float lse[4], dv[4]; bool rowok[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int q = q0 + g * 4 + reg; rowok[reg] = q < Tn;
+            const long long si = ((long long)b * H + h) * Tn + (rowok[reg] ? q : 0);
+            lse[reg] = p.lse[si]; dv[reg] = p.Dv[si];
+        }
+        float dsr[RES_NB][4];
+        f32x4 rprev;
+        { bf16x8 ef[DPK]; lds_row_frags<DPK>(ef, Es, PK, m_org + 16 * jlo + c + PL, g); rprev = dot8<DPK>(qf, ef); }
+#pragma unroll
+        for (int j = 0; j < RES_NB; ++j) {
+            if (j >= jlo && j <= jhi) {
+                bf16x8 kf[DPK], vf[DPK], ef[DPK];
+                lds_row_frags<DPK>(kf, Ks, PK, 16 * j + c, g);
+                lds_row_frags<DPK>(vf, Vs, PK, 16 * j + c, g);
+                lds_row_frags<DPK>(ef, Es, PK, m_org + 16 * (j + 1) + c + PL, g);
+                const f32x4 s = dot8<DPK>(qf, kf);
+                const f32x4 rn = dot8<DPK>(qf, ef);
+                const f32x4 dpv = dot8<DPK>(dof, vf);
+                float pos[4], lgt[4], pd[4];
+                skew_gather(rprev, rn, lane, pos);
+                finish_logits(s, pos, q0, 16 * j, lane, Tn, D, p.scale, lgt);
+                prob_ds(lgt, dpv, lse, dv, rowok, p, b, h, q0, 16 * j, lane, pd, dsr[j]);
+                rprev = rn;
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) dsr[j][reg] = 0.f;
+            }
+        }
+        f32x4 acc[2 * DPK];
+#pragma unroll
+        for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[n] = z; }
+        // content term: dS . K  (B operand = K rows read transposed; rows past Tr belong to the V tile and meet dS = 0)
+#pragma unroll
+        for (int kc = 0; kc < (RES_NB + 1) / 2; ++kc) {
+            if (2 * kc > jhi || 2 * kc + 1 < jlo) continue;
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    tA[(g * 4 + reg) * RT_LD + 16 * half + c] = f2bf(2 * kc + half < RES_NB ? dsr[2 * kc + half < RES_NB ? 2 * kc + half : 0][reg] : 0.f);
+            wave_lds_sync();
+            const bf16x8 a = lds_a_tr(tA + c * RT_LD, g);
+#pragma unroll
+            for (int n = 0; n < 2 * DPK; ++n) acc[n] = mfma_bf16_16x16x32(a, lds_b_tr(Ks, PK, kc * 32, n * 32, c, g), acc[n]);
+            wave_lds_sync();
+        }
+#pragma unroll
+        for (int n = 0; n < 2 * DPK; ++n) acc[n] = acc[n] * p.scale;
+        // positional term: dR . E with dR[q][m] = dS[q][k = m - (D-1) + q]: blocks u of 16 relative positions on the grid
+        // m = m_org + 16u + col hold, for row r, column (col + r - 15) of key block u (col + r >= 15) or u-1 (otherwise)
+#pragma unroll
+        for (int mc = 0; mc < (RES_NB + 2) / 2; ++mc) {
+            if (2 * mc > jhi + 1 || 2 * mc + 1 < jlo) continue;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int u = 2 * mc + half;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int ql = g * 4 + reg, src = ((c + ql + 1) & 15) + 16 * g;
+                    const float lo = u >= 1 && u - 1 < RES_NB ? dsr[(u >= 1 && u - 1 < RES_NB) ? u - 1 : 0][reg] : 0.f;
+                    const float hi = u < RES_NB ? dsr[u < RES_NB ? u : 0][reg] : 0.f;
+                    const float a = __shfl(lo, src), bb = __shfl(hi, src);
+                    tA[ql * RT_LD + 16 * half + c] = f2bf(c + ql >= 15 ? bb : a);
+                }
+            }
+            wave_lds_sync();
+            const bf16x8 a = lds_a_tr(tA + c * RT_LD, g);
+            const int er0 = m_org + 32 * mc + PL;                       // >= 2 and + 31 < ER for every chunk that passes the test above
+#pragma unroll
+            for (int n = 0; n < 2 * DPK; ++n) acc[n] = mfma_bf16_16x16x32(a, lds_b_tr(Es, PK, er0, n * 32, c, g), acc[n]);
+            wave_lds_sync();
+        }
+        RT* dQ = (RT*)p.dqkv + (long long)b * Tn * ldq + h * dp;
+#pragma unroll
+        for (int n = 0; n < 2 * DPK; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) { const int q = q0 + g * 4 + reg; if (q < Tn) dQ[(long long)q * ldq + n * 16 + c] = f2bf(acc[n][reg]); }
+    }
+}
+
+// key-major backward (dK, dV) on resident Q, dO rows
+template <int DPK>
+__global__ __launch_bounds__(RES_W * 64) void attn_bwd_kv_res_kernel(AttnP p)
+{
+    SS_DYN_SMEM(smem);
+    constexpr int dp = DPK * 32, PK = dp * 2 + 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int H = p.H, h = blockIdx.x % H, b = blockIdx.x / H;
+    const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, NE = 2 * D - 1;
+    const int TQ = ((nb + 1) >> 1) * 32;                               // whole 32-query steps
+    unsigned char* Qs = (unsigned char*)smem;
+    unsigned char* dOs = Qs + TQ * PK;
+    unsigned char* Es = dOs + TQ * PK;
+    RT* tP = (RT*)(Es + NE * PK) + w * 2 * 16 * RT_LD;
+    RT* tS = tP + 16 * RT_LD;
+    int* ctr = (int*)(Es + NE * PK + RES_W * 2 * 16 * RT_LD * 2);
+    const long long ldq = 3LL * H * dp;
+    const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
+    const RT* K = Q + H * dp;
+    const RT* V = Q + 2 * H * dp;
+    {
+        stage_rows<DPK>(Qs, PK, Q, ldq, Tn, TQ, tid, RES_W * 64);
+        stage_rows<DPK>(dOs, PK, (const RT*)p.dO + (long long)b * Tn * (H * dp) + h * dp, (long long)H * dp, Tn, TQ, tid, RES_W * 64);
+        stage_rows<DPK>(Es, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE, tid, RES_W * 64);
+        if (tid == 0) *ctr = 0;
+    }
+    __syncthreads();
+    for (;;) {
+        const int it = res_next(ctr, lane);
+        if (it >= nb) break;
+        const int k0 = res_tile_of(it, nb) * 16;
+        int jlo = k0 - (D - 1); jlo = jlo < 0 ? 0 : jlo >> 4;
+        int jhi = (k0 + 15 + D - 1) >> 4; jhi = jhi > nb - 1 ? nb - 1 : jhi;
+        bf16x8 kf[DPK], vf[DPK];
+        { int kr = k0 + c; const bool ok = kr < Tn; kr = ok ? kr : Tn - 1;
+          glb_row_frags<DPK>(kf, K + (long long)kr * ldq, ok, g);
+          glb_row_frags<DPK>(vf, V + (long long)kr * ldq, ok, g); }
+        f32x4 dk[2 * DPK], dvv[2 * DPK];
+#pragma unroll
+        for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; dk[n] = z; dvv[n] = z; }
+        for (int pr = jlo >> 1; pr <= jhi >> 1; ++pr) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int jq = 2 * pr + half, qb0 = 16 * jq;
+                float pd[4] = {0.f, 0.f, 0.f, 0.f}, ds[4] = {0.f, 0.f, 0.f, 0.f};
+                if (jq >= jlo && jq <= jhi) {
+                    bf16x8 qf[DPK], dof[DPK], e0[DPK], e1[DPK];
+                    lds_row_frags<DPK>(qf, Qs, PK, qb0 + c, g);
+                    lds_row_frags<DPK>(dof, dOs, PK, qb0 + c, g);
+                    const int m0 = k0 - qb0 - 15 + (D - 1);
+                    lds_e_frags<DPK>(e0, Es, PK, m0 + c, NE, g);
+                    lds_e_frags<DPK>(e1, Es, PK, m0 + 16 + c, NE, g);
+                    const f32x4 s = dot8<DPK>(qf, kf);
+                    const f32x4 rlo = dot8<DPK>(qf, e0), rhi = dot8<DPK>(qf, e1);
+                    const f32x4 dpv = dot8<DPK>(dof, vf);
+                    float pos[4], lgt[4], lse[4], dv[4]; bool rowok[4];
+                    skew_gather(rlo, rhi, lane, pos);
+                    finish_logits(s, pos, qb0, k0, lane, Tn, D, p.scale, lgt);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int q = qb0 + g * 4 + reg; rowok[reg] = q < Tn;
+                        const long long si = ((long long)b * H + h) * Tn + (q < Tn ? q : Tn - 1);
+                        lse[reg] = p.lse[si]; dv[reg] = p.Dv[si];
+                    }
+                    prob_ds(lgt, dpv, lse, dv, rowok, p, b, h, qb0, k0, lane, pd, ds);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) { tP[c * RT_LD + half * 16 + g * 4 + reg] = f2bf(pd[reg]); tS[c * RT_LD + half * 16 + g * 4 + reg] = f2bf(ds[reg]); }
+            }
+            wave_lds_sync();
+            {
+                const bf16x8 pa = lds_a_tr(tP + c * RT_LD, g), sa = lds_a_tr(tS + c * RT_LD, g);
+#pragma unroll
+                for (int n = 0; n < 2 * DPK; ++n) {
+                    dvv[n] = mfma_bf16_16x16x32(pa, lds_b_tr(dOs, PK, 32 * pr, n * 32, c, g), dvv[n]);
+                    dk[n] = mfma_bf16_16x16x32(sa, lds_b_tr(Qs, PK, 32 * pr, n * 32, c, g), dk[n]);
+                }
+            }
+            wave_lds_sync();
+        }
+        RT* dK = (RT*)p.dqkv + (long long)b * Tn * ldq + H * dp + h * dp;
+        RT* dV = dK + H * dp;
+#pragma unroll
+        for (int n = 0; n < 2 * DPK; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int k = k0 + g * 4 + reg;
+                if (k < Tn) { dK[(long long)k * ldq + n * 16 + c] = f2bf(dk[n][reg] * p.scale); dV[(long long)k * ldq + n * 16 + c] = f2bf(dvv[n][reg]); }
+            }
+    }
+}
+
 // =========================================================================== host side
 static int attn_check(const char* what, int dtype, int B, int H, int T, int Tp, int dp, int D, float dropout_p)
 {
@@ -522,6 +995,42 @@ static void attn_fill(AttnP& p, int B, int H, int T, int Tp, int dp, int D, floa
         }                                                                                                       \
     } while (0)
 
+// ---- resident-path dispatch
+#include <stdlib.h>
+static const size_t RES_LDS_MAX = 160 * 1024;
+static size_t res_smem(int which, int T, int dp, int D) {
+    const size_t PK = (size_t)dp * 2 + 16, nb = (size_t)(T + 15) / 16, Tr = nb * 16, NE = 2 * (size_t)D - 1, TQ = (nb + 1) / 2 * 32, tile = 16 * RT_LD * 2;
+    if (which == 0) return Tr * PK + (NE + 2 * RES_PL) * PK + (size_t)dp * ((nb + 2) / 2 * 32 * 2 + 16) + RES_W * tile + 16;
+    if (which == 1) return 2 * Tr * PK + (NE + 96) * PK + RES_W * tile + 16;
+    return 2 * TQ * PK + NE * PK + RES_W * 2 * tile + 16;
+}
+static bool res_enabled(int dtype, int T) {
+    if (dtype != SS_BF16 || (T + 15) / 16 > RES_NB) return false;
+    const char* e = getenv("SS_ATTN_RESIDENT");           // "0" forces the per-tile kernels (A/B measurements, tests of both paths)
+    return !(e && e[0] == '0');
+}
+typedef void (*ResKernel)(AttnP);
+static int res_launch(ResKernel k, int slot, int blocks, size_t smem, void* stream, const AttnP& p) {
+#if !defined(SS_EMU)
+    static size_t granted[16] = {0};
+    if (granted[slot] < smem) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("attention: cannot reserve %zu bytes of LDS", smem); return 1; }
+        granted[slot] = smem;
+    }
+#endif
+    SS_LAUNCH(k, dim3(blocks), dim3(RES_W * 64), smem, stream, p);
+    return 0;
+}
+static ResKernel res_pick(int which, int dpk, bool drop = false) {
+    static const ResKernel fwd_drop[3] = {attn_fwd_res_kernel<1, true>, attn_fwd_res_kernel<2, true>, attn_fwd_res_kernel<3, true>};
+    if (which == 0 && drop && dpk >= 1 && dpk <= 3) return fwd_drop[dpk - 1];
+    static const ResKernel tab[3][3] = {
+        {attn_fwd_res_kernel<1, false>, attn_fwd_res_kernel<2, false>, attn_fwd_res_kernel<3, false>},
+        {attn_bwd_q_res_kernel<1>, attn_bwd_q_res_kernel<2>, attn_bwd_q_res_kernel<3>},
+        {attn_bwd_kv_res_kernel<1>, attn_bwd_kv_res_kernel<2>, attn_bwd_kv_res_kernel<3>}};
+    return dpk >= 1 && dpk <= 3 ? tab[which][dpk - 1] : (ResKernel)0;
+}
+
 extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse,
                                            int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
@@ -529,6 +1038,11 @@ extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const voi
     SS_CHECK(qkv && qkvT && E && out && lse, "ss_relpos_attention_forward: null pointer");
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
     p.qkv = qkv; p.qkvT = qkvT; p.E = E; p.out = out; p.lse = lse;
+    if (res_enabled(dtype, T) && res_pick(0, dp / 32) && res_smem(0, T, dp, D) <= RES_LDS_MAX) {
+        if (res_launch(res_pick(0, dp / 32, p.drop_thresh != 0), dp / 32 + (p.drop_thresh ? 12 : 0), B * H, res_smem(0, T, dp, D), stream, p)) return 1;
+        SS_LAUNCH_CHECK("ss_relpos_attention_forward");
+        return 0;
+    }
     p.gx = ((T + 15) / 16 + 3) / 4;
     dim3 grid(p.gx * H * B);
     SS_ATTN_DISPATCH(attn_fwd_kernel, grid, 256, 0);
@@ -548,6 +1062,12 @@ extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const vo
         long long blocks = ((long long)B * T + 3) / 4; if (blocks > 8192) blocks = 8192;
         if (dtype == SS_BF16) SS_LAUNCH(attn_dsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dO, (const bf16_t*)out, Dscratch, B, H, T, dp);
         else SS_LAUNCH(attn_dsum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)dO, (const float*)out, Dscratch, B, H, T, dp);
+    }
+    if (res_enabled(dtype, T) && res_pick(1, dp / 32) && res_smem(1, T, dp, D) <= RES_LDS_MAX && res_smem(2, T, dp, D) <= RES_LDS_MAX) {
+        if (res_launch(res_pick(1, dp / 32), 4 + dp / 32, B * H, res_smem(1, T, dp, D), stream, p)) return 1;
+        if (res_launch(res_pick(2, dp / 32), 8 + dp / 32, B * H, res_smem(2, T, dp, D), stream, p)) return 1;
+        SS_LAUNCH_CHECK("ss_relpos_attention_backward");
+        return 0;
     }
     const size_t esz = dtype == SS_BF16 ? 2 : 4;
     const int nwq = dtype == SS_BF16 ? 4 : 2;                         // keep the dynamic LDS request under 64 KiB

@@ -111,6 +111,24 @@ __device__ __forceinline__ void wave_lds_sync() {
 #endif
 }
 
+// 2^x and 1/x straight on the transcendental unit (v_exp_f32 / v_rcp_f32, 1 ulp; no denormal fix-up code)
+__device__ __forceinline__ float fast_exp2(float x) {
+#if defined(SS_EMU)
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+#if defined(SS_EMU)
+    return 1.f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+// two floats -> packed bf16 pair (lo in bits 0..15)
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
 // ------------------------------------------------------------------ MFMA wrappers
 __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
 #if defined(SS_EMU)

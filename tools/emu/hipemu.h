@@ -168,7 +168,7 @@ template <class F>
 inline void launch(dim3 grid, dim3 block, size_t smem, F&& body) {
     State& s = S();
     s.body = body;
-    std::vector<char> dyn(smem + 64);
+    std::vector<char> dyn(smem + 64, (char)0xFF);      // LDS is not zeroed on hardware: 0xFF.. = NaN in bf16 and f32, so stale reads show up in the CPU tier
     s.dyn_smem = (char*)(((uintptr_t)dyn.data() + 63) & ~(uintptr_t)63);
     gridDim = grid; blockDim = block;
     for (unsigned z = 0; z < grid.z; ++z)
