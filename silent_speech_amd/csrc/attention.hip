@@ -748,23 +748,42 @@ __global__ __launch_bounds__(RES_W * 64) void attn_fwd_res_kernel(AttnP p)
     }
 }
 
+// probability and dS of one block from log2-domain logits:  p = 2^(l2 - lse2);  dS = p * (keep ? dP/(1-pd) : 0  -  D).
+// Masked entries carry l2 = -1e8*log2(e), so p is exactly 0 there; rows past the sequence are cut by rowok.
+template <bool DROP>
+__device__ __forceinline__ void res_prob_ds(const float (&l2)[4], const f32x4& dpv, const float (&lse2)[4], const float (&dv)[4], const bool (&rowok)[4],
+                                            const AttnP& p, int b, int h, int q0, int k0, int lane, float (&pd)[4], float (&ds)[4])
+{
+    const int c = lane & 15, g = lane >> 4;
+    bool kp[4] = {true, true, true, true};
+    if (DROP) dropout_keep4(p.seed, p.stream, (((unsigned long long)b * p.H + h) * p.T + ((q0 >> 2) + g)) * p.T + (k0 + c), p.drop_thresh, kp);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const float pr = rowok[reg] ? fast_exp2(l2[reg] - lse2[reg]) : 0.f;
+        const float keep = DROP ? (kp[reg] ? p.drop_scale : 0.f) : 1.f;
+        pd[reg] = pr * keep;
+        ds[reg] = pr * (dpv[reg] * keep - dv[reg]);
+    }
+}
+
 // query-major backward (dQ) on resident K, V rows and a zero-padded embedding table (PL rows below, PH above)
-template <int DPK>
+template <int DPK, bool DROP>
 __global__ __launch_bounds__(RES_W * 64) void attn_bwd_q_res_kernel(AttnP p)
 {
     SS_DYN_SMEM(smem);
-    constexpr int dp = DPK * 32, PK = dp * 2 + 16, PL = 48, PH = 48;
+    constexpr int dp = DPK * 32, PK = dp * 2 + 16, PL = 48, PH = 48, PTL = 20;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
     const int H = p.H, h = blockIdx.x % H, b = blockIdx.x / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1, ER = NE + PL + PH;
     unsigned char* Ks = (unsigned char*)smem;
     unsigned char* Vs = Ks + Tr * PK;
     unsigned char* Es = Vs + Tr * PK;                                  // row m + PL holds embedding m
-    RT* tA = (RT*)(Es + ER * PK) + w * 16 * RT_LD;
+    RT* tA = (RT*)(Es + ER * PK) + w * 16 * RT_LD;                     // dS^T / dR^T chunk: [32 contraction rows][16 queries (+4)]
     int* ctr = (int*)(Es + ER * PK + RES_W * 16 * RT_LD * 2);
     const long long ldq = 3LL * H * dp;
     const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
     const RT* dO = (const RT*)p.dO + (long long)b * Tn * (H * dp) + h * dp;
+    const float scale2 = p.scale * LOG2E;
     {
         stage_rows<DPK>(Ks, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W * 64);
         stage_rows<DPK>(Vs, PK, Q + 2 * H * dp, ldq, Tn, Tr, tid, RES_W * 64);
@@ -773,24 +792,28 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_q_res_kernel(AttnP p)
         if (tid == 0) *ctr = 0;
     }
     __syncthreads();
-    for (;;) {
-        const int it = res_next(ctr, lane);
-        if (it >= nb) break;
+    int bandA[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) bandA[reg] = c - (g * 4 + reg) + (D - 1);
+    int it = res_next(ctr, lane);
+    bf16x8 qf[DPK], dof[DPK], qn[DPK], don[DPK];
+    if (it < nb) { int qr = res_tile_of(it, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1;
+                   glb_row_frags<DPK>(qf, Q + (long long)qr * ldq, true, g); glb_row_frags<DPK>(dof, dO + (long long)qr * (H * dp), true, g); }
+    while (it < nb) {
         const int q0 = res_tile_of(it, nb) * 16;
         int jlo = q0 - (D - 1); jlo = jlo < 0 ? 0 : jlo >> 4;
         int jhi = (q0 + 15 + D - 1) >> 4; jhi = jhi > nb - 1 ? nb - 1 : jhi;
         const int m_org = -q0 - 15 + (D - 1);
-        bf16x8 qf[DPK], dof[DPK];
-        { int qr = q0 + c; qr = qr < Tn ? qr : Tn - 1;
-          glb_row_frags<DPK>(qf, Q + (long long)qr * ldq, true, g);
-          glb_row_frags<DPK>(dof, dO + (long long)qr * (H * dp), true, g); }
-        float lse[4], dv[4]; bool rowok[4];
+        float lse2[4], dv[4]; bool rowok[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int q = q0 + g * 4 + reg; rowok[reg] = q < Tn;
             const long long si = ((long long)b * H + h) * Tn + (rowok[reg] ? q : 0);
-            lse[reg] = p.lse[si]; dv[reg] = p.Dv[si];
+            lse2[reg] = p.lse[si] * LOG2E; dv[reg] = p.Dv[si];
         }
+        const int itn = res_next(ctr, lane);
+        if (itn < nb) { int qr = res_tile_of(itn, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1;
+                        glb_row_frags<DPK>(qn, Q + (long long)qr * ldq, true, g); glb_row_frags<DPK>(don, dO + (long long)qr * (H * dp), true, g); }
         float dsr[RES_NB][4];
         f32x4 rprev;
         { bf16x8 ef[DPK]; lds_row_frags<DPK>(ef, Es, PK, m_org + 16 * jlo + c + PL, g); rprev = dot8<DPK>(qf, ef); }
@@ -804,10 +827,10 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_q_res_kernel(AttnP p)
                 const f32x4 s = dot8<DPK>(qf, kf);
                 const f32x4 rn = dot8<DPK>(qf, ef);
                 const f32x4 dpv = dot8<DPK>(dof, vf);
-                float pos[4], lgt[4], pd[4];
+                float pos[4], l2[4], pd[4];
                 skew_gather(rprev, rn, lane, pos);
-                finish_logits(s, pos, q0, 16 * j, lane, Tn, D, p.scale, lgt);
-                prob_ds(lgt, dpv, lse, dv, rowok, p, b, h, q0, 16 * j, lane, pd, dsr[j]);
+                res_logits(s, pos, bandA, 16 * j - q0, 16 * j + c < Tn, 2u * (unsigned)(D - 1), scale2, l2);
+                res_prob_ds<DROP>(l2, dpv, lse2, dv, rowok, p, b, h, q0, 16 * j, lane, pd, dsr[j]);
                 rprev = rn;
             } else {
 #pragma unroll
@@ -817,17 +840,20 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_q_res_kernel(AttnP p)
         f32x4 acc[2 * DPK];
 #pragma unroll
         for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[n] = z; }
-        // content term: dS . K  (B operand = K rows read transposed; rows past Tr belong to the V tile and meet dS = 0)
+        // content term: dS . K.  dS^T goes to LDS as [key][query] (this lane's 4 rows are adjacent: one 8-byte store per block),
+        // both operands come back through transposing reads; key rows past Tr belong to the V tile and meet dS = 0.
 #pragma unroll
         for (int kc = 0; kc < (RES_NB + 1) / 2; ++kc) {
             if (2 * kc > jhi || 2 * kc + 1 < jlo) continue;
 #pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    tA[(g * 4 + reg) * RT_LD + 16 * half + c] = f2bf(2 * kc + half < RES_NB ? dsr[2 * kc + half < RES_NB ? 2 * kc + half : 0][reg] : 0.f);
+            for (int half = 0; half < 2; ++half) {
+                const int j = 2 * kc + half;
+                u32x2 pk = {0u, 0u};
+                if (j < RES_NB) { pk[0] = pack_bf16(dsr[j < RES_NB ? j : 0][0], dsr[j < RES_NB ? j : 0][1]); pk[1] = pack_bf16(dsr[j < RES_NB ? j : 0][2], dsr[j < RES_NB ? j : 0][3]); }
+                *(u32x2*)(tA + (16 * half + c) * PTL + g * 4) = pk;
+            }
             wave_lds_sync();
-            const bf16x8 a = lds_a_tr(tA + c * RT_LD, g);
+            const bf16x8 a = lds_b_tr((const unsigned char*)tA, PTL * 2, 0, 0, c, g);
 #pragma unroll
             for (int n = 0; n < 2 * DPK; ++n) acc[n] = mfma_bf16_16x16x32(a, lds_b_tr(Ks, PK, kc * 32, n * 32, c, g), acc[n]);
             wave_lds_sync();
@@ -842,32 +868,34 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_q_res_kernel(AttnP p)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int u = 2 * mc + half;
+                float val[4];
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int ql = g * 4 + reg, src = ((c + ql + 1) & 15) + 16 * g;
                     const float lo = u >= 1 && u - 1 < RES_NB ? dsr[(u >= 1 && u - 1 < RES_NB) ? u - 1 : 0][reg] : 0.f;
                     const float hi = u < RES_NB ? dsr[u < RES_NB ? u : 0][reg] : 0.f;
                     const float a = __shfl(lo, src), bb = __shfl(hi, src);
-                    tA[ql * RT_LD + 16 * half + c] = f2bf(c + ql >= 15 ? bb : a);
+                    val[reg] = c + ql >= 15 ? bb : a;
                 }
+                u32x2 pk = {pack_bf16(val[0], val[1]), pack_bf16(val[2], val[3])};
+                *(u32x2*)(tA + (16 * half + c) * PTL + g * 4) = pk;
             }
             wave_lds_sync();
-            const bf16x8 a = lds_a_tr(tA + c * RT_LD, g);
+            const bf16x8 a = lds_b_tr((const unsigned char*)tA, PTL * 2, 0, 0, c, g);
             const int er0 = m_org + 32 * mc + PL;                       // >= 2 and + 31 < ER for every chunk that passes the test above
 #pragma unroll
             for (int n = 0; n < 2 * DPK; ++n) acc[n] = mfma_bf16_16x16x32(a, lds_b_tr(Es, PK, er0, n * 32, c, g), acc[n]);
             wave_lds_sync();
         }
-        RT* dQ = (RT*)p.dqkv + (long long)b * Tn * ldq + h * dp;
+        store_tile_rows<DPK>(tA, acc, 1.f, (RT*)p.dqkv + (long long)b * Tn * ldq + h * dp, ldq, q0, Tn, lane);
+        it = itn;
 #pragma unroll
-        for (int n = 0; n < 2 * DPK; ++n)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) { const int q = q0 + g * 4 + reg; if (q < Tn) dQ[(long long)q * ldq + n * 16 + c] = f2bf(acc[n][reg]); }
+        for (int kk = 0; kk < DPK; ++kk) { qf[kk] = qn[kk]; dof[kk] = don[kk]; }
     }
 }
 
 // key-major backward (dK, dV) on resident Q, dO rows
-template <int DPK>
+template <int DPK, bool DROP>
 __global__ __launch_bounds__(RES_W * 64) void attn_bwd_kv_res_kernel(AttnP p)
 {
     SS_DYN_SMEM(smem);
@@ -879,33 +907,42 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_kv_res_kernel(AttnP p)
     unsigned char* Qs = (unsigned char*)smem;
     unsigned char* dOs = Qs + TQ * PK;
     unsigned char* Es = dOs + TQ * PK;
-    RT* tP = (RT*)(Es + NE * PK) + w * 2 * 16 * RT_LD;
+    RT* tP = (RT*)(Es + NE * PK) + w * 2 * 16 * RT_LD;                 // P~^T, dS^T chunks: [16 keys][32 queries (+8)]
     RT* tS = tP + 16 * RT_LD;
-    int* ctr = (int*)(Es + NE * PK + RES_W * 2 * 16 * RT_LD * 2);
+    float* lse2s = (float*)(Es + NE * PK + RES_W * 2 * 16 * RT_LD * 2);
+    float* dvs = lse2s + TQ;
+    int* ctr = (int*)(dvs + TQ);
     const long long ldq = 3LL * H * dp;
     const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
     const RT* K = Q + H * dp;
     const RT* V = Q + 2 * H * dp;
+    const float scale2 = p.scale * LOG2E;
     {
         stage_rows<DPK>(Qs, PK, Q, ldq, Tn, TQ, tid, RES_W * 64);
         stage_rows<DPK>(dOs, PK, (const RT*)p.dO + (long long)b * Tn * (H * dp) + h * dp, (long long)H * dp, Tn, TQ, tid, RES_W * 64);
         stage_rows<DPK>(Es, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE, tid, RES_W * 64);
+        for (int i = tid; i < TQ; i += RES_W * 64) {
+            const long long si = ((long long)b * H + h) * Tn + (i < Tn ? i : Tn - 1);
+            lse2s[i] = p.lse[si] * LOG2E; dvs[i] = p.Dv[si];
+        }
         if (tid == 0) *ctr = 0;
     }
     __syncthreads();
-    for (;;) {
-        const int it = res_next(ctr, lane);
-        if (it >= nb) break;
+    int it = res_next(ctr, lane);
+    bf16x8 kf[DPK], vf[DPK], kn[DPK], vn[DPK];
+    if (it < nb) { int kr = res_tile_of(it, nb) * 16 + c; const bool ok = kr < Tn; kr = ok ? kr : Tn - 1;
+                   glb_row_frags<DPK>(kf, K + (long long)kr * ldq, ok, g); glb_row_frags<DPK>(vf, V + (long long)kr * ldq, ok, g); }
+    while (it < nb) {
         const int k0 = res_tile_of(it, nb) * 16;
         int jlo = k0 - (D - 1); jlo = jlo < 0 ? 0 : jlo >> 4;
         int jhi = (k0 + 15 + D - 1) >> 4; jhi = jhi > nb - 1 ? nb - 1 : jhi;
-        bf16x8 kf[DPK], vf[DPK];
-        { int kr = k0 + c; const bool ok = kr < Tn; kr = ok ? kr : Tn - 1;
-          glb_row_frags<DPK>(kf, K + (long long)kr * ldq, ok, g);
-          glb_row_frags<DPK>(vf, V + (long long)kr * ldq, ok, g); }
+        const int itn = res_next(ctr, lane);
+        if (itn < nb) { int kr = res_tile_of(itn, nb) * 16 + c; const bool ok = kr < Tn; kr = ok ? kr : Tn - 1;
+                        glb_row_frags<DPK>(kn, K + (long long)kr * ldq, ok, g); glb_row_frags<DPK>(vn, V + (long long)kr * ldq, ok, g); }
         f32x4 dk[2 * DPK], dvv[2 * DPK];
 #pragma unroll
         for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; dk[n] = z; dvv[n] = z; }
+        const bool key_ok = k0 + c < Tn;
         for (int pr = jlo >> 1; pr <= jhi >> 1; ++pr) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -921,19 +958,17 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_kv_res_kernel(AttnP p)
                     const f32x4 s = dot8<DPK>(qf, kf);
                     const f32x4 rlo = dot8<DPK>(qf, e0), rhi = dot8<DPK>(qf, e1);
                     const f32x4 dpv = dot8<DPK>(dof, vf);
-                    float pos[4], lgt[4], lse[4], dv[4]; bool rowok[4];
+                    float pos[4], l2[4], lse2[4], dv[4]; bool rowok[4]; int bandA[4];
                     skew_gather(rlo, rhi, lane, pos);
-                    finish_logits(s, pos, qb0, k0, lane, Tn, D, p.scale, lgt);
+                    const f32x4 lv = *(const f32x4*)(lse2s + qb0 + g * 4), dq = *(const f32x4*)(dvs + qb0 + g * 4);
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int q = qb0 + g * 4 + reg; rowok[reg] = q < Tn;
-                        const long long si = ((long long)b * H + h) * Tn + (q < Tn ? q : Tn - 1);
-                        lse[reg] = p.lse[si]; dv[reg] = p.Dv[si];
-                    }
-                    prob_ds(lgt, dpv, lse, dv, rowok, p, b, h, qb0, k0, lane, pd, ds);
+                    for (int reg = 0; reg < 4; ++reg) { bandA[reg] = c - (g * 4 + reg) + (D - 1); rowok[reg] = qb0 + g * 4 + reg < Tn; lse2[reg] = lv[reg]; dv[reg] = dq[reg]; }
+                    res_logits(s, pos, bandA, k0 - qb0, key_ok, 2u * (unsigned)(D - 1), scale2, l2);
+                    res_prob_ds<DROP>(l2, dpv, lse2, dv, rowok, p, b, h, qb0, k0, lane, pd, ds);
                 }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) { tP[c * RT_LD + half * 16 + g * 4 + reg] = f2bf(pd[reg]); tS[c * RT_LD + half * 16 + g * 4 + reg] = f2bf(ds[reg]); }
+                u32x2 pp = {pack_bf16(pd[0], pd[1]), pack_bf16(pd[2], pd[3])}, ss = {pack_bf16(ds[0], ds[1]), pack_bf16(ds[2], ds[3])};
+                *(u32x2*)(tP + c * RT_LD + half * 16 + g * 4) = pp;
+                *(u32x2*)(tS + c * RT_LD + half * 16 + g * 4) = ss;
             }
             wave_lds_sync();
             {
@@ -947,14 +982,11 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_kv_res_kernel(AttnP p)
             wave_lds_sync();
         }
         RT* dK = (RT*)p.dqkv + (long long)b * Tn * ldq + H * dp + h * dp;
-        RT* dV = dK + H * dp;
+        store_tile_rows<DPK>(tP, dk, p.scale, dK, ldq, k0, Tn, lane);
+        store_tile_rows<DPK>(tS, dvv, 1.f, dK + H * dp, ldq, k0, Tn, lane);
+        it = itn;
 #pragma unroll
-        for (int n = 0; n < 2 * DPK; ++n)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int k = k0 + g * 4 + reg;
-                if (k < Tn) { dK[(long long)k * ldq + n * 16 + c] = f2bf(dk[n][reg] * p.scale); dV[(long long)k * ldq + n * 16 + c] = f2bf(dvv[n][reg]); }
-            }
+        for (int kk = 0; kk < DPK; ++kk) { kf[kk] = kn[kk]; vf[kk] = vn[kk]; }
     }
 }
 
@@ -1002,7 +1034,7 @@ static size_t res_smem(int which, int T, int dp, int D) {
     const size_t PK = (size_t)dp * 2 + 16, nb = (size_t)(T + 15) / 16, Tr = nb * 16, NE = 2 * (size_t)D - 1, TQ = (nb + 1) / 2 * 32, tile = 16 * RT_LD * 2;
     if (which == 0) return Tr * PK + (NE + 2 * RES_PL) * PK + (size_t)dp * ((nb + 2) / 2 * 32 * 2 + 16) + RES_W * tile + 16;
     if (which == 1) return 2 * Tr * PK + (NE + 96) * PK + RES_W * tile + 16;
-    return 2 * TQ * PK + NE * PK + RES_W * 2 * tile + 16;
+    return 2 * TQ * PK + NE * PK + RES_W * 2 * tile + 8 * TQ + 16;
 }
 static bool res_enabled(int dtype, int T) {
     if (dtype != SS_BF16 || (T + 15) / 16 > RES_NB) return false;
@@ -1012,7 +1044,7 @@ static bool res_enabled(int dtype, int T) {
 typedef void (*ResKernel)(AttnP);
 static int res_launch(ResKernel k, int slot, int blocks, size_t smem, void* stream, const AttnP& p) {
 #if !defined(SS_EMU)
-    static size_t granted[16] = {0};
+    static size_t granted[24] = {0};
     if (granted[slot] < smem) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("attention: cannot reserve %zu bytes of LDS", smem); return 1; }
         granted[slot] = smem;
@@ -1026,8 +1058,12 @@ static ResKernel res_pick(int which, int dpk, bool drop = false) {
     if (which == 0 && drop && dpk >= 1 && dpk <= 3) return fwd_drop[dpk - 1];
     static const ResKernel tab[3][3] = {
         {attn_fwd_res_kernel<1, false>, attn_fwd_res_kernel<2, false>, attn_fwd_res_kernel<3, false>},
-        {attn_bwd_q_res_kernel<1>, attn_bwd_q_res_kernel<2>, attn_bwd_q_res_kernel<3>},
-        {attn_bwd_kv_res_kernel<1>, attn_bwd_kv_res_kernel<2>, attn_bwd_kv_res_kernel<3>}};
+        {attn_bwd_q_res_kernel<1, false>, attn_bwd_q_res_kernel<2, false>, attn_bwd_q_res_kernel<3, false>},
+        {attn_bwd_kv_res_kernel<1, false>, attn_bwd_kv_res_kernel<2, false>, attn_bwd_kv_res_kernel<3, false>}};
+    static const ResKernel bq_drop[3] = {attn_bwd_q_res_kernel<1, true>, attn_bwd_q_res_kernel<2, true>, attn_bwd_q_res_kernel<3, true>};
+    static const ResKernel bkv_drop[3] = {attn_bwd_kv_res_kernel<1, true>, attn_bwd_kv_res_kernel<2, true>, attn_bwd_kv_res_kernel<3, true>};
+    if (drop && dpk >= 1 && dpk <= 3 && which == 1) return bq_drop[dpk - 1];
+    if (drop && dpk >= 1 && dpk <= 3 && which == 2) return bkv_drop[dpk - 1];
     return dpk >= 1 && dpk <= 3 ? tab[which][dpk - 1] : (ResKernel)0;
 }
 
@@ -1064,8 +1100,9 @@ extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const vo
         else SS_LAUNCH(attn_dsum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)dO, (const float*)out, Dscratch, B, H, T, dp);
     }
     if (res_enabled(dtype, T) && res_pick(1, dp / 32) && res_smem(1, T, dp, D) <= RES_LDS_MAX && res_smem(2, T, dp, D) <= RES_LDS_MAX) {
-        if (res_launch(res_pick(1, dp / 32), 4 + dp / 32, B * H, res_smem(1, T, dp, D), stream, p)) return 1;
-        if (res_launch(res_pick(2, dp / 32), 8 + dp / 32, B * H, res_smem(2, T, dp, D), stream, p)) return 1;
+        const bool drop = p.drop_thresh != 0;
+        if (res_launch(res_pick(1, dp / 32, drop), (drop ? 16 : 4) + dp / 32, B * H, res_smem(1, T, dp, D), stream, p)) return 1;
+        if (res_launch(res_pick(2, dp / 32, drop), (drop ? 20 : 8) + dp / 32, B * H, res_smem(2, T, dp, D), stream, p)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_backward");
         return 0;
     }
