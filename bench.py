@@ -157,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_enqueue = time.perf_counter() - t0               # host time to ENQUEUE the steps (the GPU runs behind, asynchronously)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -180,7 +181,8 @@ def main():
             'config': {'workload': 'configs[1]: full transduction model (768-d, 6-layer rel-pos encoder, 3 ResBlocks) training step '
                                    '(pack+fwd+dtw_loss incl. on-device DTW+bwd+AdamW), dropout 0.2, synthetic 8-ch EMG',
                        'frames_per_gpu_step': frames, 'rows_per_gpu_step': rows, 'utterances_per_gpu_step': len(batch['lengths']),
-                       'silent_utterances': int(sum(batch['silent'])), 'parallelism': 'dp%d' % world, 'final_loss': final_loss},
+                       'silent_utterances': int(sum(batch['silent'])), 'parallelism': 'dp%d' % world, 'final_loss': final_loss,
+                       'host_enqueue_ms_per_step': host_enqueue / args.steps * 1e3},
         }
         if prof is not None:
             summ = prof.summary()

@@ -68,11 +68,81 @@ struct PermuteJob {       // mirrored by ctypes in silent_speech_amd/_lib.py
     float scale; int first_block, nblocks, pad_;
 };
 
+// Three paths per job (wave-uniform choice):
+//   rows      input contiguous along c (s2 == 1): 4 elements per thread, 16-byte loads
+//   transpose input contiguous along a or b, strided along c: 64 x 64 tiles through LDS, both sides coalesced
+//             (the per-step weight re-layouts are mostly [n][k] -> [k][n] and (O, I, 3) -> (O, 3, I) of this kind)
+//   generic   anything else (negative strides of the flipped-tap conv forms, tiny jobs)
+template <class TI> struct Vec4;
+template <> struct Vec4<float> { static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { const f32x4 a = *(const f32x4*)p; v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; } };
+template <> struct Vec4<bf16_t> { static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) { const u32x2 a = *(const u32x2*)p; v[0] = __uint_as_float(a[0] << 16); v[1] = __uint_as_float(a[0] & 0xffff0000u); v[2] = __uint_as_float(a[1] << 16); v[3] = __uint_as_float(a[1] & 0xffff0000u); } };
+
 template <class TI, class TO>
-__device__ __forceinline__ void permute_job(const PermuteJob& j, int lb, int nthreads, int tid)
+__device__ __forceinline__ void permute_job(const PermuteJob& j, int lb, int nthreads, int tid, float* tile)
 {
     const long long total = (long long)j.d0 * j.d1 * j.d2;
     const TI* in = (const TI*)j.in; TO* out = (TO*)j.out;
+    // X = the outer dimension along which the input is (nearly) contiguous: |stride| <= 4 elements, the longer one if both are
+    const long long as0 = j.s0 < 0 ? -j.s0 : j.s0, as1 = j.s1 < 0 ? -j.s1 : j.s1, as2 = j.s2 < 0 ? -j.s2 : j.s2;
+    const bool c0 = j.d0 > 1 && as0 >= 1 && as0 <= 4, c1 = j.d1 > 1 && as1 >= 1 && as1 <= 4;
+    const bool fx1 = c1 && (!c0 || j.d1 >= j.d0), fx0 = c0 && !fx1;
+    if (as2 > 4 && (fx0 || fx1) && nthreads == 256 && total >= 4096) {
+        // ---- transpose path: X as above, O = the other outer dimension.  Tile = TX (along X) x TC (along c) = 4096 elements;
+        // the shape follows the short side (3 conv taps along X on the way in, along c on the way out).
+        const int dX = fx1 ? j.d1 : j.d0, dO = fx1 ? j.d0 : j.d1;
+        const long long sX = fx1 ? j.s1 : j.s0, sO = fx1 ? j.s0 : j.s1, oX = fx1 ? j.o1 : j.o0, oO = fx1 ? j.o0 : j.o1;
+        const int lx = dX <= 4 ? 2 : (dX <= 16 ? 4 : (j.d2 <= 4 ? 10 : (j.d2 <= 16 ? 8 : 6)));
+        const int TX = 1 << lx, lc = 12 - lx, TC = 1 << lc, P = TX + 1;
+        const int tiles_x = (dX + TX - 1) >> lx, tiles_c = (j.d2 + TC - 1) >> lc;
+        const long long ntiles = (long long)dO * tiles_x * tiles_c;
+        for (long long t = lb; t < ntiles; t += j.nblocks) {
+            const int oi = (int)(t / (tiles_x * tiles_c)), rem = (int)(t - (long long)oi * (tiles_x * tiles_c));
+            const int tx = rem / tiles_c, tc = rem - tx * tiles_c;
+            {
+                float v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int f = k * 256 + tid, x = f & (TX - 1), cc = f >> lx;                 // X fastest: coalesced input
+                    const int gx = tx * TX + x, gc = tc * TC + cc, bb = fx1 ? gx : oi;
+                    v[k] = 0.f;
+                    if (gx < dX && gc < j.d2 && bb < j.valid1 && gc < j.valid2) v[k] = ldf(in + oi * sO + gx * sX + (long long)gc * j.s2) * j.scale;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const int f = k * 256 + tid; tile[(f >> lx) * P + (f & (TX - 1))] = v[k]; }
+            }
+            __syncthreads();
+            {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int f = k * 256 + tid, x = f >> lc, cc = f & (TC - 1);                 // c fastest: coalesced output
+                    const int gx = tx * TX + x, gc = tc * TC + cc;
+                    if (gx < dX && gc < j.d2) {
+                        TO* o = out + oi * oO + gx * oX + gc;
+                        float w = tile[cc * P + x];
+                        if (j.accumulate) w += ldf(o);
+                        stf(o, w);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    if (j.s2 == 1 && !(j.d2 & 3) && !(j.s0 & 3) && !(j.s1 & 3) && !(j.o0 & 3) && !(j.o1 & 3) && !(j.valid2 & 3) &&
+        ((uintptr_t)in % (4 * sizeof(TI))) == 0 && ((uintptr_t)out % (4 * sizeof(TO))) == 0) {
+        // ---- row path
+        const int c4n = j.d2 >> 2;
+        for (long long i = (long long)lb * nthreads + tid; i < (total >> 2); i += (long long)j.nblocks * nthreads) {
+            const int c = (int)(i % c4n) * 4; const long long t = i / c4n; const int b = (int)(t % j.d1); const int a = (int)(t / j.d1);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (b < j.valid1 && c < j.valid2) { Vec4<TI>::load(in + a * j.s0 + b * j.s1 + c, v); v[0] *= j.scale; v[1] *= j.scale; v[2] *= j.scale; v[3] *= j.scale; }
+            TO* o = out + a * j.o0 + b * j.o1 + c;
+            if (j.accumulate) { float w[4]; Vec4<TO>::load(o, w); v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3]; }
+            if (sizeof(TO) == 4) { const f32x4 r = {v[0], v[1], v[2], v[3]}; *(f32x4*)o = r; }
+            else { const u32x2 r = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])}; *(u32x2*)o = r; }
+        }
+        return;
+    }
     for (long long i = (long long)lb * nthreads + tid; i < total; i += (long long)j.nblocks * nthreads) {
         const int c = (int)(i % j.d2); const long long t = i / j.d2; const int b = (int)(t % j.d1); const int a = (int)(t / j.d1);
         float v = (b < j.valid1 && c < j.valid2) ? ldf(in + a * j.s0 + b * j.s1 + c * j.s2) * j.scale : 0.f;
@@ -84,12 +154,13 @@ __device__ __forceinline__ void permute_job(const PermuteJob& j, int lb, int nth
 
 __global__ void permute3d_batch_kernel(const PermuteJob* __restrict__ jobs, const int* __restrict__ job_of_block)
 {
+    __shared__ float tile[1024 * 5];                    // TC x (TX + 1) for TX = 4 / 16 / 64
     const PermuteJob j = jobs[job_of_block[blockIdx.x]];
     const int lb = blockIdx.x - j.first_block;
-    if (j.in_dtype == SS_F32 && j.out_dtype == SS_F32) permute_job<float, float>(j, lb, blockDim.x, threadIdx.x);
-    else if (j.in_dtype == SS_F32) permute_job<float, bf16_t>(j, lb, blockDim.x, threadIdx.x);
-    else if (j.out_dtype == SS_F32) permute_job<bf16_t, float>(j, lb, blockDim.x, threadIdx.x);
-    else permute_job<bf16_t, bf16_t>(j, lb, blockDim.x, threadIdx.x);
+    if (j.in_dtype == SS_F32 && j.out_dtype == SS_F32) permute_job<float, float>(j, lb, blockDim.x, threadIdx.x, tile);
+    else if (j.in_dtype == SS_F32) permute_job<float, bf16_t>(j, lb, blockDim.x, threadIdx.x, tile);
+    else if (j.out_dtype == SS_F32) permute_job<bf16_t, float>(j, lb, blockDim.x, threadIdx.x, tile);
+    else permute_job<bf16_t, bf16_t>(j, lb, blockDim.x, threadIdx.x, tile);
 }
 
 extern "C" int ss_permute3d_batch(const void* jobs_dev, const int32_t* job_of_block_dev, int total_blocks, void* stream)

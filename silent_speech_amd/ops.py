@@ -236,7 +236,7 @@ class PermuteBatch(object):
         j.valid2 = d2 if valid2 is None else valid2
         j.in_dtype, j.out_dtype, j.accumulate, j.scale = _dt(inp), _dt(out), int(accumulate), float(scale)
         total = d0 * d1 * d2
-        j.nblocks = max(1, min(64, (total + 2047) // 2048))
+        j.nblocks = max(1, min(2048, (total + 4095) // 4096))       # one 4096-element tile (16 elements per thread) per block and pass
         self.jobs.append(j)
         self.keep.append((inp, out))
         self._dev = None
