@@ -73,16 +73,30 @@ __global__ void dtw_skew_kernel(const float* __restrict__ costs, const long long
 }
 
 // ------------------------------------------------------------------ cumulative cost + backtrace
-__device__ __forceinline__ void dtw_step(int t, int lane, int w, int k, int M, const f32x4& cv, float (&prev)[DR], float& diag_sv, float& last_out,
-                                         unsigned char* __restrict__ dp, float (*lds_bnd)[DRING], const float* bnd_prev, float* bnd_cur)
+// lane l <- lane l-1, lane 0 <- `first`: one DPP move (wave_shr:1) instead of a ds_bpermute round trip through the LDS
+// crossbar -- this shift sits on the serial dependency chain of every DTW step.
+__device__ __forceinline__ float wave_shift_in(float v, float first, int lane) {
+#if defined(SS_EMU)
+    const float u = __shfl_up(v, 1);
+    return lane == 0 ? first : u;
+#else
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+#endif
+}
+__device__ __forceinline__ float wave_pick(float v, int src_lane) {   // src_lane is wave-uniform
+#if defined(SS_EMU)
+    return __shfl(v, src_lane);
+#else
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+#endif
+}
+
+__device__ __forceinline__ void dtw_step(int t, int lane, int w, int M, const f32x4& cv, float top, float (&prev)[DR], float& diag_sv, float& last_out,
+                                         unsigned char* __restrict__ dp, float (*lds_bnd)[DRING], float* bnd_cur)
 {
     const int s = t + 1 - lane;
     const bool act = s >= 1 && s < M;
-    float up_in = __shfl_up(last_out, 1);
-    if (lane == 0 && act) {
-        if (w == 0) up_in = k == 0 ? INFINITY : bnd_prev[s];
-        else up_in = lds_bnd[w][s & (DRING - 1)];
-    }
+    const float up_in = wave_shift_in(last_out, top, lane);          // lane 0 takes the row above the strip / the previous wave's last row
     if (act) {
         float a = up_in, dg = diag_sv;
         unsigned bits = 0;
@@ -134,6 +148,11 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
             const int u = ss - 2 * w;
             if (u >= 0 && u < nss) {
                 const int t0 = u * DG;
+                // the 64 values lane 0 will need from above during this super-step (one per step), fetched up front
+                float topv;
+                { const int sb = t0 + 1 + lane;
+                  if (w == 0) topv = (k == 0 || sb >= M) ? INFINITY : bnd_prev[sb];
+                  else topv = lds_bnd[w][sb & (DRING - 1)]; }
                 f32x4 cb[8];
                 const f32x4 inf4 = {INFINITY, INFINITY, INFINITY, INFINITY};
 #pragma unroll
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int t = t0 + g * 8 + e;
-                        if (t < ts) dtw_step(t, lane, w, k, M, cb[e], prev, diag_sv, last_out, dp, lds_bnd, bnd_prev, bnd_cur);
+                        if (t < ts) dtw_step(t, lane, w, M, cb[e], wave_pick(topv, g * 8 + e), prev, diag_sv, last_out, dp, lds_bnd, bnd_cur);
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) cb[e] = nb[e];

@@ -357,10 +357,19 @@ __global__ __launch_bounds__(RED_THREADS) void colsum_partial_kernel(const T* __
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = 0.f;
         const bool cv = m.active && cx < m.CV;
-        if (cv)
-            for (int r = r0 + m.ry; r < r1; r += m.RY) { float v[8]; Vec8<T>::load(x + (long long)r * ld + cx * 8, v);
+        if (cv) {
+            int r = r0 + m.ry;
+            for (; r + 3 * m.RY < r1; r += 4 * m.RY) {            // 4 independent 16-byte loads in flight per thread
+                float v[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Vec8<T>::load(x + (long long)(r + u * m.RY) * ld + cx * 8, v[u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (v[0][e] + v[1][e]) + (v[2][e] + v[3][e]);
+            }
+            for (; r < r1; r += m.RY) { float v[8]; Vec8<T>::load(x + (long long)r * ld + cx * 8, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s[e] += v[e]; }
+        }
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     out[c] += t[0];
 }
 
-static int colsum_chunks(int rows) { int c = (rows + 63) / 64; if (c > 512) c = 512; if (c < 1) c = 1; return c; }
+static int colsum_chunks(int rows) { int c = (rows + 15) / 16; if (c > 2048) c = 2048; if (c < 1) c = 1; return c; }
 extern "C" int64_t ss_colsum_scratch_floats(int rows, int C) { return (int64_t)colsum_chunks(rows) * C; }
 
 extern "C" int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, float* scratch, float* out_accum, void* stream)
