@@ -494,7 +494,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p)
 // Contractions over the time axis take their B operand straight from the row-major tiles with ds_read_b64_tr_b16, so no
 // transposed copies are staged; only key blocks that intersect the +-(D-1) band are computed.
 namespace {
-constexpr int RES_NB = 13, RES_W = 8, RT_LD = 40;      // <= 13 key blocks (T <= 208), 8 waves, chunk-tile row length
+constexpr int RES_NB = 13, RT_LD = 40;                  // <= 13 key blocks (T <= 208), chunk-tile row length
+constexpr int RES_W_FWD = 8, RES_W_BQ = 8, RES_W_BKV = 8;      // waves per workgroup (12 = 3 per SIMD was measured slower: the 168-register cap spills)
 typedef bf16_t RT;
 
 __device__ __forceinline__ bf16x8 lds16(const unsigned char* p) { return *(const bf16x8*)p; }
@@ -686,7 +687,7 @@ __device__ __forceinline__ void fwd_res_tile(const AttnP& p, const unsigned char
 }
 
 template <int DPK, bool DROP>
-__global__ __launch_bounds__(RES_W * 64) void attn_fwd_res_kernel(AttnP p)
+__global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res_kernel(AttnP p)
 {
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + 16;
@@ -698,20 +699,20 @@ __global__ __launch_bounds__(RES_W * 64) void attn_fwd_res_kernel(AttnP p)
     unsigned char* Es = Ks + Tr * PK;                                   // row m + RES_PL holds embedding m
     unsigned char* VTs = Es + ER * PK;
     RT* Pt = (RT*)(VTs + dp * PVT) + w * 16 * RT_LD;
-    int* ctr = (int*)(VTs + dp * PVT + RES_W * 16 * RT_LD * 2);
+    int* ctr = (int*)(VTs + dp * PVT + RES_W_FWD * 16 * RT_LD * 2);
     const long long ldq = 3LL * H * dp;
     const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
     {
-        stage_rows<DPK>(Ks, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W * 64);
-        stage_rows<DPK>(Es, PK, (const RT*)p.E, dp, 0, RES_PL, tid, RES_W * 64);
-        stage_rows<DPK>(Es + RES_PL * PK, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE + RES_PL, tid, RES_W * 64);
+        stage_rows<DPK>(Ks, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W_FWD * 64);
+        stage_rows<DPK>(Es, PK, (const RT*)p.E, dp, 0, RES_PL, tid, RES_W_FWD * 64);
+        stage_rows<DPK>(Es + RES_PL * PK, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE + RES_PL, tid, RES_W_FWD * 64);
         const RT* VT = (const RT*)p.qkvT + ((long long)b * 3 * H * dp + 2 * H * dp + h * dp) * p.Tp;
         const int cpr = WV >> 3, total = dp * cpr;
-        for (int base = tid; base < total; base += RES_W * 64 * 8) {
+        for (int base = tid; base < total; base += RES_W_FWD * 64 * 8) {
             bf16x8 v[8]; int off[8], t0s[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = base + u * RES_W * 64, r = i / cpr, t0 = (i - r * cpr) * 8;
+                const int i = base + u * RES_W_FWD * 64, r = i / cpr, t0 = (i - r * cpr) * 8;
                 v[u] = bzero8(); off[u] = i < total ? r * PVT + t0 * 2 : -1; t0s[u] = t0;
                 if (i < total && t0 < Tn) v[u] = *(const bf16x8*)(VT + (long long)r * p.Tp + t0);
             }
@@ -768,7 +769,7 @@ __device__ __forceinline__ void res_prob_ds(const float (&l2)[4], const f32x4& d
 
 // query-major backward (dQ) on resident K, V rows and a zero-padded embedding table (PL rows below, PH above)
 template <int DPK, bool DROP>
-__global__ __launch_bounds__(RES_W * 64) void attn_bwd_q_res_kernel(AttnP p)
+__global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q_res_kernel(AttnP p)
 {
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + 16, PL = 48, PH = 48, PTL = 20;
@@ -779,16 +780,16 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_q_res_kernel(AttnP p)
     unsigned char* Vs = Ks + Tr * PK;
     unsigned char* Es = Vs + Tr * PK;                                  // row m + PL holds embedding m
     RT* tA = (RT*)(Es + ER * PK) + w * 16 * RT_LD;                     // dS^T / dR^T chunk: [32 contraction rows][16 queries (+4)]
-    int* ctr = (int*)(Es + ER * PK + RES_W * 16 * RT_LD * 2);
+    int* ctr = (int*)(Es + ER * PK + RES_W_BQ * 16 * RT_LD * 2);
     const long long ldq = 3LL * H * dp;
     const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
     const RT* dO = (const RT*)p.dO + (long long)b * Tn * (H * dp) + h * dp;
     const float scale2 = p.scale * LOG2E;
     {
-        stage_rows<DPK>(Ks, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W * 64);
-        stage_rows<DPK>(Vs, PK, Q + 2 * H * dp, ldq, Tn, Tr, tid, RES_W * 64);
-        stage_rows<DPK>(Es, PK, (const RT*)p.E, dp, 0, PL, tid, RES_W * 64);
-        stage_rows<DPK>(Es + PL * PK, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE + PH, tid, RES_W * 64);
+        stage_rows<DPK>(Ks, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W_BQ * 64);
+        stage_rows<DPK>(Vs, PK, Q + 2 * H * dp, ldq, Tn, Tr, tid, RES_W_BQ * 64);
+        stage_rows<DPK>(Es, PK, (const RT*)p.E, dp, 0, PL, tid, RES_W_BQ * 64);
+        stage_rows<DPK>(Es + PL * PK, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE + PH, tid, RES_W_BQ * 64);
         if (tid == 0) *ctr = 0;
     }
     __syncthreads();
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_q_res_kernel(AttnP p)
 
 // key-major backward (dK, dV) on resident Q, dO rows
 template <int DPK, bool DROP>
-__global__ __launch_bounds__(RES_W * 64) void attn_bwd_kv_res_kernel(AttnP p)
+__global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv_res_kernel(AttnP p)
 {
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + 16;
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_kv_res_kernel(AttnP p)
     unsigned char* Es = dOs + TQ * PK;
     RT* tP = (RT*)(Es + NE * PK) + w * 2 * 16 * RT_LD;                 // P~^T, dS^T chunks: [16 keys][32 queries (+8)]
     RT* tS = tP + 16 * RT_LD;
-    float* lse2s = (float*)(Es + NE * PK + RES_W * 2 * 16 * RT_LD * 2);
+    float* lse2s = (float*)(Es + NE * PK + RES_W_BKV * 2 * 16 * RT_LD * 2);
     float* dvs = lse2s + TQ;
     int* ctr = (int*)(dvs + TQ);
     const long long ldq = 3LL * H * dp;
@@ -918,10 +919,10 @@ __global__ __launch_bounds__(RES_W * 64) void attn_bwd_kv_res_kernel(AttnP p)
     const RT* V = Q + 2 * H * dp;
     const float scale2 = p.scale * LOG2E;
     {
-        stage_rows<DPK>(Qs, PK, Q, ldq, Tn, TQ, tid, RES_W * 64);
-        stage_rows<DPK>(dOs, PK, (const RT*)p.dO + (long long)b * Tn * (H * dp) + h * dp, (long long)H * dp, Tn, TQ, tid, RES_W * 64);
-        stage_rows<DPK>(Es, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE, tid, RES_W * 64);
-        for (int i = tid; i < TQ; i += RES_W * 64) {
+        stage_rows<DPK>(Qs, PK, Q, ldq, Tn, TQ, tid, RES_W_BKV * 64);
+        stage_rows<DPK>(dOs, PK, (const RT*)p.dO + (long long)b * Tn * (H * dp) + h * dp, (long long)H * dp, Tn, TQ, tid, RES_W_BKV * 64);
+        stage_rows<DPK>(Es, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE, tid, RES_W_BKV * 64);
+        for (int i = tid; i < TQ; i += RES_W_BKV * 64) {
             const long long si = ((long long)b * H + h) * Tn + (i < Tn ? i : Tn - 1);
             lse2s[i] = p.lse[si] * LOG2E; dvs[i] = p.Dv[si];
         }
@@ -1032,9 +1033,9 @@ static void attn_fill(AttnP& p, int B, int H, int T, int Tp, int dp, int D, floa
 static const size_t RES_LDS_MAX = 160 * 1024;
 static size_t res_smem(int which, int T, int dp, int D) {
     const size_t PK = (size_t)dp * 2 + 16, nb = (size_t)(T + 15) / 16, Tr = nb * 16, NE = 2 * (size_t)D - 1, TQ = (nb + 1) / 2 * 32, tile = 16 * RT_LD * 2;
-    if (which == 0) return Tr * PK + (NE + 2 * RES_PL) * PK + (size_t)dp * ((nb + 2) / 2 * 32 * 2 + 16) + RES_W * tile + 16;
-    if (which == 1) return 2 * Tr * PK + (NE + 96) * PK + RES_W * tile + 16;
-    return 2 * TQ * PK + NE * PK + RES_W * 2 * tile + 8 * TQ + 16;
+    if (which == 0) return Tr * PK + (NE + 2 * RES_PL) * PK + (size_t)dp * ((nb + 2) / 2 * 32 * 2 + 16) + RES_W_FWD * tile + 16;
+    if (which == 1) return 2 * Tr * PK + (NE + 96) * PK + RES_W_BQ * tile + 16;
+    return 2 * TQ * PK + NE * PK + RES_W_BKV * 2 * tile + 8 * TQ + 16;
 }
 static bool res_enabled(int dtype, int T) {
     if (dtype != SS_BF16 || (T + 15) / 16 > RES_NB) return false;
@@ -1042,7 +1043,7 @@ static bool res_enabled(int dtype, int T) {
     return !(e && e[0] == '0');
 }
 typedef void (*ResKernel)(AttnP);
-static int res_launch(ResKernel k, int slot, int blocks, size_t smem, void* stream, const AttnP& p) {
+static int res_launch(ResKernel k, int slot, int blocks, int waves, size_t smem, void* stream, const AttnP& p) {
 #if !defined(SS_EMU)
     static size_t granted[24] = {0};
     if (granted[slot] < smem) {
@@ -1050,7 +1051,7 @@ static int res_launch(ResKernel k, int slot, int blocks, size_t smem, void* stre
         granted[slot] = smem;
     }
 #endif
-    SS_LAUNCH(k, dim3(blocks), dim3(RES_W * 64), smem, stream, p);
+    SS_LAUNCH(k, dim3(blocks), dim3(waves * 64), smem, stream, p);
     return 0;
 }
 static ResKernel res_pick(int which, int dpk, bool drop = false) {
@@ -1075,7 +1076,7 @@ extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const voi
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
     p.qkv = qkv; p.qkvT = qkvT; p.E = E; p.out = out; p.lse = lse;
     if (res_enabled(dtype, T) && res_pick(0, dp / 32) && res_smem(0, T, dp, D) <= RES_LDS_MAX) {
-        if (res_launch(res_pick(0, dp / 32, p.drop_thresh != 0), dp / 32 + (p.drop_thresh ? 12 : 0), B * H, res_smem(0, T, dp, D), stream, p)) return 1;
+        if (res_launch(res_pick(0, dp / 32, p.drop_thresh != 0), dp / 32 + (p.drop_thresh ? 12 : 0), B * H, RES_W_FWD, res_smem(0, T, dp, D), stream, p)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_forward");
         return 0;
     }
@@ -1101,8 +1102,8 @@ extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const vo
     }
     if (res_enabled(dtype, T) && res_pick(1, dp / 32) && res_smem(1, T, dp, D) <= RES_LDS_MAX && res_smem(2, T, dp, D) <= RES_LDS_MAX) {
         const bool drop = p.drop_thresh != 0;
-        if (res_launch(res_pick(1, dp / 32, drop), (drop ? 16 : 4) + dp / 32, B * H, res_smem(1, T, dp, D), stream, p)) return 1;
-        if (res_launch(res_pick(2, dp / 32, drop), (drop ? 20 : 8) + dp / 32, B * H, res_smem(2, T, dp, D), stream, p)) return 1;
+        if (res_launch(res_pick(1, dp / 32, drop), (drop ? 16 : 4) + dp / 32, B * H, RES_W_BQ, res_smem(1, T, dp, D), stream, p)) return 1;
+        if (res_launch(res_pick(2, dp / 32, drop), (drop ? 20 : 8) + dp / 32, B * H, RES_W_BKV, res_smem(2, T, dp, D), stream, p)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_backward");
         return 0;
     }
