@@ -50,6 +50,23 @@ extern "C" int ss_frame_lse(const float* head, int64_t ld, int col0, int ncls, i
     return 0;
 }
 
+// per-wave partial sums (held by lane 0) -> ONE atomic per workgroup: thousands of waves hitting the same two addresses
+// serialise in the L2 atomic unit (that, not the arithmetic, was most of these kernels' time)
+__device__ __forceinline__ void loss_block_commit(float lsum, int csum, float inv_total, float* loss_acc, int* correct_acc)
+{
+    __shared__ float ls[16];
+    __shared__ int cs[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    if (lane == 0) { ls[w] = lsum; cs[w] = csum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f; int c = 0;
+        for (int i = 0; i < wpb; ++i) { a += ls[i]; c += cs[i]; }
+        if (a != 0.f) atomicAdd(loss_acc, a * inv_total);
+        if (c) atomicAdd(correct_acc, c);
+    }
+}
+
 // ---------------------------------------------------------------- voiced frames: value + gradient, one wave per frame
 __global__ void voiced_loss_kernel(const float* __restrict__ head, long long ld, int n_mel, int n_ph, const float* __restrict__ lse, const int* __restrict__ amax,
                                    const float* __restrict__ Y, const long long* __restrict__ phones, const int* __restrict__ pred_row, const int* __restrict__ tgt_row,
@@ -71,7 +88,7 @@ __global__ void voiced_loss_kernel(const float* __restrict__ head, long long ld,
         for (int c = lane; c < n_ph; c += 64) dp[n_mel + c] = lam * inv_total * (expf(p[n_mel + c] - L) - (c == ph ? 1.f : 0.f));
         if (lane == 0) { lsum += dist + lam * (L - p[n_mel + ph]); csum += amax[pr] == ph; }
     }
-    if (lane == 0) { if (lsum != 0.f) atomicAdd(loss_acc, lsum * inv_total); if (csum) atomicAdd(correct_acc, csum); }
+    loss_block_commit(lsum, csum, inv_total, loss_acc, correct_acc);
 }
 
 extern "C" int ss_voiced_loss(const float* head, int64_t ld, int n_mel, int n_phone, const float* lse, const int32_t* argmax, const float* Y, const int64_t* phones,
@@ -81,7 +98,7 @@ extern "C" int ss_voiced_loss(const float* head, int64_t ld, int n_mel, int n_ph
     SS_CHECK(nframes >= 0, "ss_voiced_loss: negative frame count");
     if (nframes == 0) return 0;
     SS_CHECK(head && lse && argmax && Y && phones && pred_row && tgt_row && dhead && loss_accum && correct_accum, "ss_voiced_loss: null pointer");
-    int blocks = (nframes + 3) / 4; if (blocks > 2048) blocks = 2048;
+    int blocks = (nframes + 3) / 4; if (blocks > 1024) blocks = 1024;
     SS_LAUNCH(voiced_loss_kernel, dim3(blocks), dim3(256), 0, stream, head, (long long)ld, n_mel, n_phone, lse, (const int*)argmax, Y, (const long long*)phones,
               (const int*)pred_row, (const int*)tgt_row, nframes, lam, inv_total, dhead, loss_accum, (int*)correct_accum);
     SS_LAUNCH_CHECK("ss_voiced_loss");
@@ -160,7 +177,7 @@ __global__ void silent_loss_kernel(const float* __restrict__ head, long long ld,
         for (int c = lane; c < n_ph; c += 64) atomicAdd(dp + n_mel + c, lam * inv_total * (expf(p[n_mel + c] - L) - (c == ph ? 1.f : 0.f)));
         if (lane == 0) { lsum += dist + lam * (L - p[n_mel + ph]); csum += amax[pr] == ph; }
     }
-    if (lane == 0) { if (lsum != 0.f) atomicAdd(loss_acc, lsum * inv_total); if (csum) atomicAdd(correct_acc, csum); }
+    loss_block_commit(lsum, csum, inv_total, loss_acc, correct_acc);
 }
 
 extern "C" int ss_silent_loss(const float* head, int64_t ld, int n_mel, int n_phone, const float* lse, const int32_t* argmax, const float* Y, const int64_t* phones,
@@ -170,7 +187,7 @@ extern "C" int ss_silent_loss(const float* head, int64_t ld, int n_mel, int n_ph
     SS_CHECK(nframes >= 0, "ss_silent_loss: negative frame count");
     if (nframes == 0) return 0;
     SS_CHECK(head && lse && argmax && Y && phones && results && tgt_row && pred_base && res_idx && dhead && loss_accum && correct_accum, "ss_silent_loss: null pointer");
-    int blocks = (nframes + 3) / 4; if (blocks > 2048) blocks = 2048;
+    int blocks = (nframes + 3) / 4; if (blocks > 1024) blocks = 1024;
     SS_LAUNCH(silent_loss_kernel, dim3(blocks), dim3(256), 0, stream, head, (long long)ld, n_mel, n_phone, lse, (const int*)argmax, Y, (const long long*)phones,
               (const int*)results, (const int*)tgt_row, (const int*)pred_base, (const int*)res_idx, nframes, lam, inv_total, dhead, loss_accum, (int*)correct_accum);
     SS_LAUNCH_CHECK("ss_silent_loss");

@@ -571,7 +571,7 @@ extern "C" int ss_layernorm_backward(int dtype, const void* dy, const void* z, c
     SS_CHECK(C % 8 == 0 && C > 0 && C <= 4096, "ss_layernorm_backward: C=%d must be a multiple of 8 and <= 4096", C);
     if (rows <= 0) return 0;
     const unsigned th = dropout_threshold(dropout_p); const float ks = 1.f / (1.f - dropout_p);
-    int blocks = (rows + 15) / 16; if (blocks > 1024) blocks = 1024;
+    int blocks = (rows + 15) / 16; if (blocks > 512) blocks = 512;       // 2 blocks per CU: fewer same-address atomics on dgamma/dbeta than 1024 (measured 42 vs 47 us)
 #define SS_LNB(TT, NV) SS_LAUNCH(SS_KERNEL(ln_bwd_kernel<TT, NV>), dim3(blocks), dim3(256), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, dgamma, dbeta, rows, C, th, ks, (unsigned long long)seed, rng_stream)
     if (dtype == SS_BF16) { if (C <= 1024) SS_LNB(bf16_t, 2); else SS_LNB(bf16_t, 8); }
     else { if (C <= 1024) SS_LNB(float, 2); else SS_LNB(float, 8); }
