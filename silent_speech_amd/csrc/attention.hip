@@ -694,7 +694,8 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res_kernel(AttnP p)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
     const int H = p.H, h = blockIdx.x % H, b = blockIdx.x / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1, ER = NE + 2 * RES_PL;
-    const int WV = ((nb + 2) >> 1) * 32, PVT = WV * 2 + 16;            // a chunk starting at an odd block may end 16 keys past Tr
+    const int WV = ((nb + 2) >> 1) * 32, PVT = WV * 2 + 8;             // a chunk starting at an odd block may end 16 keys past Tr;
+                                                                       // pitch = 2 (mod 32) words: the 16 rows of an 8-byte fragment read hit 16 distinct bank pairs
     unsigned char* Ks = (unsigned char*)smem;
     unsigned char* Es = Ks + Tr * PK;                                   // row m + RES_PL holds embedding m
     unsigned char* VTs = Es + ER * PK;
@@ -721,7 +722,8 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res_kernel(AttnP p)
                 if (off[u] < 0) continue;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (t0s[u] + e >= Tn) v[u][e] = 0;
-                *(bf16x8*)(VTs + off[u]) = v[u];
+                { const u32x4 q = __builtin_bit_cast(u32x4, v[u]); const u32x2 lo = {q[0], q[1]}, hi = {q[2], q[3]};     // rows are only 8-byte aligned
+                  *(u32x2*)(VTs + off[u]) = lo; *(u32x2*)(VTs + off[u] + 8) = hi; }
             }
         }
         if (tid == 0) *ctr = 0;
@@ -1033,7 +1035,7 @@ static void attn_fill(AttnP& p, int B, int H, int T, int Tp, int dp, int D, floa
 static const size_t RES_LDS_MAX = 160 * 1024;
 static size_t res_smem(int which, int T, int dp, int D) {
     const size_t PK = (size_t)dp * 2 + 16, nb = (size_t)(T + 15) / 16, Tr = nb * 16, NE = 2 * (size_t)D - 1, TQ = (nb + 1) / 2 * 32, tile = 16 * RT_LD * 2;
-    if (which == 0) return Tr * PK + (NE + 2 * RES_PL) * PK + (size_t)dp * ((nb + 2) / 2 * 32 * 2 + 16) + RES_W_FWD * tile + 16;
+    if (which == 0) return Tr * PK + (NE + 2 * RES_PL) * PK + (size_t)dp * ((nb + 2) / 2 * 32 * 2 + 8) + RES_W_FWD * tile + 16;
     if (which == 1) return 2 * Tr * PK + (NE + 96) * PK + RES_W_BQ * tile + 16;
     return 2 * TQ * PK + NE * PK + RES_W_BKV * 2 * tile + 8 * TQ + 16;
 }

@@ -20,8 +20,11 @@ class GemmProfiler(object):
 
     def __init__(self):
         self.records = []
+        self.enabled = True          # bench.py switches it on for a sample of the timed steps to keep the event overhead small
 
     def run(self, key, flops, fn, stream_tensor):
+        if not self.enabled:
+            return fn()
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
