@@ -23,6 +23,11 @@ class DataParallel(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._rows_total = None
+        # Host-known scalars (row / frame counts) travel over a gloo group: an all-reduce on the GPU stream would need an
+        # .item() per step, i.e. a full device sync that lets the GPU run dry while the host re-fills the launch queue.
+        self.host_group = None
+        if self.world > 1 and dist.get_backend(group) != 'gloo':
+            self.host_group = dist.new_group(backend='gloo')
 
     def attach(self, model):
         if self.world > 1:
@@ -41,11 +46,19 @@ class DataParallel(object):
         if self.world == 1:
             self._ratio = 1.0
             return
-        t = torch.tensor([float(local_rows_b_times_t)], dtype=torch.float64)
-        dev = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
-        t = t.to(dev)
-        dist.all_reduce(t, group=self.group)
-        self._ratio = float(t.item()) / float(local_rows_b_times_t)
+        self._ratio = self._host_sum(float(local_rows_b_times_t)) / float(local_rows_b_times_t)
+
+    def _host_sum(self, value):
+        """Sum of a Python scalar over the ranks without touching the GPU stream."""
+        t = torch.tensor([value], dtype=torch.float64)
+        if self.host_group is not None:
+            dist.all_reduce(t, group=self.host_group)
+        elif dist.get_backend(self.group) == 'gloo':
+            dist.all_reduce(t, group=self.group)
+        else:                                       # no host group available: fall back to the device collective (+ sync)
+            t = t.to(torch.device('cuda', torch.cuda.current_device()))
+            dist.all_reduce(t, group=self.group)
+        return float(t.item())
 
     def _reduce_sums(self, sums, n_local):
         dist.all_reduce(sums, group=self.group)
@@ -56,10 +69,7 @@ class DataParallel(object):
         local = float(sum(int(a.shape[0]) for a in batch['audio_features']))
         if self.world == 1:
             return local
-        dev = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
-        t = torch.tensor([local], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, group=self.group)
-        return float(t.item())
+        return self._host_sum(local)
 
     def sync_gradients(self, model):
         if self.world == 1:
