@@ -99,7 +99,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
 
-    from silent_speech_amd import ops
+    from silent_speech_amd import engine, ops
     from silent_speech_amd.architecture import Model
     from silent_speech_amd.data_utils import combine_fixed_length
     from silent_speech_amd.distributed import DataParallel
@@ -157,8 +157,12 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if prof is not None:
-            prof.enabled = i % 4 == 0            # every 4th timed step carries the per-launch HIP events (roofline numerator)
+            # every 4th timed step carries the per-launch HIP events (roofline numerator); on those steps the weight-gradient
+            # GEMMs stay on the main stream: a duration taken while a second stream shares the CUs is not a per-kernel quantity
+            prof.enabled = i % 4 == 0
+            engine.SIDE_STREAM_ENABLED = not prof.enabled
         loss = step()
+    engine.SIDE_STREAM_ENABLED = True
     host_enqueue = time.perf_counter() - t0               # host time to ENQUEUE the steps (the GPU runs behind, asynchronously)
     torch.cuda.synchronize()
     if world > 1:
@@ -209,6 +213,7 @@ def main():
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
                                'traffic_source': traffic_src,
                                'kernel': 'gemm_kernel<%s,%s,a_mode=%d,b_mode=%d>' % key, 'launches_per_step': d['launches'] / psteps, 'event_timed_steps': psteps,
+                               'timing': 'HIP events around every ss_gemm launch on every 4th timed step; those steps keep the dW GEMMs on the main stream (exclusive durations); rocprofv3 counterpart: profiles/*_serial_kernel_stats.txt (SS_AMD_SIDE_STREAM=0)',
                                'avg_launch_us': d['seconds'] / d['launches'] * 1e6, 'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                                'all_gemm_variants': {str(k): {'tflops': v['flops'] / v['seconds'] / 1e12, 'ms_per_step': v['seconds'] / psteps * 1e3,
                                                               'launches_per_step': v['launches'] / psteps} for k, v in summ.items()}}

@@ -345,13 +345,13 @@ __device__ __forceinline__ void outvec_store(bf16_t* p, const float (&v)[8]) { V
 __device__ __forceinline__ void outvec_load(const float* p, float (&v)[4]) { f32x4 a = *(const f32x4*)p; v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
 __device__ __forceinline__ void outvec_store(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = a; }
 
-template <class TO>
+template <class TO, int NTHR = 256>
 __device__ __forceinline__ void epilogue_flush(const TO* __restrict__ ct, int ldc, TO* __restrict__ C, const GemmEpi& epi, int row_base, int nrows, int n0, int M, int N, int tid)
 {
     constexpr int EV = OutVec<TO>::N;
     constexpr int CPR = BN / EV;                       // 16-byte chunks per tile row
     const int total = nrows * CPR;
-    for (int idx = tid; idx < total; idx += 256) {
+    for (int idx = tid; idx < total; idx += NTHR) {
         const int r = idx / CPR, ch = idx - r * CPR;
         const int row = row_base + r, col = n0 + ch * EV;
         if (row < M && col < N) {
@@ -626,6 +626,104 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const T* __restrict__
     }
 }
 
+// ================================================================ KC x KC bf16 kernel, 2 waves x (128 x 64) per tile
+// Same 128 x 128 output tile and persistent schedule, but the tile belongs to TWO waves that each keep a 128 x 64 block
+// (8 x 4 MFMA tiles, 128 accumulator registers): one K step of 32 needs 8 + 4 = 12 fragment reads for 32 MFMAs
+// (0.375 ds_read_b128 per MFMA instead of 0.5), a K tile is 32 deep (16 KiB per stage, 32 KiB per workgroup) so FOUR
+// workgroups share a CU (still 8 waves), and the per-tile barrier involves 2 waves instead of 4.
+// LDS image: dense 64-byte rows; 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 3), which spreads the
+// 8 rows served together by a ds_read_b128 over all 32 banks.  Staging is global_load_lds (the swizzle is applied to the
+// per-lane source chunk, the destination stays lane-linear).
+namespace w2 {
+constexpr int BK2 = 32, ROW2 = 64, STAGE = (BM + BN) * ROW2;          // 16 KiB per stage
+struct Stage {
+    const bf16_t* src[4];
+    int base_row;
+    __device__ __forceinline__ void init(const bf16_t* p, const RowMap& map, int outer0, int outer_size, int k_begin, int tid) {
+        const int lane = tid & 63, wave = tid >> 6;
+        base_row = wave * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 32 + wave * 16 + (lane >> 2);
+            int o = outer0 + r; o = o < outer_size ? o : outer_size - 1;
+            const int chunk = (lane & 3) ^ ((r >> 1) & 3);
+            src[i] = p + rowmap_off(map, o) + k_begin + chunk * 8;
+        }
+    }
+    __device__ __forceinline__ void issue(unsigned char* tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { glds16(src[i], tile + (i * 32 + base_row) * ROW2); src[i] += BK2; }
+    }
+};
+__device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int row, int q) { return *(const bf16x8*)(tile + row * ROW2 + ((q ^ ((row >> 1) & 3)) << 4)); }
+}  // namespace w2
+
+template <class TO>
+__global__ __launch_bounds__(128, 2) void gemm_w2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
+                                                         int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi,
+                                                         int k_chunk, int tiles_m, int tiles_n, int nitems)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][w2::STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int G = gridDim.x, ntiles = tiles_m * tiles_n;
+    w2::Stage sa, sb;
+    int it = blockIdx.x, m0, n0, k_begin, k_end, cur = 0;
+    item_coord(it, G, nitems, ntiles, tiles_n, k_chunk, K, m0, n0, k_begin, k_end);
+    sa.init(A, amap, m0, M, k_begin, tid); sb.init(B, bmap, n0, N, k_begin, tid);
+    sa.issue(lds[cur]); sb.issue(lds[cur] + BM * w2::ROW2);
+    for (;;) {
+        const int nsteps = (k_end - k_begin) / w2::BK2;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+        for (int s = 0; s < nsteps; ++s) {
+            __syncthreads();                                  // K tile s has landed in stage `cur`; stage cur^1 is free
+            if (s + 1 < nsteps) { sa.issue(lds[cur ^ 1]); sb.issue(lds[cur ^ 1] + BM * w2::ROW2); }
+            const unsigned char* As = lds[cur]; const unsigned char* Bs = lds[cur] + BM * w2::ROW2;
+            bf16x8 a[8], b[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = w2::frag(As, i * 16 + r, q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = w2::frag(Bs, wn * 64 + j * 16 + r, q);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+            cur ^= 1;
+        }
+        const int cm0 = m0, cn0 = n0;
+        const bool has_next = it + G < nitems;
+        if (has_next) {
+            it += G;
+            item_coord(it, G, nitems, ntiles, tiles_n, k_chunk, K, m0, n0, k_begin, k_end);
+            sa.init(A, amap, m0, M, k_begin, tid); sb.init(B, bmap, n0, N, k_begin, tid);
+            sa.issue(lds[cur]); sb.issue(lds[cur] + BM * w2::ROW2);
+        }
+        barrier_keep_vm();                                    // both waves are done reading stage cur^1 -> it becomes the C piece
+        // ---- epilogue through the free stage: R-row pieces [R][BN + pad], 16-byte row-contiguous stores
+        TO* ct = (TO*)&lds[cur ^ 1][0];
+        constexpr int LDC = BN + 16 / (int)sizeof(TO);
+        constexpr int R = sizeof(TO) == 2 ? 32 : 16, IPP = R / 16;        // rows and 16-row MFMA tiles per pass
+#define SS_W2_STAGE(GEN, I) \
+        { _Pragma("unroll") for (int j = 0; j < 4; ++j) epilogue_stage<TO, GEN>(acc[I][j], ct, LDC, ((I) % IPP) * 16 + q * 4, wn * 64 + j * 16 + r, epi, cm0 + (I) * 16 + q * 4, cn0 + wn * 64 + j * 16 + r, M, N); }
+#define SS_W2_PASS(GEN, P) \
+        { if (IPP == 2) { SS_W2_STAGE(GEN, ((P) * IPP) % 8) SS_W2_STAGE(GEN, ((P) * IPP + 1) % 8) } else { SS_W2_STAGE(GEN, (P) % 8) } \
+          barrier_keep_vm(); \
+          epilogue_flush<TO, 128>(ct, LDC, C, epi, cm0 + (P) * R, R, cn0, M, N, tid); \
+          barrier_keep_vm(); }
+#define SS_W2_ALL(GEN) \
+        { SS_W2_PASS(GEN, 0) SS_W2_PASS(GEN, 1) SS_W2_PASS(GEN, 2) SS_W2_PASS(GEN, 3) \
+          if (IPP == 1) { SS_W2_PASS(GEN, 4) SS_W2_PASS(GEN, 5) SS_W2_PASS(GEN, 6) SS_W2_PASS(GEN, 7) } }
+        if (epi.general == 1) SS_W2_ALL(1) else if (epi.general == 2) SS_W2_ALL(2) else SS_W2_ALL(0)
+#undef SS_W2_ALL
+#undef SS_W2_PASS
+#undef SS_W2_STAGE
+        if (!has_next) break;
+    }
+}
+
 // ---------------------------------------------------------------- host launcher
 static RowMap to_rowmap(const ss_rowmap* m) {
     RowMap r; r.base = m->base; r.batch_stride = m->batch_stride; r.row_stride = m->row_stride; r.rows_per_batch = m->rows_per_batch > 0 ? m->rows_per_batch : 0x7fffffff;
@@ -664,6 +762,20 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     const int nitems = tiles_m * tiles_n * split_k;
     const int slots = gemm_slots();
     dim3 grid(nitems < slots ? nitems : slots), block(256);
+    {   // 2-wave kernel: bf16 KC x KC with the plain LDS-staged epilogue (no transposed second output)
+        static int w2_on = -1;
+        if (w2_on < 0) { const char* e = getenv("SS_GEMM_W2"); w2_on = e ? atoi(e) : 1; }     // 0 never, 1 heuristic, 2 whenever possible
+        // Measured (22 k rows): +18 % on N=3072, K=768 (FFN1 forward, FFN2 input gradient), parity on 768 x 768, but -18 % on
+        // N=768 with K >= 2304: there 1032 tiles on 1024 slots leave an 8-tile tail that runs on 2 of a CU's 4 SIMDs.
+        const bool w2_shape = w2_on == 2 || (K <= 1024 && N >= 1536);
+        if (w2_on && w2_shape && sizeof(T) == 2 && a_mode == OP_KC && b_mode == OP_KC && epi.fast && !epi.c2 && K % 32 == 0 && k_chunk % 32 == 0) {
+            const int slots2 = slots / g_blocks_per_cu * 4;
+            dim3 grid2(nitems < slots2 ? nitems : slots2);
+            SS_LAUNCH(SS_KERNEL(gemm_w2_kernel<TO>), grid2, dim3(128), 0, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems);
+            SS_LAUNCH_CHECK("ss_gemm(w2)");
+            return 0;
+        }
+    }
     if (a_mode == OP_KC && b_mode == OP_KC && epi.fast && K % BK == 0 && k_chunk % BK == 0 && !(epi.debug & 8)) {
         SS_LAUNCH(SS_KERNEL(gemm_glds_kernel<T, TO>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems);
         SS_LAUNCH_CHECK("ss_gemm(glds)");

@@ -318,6 +318,9 @@ def grad_unpack(model, dev):
     return gu
 
 
+SIDE_STREAM_ENABLED = True      # bench.py clears this on its event-timed steps so that per-launch durations are exclusive
+
+
 class _SideStream(object):
     """Weight-gradient GEMMs (dW = dY^T X), bias column sums and gradient re-layouts do not feed the backward chain,
     so they run on a second HIP stream: their workgroups fill the CUs that the dependent chain (dX GEMMs, attention,
@@ -325,7 +328,7 @@ class _SideStream(object):
     Inputs are kept alive (and never written again on the main stream) until join()."""
 
     def __init__(self, model, dev):
-        self.enabled = dev.type == 'cuda' and os.environ.get('SS_AMD_SIDE_STREAM', '1') != '0'
+        self.enabled = dev.type == 'cuda' and SIDE_STREAM_ENABLED and os.environ.get('SS_AMD_SIDE_STREAM', '1') != '0'
         self.keep = []
         self.blocks_per_cu = int(os.environ.get('SS_AMD_SIDE_BLOCKS', '2'))
         if self.enabled:
