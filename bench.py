@@ -201,7 +201,7 @@ def main():
             try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py)
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
                 ctype = {'torch.bfloat16': 'unsigned short', 'torch.float32': 'float'}
-                names = ['gemm_glds_kernel<%s, %s>' % (ctype[key[0]], ctype[key[1]])] if key[2] == 0 and key[3] == 0 else []
+                names = {1: ['gemm_glds_kernel<%s, %s>' % (ctype[key[0]], ctype[key[1]])], 2: ['gemm_w2_kernel<%s>' % ctype[key[1]]]}.get(key[4], [])
                 names.append('gemm_kernel<%s, %s, %d, %d>' % (ctype[key[0]], ctype[key[1]], key[2], key[3]))
                 for nm in names:
                     hit = [v for k, v in pmc.items() if nm in k]
@@ -212,7 +212,7 @@ def main():
                 pass
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
                                'traffic_source': traffic_src,
-                               'kernel': 'gemm_kernel<%s,%s,a_mode=%d,b_mode=%d>' % key, 'launches_per_step': d['launches'] / psteps, 'event_timed_steps': psteps,
+                               'kernel': '%s<%s,%s,a_mode=%d,b_mode=%d>' % (('gemm_kernel', 'gemm_glds_kernel', 'gemm_w2_kernel')[key[4]],) + key[:4], 'launches_per_step': d['launches'] / psteps, 'event_timed_steps': psteps,
                                'timing': 'HIP events around every ss_gemm launch on every 4th timed step; those steps keep the dW GEMMs on the main stream (exclusive durations); rocprofv3 counterpart: profiles/*_serial_kernel_stats.txt (SS_AMD_SIDE_STREAM=0)',
                                'avg_launch_us': d['seconds'] / d['launches'] * 1e6, 'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                                'all_gemm_variants': {str(k): {'tflops': v['flops'] / v['seconds'] / 1e12, 'ms_per_step': v['seconds'] / psteps * 1e3,

@@ -79,6 +79,9 @@ int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, 
 /* Persistent-grid size of ss_gemm for the calling thread: 2 (default) or 1 workgroup per CU.  The weight-gradient GEMMs that
  * run on a side stream use 1 so that the dependent chain on the main stream can co-reside on every CU.  Returns the old value. */
 int ss_gemm_set_blocks_per_cu(int n); /* [host] */
+/* Which kernel the calling thread's last ss_gemm launch used: 0 register-staged gemm_kernel, 1 gemm_glds_kernel,
+ * 2 gemm_w2_kernel (so that a profiler can attribute per-launch timings to the kernel names rocprofv3 reports). */
+int ss_gemm_last_kernel(void); /* [host] */
 
 /* out[a][b][c] (contiguous, dims d0 x d1 x d2) (+)= scale * in[a*s0 + b*s1 + c*s2] for b < valid1 and
  * c < valid2, else 0 (zero padding).  Converts between the reference's parameter layouts (state_dict:

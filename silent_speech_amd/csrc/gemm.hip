@@ -732,6 +732,8 @@ static RowMap to_rowmap(const ss_rowmap* m) {
 
 // resident block slots: 2 blocks (64 KiB LDS, <=256 registers) per CU
 static thread_local int g_blocks_per_cu = 2;
+static thread_local int g_last_kernel = 0;
+extern "C" int ss_gemm_last_kernel(void) { return g_last_kernel; }
 extern "C" int ss_gemm_set_blocks_per_cu(int n) { int old = g_blocks_per_cu; if (n >= 1 && n <= 2) g_blocks_per_cu = n; return old; }
 
 static int gemm_slots() {
@@ -773,12 +775,14 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
             dim3 grid2(nitems < slots2 ? nitems : slots2);
             SS_LAUNCH(SS_KERNEL(gemm_w2_kernel<TO>), grid2, dim3(128), 0, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems);
             SS_LAUNCH_CHECK("ss_gemm(w2)");
+            g_last_kernel = 2;
             return 0;
         }
     }
     if (a_mode == OP_KC && b_mode == OP_KC && epi.fast && K % BK == 0 && k_chunk % BK == 0 && !(epi.debug & 8)) {
         SS_LAUNCH(SS_KERNEL(gemm_glds_kernel<T, TO>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems);
         SS_LAUNCH_CHECK("ss_gemm(glds)");
+        g_last_kernel = 1;
         return 0;
     }
     // (measured: a global_load_lds + XOR-swizzled ds_read_b64_tr_b16 variant of the OC x OC kernel is ~7 % SLOWER than the
@@ -791,6 +795,7 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     else if (a_mode == OP_OC && b_mode == OP_KC) SS_GEMM_CASE(OP_OC, OP_KC);
 #undef SS_GEMM_CASE
     SS_LAUNCH_CHECK("ss_gemm");
+    g_last_kernel = 0;
     return 0;
 }
 

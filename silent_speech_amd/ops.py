@@ -30,7 +30,7 @@ class GemmProfiler(object):
         s.record()
         fn()
         e.record()
-        self.records.append((key, flops, s, e))
+        self.records.append((key + (_lib.lib().ss_gemm_last_kernel(),), flops, s, e))       # + which kernel ran (0 staged, 1 glds, 2 w2)
 
     def summary(self):
         torch.cuda.synchronize()
