@@ -24,6 +24,9 @@
 #include <math.h>
 
 enum { OP_KC = 0, OP_OC = 1 };
+#ifndef SS_GEMM_PRIO
+#define SS_GEMM_PRIO 0
+#endif
 constexpr int BM = 128, BN = 128, ROWB = 128;   // ROWB: bytes of K per tile row
 
 struct GemmEpi {
@@ -209,18 +212,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int sub, in
 struct TileMmaTR {
     static __device__ __forceinline__ void run(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
         const int c = lane & 15, q = lane >> 4;
+        bf16x8 a[2][4], b[2][4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = tr_frag(As, wm * 4 + i, kk, c, q);
+            for (int i = 0; i < 4; ++i) a[kk][i] = tr_frag(As, wm * 4 + i, kk, c, q);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = tr_frag(Bs, wn * 4 + j, kk, c, q);
+            for (int j = 0; j < 4; ++j) b[kk][j] = tr_frag(Bs, wn * 4 + j, kk, c, q);
+        }
+#if !defined(SS_EMU)
+        __builtin_amdgcn_sched_barrier(0);                 // the 32 transposing reads go out together, ahead of the MFMAs
+#endif
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
-        }
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[kk][i], b[kk][j], acc[i][j]);
     }
 };
 
@@ -233,18 +241,29 @@ template <>
 struct TileMma<bf16_t> {
     static __device__ __forceinline__ void run(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
         int r = lane & 15, q = lane >> 4;
+        // both 32-deep halves of the K tile are fetched up front (16 x ds_read_b128): the second half's LDS latency hides under
+        // the first half's 16 MFMAs instead of being re-exposed in front of every group of four
+        bf16x8 a[2][4], b[2][4];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(As + swz(wm * 64 + i * 16 + r, kk * 4 + q));
+            for (int i = 0; i < 4; ++i) a[kk][i] = *(const bf16x8*)(As + swz(wm * 64 + i * 16 + r, kk * 4 + q));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *(const bf16x8*)(Bs + swz(wn * 64 + j * 16 + r, kk * 4 + q));
+            for (int j = 0; j < 4; ++j) b[kk][j] = *(const bf16x8*)(Bs + swz(wn * 64 + j * 16 + r, kk * 4 + q));
+        }
+#if !defined(SS_EMU)
+        __builtin_amdgcn_sched_barrier(0);                 // keep the 16 reads ahead of the MFMAs (the scheduler would sink them again)
+        if (SS_GEMM_PRIO) __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
-        }
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[kk][i], b[kk][j], acc[i][j]);
+#if !defined(SS_EMU)
+        if (SS_GEMM_PRIO) __builtin_amdgcn_s_setprio(0);
+#endif
     }
 };
 template <>
@@ -687,6 +706,9 @@ __global__ __launch_bounds__(128, 2) void gemm_w2_kernel(const bf16_t* __restric
             for (int i = 0; i < 8; ++i) a[i] = w2::frag(As, i * 16 + r, q);
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = w2::frag(Bs, wn * 64 + j * 16 + r, q);
+#if !defined(SS_EMU)
+            __builtin_amdgcn_sched_barrier(0);               // all 12 reads in flight before the first MFMA
+#endif
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
