@@ -201,6 +201,11 @@ int ss_ctc_loss(const float* logits, int64_t ld, int V, int blank, const float* 
 int ss_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float grad_scale, void* stream);
 int ss_cast_f32(const float* in, void* out, int out_dtype, int64_t n, void* stream);
+/* Input conditioning of the dataset on the device ("next" row N3): out = limit * tanh(((x - mean[c]) / std[c]) / pre_div / limit)
+ * with mean/std optional (both NULL = no affine; C = row length they index) and limit <= 0 = no clipping.
+ * raw EMG: pre_div 20, limit 50 (read_emg.py:227-228); EMG features: FeatureNormalizer + limit 8 (read_emg.py:231-233);
+ * mel targets: FeatureNormalizer only (read_emg.py:231).  In place is allowed. */
+int ss_soft_clip(const float* x, float* out, int64_t n, int C, const float* mean, const float* stdv, float pre_div, float limit, void* stream);
 
 /* mel target extraction (data_utils.py:39-62): reflect pad (:51); the STFT itself is ss_gemm against a
  * windowed DFT matrix with overlapping hop-strided rows; magnitude (:57); mel matmul + log clamp (:59-60)

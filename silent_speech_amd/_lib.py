@@ -67,6 +67,7 @@ SIGNATURES = {
     'ss_ctc_loss': [_P, _L, _I, _I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P],
     'ss_adamw_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     'ss_cast_f32': [_P, _P, _I, _L, _P],
+    'ss_soft_clip': [_P, _P, _L, _I, _P, _P, _F, _F, _P],
     'ss_reflect_pad': [_P, _P, _I, _I, _I, _L, _P],
     'ss_stft_magnitude': [_P, _L, _I, _P, _L, _I, _P],
 }

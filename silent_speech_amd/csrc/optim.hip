@@ -63,6 +63,31 @@ extern "C" int ss_cast_f32(const float* in, void* out, int out_dtype, int64_t n,
     return 0;
 }
 
+// ---------------------------------------------------------------- soft clipping of the input pipeline ("next" row N3)
+// read_emg.py:227-228  raw_emg = raw_emg / 20; raw_emg = 50 * tanh(raw_emg / 50)      (pre_div = 20, limit = 50)
+// read_emg.py:233      emg = 8 * tanh(emg / 8) after FeatureNormalizer.normalize         (pre_div = 1,  limit = 8)
+// optional per-column affine first (FeatureNormalizer: (x - mean[c]) / std[c], data_utils.py:228-231).
+__global__ void soft_clip_kernel(const float* __restrict__ x, float* __restrict__ out, long long n, int C, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                 float pre_div, float limit)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        if (mean) { const int c = (int)(i % C); v = (v - mean[c]) / stdv[c]; }
+        v = v / pre_div;
+        out[i] = limit > 0.f ? limit * tanhf(v / limit) : v;
+    }
+}
+extern "C" int ss_soft_clip(const float* x, float* out, int64_t n, int C, const float* mean, const float* stdv, float pre_div, float limit, void* stream)
+{
+    SS_CHECK(x && out, "ss_soft_clip: null pointer");
+    SS_CHECK((mean == nullptr) == (stdv == nullptr) && (!mean || C > 0) && pre_div != 0.f, "ss_soft_clip: bad normaliser arguments");
+    if (n <= 0) return 0;
+    long long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    SS_LAUNCH(soft_clip_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, out, (long long)n, C, mean, stdv, pre_div, limit);
+    SS_LAUNCH_CHECK("ss_soft_clip");
+    return 0;
+}
+
 // ---------------------------------------------------------------- mel targets: reflect padding and |STFT|
 // data_utils.py:51  F.pad(y, (p, p), mode='reflect')
 __global__ void reflect_pad_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int L, int pad, long long ld_out)

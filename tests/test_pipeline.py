@@ -1,0 +1,72 @@
+"""Device-side input pipeline ("next" row N3): conditioning kernels vs the reference's numpy expressions, mel targets vs
+the oracle, the sharded size-aware sampler vs the reference's packing rule."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import mel_ref
+from silent_speech_amd import pipeline
+from silent_speech_amd.data_utils import FeatureNormalizer
+from tests.backend import dev, is_emu  # noqa: F401
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def test_condition_raw_emg_matches_reference_expression(dev):
+    rng = np.random.default_rng(0)
+    raw = (rng.standard_normal((123, 8)) * 400).astype(np.float32)
+    want = raw / 20
+    want = 50 * np.tanh(want / 50.)                                   # read_emg.py:227-228
+    got = pipeline.condition_raw_emg(torch.from_numpy(raw).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+
+
+def test_normalize_features_with_the_shipped_normalizers(dev):
+    z = np.load(os.path.join(GOLD, 'normalizers.npz'))
+    rng = np.random.default_rng(1)
+    norm = FeatureNormalizer([rng.standard_normal((4, 112)).astype(np.float32)])
+    norm.feature_means, norm.feature_stddevs = z['emg_means'], z['emg_stds']
+    x = (rng.standard_normal((57, 112)) * 30 + 5).astype(np.float32)
+    want = 8 * np.tanh(norm.normalize(x.copy()) / 8.)                 # read_emg.py:231-233
+    got = pipeline.normalize_features(torch.from_numpy(x).to(dev), norm, limit=8.0).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    mnorm = FeatureNormalizer([rng.standard_normal((4, 80)).astype(np.float32)], share_scale=True)
+    mnorm.feature_means, mnorm.feature_stddevs = z['mfcc_means'], float(z['mfcc_std'])
+    m = rng.standard_normal((31, 80)).astype(np.float32)
+    got = pipeline.normalize_features(torch.from_numpy(m).to(dev), mnorm).cpu().numpy()
+    np.testing.assert_allclose(got, mnorm.normalize(m.copy()), rtol=1e-5, atol=1e-5)
+
+
+def test_mel_targets_match_the_reference_mel(dev):
+    z = np.load(os.path.join(GOLD, 'mel.npz'))                          # reference mel_spectrogram output of 3 signals
+    y = torch.from_numpy(z['y'][2][:256 * 13]).to(dev)                  # the chirp, 12 frames (small enough for the emulator)
+    got = pipeline.mel_targets(y, None, max_frames=10).cpu().numpy()
+    want = z['mel'][2].T[:10]
+    assert got.shape == (10, 80)
+    assert np.abs(got - want).mean() < 1e-4 and np.abs(got - want).max() < 1e-2
+
+
+def test_sharded_sampler_partitions_the_reference_packing():
+    rng = np.random.default_rng(2)
+    lengths = [int(v) for v in rng.integers(2000, 12000, 200)]
+    full = pipeline.ShardedSizeAwareSampler(lengths, 128000, 0, 1, seed=3)
+    batches = full.all_batches()
+    for b in batches:
+        assert sum(lengths[i] for i in b) <= 128000
+    flat = [i for b in batches for i in b]
+    assert len(set(flat)) == len(flat)
+    # greedy rule of read_emg.py:131-137: the next utterance would not have fitted
+    order = list(range(len(lengths)))
+    import random
+    random.Random(3 * 1000003).shuffle(order)
+    pos = {v: k for k, v in enumerate(order)}
+    for b in batches:
+        nxt = pos[b[-1]] + 1
+        assert nxt < len(order) and sum(lengths[i] for i in b) + lengths[order[nxt]] > 128000
+    shards = [list(pipeline.ShardedSizeAwareSampler(lengths, 128000, r, 4, seed=3)) for r in range(4)]
+    assert len({len(s) for s in shards}) == 1                           # same number of steps on every rank
+    dealt = [b for k in range(len(shards[0])) for s in shards for b in [s[k]]]
+    assert dealt == batches[:len(dealt)]
+    ep1 = pipeline.ShardedSizeAwareSampler(lengths, 128000, 0, 1, seed=3); ep1.set_epoch(1)
+    assert ep1.all_batches() != batches
