@@ -96,8 +96,9 @@ int ss_permute3d(const void* in, int in_dtype, void* out, int out_dtype, int d0,
  * jobs_dev: device array of
  *   struct { const void* in; void* out; int64 s0,s1,s2 (input strides), o0,o1 (output strides of dims 0,1; dim 2 contiguous);
  *            int32 d0,d1,d2, valid1,valid2, in_dtype,out_dtype, accumulate; float scale; int32 first_block, nblocks, pad; }
- * job_of_block_dev[b] = job index of workgroup b (workgroups first_block .. first_block+nblocks-1 grid-stride over the job). */
-int ss_permute3d_batch(const void* jobs_dev, const int32_t* job_of_block_dev, int total_blocks, void* stream);
+ * job_of_block_dev[b] = job index of workgroup b (workgroups first_block .. first_block+nblocks-1 grid-stride over the job).
+ * all_f32 != 0 promises that every job is f32 -> f32 (the gradient un-layout): a kernel specialised for read-modify-write runs. */
+int ss_permute3d_batch(const void* jobs_dev, const int32_t* job_of_block_dev, int total_blocks, int all_f32, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DTW alignment (align.py:5-14 time_warp + align.py:16-34 align_from_distances; call site

@@ -46,7 +46,7 @@ SIGNATURES = {
     'ss_gemm': [_I, _I, _I, _I, _P, _P, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap),
                 ctypes.POINTER(RowMap), ctypes.POINTER(GemmEpilogue), _I, _P],
     'ss_permute3d': [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _I, _P],
-    'ss_permute3d_batch': [_P, _P, _I, _P],
+    'ss_permute3d_batch': [_P, _P, _I, _I, _P],
     'ss_dtw_align': [_P, _P, _I, _I, _I, _P, _P, _P],
     'ss_dtw_align_skewed': [_P, _I, _P, _P, _P],
     'ss_relpos_attention_forward': [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],

@@ -77,7 +77,7 @@ template <class TI> struct Vec4;
 template <> struct Vec4<float> { static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { const f32x4 a = *(const f32x4*)p; v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; } };
 template <> struct Vec4<bf16_t> { static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) { const u32x2 a = *(const u32x2*)p; v[0] = __uint_as_float(a[0] << 16); v[1] = __uint_as_float(a[0] & 0xffff0000u); v[2] = __uint_as_float(a[1] << 16); v[3] = __uint_as_float(a[1] & 0xffff0000u); } };
 
-template <class TI, class TO>
+template <class TI, class TO, bool GROUPED_RMW = false>
 __device__ __forceinline__ void permute_job(const PermuteJob& j, int lb, int nthreads, int tid, float* tile)
 {
     const long long total = (long long)j.d0 * j.d1 * j.d2;
@@ -86,7 +86,10 @@ __device__ __forceinline__ void permute_job(const PermuteJob& j, int lb, int nth
     const long long as0 = j.s0 < 0 ? -j.s0 : j.s0, as1 = j.s1 < 0 ? -j.s1 : j.s1, as2 = j.s2 < 0 ? -j.s2 : j.s2;
     const bool c0 = j.d0 > 1 && as0 >= 1 && as0 <= 4, c1 = j.d1 > 1 && as1 >= 1 && as1 <= 4;
     const bool fx1 = c1 && (!c0 || j.d1 >= j.d0), fx0 = c0 && !fx1;
-    if (as2 > 4 && (fx0 || fx1) && nthreads == 256 && total >= 4096) {
+    const int dXq = fx1 ? j.d1 : j.d0;
+    // (a 4096-element tile must be reasonably full: an (O, 8, 3) conv weight would put 24 elements in each and its few
+    //  workgroups would walk hundreds of almost empty tiles -- the generic path is faster there)
+    if (as2 > 4 && (fx0 || fx1) && nthreads == 256 && total >= 4096 && (long long)(dXq < 64 ? dXq : 64) * (j.d2 < 64 ? j.d2 : 64) >= 192) {
         // ---- transpose path: X as above, O = the other outer dimension.  Tile = TX (along X) x TC (along c) = 4096 elements;
         // the shape follows the short side (3 conv taps along X on the way in, along c on the way out).
         const int dX = fx1 ? j.d1 : j.d0, dO = fx1 ? j.d0 : j.d1;
@@ -111,7 +114,7 @@ __device__ __forceinline__ void permute_job(const PermuteJob& j, int lb, int nth
                 for (int k = 0; k < 16; ++k) { const int f = k * 256 + tid; tile[(f >> lx) * P + (f & (TX - 1))] = v[k]; }
             }
             __syncthreads();
-            {
+            if (!GROUPED_RMW || !j.accumulate) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int f = k * 256 + tid, x = f >> lc, cc = f & (TC - 1);                 // c fastest: coalesced output
@@ -121,6 +124,25 @@ __device__ __forceinline__ void permute_job(const PermuteJob& j, int lb, int nth
                         float w = tile[cc * P + x];
                         if (j.accumulate) w += ldf(o);
                         stf(o, w);
+                    }
+                }
+            } else {
+                // read-modify-write: 8 loads in flight, then 8 stores (a load / add / store chain per element costs 16 round trips)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float w[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int f = (h * 8 + k) * 256 + tid, x = f >> lc, cc = f & (TC - 1);
+                        const int gx = tx * TX + x, gc = tc * TC + cc;
+                        w[k] = tile[cc * P + x];
+                        if (gx < dX && gc < j.d2) w[k] += ldf(out + oi * oO + gx * oX + gc);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int f = (h * 8 + k) * 256 + tid, x = f >> lc, cc = f & (TC - 1);
+                        const int gx = tx * TX + x, gc = tc * TC + cc;
+                        if (gx < dX && gc < j.d2) stf(out + oi * oO + gx * oX + gc, w[k]);
                     }
                 }
             }
@@ -163,12 +185,22 @@ __global__ void permute3d_batch_kernel(const PermuteJob* __restrict__ jobs, cons
     else permute_job<bf16_t, bf16_t>(j, lb, blockDim.x, threadIdx.x, tile);
 }
 
-extern "C" int ss_permute3d_batch(const void* jobs_dev, const int32_t* job_of_block_dev, int total_blocks, void* stream)
+// the gradient un-layout batch is all f32 -> f32 read-modify-write: its own kernel, so that the 8-deep load groups of that path
+// do not push the mixed-dtype kernel above 128 registers
+__global__ __launch_bounds__(256) void permute3d_batch_f32_kernel(const PermuteJob* __restrict__ jobs, const int* __restrict__ job_of_block)
+{
+    __shared__ float tile[1024 * 5];
+    const PermuteJob j = jobs[job_of_block[blockIdx.x]];
+    permute_job<float, float, true>(j, blockIdx.x - j.first_block, blockDim.x, threadIdx.x, tile);
+}
+
+extern "C" int ss_permute3d_batch(const void* jobs_dev, const int32_t* job_of_block_dev, int total_blocks, int all_f32, void* stream)
 {
     SS_CHECK(total_blocks >= 0, "ss_permute3d_batch: negative block count");
     if (total_blocks == 0) return 0;
     SS_CHECK(jobs_dev && job_of_block_dev, "ss_permute3d_batch: null pointer");
-    SS_LAUNCH(permute3d_batch_kernel, dim3(total_blocks), dim3(256), 0, stream, (const PermuteJob*)jobs_dev, (const int*)job_of_block_dev);
+    if (all_f32) SS_LAUNCH(permute3d_batch_f32_kernel, dim3(total_blocks), dim3(256), 0, stream, (const PermuteJob*)jobs_dev, (const int*)job_of_block_dev);
+    else SS_LAUNCH(permute3d_batch_kernel, dim3(total_blocks), dim3(256), 0, stream, (const PermuteJob*)jobs_dev, (const int*)job_of_block_dev);
     SS_LAUNCH_CHECK("ss_permute3d_batch");
     return 0;
 }

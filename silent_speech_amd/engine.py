@@ -283,6 +283,8 @@ class GradUnpack(object):
         for k, n in sizes:
             self.buf[k] = self.arena[off:off + n]
             off += (n + 3) // 4 * 4
+        # One batched launch per group, issued on the side stream as soon as the group's dW GEMMs are queued: the encoder
+        # group overlaps the conv backward; only conv block 0 (the last to finish) is left for the end of the step.
         ub = ops.PermuteBatch()
         n_out = model.w_out.weight.shape[0]
         n_aux = model.w_aux.weight.shape[0] if model.has_aux_out else 0
@@ -297,11 +299,14 @@ class GradUnpack(object):
             ub.add(self.buf['wo%d' % l], a.w_o.grad, (H, dh, d), (dp, 1, H * dp), accumulate=True)
             for i, wp in enumerate((a.w_q, a.w_k, a.w_v)):
                 ub.add(self.buf['wqkv%d' % l][i * H * dp * d:], wp.grad, (H, d, dh), (dp * d, 1, d), accumulate=True)
+        self.encoder_batch = ub
+        self.conv_batches = []
         for i, blk in enumerate(model.conv_blocks):
             O, I, _ = blk.conv1.weight.shape
-            ub.add(self.buf['c2_%d' % i], blk.conv2.weight.grad, (O, O, 3), (3 * O, 1, O), accumulate=True)
-            ub.add(self.buf['c1_%d' % i], blk.conv1.weight.grad, (O, I, 3), (3 * I, 1, I), accumulate=True)
-        self.batch = ub
+            cb = ops.PermuteBatch()
+            cb.add(self.buf['c2_%d' % i], blk.conv2.weight.grad, (O, O, 3), (3 * O, 1, O), accumulate=True)
+            cb.add(self.buf['c1_%d' % i], blk.conv1.weight.grad, (O, I, 3), (3 * I, 1, I), accumulate=True)
+            self.conv_batches.append(cb)
         self.sig = self.signature(model)
 
     @staticmethod
@@ -445,6 +450,7 @@ def backward(model, ctx, dhead):
         _dw_direct(G, ctx.conv_out, model.w_raw_in.weight.grad, d, d, M, RM(d), RM(d))
         ops.colsum(G, M, d, d, model.w_raw_in.bias.grad)
     side.run(raw_in_grads, G)
+    side.run(lambda: gu.encoder_batch.run(dev))                # heads + encoder layers: re-laid-out gradients -> .grad arena, under the conv backward
     dy = torch.empty(M, d, dtype=dt, device=dev)
     ops.gemm(G, pr.w_raw_in_T, dy, M, d, d, RM(d), RM(d), RM(d))
     del G
@@ -482,6 +488,7 @@ def backward(model, ctx, dhead):
             ops.gemm(dcr, s.xin, blk.residual_path.weight.grad, O, Cin, rows, RM(O), RM(2 * Cin, Tout, in_bs, base=Cin), RM(Cin), a_mode=OP_OC,
                      b_mode=OP_OC, mode=2, split_k=_split_k(O, Cin, rows))
         side.run(conv1_grads, dc1, dcr)
+        side.run(lambda i=i: gu.conv_batches[i].run(dev))          # this block's conv gradients -> parameter layout
         if i > 0:
             dx = torch.empty(B * Tin, Cin, dtype=dt, device=dev)
             out_even = RM(2 * Cin, Tout, Tin * Cin)
@@ -491,5 +498,4 @@ def backward(model, ctx, dhead):
             ops.gemm(dc1, w['w1b_odd'], dx, rows, Cin, 2 * O, RM(O, Tout, pbs, base=O), RM(2 * O), out_odd)
             dy = dx
         del dc1, dcr
-    side.run(lambda: gu.batch.run(dev))       # all re-laid-out weight gradients -> .grad arena, one launch
     side.join()

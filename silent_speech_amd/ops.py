@@ -262,4 +262,5 @@ class PermuteBatch(object):
         if self._dev is None or self._dev[0].device != device:
             self._finalize(device)
         jobs, jb, total = self._dev
-        _lib.check(_L().ss_permute3d_batch(_p(jobs), _p(jb), total, _s(jobs)), 'ss_permute3d_batch')
+        all_f32 = int(all(j.in_dtype == 0 and j.out_dtype == 0 for j in self.jobs))     # f32 -> f32 batches (gradient un-layout) have their own kernel
+        _lib.check(_L().ss_permute3d_batch(_p(jobs), _p(jb), total, all_f32, _s(jobs)), 'ss_permute3d_batch')
