@@ -212,7 +212,7 @@ def main():
                 pass
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
                                'traffic_source': traffic_src,
-                               'kernel': '%s<%s,%s,a_mode=%d,b_mode=%d>' % (('gemm_kernel', 'gemm_glds_kernel', 'gemm_w2_kernel')[key[4]],) + key[:4], 'launches_per_step': d['launches'] / psteps, 'event_timed_steps': psteps,
+                               'kernel': '%s<%s,%s,a_mode=%d,b_mode=%d>' % ((('gemm_kernel', 'gemm_glds_kernel', 'gemm_w2_kernel')[key[4]],) + tuple(key[:4])), 'launches_per_step': d['launches'] / psteps, 'event_timed_steps': psteps,
                                'timing': 'HIP events around every ss_gemm launch on every 4th timed step; those steps keep the dW GEMMs on the main stream (exclusive durations); rocprofv3 counterpart: profiles/*_serial_kernel_stats.txt (SS_AMD_SIDE_STREAM=0)',
                                'avg_launch_us': d['seconds'] / d['launches'] * 1e6, 'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                                'all_gemm_variants': {str(k): {'tflops': v['flops'] / v['seconds'] / 1e12, 'ms_per_step': v['seconds'] / psteps * 1e3,
