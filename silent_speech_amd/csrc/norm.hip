@@ -34,10 +34,23 @@ __device__ __forceinline__ bool chunk_reduce(const float* __restrict__ partial, 
     float acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
-    if (c < C)
-        for (int k = ln; k < nchunks; k += 8)
+    if (c < C) {
+        int k = ln;
+        for (; k + 56 < nchunks; k += 64) {                 // 8 independent loads per quantity in flight (the serial loop was latency-bound)
+            float v[8][NQ];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) v[u][q] = partial[((long long)(k + 8 * u) * NQ + q) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] += v[u][q];
+        }
+        for (; k < nchunks; k += 8)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) acc[q] += partial[((long long)k * NQ + q) * C + c];
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) red[q][ln][cl] = acc[q];
     __syncthreads();
