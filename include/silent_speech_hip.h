@@ -225,6 +225,10 @@ int ss_stft_magnitude(const float* spec, int64_t ld_spec, int n_bins, float* mag
  * backward (transduction_model.py:209): dqkv [B*T][3*H*dp] = (dQ|dK|dV); dO/dOT like out / its
  * transposed copy [B][H*dp][Tp]; Dscratch [B][H][T] f32.  The embeddings receive no gradient
  * (transformer.py:214-218). */
+/* 1 if (dtype, T, dp, D) runs the per-tile attention kernels, which read the per-sequence transposed copies qkvT / dOT;
+ * 0 if the LDS-resident kernels run (bf16, T <= 208, operands fit the 160 KB LDS): then qkvT and dOT may be NULL and the
+ * producing GEMMs need not emit them. */
+int ss_relpos_attention_needs_transposed(int dtype, int T, int dp, int D); /* [host] */
 int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse,
                                 int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
                                 uint32_t rng_stream, void* stream);

@@ -76,7 +76,8 @@ _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int6
                'ss_bn_scratch_floats': ([_I, _I, _I], ctypes.c_int64),
                'ss_colsum_scratch_floats': ([_I, _I], ctypes.c_int64),
                'ss_gemm_set_blocks_per_cu': ([_I], ctypes.c_int),
-               'ss_gemm_last_kernel': ([], ctypes.c_int)}
+               'ss_gemm_last_kernel': ([], ctypes.c_int),
+               'ss_relpos_attention_needs_transposed': ([_I, _I, _I, _I], ctypes.c_int)}
 _RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}
 
 _lib = None

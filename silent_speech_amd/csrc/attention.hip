@@ -609,8 +609,8 @@ __device__ __forceinline__ void lds_e_pad(bf16x8 (&f)[DPK], const unsigned char*
 }
 
 template <int DPK, int NBLK, bool DROP>
-__device__ __forceinline__ void fwd_res_tile(const AttnP& p, const unsigned char* Ks, const unsigned char* Es, const unsigned char* VTs, RT* Pt,
-                                             const bf16x8 (&qf)[DPK], int b, int h, int q0, int jlo, int nblk, int lane, int PVT, int ER, f32x4 (&o)[2 * DPK])
+__device__ __forceinline__ void fwd_res_tile(const AttnP& p, const unsigned char* Ks, const unsigned char* Es, const unsigned char* Vs, RT* Pt,
+                                             const bf16x8 (&qf)[DPK], int b, int h, int q0, int jlo, int nblk, int lane, int ER, f32x4 (&o)[2 * DPK])
 {
     constexpr int PK = DPK * 64 + 16, PTL = 20;
     const int c = lane & 15, g = lane >> 4, Tn = p.T, D = p.D, H = p.H;
@@ -652,7 +652,7 @@ __device__ __forceinline__ void fwd_res_tile(const AttnP& p, const unsigned char
 #pragma unroll
     for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; o[n] = z; }
     // O = P~ V per 32-key chunk: P~^T goes to LDS as [key][query] (one 8-byte store per block: this lane's 4 rows are adjacent),
-    // the A operand comes back through a transposing read, V^T fragments are read in the same k order
+    // both operands come back through transposing reads (V stays row-major: no transposed copy of qkv is needed)
 #pragma unroll
     for (int kc = 0; kc < (NBLK + 1) / 2; ++kc) {
 #pragma unroll
@@ -674,14 +674,9 @@ __device__ __forceinline__ void fwd_res_tile(const AttnP& p, const unsigned char
         }
         wave_lds_sync();
         const bf16x8 pa = lds_b_tr((const unsigned char*)Pt, PTL * 2, 0, 0, c, g);
-        int vcol = 16 * jlo + kc * 32; vcol = 2 * kc < nblk ? vcol : 0;          // chunks past the band hold P = 0: keep their reads on staged (finite) data
+        int vrow = 16 * jlo + kc * 32; vrow = 2 * kc < nblk ? vrow : 0;          // chunks past the band hold P = 0: keep their reads on staged (finite) rows
 #pragma unroll
-        for (int n = 0; n < 2 * DPK; ++n) {
-            const unsigned char* vp = VTs + (n * 16 + c) * PVT + (vcol + g * 4) * 2;
-            const s16x4 lo = *(const s16x4*)vp, hi = *(const s16x4*)(vp + 32);
-            const bf16x8 vb = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            o[n] = mfma_bf16_16x16x32(pa, vb, o[n]);
-        }
+        for (int n = 0; n < 2 * DPK; ++n) o[n] = mfma_bf16_16x16x32(pa, lds_b_tr(Vs, PK, vrow, n * 32, c, g), o[n]);
         wave_lds_sync();
     }
 }
@@ -694,38 +689,18 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res_kernel(AttnP p)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
     const int H = p.H, h = blockIdx.x % H, b = blockIdx.x / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1, ER = NE + 2 * RES_PL;
-    const int WV = ((nb + 2) >> 1) * 32, PVT = WV * 2 + 8;             // a chunk starting at an odd block may end 16 keys past Tr;
-                                                                       // pitch = 2 (mod 32) words: the 16 rows of an 8-byte fragment read hit 16 distinct bank pairs
     unsigned char* Ks = (unsigned char*)smem;
-    unsigned char* Es = Ks + Tr * PK;                                   // row m + RES_PL holds embedding m
-    unsigned char* VTs = Es + ER * PK;
-    RT* Pt = (RT*)(VTs + dp * PVT) + w * 16 * RT_LD;
-    int* ctr = (int*)(VTs + dp * PVT + RES_W_FWD * 16 * RT_LD * 2);
+    unsigned char* Vs = Ks + Tr * PK;                                   // a chunk starting at an odd block reads up to 16 rows past Tr: they
+    unsigned char* Es = Vs + Tr * PK;                                   // land in the (finite) embedding rows and meet P = 0
+    RT* Pt = (RT*)(Es + ER * PK) + w * 16 * RT_LD;                      // row m + RES_PL of Es holds embedding m
+    int* ctr = (int*)(Es + ER * PK + RES_W_FWD * 16 * RT_LD * 2);
     const long long ldq = 3LL * H * dp;
     const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
     {
         stage_rows<DPK>(Ks, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W_FWD * 64);
+        stage_rows<DPK>(Vs, PK, Q + 2 * H * dp, ldq, Tn, Tr, tid, RES_W_FWD * 64);
         stage_rows<DPK>(Es, PK, (const RT*)p.E, dp, 0, RES_PL, tid, RES_W_FWD * 64);
         stage_rows<DPK>(Es + RES_PL * PK, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE + RES_PL, tid, RES_W_FWD * 64);
-        const RT* VT = (const RT*)p.qkvT + ((long long)b * 3 * H * dp + 2 * H * dp + h * dp) * p.Tp;
-        const int cpr = WV >> 3, total = dp * cpr;
-        for (int base = tid; base < total; base += RES_W_FWD * 64 * 8) {
-            bf16x8 v[8]; int off[8], t0s[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * RES_W_FWD * 64, r = i / cpr, t0 = (i - r * cpr) * 8;
-                v[u] = bzero8(); off[u] = i < total ? r * PVT + t0 * 2 : -1; t0s[u] = t0;
-                if (i < total && t0 < Tn) v[u] = *(const bf16x8*)(VT + (long long)r * p.Tp + t0);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (off[u] < 0) continue;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (t0s[u] + e >= Tn) v[u][e] = 0;
-                { const u32x4 q = __builtin_bit_cast(u32x4, v[u]); const u32x2 lo = {q[0], q[1]}, hi = {q[2], q[3]};     // rows are only 8-byte aligned
-                  *(u32x2*)(VTs + off[u]) = lo; *(u32x2*)(VTs + off[u] + 8) = hi; }
-            }
-        }
         if (tid == 0) *ctr = 0;
     }
     __syncthreads();
@@ -741,9 +716,9 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res_kernel(AttnP p)
         const int itn = res_next(ctr, lane);
         if (itn < nb) { int qr = res_tile_of(itn, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1; glb_row_frags<DPK>(qn, Q + (long long)qr * ldq, true, g); }
         f32x4 o[2 * DPK];
-        if (nblk <= 4) fwd_res_tile<DPK, 4, DROP>(p, Ks, Es, VTs, Pt, qf, b, h, q0, jlo, nblk, lane, PVT, ER, o);
-        else if (nblk <= 10) fwd_res_tile<DPK, 10, DROP>(p, Ks, Es, VTs, Pt, qf, b, h, q0, jlo, nblk, lane, PVT, ER, o);
-        else fwd_res_tile<DPK, RES_NB, DROP>(p, Ks, Es, VTs, Pt, qf, b, h, q0, jlo, nblk, lane, PVT, ER, o);
+        if (nblk <= 4) fwd_res_tile<DPK, 4, DROP>(p, Ks, Es, Vs, Pt, qf, b, h, q0, jlo, nblk, lane, ER, o);
+        else if (nblk <= 10) fwd_res_tile<DPK, 10, DROP>(p, Ks, Es, Vs, Pt, qf, b, h, q0, jlo, nblk, lane, ER, o);
+        else fwd_res_tile<DPK, RES_NB, DROP>(p, Ks, Es, Vs, Pt, qf, b, h, q0, jlo, nblk, lane, ER, o);
         store_tile_rows<DPK>(Pt, o, 1.f, (RT*)p.out + (long long)b * Tn * (H * dp) + h * dp, (long long)H * dp, q0, Tn, lane);
         it = itn;
 #pragma unroll
@@ -1035,7 +1010,7 @@ static void attn_fill(AttnP& p, int B, int H, int T, int Tp, int dp, int D, floa
 static const size_t RES_LDS_MAX = 160 * 1024;
 static size_t res_smem(int which, int T, int dp, int D) {
     const size_t PK = (size_t)dp * 2 + 16, nb = (size_t)(T + 15) / 16, Tr = nb * 16, NE = 2 * (size_t)D - 1, TQ = (nb + 1) / 2 * 32, tile = 16 * RT_LD * 2;
-    if (which == 0) return Tr * PK + (NE + 2 * RES_PL) * PK + (size_t)dp * ((nb + 2) / 2 * 32 * 2 + 8) + RES_W_FWD * tile + 16;
+    if (which == 0) return 2 * Tr * PK + (NE + 2 * RES_PL) * PK + RES_W_FWD * tile + 16;
     if (which == 1) return 2 * Tr * PK + (NE + 96) * PK + RES_W_BQ * tile + 16;
     return 2 * TQ * PK + NE * PK + RES_W_BKV * 2 * tile + 8 * TQ + 16;
 }
@@ -1070,14 +1045,24 @@ static ResKernel res_pick(int which, int dpk, bool drop = false) {
     return dpk >= 1 && dpk <= 3 ? tab[which][dpk - 1] : (ResKernel)0;
 }
 
+// 1 if this problem runs the per-tile kernels (which read the transposed copies qkvT / dOT), 0 if the LDS-resident ones do
+extern "C" int ss_relpos_attention_needs_transposed(int dtype, int T, int dp, int D)
+{
+    const int dpk = dp / 32;
+    const bool resident = res_enabled(dtype, T) && dp % 32 == 0 && dpk >= 1 && dpk <= 3 && res_smem(0, T, dp, D) <= RES_LDS_MAX && res_smem(1, T, dp, D) <= RES_LDS_MAX &&
+                          res_smem(2, T, dp, D) <= RES_LDS_MAX;
+    return resident ? 0 : 1;
+}
+
 extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse,
                                            int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
     if (attn_check("ss_relpos_attention_forward", dtype, B, H, T, Tp, dp, D, dropout_p)) return 1;
-    SS_CHECK(qkv && qkvT && E && out && lse, "ss_relpos_attention_forward: null pointer");
+    SS_CHECK(qkv && E && out && lse, "ss_relpos_attention_forward: null pointer");
+    SS_CHECK(qkvT || !ss_relpos_attention_needs_transposed(dtype, T, dp, D), "ss_relpos_attention_forward: this shape runs the per-tile kernels, which need the transposed copy qkvT");
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
     p.qkv = qkv; p.qkvT = qkvT; p.E = E; p.out = out; p.lse = lse;
-    if (res_enabled(dtype, T) && res_pick(0, dp / 32) && res_smem(0, T, dp, D) <= RES_LDS_MAX) {
+    if (!ss_relpos_attention_needs_transposed(dtype, T, dp, D)) {
         if (res_launch(res_pick(0, dp / 32, p.drop_thresh != 0), dp / 32 + (p.drop_thresh ? 12 : 0), B * H, RES_W_FWD, res_smem(0, T, dp, D), stream, p)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_forward");
         return 0;
@@ -1094,7 +1079,8 @@ extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const vo
                                             int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
     if (attn_check("ss_relpos_attention_backward", dtype, B, H, T, Tp, dp, D, dropout_p)) return 1;
-    SS_CHECK(qkv && qkvT && E && ET && out && lse && dO && dOT && Dscratch && dqkv, "ss_relpos_attention_backward: null pointer");
+    SS_CHECK(qkv && E && ET && out && lse && dO && Dscratch && dqkv, "ss_relpos_attention_backward: null pointer");
+    SS_CHECK((qkvT && dOT) || !ss_relpos_attention_needs_transposed(dtype, T, dp, D), "ss_relpos_attention_backward: this shape runs the per-tile kernels, which need qkvT and dOT");
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
     p.qkv = qkv; p.qkvT = qkvT; p.E = E; p.ET = ET; p.out = (void*)out; p.lse = (float*)lse; p.dO = dO; p.dOT = dOT; p.Dv = Dscratch; p.dqkv = dqkv;
     {
@@ -1102,7 +1088,7 @@ extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const vo
         if (dtype == SS_BF16) SS_LAUNCH(attn_dsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dO, (const bf16_t*)out, Dscratch, B, H, T, dp);
         else SS_LAUNCH(attn_dsum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)dO, (const float*)out, Dscratch, B, H, T, dp);
     }
-    if (res_enabled(dtype, T) && res_pick(1, dp / 32) && res_smem(1, T, dp, D) <= RES_LDS_MAX && res_smem(2, T, dp, D) <= RES_LDS_MAX) {
+    if (!ss_relpos_attention_needs_transposed(dtype, T, dp, D)) {
         const bool drop = p.drop_thresh != 0;
         if (res_launch(res_pick(1, dp / 32, drop), (drop ? 16 : 4) + dp / 32, B * H, RES_W_BQ, res_smem(1, T, dp, D), stream, p)) return 1;
         if (res_launch(res_pick(2, dp / 32, drop), (drop ? 20 : 8) + dp / 32, B * H, RES_W_BKV, res_smem(2, T, dp, D), stream, p)) return 1;

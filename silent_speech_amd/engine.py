@@ -16,7 +16,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import OP_KC, OP_OC
 
 RM = ops.rowmap
@@ -218,14 +218,19 @@ def forward(model, x_raw, training, shift_r, seed):
     Tp = _round_up(T, 8)
     scale = 1.0 / math.sqrt(model.d_qkv)
     ctx.Tp, ctx.scale = Tp, scale
+    ctx.need_T = bool(_lib.lib().ss_relpos_attention_needs_transposed(_lib.dtype_code(dt), T, dp, D))
     ctx.layers = []
     for l, (layer, w) in enumerate(zip(model.transformer.layers, pr.layers)):
         s = Ctx()
         s.x = x
         qkv = torch.empty(M, 3 * H * dp, dtype=dt, device=dev)
-        qkvT = torch.empty(B, 3 * H * dp, Tp, dtype=dt, device=dev)
-        ops.gemm_ex(x, w['wqkv'], qkv, M, 3 * H * dp, d, RM(d), RM(d), RM(3 * H * dp),
-                    c2=qkvT, cmap2=RM(1, T, 3 * H * dp * Tp), col_stride2=Tp)
+        if ctx.need_T:      # the per-tile attention kernels read a per-sequence transposed copy, written by the same GEMM epilogue
+            qkvT = torch.empty(B, 3 * H * dp, Tp, dtype=dt, device=dev)
+            ops.gemm_ex(x, w['wqkv'], qkv, M, 3 * H * dp, d, RM(d), RM(d), RM(3 * H * dp),
+                        c2=qkvT, cmap2=RM(1, T, 3 * H * dp * Tp), col_stride2=Tp)
+        else:               # LDS-resident attention (bf16 rows of <= 208 frames): row-major operands only
+            qkvT = None
+            ops.gemm(x, w['wqkv'], qkv, M, 3 * H * dp, d, RM(d), RM(d), RM(3 * H * dp))
         o = torch.empty(M, H * dp, dtype=dt, device=dev)
         lse = torch.empty(B, H, T, dtype=torch.float32, device=dev)
         ops.relpos_attention_forward(qkv, qkvT, w['E'], o, lse, B, H, T, Tp, dp, D, scale, p=p_drop, seed=seed, rng_stream=4 * l)
@@ -432,9 +437,13 @@ def backward(model, ctx, dhead):
             _dw_direct(dA, s.o, gu.buf['wo%d' % l], d, H * dp, M, RM(d), RM(H * dp))
         side.run(wo_grads, dA)
         dO = torch.empty(M, H * dp, dtype=dt, device=dev)
-        dOT = torch.empty(B, H * dp, Tp, dtype=dt, device=dev)
-        ops.gemm_ex(dA, w['woT'], dO, M, H * dp, d, RM(d), RM(d), RM(H * dp),
-                    c2=dOT, cmap2=RM(1, T, H * dp * Tp), col_stride2=Tp)
+        if ctx.need_T:
+            dOT = torch.empty(B, H * dp, Tp, dtype=dt, device=dev)
+            ops.gemm_ex(dA, w['woT'], dO, M, H * dp, d, RM(d), RM(d), RM(H * dp),
+                        c2=dOT, cmap2=RM(1, T, H * dp * Tp), col_stride2=Tp)
+        else:
+            dOT = None
+            ops.gemm(dA, w['woT'], dO, M, H * dp, d, RM(d), RM(d), RM(H * dp))
         dqkv = torch.empty(M, 3 * H * dp, dtype=dt, device=dev)
         dsc = torch.empty(B, H, T, dtype=torch.float32, device=dev)
         ops.relpos_attention_backward(s.qkv, s.qkvT, w['E'], w['ET'], s.o, s.lse, dO, dOT, dsc, dqkv, B, H, T, Tp, dp, D, ctx.scale,
