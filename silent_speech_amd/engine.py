@@ -27,12 +27,13 @@ def _round_up(x, m):
 
 
 def _split_k(M, N, K):
-    """Split-K factor of a weight-gradient GEMM: the largest one that keeps tiles x split within ONE round of the 512
-    persistent workgroup slots (2 per CU).  Measured (tools/dw_split_probe.py, K = 22 016): 144 tiles x 3 = 432 items 201 us,
-    x 4 = 576 items 292 us (a second, nearly empty round), x 7 = 1008 items 206 us (two full rounds, but twice the f32 atomic
-    epilogues); 36 tiles: x 14 -> 72 us, x 28 -> 103 us."""
+    """Split-K factor of a weight-gradient GEMM: the largest one that keeps tiles x split within ~400 work items, i.e. inside
+    ONE round of the 512 persistent workgroup slots (2 per CU) with room left for the main-stream kernels these GEMMs run
+    beside.  Measured alone (tools/dw_split_probe.py, K = 22 016): 144 tiles x 3 = 432 items 201 us, x 4 = 576 items 292 us
+    (a second, nearly empty round), x 7 = 1008 items 206 us (two full rounds, twice the f32 atomic epilogues); 36 tiles:
+    x 14 -> 72 us, x 28 -> 103 us.  Measured in the step: budgets of 340-420 items give 20.8-21.0 ms, 512 gives 21.4, 1024 gave 22.6."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    s = max(1, min(64, 512 // max(tiles, 1)))
+    s = max(1, min(64, 400 // max(tiles, 1)))
     return max(1, min(s, K // 512 if K >= 512 else 1))
 
 
