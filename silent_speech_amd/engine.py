@@ -33,7 +33,8 @@ def _split_k(M, N, K):
     (a second, nearly empty round), x 7 = 1008 items 206 us (two full rounds, twice the f32 atomic epilogues); 36 tiles:
     x 14 -> 72 us, x 28 -> 103 us.  Measured in the step: budgets of 340-420 items give 20.8-21.0 ms, 512 gives 21.4, 1024 gave 22.6."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    s = max(1, min(64, 400 // max(tiles, 1)))
+    overlapped = SIDE_STREAM_ENABLED and os.environ.get('SS_AMD_SIDE_STREAM', '1') != '0'
+    s = max(1, min(64, (400 if overlapped else 512) // max(tiles, 1)))     # alone on the GPU a full round (<= 512 items) is best
     return max(1, min(s, K // 512 if K >= 512 else 1))
 
 
