@@ -80,7 +80,17 @@ __global__ __launch_bounds__(RED_THREADS) void bn_partial_kernel(const T* __rest
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sh[e] = shift[cx * 8 + e];
             } else Vec8<T>::load(x + sx.row(0) * C + cx * 8, sh);   // shift = first row: tames E[x^2]-E[x]^2 cancellation
-            for (int r = r0 + m.ry; r < r1; r += m.RY) {
+            int r = r0 + m.ry;
+            for (; r + 3 * m.RY < r1; r += 4 * m.RY) {                    // 4 independent 16-byte loads in flight per thread
+                float v[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Vec8<T>::load(x + sx.row(r + u * m.RY) * C + cx * 8, v[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { float d = v[u][e] - sh[e]; s1[e] += d; s2[e] += d * d; }
+            }
+            for (; r < r1; r += m.RY) {
                 float v[8]; Vec8<T>::load(x + sx.row(r) * C + cx * 8, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { float d = v[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
@@ -231,18 +241,25 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const T* __
         if (cv) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { ma[e] = mean_a[cx * 8 + e]; ia[e] = invstd_a[cx * 8 + e]; if (xb) { mb[e] = mean_b[cx * 8 + e]; ib[e] = invstd_b[cx * 8 + e]; } }
-            for (int r = r0 + m.ry; r < r1; r += m.RY) {
-                float g[8], v[8];
-                Vec8<T>::load(dy + sdy.row(r) * C + cx * 8, g);
-                if (relu) { float o[8]; Vec8<T>::load(y + sy.row(r) * C + cx * 8, o);
+            // two rows per trip: up to 8 independent 16-byte loads in flight per thread (the sums keep their row order)
+            for (int r = r0 + m.ry; r < r1; r += 2 * m.RY) {
+                const bool two = r + m.RY < r1;
+                const int rb = two ? r + m.RY : r;
+                float g[2][8], o[2][8], va[2][8], vb[2][8];
+                Vec8<T>::load(dy + sdy.row(r) * C + cx * 8, g[0]); Vec8<T>::load(dy + sdy.row(rb) * C + cx * 8, g[1]);
+                if (relu) { Vec8<T>::load(y + sy.row(r) * C + cx * 8, o[0]); Vec8<T>::load(y + sy.row(rb) * C + cx * 8, o[1]); }
+                Vec8<T>::load(xa + sa.row(r) * C + cx * 8, va[0]); Vec8<T>::load(xa + sa.row(rb) * C + cx * 8, va[1]);
+                if (xb) { Vec8<T>::load(xb + sb.row(r) * C + cx * 8, vb[0]); Vec8<T>::load(xb + sb.row(rb) * C + cx * 8, vb[1]); }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
-                Vec8<T>::load(xa + sa.row(r) * C + cx * 8, v);
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !two) break;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { sg[e] += g[e]; sga[e] += g[e] * (v[e] - ma[e]) * ia[e]; }
-                if (xb) { Vec8<T>::load(xb + sb.row(r) * C + cx * 8, v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) sgb[e] += g[e] * (v[e] - mb[e]) * ib[e]; }
+                    for (int e = 0; e < 8; ++e) {
+                        const float gg = (!relu || o[u][e] > 0.f) ? g[u][e] : 0.f;
+                        sg[e] += gg; sga[e] += gg * (va[u][e] - ma[e]) * ia[e];
+                        if (xb) sgb[e] += gg * (vb[u][e] - mb[e]) * ib[e];
+                    }
+                }
             }
         }
         __syncthreads();
