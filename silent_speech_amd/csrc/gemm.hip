@@ -654,16 +654,19 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const T* __restrict__
 // 8 rows served together by a ds_read_b128 over all 32 banks.  Staging is global_load_lds (the swizzle is applied to the
 // per-lane source chunk, the destination stays lane-linear).
 namespace w2 {
-constexpr int BK2 = 32, ROW2 = 64, STAGE = (BM + BN) * ROW2;          // 16 KiB per stage
+constexpr int BK2 = 32, ROW2 = 64;
+// ROWS tile rows, copied 16 rows per wave instruction; wave w takes the 16-row pieces w, w+2, w+4, ...
+template <int ROWS>
 struct Stage {
-    const bf16_t* src[4];
-    int base_row;
+    static constexpr int NP = (ROWS / 16 + 1) / 2;        // pieces per wave (the last one may belong to wave 0 only)
+    const bf16_t* src[NP];
+    int wave;
     __device__ __forceinline__ void init(const bf16_t* p, const RowMap& map, int outer0, int outer_size, int k_begin, int tid) {
-        const int lane = tid & 63, wave = tid >> 6;
-        base_row = wave * 16;
+        const int lane = tid & 63;
+        wave = tid >> 6;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = i * 32 + wave * 16 + (lane >> 2);
+        for (int i = 0; i < NP; ++i) {
+            const int r = (i * 2 + wave) * 16 + (lane >> 2);
             int o = outer0 + r; o = o < outer_size ? o : outer_size - 1;
             const int chunk = (lane & 3) ^ ((r >> 1) & 3);
             src[i] = p + rowmap_off(map, o) + k_begin + chunk * 8;
@@ -671,46 +674,74 @@ struct Stage {
     }
     __device__ __forceinline__ void issue(unsigned char* tile) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { glds16(src[i], tile + (i * 32 + base_row) * ROW2); src[i] += BK2; }
+        for (int i = 0; i < NP; ++i) {
+            if ((i * 2 + wave) * 16 < ROWS) glds16(src[i], tile + (i * 2 + wave) * 16 * ROW2);
+            src[i] += BK2;
+        }
     }
 };
 __device__ __forceinline__ bf16x8 frag(const unsigned char* tile, int row, int q) { return *(const bf16x8*)(tile + row * ROW2 + ((q ^ ((row >> 1) & 3)) << 4)); }
+
+// epilogue pass P of a BMT-row tile: IPP 16-row MFMA tiles per pass go to the LDS piece, then 16-byte row-contiguous stores
+template <class TO, int GEN, int NI, int IPP, int P, int NPASS>
+struct Passes {
+    static __device__ __forceinline__ void run(const f32x4 (&acc)[NI][4], TO* ct, int ldc, TO* C, const GemmEpi& epi, int cm0, int cn0, int M, int N, int tid, int wn, int r, int q) {
+#pragma unroll
+        for (int ii = 0; ii < IPP; ++ii) {
+            constexpr int I0 = P * IPP;
+            if (I0 + ii < NI) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    epilogue_stage<TO, GEN>(acc[I0 + ii < NI ? I0 + ii : 0][j], ct, ldc, ii * 16 + q * 4, wn * 64 + j * 16 + r, epi, cm0 + (I0 + ii) * 16 + q * 4, cn0 + wn * 64 + j * 16 + r, M, N);
+            }
+        }
+        barrier_keep_vm();
+        epilogue_flush<TO, 128>(ct, ldc, C, epi, cm0 + P * IPP * 16, IPP * 16, cn0, M, N, tid);
+        barrier_keep_vm();
+        Passes<TO, GEN, NI, IPP, P + 1, NPASS>::run(acc, ct, ldc, C, epi, cm0, cn0, M, N, tid, wn, r, q);
+    }
+};
+template <class TO, int GEN, int NI, int IPP, int NPASS>
+struct Passes<TO, GEN, NI, IPP, NPASS, NPASS> {
+    static __device__ __forceinline__ void run(const f32x4 (&)[NI][4], TO*, int, TO*, const GemmEpi&, int, int, int, int, int, int, int, int) {}
+};
 }  // namespace w2
 
-template <class TO>
+template <class TO, int BMT>
 __global__ __launch_bounds__(128, 2) void gemm_w2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
                                                          int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi,
                                                          int k_chunk, int tiles_m, int tiles_n, int nitems)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][w2::STAGE];
+    constexpr int NI = BMT / 16, STAGE = (BMT + BN) * w2::ROW2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, r = lane & 15, q = lane >> 4;
     const int G = gridDim.x, ntiles = tiles_m * tiles_n;
-    w2::Stage sa, sb;
+    w2::Stage<BMT> sa; w2::Stage<BN> sb;
     int it = blockIdx.x, m0, n0, k_begin, k_end, cur = 0;
-    item_coord(it, G, nitems, ntiles, tiles_n, k_chunk, K, m0, n0, k_begin, k_end);
+    item_coord(it, G, nitems, ntiles, tiles_n, k_chunk, K, m0, n0, k_begin, k_end); m0 = m0 / BM * BMT;
     sa.init(A, amap, m0, M, k_begin, tid); sb.init(B, bmap, n0, N, k_begin, tid);
-    sa.issue(lds[cur]); sb.issue(lds[cur] + BM * w2::ROW2);
+    sa.issue(lds[cur]); sb.issue(lds[cur] + BMT * w2::ROW2);
     for (;;) {
         const int nsteps = (k_end - k_begin) / w2::BK2;
-        f32x4 acc[8][4];
+        f32x4 acc[NI][4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
         for (int s = 0; s < nsteps; ++s) {
             __syncthreads();                                  // K tile s has landed in stage `cur`; stage cur^1 is free
-            if (s + 1 < nsteps) { sa.issue(lds[cur ^ 1]); sb.issue(lds[cur ^ 1] + BM * w2::ROW2); }
-            const unsigned char* As = lds[cur]; const unsigned char* Bs = lds[cur] + BM * w2::ROW2;
-            bf16x8 a[8], b[4];
+            if (s + 1 < nsteps) { sa.issue(lds[cur ^ 1]); sb.issue(lds[cur ^ 1] + BMT * w2::ROW2); }
+            const unsigned char* As = lds[cur]; const unsigned char* Bs = lds[cur] + BMT * w2::ROW2;
+            bf16x8 a[NI], b[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = w2::frag(As, i * 16 + r, q);
+            for (int i = 0; i < NI; ++i) a[i] = w2::frag(As, i * 16 + r, q);
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = w2::frag(Bs, wn * 64 + j * 16 + r, q);
 #if !defined(SS_EMU)
-            __builtin_amdgcn_sched_barrier(0);               // all 12 reads in flight before the first MFMA
+            __builtin_amdgcn_sched_barrier(0);               // all fragment reads in flight before the first MFMA
 #endif
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
             cur ^= 1;
@@ -719,29 +750,20 @@ __global__ __launch_bounds__(128, 2) void gemm_w2_kernel(const bf16_t* __restric
         const bool has_next = it + G < nitems;
         if (has_next) {
             it += G;
-            item_coord(it, G, nitems, ntiles, tiles_n, k_chunk, K, m0, n0, k_begin, k_end);
+            item_coord(it, G, nitems, ntiles, tiles_n, k_chunk, K, m0, n0, k_begin, k_end); m0 = m0 / BM * BMT;
             sa.init(A, amap, m0, M, k_begin, tid); sb.init(B, bmap, n0, N, k_begin, tid);
-            sa.issue(lds[cur]); sb.issue(lds[cur] + BM * w2::ROW2);
+            sa.issue(lds[cur]); sb.issue(lds[cur] + BMT * w2::ROW2);
         }
         barrier_keep_vm();                                    // both waves are done reading stage cur^1 -> it becomes the C piece
         // ---- epilogue through the free stage: R-row pieces [R][BN + pad], 16-byte row-contiguous stores
         TO* ct = (TO*)&lds[cur ^ 1][0];
         constexpr int LDC = BN + 16 / (int)sizeof(TO);
-        constexpr int R = sizeof(TO) == 2 ? 32 : 16, IPP = R / 16;        // rows and 16-row MFMA tiles per pass
-#define SS_W2_STAGE(GEN, I) \
-        { _Pragma("unroll") for (int j = 0; j < 4; ++j) epilogue_stage<TO, GEN>(acc[I][j], ct, LDC, ((I) % IPP) * 16 + q * 4, wn * 64 + j * 16 + r, epi, cm0 + (I) * 16 + q * 4, cn0 + wn * 64 + j * 16 + r, M, N); }
-#define SS_W2_PASS(GEN, P) \
-        { if (IPP == 2) { SS_W2_STAGE(GEN, ((P) * IPP) % 8) SS_W2_STAGE(GEN, ((P) * IPP + 1) % 8) } else { SS_W2_STAGE(GEN, (P) % 8) } \
-          barrier_keep_vm(); \
-          epilogue_flush<TO, 128>(ct, LDC, C, epi, cm0 + (P) * R, R, cn0, M, N, tid); \
-          barrier_keep_vm(); }
-#define SS_W2_ALL(GEN) \
-        { SS_W2_PASS(GEN, 0) SS_W2_PASS(GEN, 1) SS_W2_PASS(GEN, 2) SS_W2_PASS(GEN, 3) \
-          if (IPP == 1) { SS_W2_PASS(GEN, 4) SS_W2_PASS(GEN, 5) SS_W2_PASS(GEN, 6) SS_W2_PASS(GEN, 7) } }
-        if (epi.general == 1) SS_W2_ALL(1) else if (epi.general == 2) SS_W2_ALL(2) else SS_W2_ALL(0)
-#undef SS_W2_ALL
-#undef SS_W2_PASS
-#undef SS_W2_STAGE
+        constexpr int IPP = sizeof(TO) == 2 ? (BMT % 48 == 0 ? 3 : 2) : 1;            // 16-row MFMA tiles per pass: 48 / 32 rows (bf16), 16 (f32)
+        constexpr int NPASS = (NI + IPP - 1) / IPP;
+        static_assert((size_t)IPP * 16 * LDC * sizeof(TO) <= (size_t)STAGE, "C piece does not fit the free stage");
+        if (epi.general == 1) w2::Passes<TO, 1, NI, IPP, 0, NPASS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wn, r, q);
+        else if (epi.general == 2) w2::Passes<TO, 2, NI, IPP, 0, NPASS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wn, r, q);
+        else w2::Passes<TO, 0, NI, IPP, 0, NPASS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wn, r, q);
         if (!has_next) break;
     }
 }
@@ -789,16 +811,39 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     {   // 2-wave kernel: bf16 KC x KC with the plain LDS-staged epilogue (no transposed second output)
         static int w2_on = -1;
         if (w2_on < 0) { const char* e = getenv("SS_GEMM_W2"); w2_on = e ? atoi(e) : 1; }     // 0 never, 1 heuristic, 2 whenever possible
-        // Measured (22 k rows): +18 % on N=3072, K=768 (FFN1 forward, FFN2 input gradient), parity on 768 x 768, but -18 % on
-        // N=768 with K >= 2304: there 1032 tiles on 1024 slots leave an 8-tile tail that runs on 2 of a CU's 4 SIMDs.
-        const bool w2_shape = w2_on == 2 || (K <= 1024 && N >= 1536);
-        if (w2_on && w2_shape && sizeof(T) == 2 && a_mode == OP_KC && b_mode == OP_KC && epi.fast && !epi.c2 && K % 32 == 0 && k_chunk % 32 == 0) {
+        if (w2_on && sizeof(T) == 2 && a_mode == OP_KC && b_mode == OP_KC && epi.fast && !epi.c2 && split_k == 1 && K % 32 == 0) {
+            // One workgroup slot = a quarter of a CU (4 resident workgroups).  The tile height (128 or 144 rows) is the one that
+            // wastes the least of the last round: 22 000 rows x 768 columns are 1032 tiles of 128 rows (a round of 1024 plus an
+            // 8-tile tail on 2 of a CU's 4 SIMDs) but 918 tiles of 144 rows -- one round.
+            // Cost model in "rows a CU works through": a round of the 4-wave kernel is 2 tiles of 128 rows per CU, a round of this
+            // kernel 4 tiles of BMT rows; a remainder below 1/8 of the slots still costs ~0.55 of a round (its tiles run alone).
+            // Measured anchors (22 000 rows): N=3072, K=768: this kernel +16 %; N=768, K=3072 with 128-row tiles: -21 % (the model's
+            // 794 vs 653), i.e. the lower fixed cost per tile is worth ~20 % at K <= 1024 and nothing at long K.
             const int slots2 = slots / g_blocks_per_cu * 4;
-            dim3 grid2(nitems < slots2 ? nitems : slots2);
-            SS_LAUNCH(SS_KERNEL(gemm_w2_kernel<TO>), grid2, dim3(128), 0, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems);
-            SS_LAUNCH_CHECK("ss_gemm(w2)");
-            g_last_kernel = 2;
-            return 0;
+            static int bm_force = -1;
+            if (bm_force < 0) { const char* e = getenv("SS_GEMM_W2_BM"); bm_force = e ? atoi(e) : 0; }      // tests: force the tile height
+            double best = 0; int bmt = 0, tm_best = 0;
+            for (int cand = 128; cand <= 144; cand += 16) {
+                if (bm_force && cand != bm_force) continue;
+                const int tm = (M + cand - 1) / cand; const long long t = (long long)tm * tiles_n;
+                const long long full = t / slots2, rem = t % slots2;
+                const double rounds = (double)full + (rem == 0 ? 0.0 : (rem * 8 < slots2 ? 0.55 : 1.0));
+                const double cost = rounds * 4 * cand;
+                if (!bmt || cost < best) { best = cost; bmt = cand; tm_best = tm; }
+            }
+            const long long t4 = (long long)tiles_m * tiles_n;
+            const double rounds4 = (double)(t4 / slots) + (t4 % slots == 0 ? 0.0 : ((t4 % slots) * 8 < slots ? 0.55 : 1.0));
+            const double cost4 = rounds4 * 2 * 128;
+            const bool w2_shape = w2_on == 2 || best * (K <= 1024 ? 0.8 : 1.0) < 0.97 * cost4;
+            if (w2_shape) {
+                const int nitems2 = tm_best * tiles_n;
+                dim3 grid2(nitems2 < slots2 ? nitems2 : slots2);
+                if (bmt == 144) SS_LAUNCH(SS_KERNEL(gemm_w2_kernel<TO, 144>), grid2, dim3(128), 0, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, K, tm_best, tiles_n, nitems2);
+                else SS_LAUNCH(SS_KERNEL(gemm_w2_kernel<TO, 128>), grid2, dim3(128), 0, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, K, tm_best, tiles_n, nitems2);
+                SS_LAUNCH_CHECK("ss_gemm(w2)");
+                g_last_kernel = 2;
+                return 0;
+            }
         }
     }
     if (a_mode == OP_KC && b_mode == OP_KC && epi.fast && K % BK == 0 && k_chunk % BK == 0 && !(epi.debug & 8)) {
