@@ -201,7 +201,7 @@ def main():
             try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py)
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
                 ctype = {'torch.bfloat16': 'unsigned short', 'torch.float32': 'float'}
-                names = {1: ['gemm_glds_kernel<%s, %s>' % (ctype[key[0]], ctype[key[1]])], 2: ['gemm_w2_kernel<%s>' % ctype[key[1]]]}.get(key[4], [])
+                names = {1: ['gemm_glds_kernel<%s, %s>' % (ctype[key[0]], ctype[key[1]])], 2: ['gemm_w2_kernel<%s, 144>' % ctype[key[1]], 'gemm_w2_kernel<%s, 128>' % ctype[key[1]]]}.get(key[4], [])
                 names.append('gemm_kernel<%s, %s, %d, %d>' % (ctype[key[0]], ctype[key[1]], key[2], key[3]))
                 for nm in names:
                     hit = [v for k, v in pmc.items() if nm in k]
