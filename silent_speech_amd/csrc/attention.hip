@@ -576,6 +576,7 @@ __device__ __forceinline__ void store_tile_rows(RT* tile, const f32x4 (&acc)[2 *
 }
 // tile index of the i-th work item: centre of the sequence (full band, most key blocks) first
 __device__ __forceinline__ int res_tile_of(int i, int nb) { const int mid = nb >> 1; return (i & 1) ? mid - ((i + 1) >> 1) : mid + (i >> 1); }
+__device__ __forceinline__ int res_split_index(int i, int half) { return half < 0 ? i : 2 * i + half; }
 __device__ __forceinline__ int res_next(int* ctr, int lane) {
     int i = 0; if (lane == 0) i = atomicAdd(ctr, 1);
 #if defined(SS_EMU)
@@ -687,7 +688,10 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res_kernel(AttnP p)
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + 16;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int H = p.H, h = blockIdx.x % H, b = blockIdx.x / H;
+    // workgroups >= p.gx are HALVES of the (sequence, head) pairs that would otherwise form a short last round: each stages the
+    // operands itself and takes every second tile of the heaviest-first order (res_split_index)
+    const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
+    const int H = p.H, h = pair % H, b = pair / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1, ER = NE + 2 * RES_PL;
     unsigned char* Ks = (unsigned char*)smem;
     unsigned char* Vs = Ks + Tr * PK;                                   // a chunk starting at an odd block reads up to 16 rows past Tr: they
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res_kernel(AttnP p)
         if (tid == 0) *ctr = 0;
     }
     __syncthreads();
-    int it = res_next(ctr, lane);
+    int it = res_split_index(res_next(ctr, lane), half);
     bf16x8 qf[DPK], qn[DPK];
     if (it < nb) { int qr = res_tile_of(it, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1; glb_row_frags<DPK>(qf, Q + (long long)qr * ldq, true, g); }
     while (it < nb) {
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res_kernel(AttnP p)
         int jhi = (q0 + 15 + D - 1) >> 4; jhi = jhi > nb - 1 ? nb - 1 : jhi;
         const int nblk = jhi - jlo + 1;
         // next tile's Q rows are requested now: loads issued before this tile's stores never wait for them
-        const int itn = res_next(ctr, lane);
+        const int itn = res_split_index(res_next(ctr, lane), half);
         if (itn < nb) { int qr = res_tile_of(itn, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1; glb_row_frags<DPK>(qn, Q + (long long)qr * ldq, true, g); }
         f32x4 o[2 * DPK];
         if (nblk <= 4) fwd_res_tile<DPK, 4, DROP>(p, Ks, Es, Vs, Pt, qf, b, h, q0, jlo, nblk, lane, ER, o);
@@ -751,7 +755,10 @@ __global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q_res_kernel(AttnP p)
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + 16, PL = 48, PH = 48, PTL = 20;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int H = p.H, h = blockIdx.x % H, b = blockIdx.x / H;
+    // workgroups >= p.gx are HALVES of the (sequence, head) pairs that would otherwise form a short last round: each stages the
+    // operands itself and takes every second tile of the heaviest-first order (res_split_index)
+    const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
+    const int H = p.H, h = pair % H, b = pair / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1, ER = NE + PL + PH;
     unsigned char* Ks = (unsigned char*)smem;
     unsigned char* Vs = Ks + Tr * PK;
@@ -773,7 +780,7 @@ __global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q_res_kernel(AttnP p)
     int bandA[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) bandA[reg] = c - (g * 4 + reg) + (D - 1);
-    int it = res_next(ctr, lane);
+    int it = res_split_index(res_next(ctr, lane), half);
     bf16x8 qf[DPK], dof[DPK], qn[DPK], don[DPK];
     if (it < nb) { int qr = res_tile_of(it, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1;
                    glb_row_frags<DPK>(qf, Q + (long long)qr * ldq, true, g); glb_row_frags<DPK>(dof, dO + (long long)qr * (H * dp), true, g); }
@@ -789,7 +796,7 @@ __global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q_res_kernel(AttnP p)
             const long long si = ((long long)b * H + h) * Tn + (rowok[reg] ? q : 0);
             lse2[reg] = p.lse[si] * LOG2E; dv[reg] = p.Dv[si];
         }
-        const int itn = res_next(ctr, lane);
+        const int itn = res_split_index(res_next(ctr, lane), half);
         if (itn < nb) { int qr = res_tile_of(itn, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1;
                         glb_row_frags<DPK>(qn, Q + (long long)qr * ldq, true, g); glb_row_frags<DPK>(don, dO + (long long)qr * (H * dp), true, g); }
         float dsr[RES_NB][4];
@@ -879,7 +886,10 @@ __global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv_res_kernel(AttnP p
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + 16;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int H = p.H, h = blockIdx.x % H, b = blockIdx.x / H;
+    // workgroups >= p.gx are HALVES of the (sequence, head) pairs that would otherwise form a short last round: each stages the
+    // operands itself and takes every second tile of the heaviest-first order (res_split_index)
+    const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
+    const int H = p.H, h = pair % H, b = pair / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, NE = 2 * D - 1;
     const int TQ = ((nb + 1) >> 1) * 32;                               // whole 32-query steps
     unsigned char* Qs = (unsigned char*)smem;
@@ -906,7 +916,7 @@ __global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv_res_kernel(AttnP p
         if (tid == 0) *ctr = 0;
     }
     __syncthreads();
-    int it = res_next(ctr, lane);
+    int it = res_split_index(res_next(ctr, lane), half);
     bf16x8 kf[DPK], vf[DPK], kn[DPK], vn[DPK];
     if (it < nb) { int kr = res_tile_of(it, nb) * 16 + c; const bool ok = kr < Tn; kr = ok ? kr : Tn - 1;
                    glb_row_frags<DPK>(kf, K + (long long)kr * ldq, ok, g); glb_row_frags<DPK>(vf, V + (long long)kr * ldq, ok, g); }
@@ -914,7 +924,7 @@ __global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv_res_kernel(AttnP p
         const int k0 = res_tile_of(it, nb) * 16;
         int jlo = k0 - (D - 1); jlo = jlo < 0 ? 0 : jlo >> 4;
         int jhi = (k0 + 15 + D - 1) >> 4; jhi = jhi > nb - 1 ? nb - 1 : jhi;
-        const int itn = res_next(ctr, lane);
+        const int itn = res_split_index(res_next(ctr, lane), half);
         if (itn < nb) { int kr = res_tile_of(itn, nb) * 16 + c; const bool ok = kr < Tn; kr = ok ? kr : Tn - 1;
                         glb_row_frags<DPK>(kn, K + (long long)kr * ldq, ok, g); glb_row_frags<DPK>(vn, V + (long long)kr * ldq, ok, g); }
         f32x4 dk[2 * DPK], dvv[2 * DPK];
@@ -1020,7 +1030,20 @@ static bool res_enabled(int dtype, int T) {
     return !(e && e[0] == '0');
 }
 typedef void (*ResKernel)(AttnP);
-static int res_launch(ResKernel k, int slot, int blocks, int waves, size_t smem, void* stream, const AttnP& p) {
+static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, void* stream, AttnP p) {
+    // one workgroup per CU at a time: pairs beyond the last full round of #CU are split in two halves when that shortens it
+    static int cus = 0;
+    if (!cus) {
+#if defined(SS_EMU)
+        cus = 4;
+#else
+        int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+#endif
+    }
+    const int rem = pairs % cus;
+    const bool split = pairs > cus && rem > 0 && 2 * rem <= cus;
+    p.gx = split ? pairs - rem : pairs;
+    const int blocks = split ? pairs + rem : pairs;
 #if !defined(SS_EMU)
     static size_t granted[24] = {0};
     if (granted[slot] < smem) {
