@@ -142,3 +142,27 @@ def test_attention_backward_uses_the_forward_dropout_mask(dev, dt):
     assert_close_robust(dv, v.grad, 5e-5, name='dV', max_outlier_frac=0)
     assert_close_robust(dk, k.grad, 5e-5, name='dK', max_outlier_frac=0)
     assert_close_robust(dq, q.grad, 5e-5, name='dQ', max_outlier_frac=0)
+
+
+def test_transposed_copies_only_needed_by_the_per_tile_kernels(dev):
+    """ss_relpos_attention_needs_transposed: bf16 rows of <= 208 frames run the LDS-resident kernels (qkvT / dOT may be NULL);
+    f32 and long sequences run the per-tile kernels, which refuse to start without them."""
+    from silent_speech_amd import _lib
+    L = _lib.lib()
+    BF16, F32 = _lib.dtype_code(torch.bfloat16), _lib.dtype_code(torch.float32)
+    assert L.ss_relpos_attention_needs_transposed(BF16, 200, 96, 100) == 0
+    assert L.ss_relpos_attention_needs_transposed(BF16, 40, 32, 100) == 0
+    assert L.ss_relpos_attention_needs_transposed(BF16, 209, 96, 100) == 1
+    assert L.ss_relpos_attention_needs_transposed(F32, 40, 32, 100) == 1
+    assert L.ss_relpos_attention_needs_transposed(BF16, 200, 128, 100) == 1          # operands do not fit the LDS
+    B, H, T, dp, D = 1, 2, 24, 32, 9
+    for dt, ok in ((torch.bfloat16, True), (torch.float32, False)):
+        qkv = torch.randn(B * T, 3 * H * dp).to(dt).to(dev)
+        E = torch.randn(H, 2 * D - 1, dp).to(dt).to(dev)
+        out = torch.zeros(B * T, H * dp, dtype=dt, device=dev); lse = torch.zeros(B, H, T, device=dev)
+        if ok:
+            ops.relpos_attention_forward(qkv, None, E, out, lse, B, H, T, 24, dp, D, 0.25)
+            assert torch.isfinite(out.float()).all() and float(out.float().abs().max()) > 0
+        else:
+            with pytest.raises(RuntimeError, match='transposed copy'):
+                ops.relpos_attention_forward(qkv, None, E, out, lse, B, H, T, 24, dp, D, 0.25)
