@@ -107,32 +107,54 @@ extern "C" int ss_voiced_loss(const float* head, int64_t ld, int n_mel, int n_ph
 
 // ---------------------------------------------------------------- silent utterances: cost matrix straight into the DTW strip layout
 // DTW runs on costs.T: row i = target frame k, column j = predicted frame q (transduction_model.py:126).
-__global__ void silent_cost_skewed_kernel(const float* __restrict__ head, long long ld, int n_mel, const float* __restrict__ lse, const float* __restrict__ Y,
-                                          const long long* __restrict__ phones, const long long* __restrict__ desc, float lam, unsigned char* __restrict__ ws, int* __restrict__ results)
+// One thread owns one (lane, row) slot of a wave-strip -- i.e. ONE target frame i -- for a chunk of CT consecutive steps t:
+// the target row y_i stays in registers (n_mel <= 128), only the predicted rows stream in, and every step's 256 results
+// (64 lanes x 4 rows) leave as one contiguous 1 KiB store.  The 80-term sum runs in the reference order (bit-exact costs).
+constexpr int CT = 32, YMAX = 128;
+__global__ __launch_bounds__(256) void silent_cost_skewed_kernel(const float* __restrict__ head, long long ld, int n_mel, const float* __restrict__ lse, const float* __restrict__ Y,
+                                                                 const long long* __restrict__ phones, const long long* __restrict__ desc, float lam, unsigned char* __restrict__ ws, int* __restrict__ results)
 {
     const long long* d = desc + (long long)blockIdx.y * DESC;
     const int N = (int)d[D_N], M = (int)d[D_M];
     const long long p0 = d[D_PRED_ROW0], y0 = d[D_TGT_ROW0];
     int* res = results + d[D_RES_OFF];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) res[i] = 0;
-    const long long ts = dtw_tsteps_d(M), total = dtw_strips_d(N) * DW * ts * 64 * DR;
+    const long long ts = dtw_tsteps_d(M), nkw = dtw_strips_d(N) * DW;
+    if (ts <= 0) return;
+    const long long tchunks = (ts + CT - 1) / CT, nwork = nkw * tchunks;
     float* sk = (float*)(ws + d[D_SK_OFF]);
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int r = (int)(e % DR); long long x = e / DR; const int l = (int)(x % 64); x /= 64; const long long t = x % ts, kw = x / ts;
-        const long long i = 1 + (kw * 64 + l) * DR + r, j = t + 1 - l;
-        float c = INFINITY;
-        if (i < N && j >= 1 && j < M) {
-            const float* p = head + (p0 + j) * ld; const float* y = Y + (y0 + i) * n_mel;
-            float ss = 0.f;
-            for (int q = 0; q < n_mel; q += 4) {
-                const f32x4 a = *(const f32x4*)(p + q), b = *(const f32x4*)(y + q);
-                const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2], d3 = a[3] - b[3];
-                ss += d0 * d0; ss += d1 * d1; ss += d2 * d2; ss += d3 * d3;
-            }
-            const int ph = (int)phones[y0 + i];
-            c = sqrtf(ss) + lam * (lse[p0 + j] - p[n_mel + ph]);
+    const int l = threadIdx.x >> 2, r = threadIdx.x & 3;
+    for (long long wk = blockIdx.x; wk < nwork; wk += gridDim.x) {
+        const long long kw = wk / tchunks, t0 = (wk - kw * tchunks) * CT;
+        const long long i = 1 + (kw * 64 + l) * DR + r;
+        const bool iv = i < N;
+        f32x4 yv[YMAX / 4];
+        int ph = 0;
+        if (iv) {
+            const float* y = Y + (y0 + i) * n_mel;
+#pragma unroll
+            for (int q = 0; q < YMAX / 4; ++q) if (q * 4 < n_mel) yv[q] = *(const f32x4*)(y + q * 4);
+            ph = (int)phones[y0 + i];
         }
-        sk[e] = c;
+        const long long tend = t0 + CT < ts ? t0 + CT : ts;
+        for (long long t = t0; t < tend; ++t) {
+            const long long j = t + 1 - l;
+            float c = INFINITY;
+            if (iv && j >= 1 && j < M) {
+                const float* p = head + (p0 + j) * ld;
+                float ss = 0.f;
+#pragma unroll
+                for (int q = 0; q < YMAX / 4; ++q) {
+                    if (q * 4 < n_mel) {
+                        const f32x4 a = *(const f32x4*)(p + q * 4), b = yv[q];
+                        const float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2], d3 = a[3] - b[3];
+                        ss += d0 * d0; ss += d1 * d1; ss += d2 * d2; ss += d3 * d3;
+                    }
+                }
+                c = sqrtf(ss) + lam * (lse[p0 + j] - p[n_mel + ph]);
+            }
+            sk[((kw * ts + t) * 64 + l) * DR + r] = c;
+        }
     }
 }
 
@@ -143,9 +165,10 @@ extern "C" int ss_silent_cost_skewed(const float* head, int64_t ld, int n_mel, c
     if (n == 0) return 0;
     SS_CHECK(head && lse && Y && phones && desc_dev && workspace && results, "ss_silent_cost_skewed: null pointer");
     SS_CHECK(n_mel % 4 == 0 && ld % 4 == 0, "ss_silent_cost_skewed: n_mel and ld must be multiples of 4 (16-byte rows)");
+    SS_CHECK(n_mel <= YMAX, "ss_silent_cost_skewed: at most %d mel bins", YMAX);
     long long strips = max_n <= 1 ? 0 : (max_n - 1 + DW * 64 * DR - 1) / (DW * 64 * DR);
-    long long total = strips * DW * (max_m <= 1 ? 0 : max_m - 1 + 63) * 64 * DR;
-    long long blocks = (total + 255) / 256;
+    const long long ts_max = max_m <= 1 ? 0 : max_m - 1 + 63;
+    long long blocks = strips * DW * ((ts_max + CT - 1) / CT);            // one workgroup per (wave-strip, chunk of CT steps)
     if (blocks < (max_n + 255) / 256) blocks = (max_n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
