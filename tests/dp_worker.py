@@ -62,13 +62,18 @@ def build_model():
 def main():
     out = sys.argv[1]
     from silent_speech_amd import _lib
-    _lib.use_library_for_testing(os.path.join(ROOT, 'silent_speech_amd', 'lib', 'libsilent_speech_emu.so'))
+    on_gpu = os.environ.get('SS_DP_DEVICE') == 'cuda'          # gpu tier: both ranks share the one MI355X, gloo moves the CUDA tensors
+    if on_gpu:
+        _lib.load()
+    else:
+        _lib.use_library_for_testing(os.path.join(ROOT, 'silent_speech_amd', 'lib', 'libsilent_speech_emu.so'))
+    dev = torch.device('cuda', 0) if on_gpu else torch.device('cpu')
     from silent_speech_amd.distributed import DataParallel
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1:
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % os.environ['MASTER_PORT'], rank=rank, world_size=world)
-    model = build_model()
+    model = build_model().to(dev)
     dp = None
     if world > 1:
         dp = DataParallel()
@@ -76,9 +81,10 @@ def main():
         batch = make_batch(UTTS[rank::world])
     else:
         batch = make_batch(UTTS[0::2] + UTTS[1::2])
+    batch = {k: ([t.to(dev) for t in v] if isinstance(v, list) and len(v) and torch.is_tensor(v[0]) else v) for k, v in batch.items()}
     loss = run_step(model, batch, dp)
     _, gflat, n = model.flat_arenas()
-    res = {'loss': float(loss), 'grads': gflat.clone(), 'rm': model.conv_blocks[0].bn1.running_mean.clone(), 'rv': model.conv_blocks[2].bn2.running_var.clone()}
+    res = {'loss': float(loss), 'grads': gflat.clone().cpu(), 'rm': model.conv_blocks[0].bn1.running_mean.clone().cpu(), 'rv': model.conv_blocks[2].bn2.running_var.clone().cpu()}
     if rank == 0:
         torch.save(res, out)
     if world > 1:

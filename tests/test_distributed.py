@@ -6,6 +6,7 @@ import socket
 import subprocess
 import sys
 
+import pytest
 import torch
 
 from tests.backend import _ensure_emu
@@ -18,10 +19,9 @@ def _free_port():
     return p
 
 
-def test_two_rank_step_equals_single_process(tmp_path):
-    _ensure_emu()
+def _two_rank_vs_single(tmp_path, extra_env):
     worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
-    env = dict(os.environ, OMP_NUM_THREADS='1')
+    env = dict(os.environ, OMP_NUM_THREADS='1', **extra_env)
     single = str(tmp_path / 'single.pt')
     p0 = subprocess.Popen([sys.executable, worker, single], env=dict(env, WORLD_SIZE='1', RANK='0'))
     port = str(_free_port())
@@ -39,3 +39,15 @@ def test_two_rank_step_equals_single_process(tmp_path):
     assert err < 2e-4, err
     assert torch.allclose(a['rm'], b['rm'], rtol=1e-4, atol=1e-6)
     assert torch.allclose(a['rv'], b['rv'], rtol=1e-4, atol=1e-6)
+
+
+def test_two_rank_step_equals_single_process(tmp_path):
+    _ensure_emu()
+    _two_rank_vs_single(tmp_path, {})
+
+
+@pytest.mark.gpu
+def test_two_rank_step_equals_single_process_on_the_gpu(tmp_path):
+    """The same contract through the HIP kernels: two gloo ranks share the one MI355X of the test box (RCCL itself needs one
+    GPU per rank and cannot be exercised here; the collectives are torch.distributed calls either way)."""
+    _two_rank_vs_single(tmp_path, {'SS_DP_DEVICE': 'cuda'})
