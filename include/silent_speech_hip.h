@@ -1,5 +1,6 @@
 /* silent_speech_hip.h -- C ABI of libsilent_speech_hip.so: the MI355X (gfx950) implementation of the
- * EMG->mel transduction TRAINING hot path of dgaddy/silent_speech.
+ * EMG->mel transduction TRAINING hot path of dgaddy/silent_speech (plus, per SURVEY section 8f, the CTC loss of the
+ * recognition trainer and the input-conditioning kernel of the device-side pipeline).
  *
  * The reference is pure Python/PyTorch and has no FFI seam; its seam for this path is the set of
  * torch operator calls made by architecture.py / transformer.py / transduction_model.py / align.py /
@@ -11,7 +12,7 @@
  *     gradients of parameters and optimizer state are always f32;
  *   - return 0 on success; non-zero on error, with a message available from ss_last_error();
  *   - inputs are never modified unless documented (the reference's in-place EMG shift,
- *     architecture.py:67-68, is such a case and is mirrored by ss_emg_conv0_forward's `shift`).
+ *     architecture.py:67-68, is such a case and is mirrored by ss_emg_prepare's `shift`).
  * The Python binding a maintainer of the reference would add is a ctypes stub.
  */
 #ifndef SILENT_SPEECH_HIP_H
