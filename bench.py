@@ -157,9 +157,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if prof is not None:
-            # every 4th timed step carries the per-launch HIP events (roofline numerator); on those steps the weight-gradient
+            # every 5th timed step carries the per-launch HIP events (roofline numerator); on those steps the weight-gradient
             # GEMMs stay on the main stream: a duration taken while a second stream shares the CUs is not a per-kernel quantity
-            prof.enabled = i % 4 == 0
+            prof.enabled = i % 5 == 0
             engine.SIDE_STREAM_ENABLED = not prof.enabled
         loss = step()
     engine.SIDE_STREAM_ENABLED = True
@@ -192,7 +192,7 @@ def main():
         }
         if prof is not None:
             summ = prof.summary()
-            psteps = len(range(0, args.steps, 4))                       # steps that carried the per-launch events
+            psteps = len(range(0, args.steps, 5))                       # steps that carried the per-launch events
             key = max(summ, key=lambda k: summ[k]['seconds'])
             d = summ[key]
             peak = PEAK_BF16_TFLOPS if 'bfloat16' in key[0] else PEAK_F32_TFLOPS
@@ -213,7 +213,7 @@ def main():
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
                                'traffic_source': traffic_src,
                                'kernel': '%s<%s,%s,a_mode=%d,b_mode=%d>' % ((('gemm_kernel', 'gemm_glds_kernel', 'gemm_w2_kernel')[key[4]],) + tuple(key[:4])), 'launches_per_step': d['launches'] / psteps, 'event_timed_steps': psteps,
-                               'timing': 'HIP events around every ss_gemm launch on every 4th timed step; those steps keep the dW GEMMs on the main stream (exclusive durations); rocprofv3 counterpart: profiles/*_serial_kernel_stats.txt (SS_AMD_SIDE_STREAM=0)',
+                               'timing': 'HIP events around every ss_gemm launch on every 5th timed step; those steps keep the dW GEMMs on the main stream (exclusive durations); rocprofv3 counterpart: profiles/*_serial_kernel_stats.txt (SS_AMD_SIDE_STREAM=0)',
                                'avg_launch_us': d['seconds'] / d['launches'] * 1e6, 'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                                'all_gemm_variants': {str(k): {'tflops': v['flops'] / v['seconds'] / 1e12, 'ms_per_step': v['seconds'] / psteps * 1e3,
                                                               'launches_per_step': v['launches'] / psteps} for k, v in summ.items()}}
