@@ -108,3 +108,32 @@ def test_pack_roundtrip_golden():
     assert np.array_equal(packed.numpy(), z['packed'])
     for a, b in zip(ts, data_utils.decollate_tensor(packed, [t.shape[0] for t in ts])):
         assert torch.equal(a, b)
+
+
+def test_dtw_loss_all_silent_and_degenerate_utterances(dev):
+    """Edge cases of the packed layout: every utterance silent, a 1-frame utterance (1 x M and N x 1 cost matrices: no
+    interior DTW cell, align.py:24 leaves results at 0), ragged rows with padding frames, targets shorter and longer than
+    the prediction."""
+    g = torch.Generator().manual_seed(21)
+    lengths = [1, 23, 9, 30]
+    t2 = [4, 1, 14, 26]
+    row = 16
+    B = (sum(lengths) + row - 1) // row
+    pred = torch.randn(B, row, 80, generator=g)
+    aux = torch.randn(B, row, 48, generator=g)
+    audio = [torch.randn(n, 80, generator=g) * 0.7 for n in t2]
+    phones = [torch.randint(0, 48, (n,), generator=g) for n in t2]
+    ex = dict(lengths=lengths, silent=[True] * 4, audio_features=audio, phonemes=phones)
+    pr, ar = pred.clone().requires_grad_(True), aux.clone().requires_grad_(True)
+    want, want_acc = loss_ref.dtw_loss_ref(pr, ar, ex, lam=0.5)
+    want.backward()
+    pd, ad = pred.to(dev).requires_grad_(True), aux.to(dev).requires_grad_(True)
+    exd = dict(ex, audio_features=[a.to(dev) for a in audio], phonemes=[p.to(dev) for p in phones])
+    got, acc = tm.dtw_loss(pd, ad, exd, True, None, phoneme_loss_weight=0.5)
+    assert abs(float(got.detach()) - float(want.detach())) < 2e-5 * abs(float(want.detach()))
+    assert abs(acc - want_acc) < 1e-9
+    got.backward()
+    assert_close_robust(pd.grad, pr.grad, 1e-4, name='dpred', max_outlier_frac=0)
+    assert_close_robust(ad.grad, ar.grad, 1e-4, name='daux', max_outlier_frac=0)
+    used = sum(lengths)
+    assert not pd.grad.reshape(-1, 80)[used:].any() and not ad.grad.reshape(-1, 48)[used:].any()
