@@ -91,36 +91,41 @@ __device__ __forceinline__ float wave_pick(float v, int src_lane) {   // src_lan
 #endif
 }
 
-__device__ __forceinline__ void dtw_step(int t, int lane, int w, int M, const f32x4& cv, float top, float (&prev)[DR], float& diag_sv, float& last_out,
-                                         unsigned char* __restrict__ dp, float (*lds_bnd)[DRING], float* bnd_cur)
+// One wavefront step.  No column predicate: cells outside the matrix carry cost +inf in the skewed layout, so a lane that
+// has not reached column 1 yet (or is past M-1) only turns +inf into +inf and its state stays what the recurrence needs
+// (dtw[i][0] = dtw[0][j] = +inf); the direction bytes it writes there are never read.  Branch-free: the per-step chain is
+// the 4 dependent (min3, add) pairs plus one DPP shift.
+__device__ __forceinline__ void dtw_step(int t, int lane, int w, bool multi_strip, int M, const f32x4& cv, float top, float (&prev)[DR], float& diag_sv, float& last_out,
+                                         unsigned char*& dp, float* ring_next, float* dump, float* bnd_cur)
 {
     const int s = t + 1 - lane;
-    const bool act = s >= 1 && s < M;
     const float up_in = wave_shift_in(last_out, top, lane);          // lane 0 takes the row above the strip / the previous wave's last row
-    if (act) {
-        float a = up_in, dg = diag_sv;
-        unsigned bits = 0;
+    float a = up_in, dg = diag_sv;
+    unsigned bits = 0;
 #pragma unroll
-        for (int r = 0; r < DR; ++r) {
-            const float b = prev[r];
-            float best; unsigned dir;
-            if (a <= b && a <= dg) { best = a; dir = 0; }        // up    (i-1, j)   first
-            else if (b <= dg)      { best = b; dir = 1; }        // left  (i, j-1)
-            else                   { best = dg; dir = 2; }       // diag  (i-1, j-1)
-            const float nv = cv[r] + best;
-            bits |= dir << (2 * r);
-            dg = b; a = nv; prev[r] = nv;
-        }
-        last_out = a;
-        diag_sv = up_in;
-        dp[(long long)t * 256] = (unsigned char)bits;
-        if (lane == 63) { if (w < DW - 1) lds_bnd[w + 1][s & (DRING - 1)] = a; else bnd_cur[s] = a; }
+    for (int r = 0; r < DR; ++r) {
+        const float b = prev[r];
+        // first minimum of (up, left, diag) [Python min() tie order]: the VALUE is min3 -- one instruction on the serial chain
+        // (min3 -> add -> next row's min3); which candidate it was is recovered off the chain: best == up wins ties, then left
+        const float best = fminf(fminf(a, b), dg);
+        const unsigned dir = best == a ? 0u : (best == b ? 1u : 2u);
+        const float nv = cv[r] + best;
+        bits |= dir << (2 * r);
+        dg = b; a = nv; prev[r] = nv;
     }
+    last_out = a;
+    diag_sv = up_in;
+    *dp = (unsigned char)bits;
+    dp += 256;
+    // hand the strip's last row to the next wave through the LDS ring: only lane 63 owns a ring slot, the others hit a dump word
+    float* slot = lane == 63 ? ring_next + (s & (DRING - 1)) : dump;
+    *slot = a;
+    if (multi_strip && w == DW - 1 && lane == 63 && s >= 1 && s < M) bnd_cur[s] = a;
 }
 
 __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ desc, unsigned char* __restrict__ ws, int* __restrict__ results)
 {
-    __shared__ float lds_bnd[DW][DRING];
+    __shared__ float lds_bnd[DW + 1][DRING];              // [w] = ring read by wave w (written by wave w-1); [DW] = dump / last wave's unused ring
     __shared__ __attribute__((aligned(16))) unsigned char chunk[DCH * 64];
     const long long* d = desc + (long long)blockIdx.x * DESC;
     const int N = (int)d[D_N], M = (int)d[D_M];
@@ -129,7 +134,11 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
     unsigned char* dirs = ws + d[D_DIRS_OFF];
     float* bnd = (float*)(ws + d[D_BND_OFF]);
     int* res = results + d[D_RES_OFF];
+#if defined(SS_EMU)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#else
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: step bounds become s_cbranch, not exec masks
+#endif
     const int ts = (int)dtw_tsteps(M), nstrips = (int)dtw_strips(N);
     const int nss = (ts + DG - 1) / DG;
 
@@ -141,18 +150,24 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         float diag_sv = rowbase == 0 ? 0.f : INFINITY;               // dtw[i-1][0]; dtw[0][0] = 0
         float last_out = INFINITY;
         const float* skp = sk + ((long long)(k * DW + w) * ts) * (64 * DR) + lane * DR;
-        unsigned char* dp = dirs + ((long long)k * ts) * 256 + w * 64 + lane;
+        unsigned char* dp0 = dirs + ((long long)k * ts) * 256 + w * 64 + lane;
         const float* bnd_prev = bnd + ((k + 1) & 1) * M;
         float* bnd_cur = bnd + (k & 1) * M;
         for (int ss = 0; ss < nss + 2 * (DW - 1); ++ss) {
             const int u = ss - 2 * w;
             if (u >= 0 && u < nss) {
                 const int t0 = u * DG;
+                unsigned char* dp = dp0 + (long long)t0 * 256;
                 // the 64 values lane 0 will need from above during this super-step (one per step), fetched up front
                 float topv;
                 { const int sb = t0 + 1 + lane;
                   if (w == 0) topv = (k == 0 || sb >= M) ? INFINITY : bnd_prev[sb];
                   else topv = lds_bnd[w][sb & (DRING - 1)]; }
+#if !defined(SS_EMU)
+                // settle the LDS read NOW: left pending, the compiler re-waits lgkmcnt(0) at the v_readlane of EVERY step, which also
+                // drains that step's ring write (an LDS round trip on the serial chain of each of the 64 steps)
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+#endif
                 f32x4 cb[8];
                 const f32x4 inf4 = {INFINITY, INFINITY, INFINITY, INFINITY};
 #pragma unroll
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int t = t0 + g * 8 + e;
-                        if (t < ts) dtw_step(t, lane, w, M, cb[e], wave_pick(topv, g * 8 + e), prev, diag_sv, last_out, dp, lds_bnd, bnd_cur);
+                        if (t < ts) dtw_step(t, lane, w, nstrips > 1, M, cb[e], wave_pick(topv, g * 8 + e), prev, diag_sv, last_out, dp, lds_bnd[w + 1], &lds_bnd[DW][lane], bnd_cur);
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) cb[e] = nb[e];
