@@ -92,12 +92,18 @@ def main():
         raise SystemExit('for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
+    if os.environ.get('SS_BENCH_BACKEND', 'nccl') != 'nccl':
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('SS_BENCH_BACKEND', 'nccl')          # 'gloo' lets two ranks share one GPU (functional check of the N>1 path)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from silent_speech_amd import engine, ops
     from silent_speech_amd.architecture import Model
