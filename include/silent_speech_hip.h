@@ -81,8 +81,35 @@ int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, 
  * run on a side stream use 1 so that the dependent chain on the main stream can co-reside on every CU.  Returns the old value. */
 int ss_gemm_set_blocks_per_cu(int n); /* [host] */
 /* Which kernel the calling thread's last ss_gemm launch used: 0 register-staged gemm_kernel, 1 gemm_glds_kernel,
- * 2 gemm_w2_kernel (so that a profiler can attribute per-launch timings to the kernel names rocprofv3 reports). */
+ * 2 gemm_w2_kernel, 3 / 4 gemm8_kc_kernel with 256 / 288-row tiles (so that a profiler can attribute per-launch timings to
+ * the kernel names rocprofv3 reports, and tests can assert which variant they exercised). */
 int ss_gemm_last_kernel(void); /* [host] */
+/* Kernel-selection knobs of ss_gemm (process-wide): what = 0 two-wave kernel (0 never / 1 cost model / 2 whenever legal),
+ * 1 its tile height (128 / 144, 0 = cost model), 2 eight-wave kernel (0 / 1 / 2 as above), 3 its tile height in 16-row units
+ * per M-wave (8 / 9, 0 = cost model), 4 its LDS reads / DMA pieces spread between MFMA groups (0 / 1, 2 = per tile height), 5 ablation mask for kernel tuning (results are
+ * wrong when non-zero).  value < 0 restores the default (environment SS_GEMM_W2, SS_GEMM_W2_BM, SS_GEMM8, SS_GEMM8_NI, SS_GEMM8_PIN,
+ * SS_GEMM_DEBUG).  Returns the previous value, -1 for a bad `what`. */
+int ss_gemm_set_option(int what, int value); /* [host] */
+
+/* Grouped weight-gradient GEMMs: for every job  C[m][n] += sum_k A(k, m) * B(k, n)  (bf16 operands, f32 C, reduction over the
+ * K = B*T frame rows; both operands outer-contiguous: element (k, m) of A at A[amap(k) + m]).  Replaces the autograd backward
+ * of nn.Linear / nn.Conv1d / the per-head einsum projections w.r.t. their weights (transduction_model.py:209 through
+ * architecture.py:18-24,51 and transformer.py:32,34,96-98,111): dW = dY^T X.  ONE persistent launch covers up to 8 jobs (e.g.
+ * the four weight gradients of an encoder layer), so the K split that fills the 256 CUs -- and with it the number of f32
+ * atomic accumulations -- is chosen for the group, not per GEMM.  M, N multiples of 8; amap / bmap must cut the rows into
+ * batches of equal length (rows_per_batch). */
+typedef struct ss_dw_job {
+    const void* A;          /* dY: K rows of M contiguous bf16 */
+    const void* B;          /* X : K rows of N contiguous bf16 */
+    float* C;               /* M x N f32, row stride ldc; accumulated into */
+    ss_rowmap amap, bmap;
+    int64_t ldc;
+    int32_t M, N, K;
+    int32_t reserved;
+} ss_dw_job;
+int ss_gemm_dw_grouped(int n_jobs, const ss_dw_job* jobs /* [host] */, void* stream);
+/* Tuning knobs of ss_gemm_dw_grouped for the calling thread: what = 0 K split override (0 = automatic), 1 scheduling fences. */
+int ss_gemm_dw_set_option(int what, int value); /* [host] */
 
 /* out[a][b][c] (contiguous, dims d0 x d1 x d2) (+)= scale * in[a*s0 + b*s1 + c*s2] for b < valid1 and
  * c < valid2, else 0 (zero padding).  Converts between the reference's parameter layouts (state_dict:

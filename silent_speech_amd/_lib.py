@@ -30,6 +30,11 @@ class GemmEpilogue(ctypes.Structure):
                 ('log_clamp', ctypes.c_float), ('c2', ctypes.c_void_p), ('cmap2', RowMap), ('col_stride2', ctypes.c_int64)]
 
 
+class DwJob(ctypes.Structure):
+    _fields_ = [('A', ctypes.c_void_p), ('B', ctypes.c_void_p), ('C', ctypes.c_void_p), ('amap', RowMap), ('bmap', RowMap),
+                ('ldc', ctypes.c_int64), ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
 class PermuteJob(ctypes.Structure):
     _fields_ = [('inp', ctypes.c_void_p), ('out', ctypes.c_void_p), ('s0', ctypes.c_int64), ('s1', ctypes.c_int64), ('s2', ctypes.c_int64),
                 ('o0', ctypes.c_int64), ('o1', ctypes.c_int64), ('d0', ctypes.c_int32), ('d1', ctypes.c_int32), ('d2', ctypes.c_int32),
@@ -45,6 +50,7 @@ _U64, _U32 = ctypes.c_uint64, ctypes.c_uint32
 SIGNATURES = {
     'ss_gemm': [_I, _I, _I, _I, _P, _P, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap),
                 ctypes.POINTER(RowMap), ctypes.POINTER(GemmEpilogue), _I, _P],
+    'ss_gemm_dw_grouped': [_I, ctypes.POINTER(DwJob), _P],
     'ss_permute3d': [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _I, _P],
     'ss_permute3d_batch': [_P, _P, _I, _I, _P],
     'ss_dtw_align': [_P, _P, _I, _I, _I, _P, _P, _P],
@@ -77,6 +83,8 @@ _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int6
                'ss_colsum_scratch_floats': ([_I, _I], ctypes.c_int64),
                'ss_gemm_set_blocks_per_cu': ([_I], ctypes.c_int),
                'ss_gemm_last_kernel': ([], ctypes.c_int),
+               'ss_gemm_set_option': ([_I, _I], ctypes.c_int),
+               'ss_gemm_dw_set_option': ([_I, _I], ctypes.c_int),
                'ss_relpos_attention_needs_transposed': ([_I, _I, _I, _I], ctypes.c_int)}
 _RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}
 

@@ -23,46 +23,7 @@
 #include <stdlib.h>
 #include <math.h>
 
-enum { OP_KC = 0, OP_OC = 1 };
-#ifndef SS_GEMM_PRIO
-#define SS_GEMM_PRIO 0
-#endif
-constexpr int BM = 128, BN = 128, ROWB = 128;   // ROWB: bytes of K per tile row
-
-struct GemmEpi {
-    const float* bias;       // [N] or null
-    const void* gate;        // TO-typed, addressed like C; out = gate>0 ? out*gate_scale : 0
-    float gate_scale;
-    float alpha;
-    int relu;
-    unsigned drop_thresh;    // 0 = none
-    float drop_scale;
-    unsigned long long seed;
-    unsigned stream;
-    int mode;                // 0 store, 1 accumulate (C += v), 2 atomicAdd (f32 out only)
-    RowMap cmap;
-    int col_mod, col_mul, col_div_mul;   // output column permutation: c -> (c % col_mod)*col_mul + (c / col_mod)*col_div_mul
-    float log_clamp;         // > 0: v = log(max(v, log_clamp))   (data_utils.py:29-30)
-    void* c2;                // optional second copy of the result at rowmap2(row) + col*col_stride2 (transposed layouts)
-    RowMap cmap2;
-    long long col_stride2;
-    int fast;                // 1: LDS-staged, 16-byte coalesced output path (host decides)
-    int c2_pack;             // 1: the 4 rows a lane holds are consecutive, aligned elements of c2 -> one packed store
-    int general;             // 1: dropout or log-clamp in the epilogue
-    int c2_lds;              // 1: the transposed copy can leave through LDS as 16-byte stores (bf16, 8-row aligned sequences)
-    int debug;               // tuning experiments only (SS_GEMM_DEBUG): 1 skip flush stores, 2 skip stage, 4 skip MFMA
-};
-
-template <class T> struct Elem;
-template <> struct Elem<float> { static constexpr int EPC = 4; static constexpr int BK = 32; };
-template <> struct Elem<bf16_t> { static constexpr int EPC = 8; static constexpr int BK = 64; };
-
-// 16-byte chunk c of tile row r lives at chunk position c ^ s(r), s(r) = (r & 7) ^ (2 * ((r >> 3) & 3)):
-//  * MFMA fragment reads (16 consecutive rows, two adjacent chunks per 16-lane service group) stay conflict-free
-//    (bit 0 of s equals bit 0 of r, so a q=0 lane and a q=1 lane can never meet on one slot);
-//  * the transposing (OC) stores write rows 8k+o / 4k+o at fixed o: the (r >> 3) term spreads them over 4 / 8 chunk
-//    positions instead of one (was a 16-way bank conflict).
-__device__ __forceinline__ unsigned swz(int row, int chunk) { return (unsigned)row * ROWB + (unsigned)((chunk ^ (row & 7) ^ (((row >> 3) & 3) << 1)) << 4); }
+#include "gemm_common.h"
 
 // ---------------------------------------------------------------- staging: KC (copy) mode
 template <class T>
@@ -286,111 +247,6 @@ struct TileMma<float> {
     }
 };
 
-__device__ __forceinline__ void out_add(float* p, float v, int mode) {
-    if (mode == 2) atomicAdd(p, v); else if (mode == 1) *p += v; else *p = v;
-}
-__device__ __forceinline__ void out_add(bf16_t* p, float v, int mode) {
-    if (mode == 1) *p = f2bf(bf2f(*p) + v); else *p = f2bf(v);
-}
-
-// one 16x16 accumulator tile: this lane holds rows row0..row0+3 of column col
-template <class TO>
-__device__ __forceinline__ void epilogue_tile(const f32x4& a, TO* __restrict__ C, const GemmEpi& epi, int row0, int col, int M, int N)
-{
-    if (col >= N) return;
-    const float bias = epi.bias ? epi.bias[col] : 0.f;
-    const int pcol = epi.col_mod ? (col % epi.col_mod) * epi.col_mul + (col / epi.col_mod) * epi.col_div_mul : col;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int row = row0 + reg;
-        if (row < M) {
-            const long long off = rowmap_off(epi.cmap, row) + pcol;
-            float v = a[reg] * epi.alpha + bias;
-            if (epi.relu) v = fmaxf(v, 0.f);
-            if (epi.drop_thresh) {   // element (row, col) <-> Philox block (row>>2)*N + col, word row & 3  (row0 is a multiple of 4)
-                bool kp[4]; dropout_keep4(epi.seed, epi.stream, (unsigned long long)(row >> 2) * (unsigned)N + col, epi.drop_thresh, kp);
-                v = kp[reg] ? v * epi.drop_scale : 0.f;
-            }
-            if (epi.gate) v = ldf((const TO*)epi.gate + off) > 0.f ? v * epi.gate_scale : 0.f;
-            if (epi.log_clamp > 0.f) v = logf(fmaxf(v, epi.log_clamp));
-            out_add(C + off, v, epi.mode);
-            if (epi.c2) stf((TO*)epi.c2 + rowmap_off(epi.cmap2, row) + (long long)col * epi.col_stride2, v);
-        }
-    }
-}
-
-// ---- fast epilogue, phase 1: elementwise part in registers, result into the LDS C tile (and the packed c2 copy)
-// GENERAL = false: alpha/bias/ReLU only (the common case; the compiler would otherwise if-convert the uniform
-// dropout / log-clamp branches into per-element selects and evaluate Philox and v_log for every element).
-template <class TO, int GENERAL, bool C2L = false>     // GENERAL: 0 alpha/bias/ReLU, 1 + dropout, 2 + log-clamp
-__device__ __forceinline__ void epilogue_stage(const f32x4& a, TO* __restrict__ ct, int ldc, int lrow0, int lcol, const GemmEpi& epi, int row0, int col, int M, int N,
-                                               TO* __restrict__ tt = nullptr, int ldt = 0)
-{
-    float v[4];
-    const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
-    const float lo = epi.relu ? 0.f : -INFINITY;
-    bool kp[4] = {true, true, true, true};
-    if (GENERAL == 1) dropout_keep4(epi.seed, epi.stream, (unsigned long long)(row0 >> 2) * (unsigned)N + col, epi.drop_thresh, kp);
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        float x = fmaxf(a[reg] * epi.alpha + bias, lo);
-        if (GENERAL == 1) x = kp[reg] ? x * epi.drop_scale : 0.f;
-        if (GENERAL == 2) x = logf(fmaxf(x, epi.log_clamp));
-        v[reg] = x;
-        stf(ct + (lrow0 + reg) * ldc + lcol, x);
-    }
-    if (C2L) {     // transposed copy goes through LDS too: [col][row], 4 consecutive rows = one 8-byte store (bf16)
-        u32x2 w; w[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); w[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-        *(u32x2*)(tt + lcol * ldt + lrow0) = w;
-    } else if (epi.c2 && col < N) {
-        TO* c2 = (TO*)epi.c2 + (long long)col * epi.col_stride2;
-        if (epi.c2_pack && row0 + 3 < M) {
-            TO* p = c2 + rowmap_off(epi.cmap2, row0);
-            if (sizeof(TO) == 2) { u32x2 w; w[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); w[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16); *(u32x2*)p = w; }
-            else { f32x4 w = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = w; }
-        } else {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) if (row0 + reg < M) stf(c2 + rowmap_off(epi.cmap2, row0 + reg), v[reg]);
-        }
-    }
-}
-
-// ---- fast epilogue, phase 2: 16-byte row-contiguous stores from the LDS C tile
-template <class TO> struct OutVec;
-template <> struct OutVec<bf16_t> { static constexpr int N = 8; };
-template <> struct OutVec<float> { static constexpr int N = 4; };
-__device__ __forceinline__ void outvec_load(const bf16_t* p, float (&v)[8]) { Vec8<bf16_t>::load(p, v); }
-__device__ __forceinline__ void outvec_store(bf16_t* p, const float (&v)[8]) { Vec8<bf16_t>::store(p, v); }
-__device__ __forceinline__ void outvec_load(const float* p, float (&v)[4]) { f32x4 a = *(const f32x4*)p; v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
-__device__ __forceinline__ void outvec_store(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = a; }
-
-template <class TO, int NTHR = 256>
-__device__ __forceinline__ void epilogue_flush(const TO* __restrict__ ct, int ldc, TO* __restrict__ C, const GemmEpi& epi, int row_base, int nrows, int n0, int M, int N, int tid)
-{
-    constexpr int EV = OutVec<TO>::N;
-    constexpr int CPR = BN / EV;                       // 16-byte chunks per tile row
-    const int total = nrows * CPR;
-    for (int idx = tid; idx < total; idx += NTHR) {
-        const int r = idx / CPR, ch = idx - r * CPR;
-        const int row = row_base + r, col = n0 + ch * EV;
-        if (row < M && col < N) {
-            float v[EV];
-            outvec_load(ct + r * ldc + ch * EV, v);
-            const long long off = rowmap_off(epi.cmap, row) + col;
-            if (epi.gate) {
-                float g[EV]; outvec_load((const TO*)epi.gate + off, g);
-#pragma unroll
-                for (int e = 0; e < EV; ++e) v[e] = g[e] > 0.f ? v[e] * epi.gate_scale : 0.f;
-            }
-            if (epi.mode == 1) {
-                float o[EV]; outvec_load(C + off, o);
-#pragma unroll
-                for (int e = 0; e < EV; ++e) v[e] += o[e];
-            }
-            outvec_store(C + off, v);
-        }
-    }
-}
 
 template <bool TR, class S> struct TrSel { typedef S type; };
 template <class S> struct TrSel<true, S> { typedef StageTR type; };
@@ -780,6 +636,29 @@ static thread_local int g_last_kernel = 0;
 extern "C" int ss_gemm_last_kernel(void) { return g_last_kernel; }
 extern "C" int ss_gemm_set_blocks_per_cu(int n) { int old = g_blocks_per_cu; if (n >= 1 && n <= 2) g_blocks_per_cu = n; return old; }
 
+// Kernel-selection knobs (process-wide; tests and the tuning tools flip them, the defaults come from the environment once):
+//   0 SS_GEMM_W2     2-wave 128/144 x 128 kernel: 0 never, 1 cost model, 2 whenever legal
+//   1 SS_GEMM_W2_BM  force its tile height (128 / 144), 0 = cost model
+//   2 SS_GEMM8       8-wave 256/288 x 256 kernel: 0 never, 1 cost model, 2 whenever legal
+//   3 SS_GEMM8_NI    force its tile height in 16-row units per M-wave (8 / 9), 0 = cost model
+//   4 SS_GEMM8_PIN   its fragment reads / DMA pieces spread between the MFMA groups (1), in a burst per phase (0), 2 = per tile height
+//   5 SS_GEMM_DEBUG  ablation mask for tuning (results are then wrong): 1 no flush stores, 2 no epilogue staging, 4 no MFMA (128-wide
+//                    kernels); 16 no MFMA, 32 no in-loop global->LDS copies, 64 no in-loop fragment reads, 128 no C flush (8-wave kernel)
+enum { OPT_W2 = 0, OPT_W2_BM, OPT_G8, OPT_G8_NI, OPT_G8_PIN, OPT_DEBUG, OPT_COUNT };
+static int g_opt[OPT_COUNT] = {-1, -1, -1, -1, -1, -1};
+static int gemm_opt(int what) {
+    static const char* names[OPT_COUNT] = {"SS_GEMM_W2", "SS_GEMM_W2_BM", "SS_GEMM8", "SS_GEMM8_NI", "SS_GEMM8_PIN", "SS_GEMM_DEBUG"};
+    static const int defaults[OPT_COUNT] = {1, 0, 1, 0, 2, 0};
+    if (g_opt[what] < 0) { const char* e = getenv(names[what]); g_opt[what] = e ? atoi(e) : defaults[what]; }
+    return g_opt[what];
+}
+extern "C" int ss_gemm_set_option(int what, int value) {
+    if (what < 0 || what >= OPT_COUNT) return -1;
+    const int old = gemm_opt(what);
+    g_opt[what] = value < 0 ? -1 : value;          // negative: back to the environment / default
+    return old;
+}
+
 static int gemm_slots() {
 #if defined(SS_EMU)
     return 3;            // tiny on purpose: the emulator tests exercise the multi-item path of the persistent loop
@@ -808,9 +687,46 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     const int nitems = tiles_m * tiles_n * split_k;
     const int slots = gemm_slots();
     dim3 grid(nitems < slots ? nitems : slots), block(256);
+    // 8-wave 256 / 288 x 256 kernel (gemm8.hip): one workgroup per CU, fragment reads travelling under the MFMAs.
+    // Cost model in MACs a CU works through: ceil(tiles / CUs) whole tiles of (rows x 256 x (K + fixed)), against the 128-wide
+    // kernels' own round model below at their measured relative rate.
+    if (sizeof(T) == 2 && gemm_opt(OPT_G8) && a_mode == OP_KC && b_mode == OP_KC && epi.fast && !epi.c2 && split_k == 1 && K % 64 == 0) {
+        const int cus = slots / g_blocks_per_cu;
+        auto max_off = [](const RowMap& m, int rows, int K_) {     // largest element offset the kernel forms for this operand
+            const long long nb = m.rows_per_batch == 0x7fffffff ? 0 : (rows - 1) / m.rows_per_batch;
+            const long long rr = m.rows_per_batch == 0x7fffffff ? rows - 1 : m.rows_per_batch - 1;
+            return m.base + nb * (m.batch_stride > 0 ? m.batch_stride : 0) + rr * (m.row_stride > 0 ? m.row_stride : 0) + K_;
+        };
+        const bool fits = am.base >= 0 && bm.base >= 0 && am.row_stride >= 0 && bm.row_stride >= 0 && am.batch_stride >= 0 && bm.batch_stride >= 0 &&
+                          max_off(am, M, K) * 2 < 0xffffffffLL && max_off(bm, N, K) * 2 < 0xffffffffLL;
+        if (fits) {
+            // Measured model (tools/gemm_bench.cpp, 22 000 .. 88 000 rows, us): a tile costs 13 + 0.0245 K (256 rows) or 13 + 0.0295 K
+            // (288 rows) while the whole chip streams; a last round of `rem` tiles runs faster (0.55 + 0.45 rem / CUs of a tile).
+            // The 128-wide kernels sustain ~560 TFLOP/s at K <= 1024 and ~680 beyond, plus ~6 us.
+            const int ni_force = gemm_opt(OPT_G8_NI);
+            double best8 = 0; int ni = 0;
+            for (int cand = 8; cand <= 9; ++cand) {
+                if (ni_force && cand != ni_force) continue;
+                const int bmt = 32 * cand;
+                const long long t = (long long)((M + bmt - 1) / bmt) * ((N + 255) / 256);
+                const double tile = 13.0 + (cand == 9 ? 0.0295 : 0.0245) * K;
+                const long long full = t / cus, rem = t % cus;
+                const double cost = 5.0 + full * tile + (rem ? tile * (0.55 + 0.45 * (double)rem / cus) : 0.0);
+                if (!ni || cost < best8) { best8 = cost; ni = cand; }
+            }
+            const double cost_old = 6.0 + 2.0 * M * N * K / ((K <= 1024 ? 560.0 : 680.0) * 1e6);
+            if (ni && (gemm_opt(OPT_G8) == 2 || best8 < cost_old)) {
+                // spreading the fragment reads / DMA pieces between the MFMA groups pays on the 256-row tiles (+12 %); the 288-row
+                // variant of it spills (144 accumulator registers) and loses on multi-tile shapes
+                const int pin = gemm_opt(OPT_G8_PIN) >= 0 && gemm_opt(OPT_G8_PIN) <= 1 ? gemm_opt(OPT_G8_PIN) : (ni == 8 ? 1 : 0);
+                if (gemm8_launch_kc<TO>(ni, pin, A, B, C, M, N, K, am, bm, epi, stream)) return 1;
+                g_last_kernel = ni == 9 ? 4 : 3;
+                return 0;
+            }
+        }
+    }
     {   // 2-wave kernel: bf16 KC x KC with the plain LDS-staged epilogue (no transposed second output)
-        static int w2_on = -1;
-        if (w2_on < 0) { const char* e = getenv("SS_GEMM_W2"); w2_on = e ? atoi(e) : 1; }     // 0 never, 1 heuristic, 2 whenever possible
+        const int w2_on = gemm_opt(OPT_W2);                                                  // 0 never, 1 heuristic, 2 whenever possible
         if (w2_on && sizeof(T) == 2 && a_mode == OP_KC && b_mode == OP_KC && epi.fast && !epi.c2 && split_k == 1 && K % 32 == 0) {
             // One workgroup slot = a quarter of a CU (4 resident workgroups).  The tile height (128 or 144 rows) is the one that
             // wastes the least of the last round: 22 000 rows x 768 columns are 1032 tiles of 128 rows (a round of 1024 plus an
@@ -820,8 +736,7 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
             // Measured anchors (22 000 rows): N=3072, K=768: this kernel +16 %; N=768, K=3072 with 128-row tiles: -21 % (the model's
             // 794 vs 653), i.e. the lower fixed cost per tile is worth ~20 % at K <= 1024 and nothing at long K.
             const int slots2 = slots / g_blocks_per_cu * 4;
-            static int bm_force = -1;
-            if (bm_force < 0) { const char* e = getenv("SS_GEMM_W2_BM"); bm_force = e ? atoi(e) : 0; }      // tests: force the tile height
+            const int bm_force = gemm_opt(OPT_W2_BM);                                                        // tests: force the tile height
             double best = 0; int bmt = 0, tm_best = 0;
             for (int cand = 128; cand <= 144; cand += 16) {
                 if (bm_force && cand != bm_force) continue;
@@ -909,7 +824,7 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
         SS_CHECK(split_k <= 1, "ss_gemm: split_k > 1 needs mode 2 (atomic accumulate)");
     }
     RowMap am = to_rowmap(amap), bm = to_rowmap(bmap);
-    { const char* dbg = getenv("SS_GEMM_DEBUG"); epi.debug = dbg ? atoi(dbg) : 0; }
+    epi.debug = gemm_opt(OPT_DEBUG);
     {
         const int ev = dtype_out == SS_BF16 ? 8 : 4;
         const RowMap& cm = epi.cmap;

@@ -1,0 +1,591 @@
+// gemm8.hip -- 8-wave, 256-column-tile MFMA kernels for the large contractions of the training step (gfx950, bf16).
+//
+// The 128 x 128 tiles of gemm.hip spend as long in per-tile fixed cost (first-tile latency, epilogue) and LDS fragment
+// traffic (0.375-0.5 ds_read_b128 per MFMA, every read exposed in front of its MFMAs) as in the MFMAs themselves.
+// Here ONE workgroup of 8 waves owns a CU (2 x 68 KiB LDS stages):
+//
+//   gemm8_kc_kernel  C[m][n] = sum_k A(m,k) B(n,k), both operands K-contiguous (forward convs / linears and every dX):
+//       tile (2*NI*16) x 256, NI = 8 or 9 (256 or 288 rows -- 22 000 frames x 768 columns are 3 x 77 = 231 tiles of 288
+//       rows = ONE round of the 256 CUs, where 256-row tiles need 258), waves 2 (M) x 4 (N), 16*NI x 64 per wave,
+//       K tile = 64 (128-byte rows, XOR-swizzled 16-byte chunks), staged by global_load_lds (swizzle on the source chunk).
+//       The K step is cut into 4 phases (K half x row half); every phase first requests the fragments of the NEXT phase
+//       (ping-pong register sets) and then issues its own 16-20 MFMAs, so LDS reads travel under MFMAs; the single
+//       barrier of a K step sits between phase 2 and 3, where the stage just consumed is handed back to the DMA and the
+//       other stage (requested one full K step earlier) is first read.
+//   gemm8_dw_kernel  C[m][n] (+)= sum_k A(k,m) B(k,n), both operands outer-contiguous, reduction over the B*T frames
+//       (every dW = dY^T X), GROUPED: one persistent launch walks the (tile x K-slice) items of up to 8 problems, so
+//       the 4 weight gradients of an encoder layer (108 tiles) need a split of 2, not 7 per GEMM -> 3.5x fewer f32
+//       atomics.  Tiles are copied untransposed ([64 k][256 m], pitch 544 B) and transposed by ds_read_b64_tr_b16.
+#include "gemm_common.h"
+#include "silent_speech_hip.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace g8 {
+
+constexpr int TBN = 256, RB = 128, BK8 = 64;
+
+__device__ __forceinline__ int fsw(int row) { return (row & 7) ^ (((row >> 3) & 3) << 1); }
+
+// ROWS tile rows copied as 8-row (1 KiB) pieces, piece p by wave p % 8
+template <int ROWS>
+struct Stage {
+    static constexpr int PIECES = ROWS / 8, NP = (PIECES + 7) / 8;
+    unsigned off[NP];                 // byte offset of this lane's source chunk (row clamped, chunk pre-swizzled), K offset excluded
+    // When PIECES is not a multiple of 8 the waves beyond the last piece repeat their previous one (same bytes to the same LDS
+    // address): a branch around one copy would split the K loop's basic block and cost the counted LDS waits more than 1 KiB does.
+    __device__ __forceinline__ void init(const RowMap& map, int outer0, int outer_size, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int p = i * 8 + wave; p = p < PIECES ? p : p - 8;
+            const int r = p * 8 + (lane >> 3);
+            int o = outer0 + r; o = o < outer_size ? o : outer_size - 1;
+            const int chunk = (lane & 7) ^ fsw(r);
+            off[i] = (unsigned)((rowmap_off(map, o) + chunk * 8) * 2);
+        }
+    }
+    __device__ __forceinline__ void issue(const unsigned char* base_k, unsigned char* tile, int wave) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int p = i * 8 + wave; p = p < PIECES ? p : p - 8;
+            glds16(base_k + off[i], tile + p * 1024);
+        }
+    }
+    template <int I>
+    __device__ __forceinline__ void issue_one(const unsigned char* base_k, unsigned char* tile, int wave) {
+        int p = I * 8 + wave; p = p < PIECES ? p : p - 8;
+        glds16(base_k + off[I], tile + p * 1024);
+    }
+};
+
+__device__ __forceinline__ void tile_coord(int it, int G, int nitems, int tiles_n, int& mt, int& nt) {
+    const int chunk0 = it / G * G, pos = it - chunk0;
+    int R = nitems - chunk0; R = R > G ? G : R;
+    const int xcd = pos & 7, q = R >> 3, r = R & 7;
+    const int idx = chunk0 + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pos >> 3);
+    mt = idx / tiles_n; nt = idx - mt * tiles_n;
+}
+
+__device__ __forceinline__ void sched_fence() {
+#if !defined(SS_EMU)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// wait for this wave's LDS reads AND its outstanding global->LDS copies, then the workgroup barrier
+__device__ __forceinline__ void barrier_all() {
+#if defined(SS_EMU)
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
+}
+
+
+// ---- fragment reads whose completion the KERNEL counts, not the compiler.  hipcc either waits lgkmcnt(0) right after the
+// reads of the next phase (fenced order) or re-serialises "one ds_read -> wait -> 4 MFMAs" (its own order): in both cases the
+// LDS latency sits in front of the MFMAs.  The reads are therefore issued from inline asm (invisible to the compiler's wait
+// insertion) and waited for by ONE s_waitcnt at the END of the phase in which they were issued, i.e. after that phase's
+// MFMAs; the wait statement names every destination register "+v" so no consumer can be scheduled above it, and nothing is
+// in flight at a loop back-edge (a register copy there would copy stale data).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128_async(bf16x8& d, const unsigned char* lds, unsigned addr) {
+#if defined(SS_EMU)
+    d = *(const bf16x8*)(lds + addr + OFF);
+#else
+    (void)lds;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+#endif
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_pin(bf16x8 (&f)[N]) {
+#if !defined(SS_EMU)
+    static_assert(N >= 2 && N <= 4, "fragment set size");
+    if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
+    else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+#endif
+}
+
+// flush of an epilogue pass: the LDS piece holds IPP*16 rows of each of the two M halves of the tile
+template <class TO, int NI, int IPP>
+__device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* __restrict__ C, const GemmEpi& epi, int m0, int n0, int pass, int M, int N, int tid)
+{
+    constexpr int EV = OutVec<TO>::N, CPR = TBN / EV, R = IPP * 16, TOTAL = 2 * R * CPR;
+    for (int idx = tid; idx < TOTAL; idx += 512) {
+        const int lr = idx / CPR, ch = idx - lr * CPR;
+        const int half = lr >= R ? 1 : 0, rr = lr - half * R;
+        const int trow = pass * R + rr;                                   // row inside the half
+        const int row = m0 + half * NI * 16 + trow, col = n0 + ch * EV;
+        if (trow < NI * 16 && row < M && col < N) {
+            float v[EV];
+            outvec_load(ct + lr * ldc + ch * EV, v);
+            const long long off = rowmap_off(epi.cmap, row) + col;
+            if (epi.gate) {
+                float g[EV]; outvec_load((const TO*)epi.gate + off, g);
+#pragma unroll
+                for (int e = 0; e < EV; ++e) v[e] = g[e] > 0.f ? v[e] * epi.gate_scale : 0.f;
+            }
+            if (epi.mode == 1) {
+                float o[EV]; outvec_load(C + off, o);
+#pragma unroll
+                for (int e = 0; e < EV; ++e) v[e] += o[e];
+            }
+            outvec_store(C + off, v);
+        }
+    }
+}
+
+template <class TO, int GEN, int NI, int IPP, int P, int NPASS>
+struct Passes8 {
+    static __device__ __forceinline__ void run(const f32x4 (&acc)[NI][4], TO* ct, int ldc, TO* C, const GemmEpi& epi, int m0, int n0, int M, int N, int tid, int wm, int wn, int r, int q) {
+#pragma unroll
+        for (int ii = 0; ii < IPP; ++ii) {
+            constexpr int I0 = P * IPP;
+            if (I0 + ii < NI) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    epilogue_stage<TO, GEN>(acc[I0 + ii < NI ? I0 + ii : 0][j], ct, ldc, (wm * IPP + ii) * 16 + q * 4, wn * 64 + j * 16 + r, epi,
+                                            m0 + (wm * NI + I0 + ii) * 16 + q * 4, n0 + wn * 64 + j * 16 + r, M, N);
+            }
+        }
+        barrier_keep_vm();
+        flush8<TO, NI, IPP>(ct, ldc, C, epi, m0, n0, P, M, N, tid);
+        if (P + 1 < NPASS) barrier_keep_vm();
+        Passes8<TO, GEN, NI, IPP, P + 1, NPASS>::run(acc, ct, ldc, C, epi, m0, n0, M, N, tid, wm, wn, r, q);
+    }
+};
+template <class TO, int GEN, int NI, int IPP, int NPASS>
+struct Passes8<TO, GEN, NI, IPP, NPASS, NPASS> {
+    static __device__ __forceinline__ void run(const f32x4 (&)[NI][4], TO*, int, TO*, const GemmEpi&, int, int, int, int, int, int, int, int, int) {}
+};
+
+}  // namespace g8
+
+// ================================================================ KC x KC
+// PIN: 1 = fragment reads and DMA pieces spread between the MFMA groups of a phase, 0 = issued in a burst at the phase start.
+// ABL: compile-time ablation mask for tuning (results are wrong): 1 no MFMA, 2 no in-loop global->LDS copies, 4 no in-loop fragment reads.
+template <class TO, int NI, int PIN, int ABL>
+__global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
+                                                       int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi, int tiles_n, int nitems)
+{
+    using namespace g8;
+    constexpr int BMT = 2 * NI * 16, STAGE = (BMT + TBN) * RB;
+    constexpr int HR = NI % 3 == 0 ? 3 : 4;                 // 16-row MFMA tiles per phase
+    constexpr int NPK = NI / HR, NPH = 2 * NPK;             // phases per K half / per K step (even: the ping-pong parity carries over)
+    static_assert(NI % HR == 0 && NPH % 2 == 0, "phase split");
+    SS_DYN_SMEM(lds_raw);
+    unsigned char* lds = (unsigned char*)lds_raw;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+#if defined(SS_EMU)
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int wm = wave >> 2, wn = wave & 3;
+    const int G = gridDim.x, nsteps = K / BK8;
+    Stage<BMT> sa; Stage<TBN> sb;
+    // per-lane fragment read offsets: entry x serves (kk ^ i) & 1 == x (A) / (kk ^ j) & 1 == x (B)
+    int aoff[2], boff[2];
+    {
+        const int f0 = (r & 7) ^ (((r >> 3) & 1) << 1), cq = q ^ f0, par = (wm * NI) & 1;
+        aoff[0] = (wm * NI * 16 + r) * RB + ((cq ^ (par << 2)) << 4);
+        aoff[1] = (wm * NI * 16 + r) * RB + ((cq ^ ((par ^ 1) << 2)) << 4);
+        boff[0] = BMT * RB + (wn * 64 + r) * RB + (cq << 4);
+        boff[1] = BMT * RB + (wn * 64 + r) * RB + ((cq ^ 4) << 4);
+    }
+#if defined(SS_EMU)
+    const unsigned lbase = 0;
+#else
+    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);      // LDS byte address of the dynamic segment
+#endif
+    int it = blockIdx.x, mt, nt, cur = 0;
+    tile_coord(it, G, nitems, tiles_n, mt, nt);
+    int m0 = mt * BMT, n0 = nt * TBN;
+    sa.init(amap, m0, M, wave, lane); sb.init(bmap, n0, N, wave, lane);
+    sa.issue((const unsigned char*)A, lds, wave); sb.issue((const unsigned char*)B, lds + BMT * RB, wave);
+
+    constexpr int SA_NP = Stage<BMT>::NP, NPW = SA_NP + Stage<TBN>::NP;     // global->LDS pieces per wave and K tile
+    constexpr int NCH = PIN ? NPH / 2 : 1, CS = (NPW + NCH - 1) / NCH;     // the copy of a K tile is issued in NCH chunks of CS pieces
+
+    for (;;) {
+        f32x4 acc[NI][4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+        bf16x8 fa[2][HR], fb[2][4];
+        // A fragment x / B fragment j of phase ph (K half ph / NPK, rows (ph % NPK) * HR ..) from the stage at byte offset st
+        auto read_a = [&](auto phc, auto xc, unsigned st) {
+            constexpr int ph = phc, x = xc, kk = ph / NPK, i = (ph % NPK) * HR + x;
+            lds_read128_async<i * 2048>(fa[ph & 1][x], lds, lbase + st + aoff[(i ^ kk) & 1]);
+        };
+        auto read_b = [&](auto phc, auto jc, unsigned st) {
+            constexpr int ph = phc, j = jc, kk = ph / NPK;
+            lds_read128_async<j * 2048>(fb[kk][j], lds, lbase + st + boff[(j ^ kk) & 1]);
+        };
+        auto wait_frags = [&](auto phc) {       // issued from the END of the phase in which the fragments of phase ph were requested
+            constexpr int ph = phc;
+            lds_wait_pin(fa[ph & 1]);
+            if constexpr (ph % NPK == 0) lds_wait_pin(fb[ph / NPK]);
+        };
+        auto dma = [&](auto kc, long long kbyte, unsigned st) {      // piece k of the K tile at byte offset kbyte -> stage at st
+            constexpr int k = kc;
+            if constexpr (k < SA_NP) sa.template issue_one<k>((const unsigned char*)A + kbyte, lds + st, wave);
+            else if constexpr (k < NPW) sb.template issue_one<k - SA_NP>((const unsigned char*)B + kbyte, lds + st + BMT * RB, wave);
+        };
+        auto mfma_row = [&](auto phc, auto xc) {
+            constexpr int ph = phc, x = xc, kk = ph / NPK, i = (ph % NPK) * HR + x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[ph & 1][x], fb[kk][j], acc[i][j]);
+        };
+        // One phase = HR groups of {a share of the NEXT phase's fragment reads, a share of a DMA chunk, 4 MFMAs}, then ONE wait for
+        // the fragments requested in it.  PIN = 0: reads and DMA in a burst at the phase start (every wave queues behind the LDS /
+        // TA pipes before its first MFMA: measured +0.35 us per K tile each); PIN = 1: spread between the MFMA groups.
+        //   DMA chunks of K tile t: chunk 0 right after the mid-step barrier of step t-2 (last phase), chunks 1.. in phases 0..
+        //   of step t-1, all of them >= 3 phases ahead of the barrier (step t-1, last phase) that waits for them.
+        auto phase = [&](auto phc, const unsigned S, const unsigned O, const int s) {
+            constexpr int ph = phc, nx = ph + 1 < NPH ? ph + 1 : 0;
+            constexpr bool last = ph + 1 == NPH;
+            constexpr int chunk = last ? 0 : ph + 1;
+            bool rd = true, dm = false; unsigned rst = S, dst = 0; long long kb = 0;
+            if constexpr (last) {
+                if (s + 1 < nsteps) {
+                    barrier_all();               // every wave holds its last fragments of stage S; K tile s+1 has landed in O
+                    rst = O; dm = s + 2 < nsteps && !(ABL & 2); kb = (long long)(s + 2) * BK8 * 2; dst = S;
+                } else rd = false;
+            } else if constexpr (chunk < NCH) { dm = s >= 1 && s + 1 < nsteps && !(ABL & 2); kb = (long long)(s + 1) * BK8 * 2; dst = O; }
+            if (ABL & 4) rd = false;
+            static_for<0, HR>([&](auto xc) {
+                constexpr int x = xc;
+                constexpr int x0 = PIN ? x : 0, x1 = PIN ? x + 1 : (x == 0 ? HR : 0);           // shares issued in front of MFMA group x
+                if (rd) {
+                    static_for<x0, x1>([&](auto xr) { read_a(std::integral_constant<int, nx>{}, xr, rst); });
+                    if constexpr (nx % NPK == 0) static_for<x0 * 4 / HR, x1 * 4 / HR>([&](auto j) { read_b(std::integral_constant<int, nx>{}, j, rst); });
+                }
+                if constexpr (chunk < NCH) {
+                    if (dm) static_for<chunk * CS + x0 * CS / HR, chunk * CS + x1 * CS / HR>([&](auto k) { dma(k, kb, dst); });
+                }
+                sched_fence();
+                if (!(ABL & 1)) mfma_row(phc, xc);
+                sched_fence();
+            });
+            if (rd) wait_frags(std::integral_constant<int, nx>{});
+            sched_fence();
+        };
+        barrier_all();                                       // K tile 0 of this item has landed in stage `cur`; stage cur^1 is free
+        if (nsteps > 1) { sa.issue((const unsigned char*)A + BK8 * 2, lds + (cur ^ 1) * STAGE, wave); sb.issue((const unsigned char*)B + BK8 * 2, lds + (cur ^ 1) * STAGE + BMT * RB, wave); }
+        static_for<0, HR>([&](auto x) { read_a(std::integral_constant<int, 0>{}, x, (unsigned)(cur * STAGE)); });
+        static_for<0, 4>([&](auto j) { read_b(std::integral_constant<int, 0>{}, j, (unsigned)(cur * STAGE)); });
+        wait_frags(std::integral_constant<int, 0>{});
+        sched_fence();
+        for (int s = 0; s < nsteps; ++s) {
+            const unsigned S = cur * STAGE, O = (cur ^ 1) * STAGE;
+            static_for<0, NPH>([&](auto ph) { phase(ph, S, O, s); });
+            cur ^= 1;
+        }
+        // `cur` names the stage the last K tile did NOT use (free since the previous mid-step barrier): the next item's first
+        // K tile goes there while this item's C tile leaves through the other stage
+        const int cm0 = m0, cn0 = n0;
+        const bool has_next = it + G < nitems;
+        if (has_next) {
+            it += G;
+            tile_coord(it, G, nitems, tiles_n, mt, nt);
+            m0 = mt * BMT; n0 = nt * TBN;
+            sa.init(amap, m0, M, wave, lane); sb.init(bmap, n0, N, wave, lane);
+            sa.issue((const unsigned char*)A, lds + cur * STAGE, wave); sb.issue((const unsigned char*)B, lds + cur * STAGE + BMT * RB, wave);
+        }
+        barrier_keep_vm();                                   // every wave is done reading stage cur^1 -> it becomes the C piece
+        TO* ct = (TO*)(lds + (cur ^ 1) * STAGE);
+        constexpr int LDC = TBN + 16 / (int)sizeof(TO);
+        constexpr int IPP = sizeof(TO) == 2 ? (NI % 3 == 0 ? 3 : 2) : 1;
+        constexpr int NPASS = (NI + IPP - 1) / IPP;
+        static_assert((size_t)2 * IPP * 16 * LDC * sizeof(TO) <= (size_t)STAGE, "C piece does not fit the free stage");
+        if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q);
+        else if (epi.general == 2) Passes8<TO, 2, NI, IPP, 0, NPASS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q);
+        else Passes8<TO, 0, NI, IPP, 0, NPASS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q);
+        if (!has_next) break;
+    }
+}
+
+// ================================================================ grouped dW (OC x OC)
+struct DwJob {
+    const bf16_t* A; const bf16_t* B; float* C;
+    RowMap amap, bmap;                  // frame k -> element offset of its row (equal rows_per_batch)
+    long long ldc;
+    int M, N, K;                        // C is M x N, reduction over K frames
+    int tiles_n, ntiles, split, k_chunk, item0, nitem, atomic;
+};
+constexpr int DW_MAX_JOBS = 8;
+struct DwJobs { DwJob job[DW_MAX_JOBS]; int n; };
+
+namespace g8 {
+constexpr int TRP = 544;                // LDS row pitch of the untransposed [64 k][256 m] tiles: 512 B + 32 B (rows 8 banks apart)
+constexpr int TR_STAGE = 2 * 64 * TRP;  // A tile + B tile
+
+// Per thread: 16-byte chunk c of k rows r0 + 16 i (i < 4) of every 64-row K tile, for A and for B.  The frame -> row maps of
+// both operands cut the frames into batches of the same length, so ONE (frame-in-batch) counter per row serves both; the
+// element offsets advance incrementally (no division, no 64-bit multiply in the loop).  Outer columns beyond the matrix are
+// clamped to column 0 (their products land in C entries that are never stored); frames beyond k_end must read as zero in
+// both operands and only occur in the last K tile of an item (predicated variant).
+struct StageTR8 {
+    const unsigned char* pa; const unsigned char* pb;      // operand bases (+ this thread's outer column), bytes
+    unsigned offa[4], offb[4];                             // byte offsets of the 4 rows
+    int tt[4];                                             // frame index inside its batch
+    int c, r0, rpb, wraps;
+    unsigned stepa, stepb, wrapa, wrapb;                   // byte advance per 64 frames / extra advance per batch wrap
+    __device__ __forceinline__ void init(const DwJob& J, int m0, int n0, int k_begin, int tid) {
+        c = tid & 31; r0 = tid >> 5;
+        const int ca = m0 + c * 8 < J.M ? m0 + c * 8 : 0, cb = n0 + c * 8 < J.N ? n0 + c * 8 : 0;
+        pa = (const unsigned char*)(J.A + J.amap.base + ca); pb = (const unsigned char*)(J.B + J.bmap.base + cb);
+        rpb = J.amap.rows_per_batch;
+        wraps = rpb >= BK8 ? 1 : (BK8 + rpb - 1) / rpb;
+        stepa = (unsigned)(J.amap.row_stride * BK8 * 2); stepb = (unsigned)(J.bmap.row_stride * BK8 * 2);
+        wrapa = (unsigned)((J.amap.batch_stride - (long long)rpb * J.amap.row_stride) * 2);
+        wrapb = (unsigned)((J.bmap.batch_stride - (long long)rpb * J.bmap.row_stride) * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = k_begin + r0 + 16 * i;
+            int b_ = 0, t_ = rr;
+            if (rpb != 0x7fffffff) { b_ = rr / rpb; t_ = rr - b_ * rpb; }
+            tt[i] = t_;
+            offa[i] = (unsigned)(((long long)b_ * J.amap.batch_stride + (long long)t_ * J.amap.row_stride) * 2);
+            offb[i] = (unsigned)(((long long)b_ * J.bmap.batch_stride + (long long)t_ * J.bmap.row_stride) * 2);
+        }
+    }
+    __device__ __forceinline__ void advance() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tt[i] += BK8; offa[i] += stepa; offb[i] += stepb;
+            for (int w = 0; w < wraps; ++w) { const bool over = tt[i] >= rpb; tt[i] -= over ? rpb : 0; offa[i] += over ? wrapa : 0u; offb[i] += over ? wrapb : 0u; }
+        }
+    }
+    template <bool PRED>
+    __device__ __forceinline__ void load(int k0, int kend, u32x4 (&ra)[4], u32x4 (&rb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (PRED) {
+                u32x4 z = {0u, 0u, 0u, 0u};
+                const bool v = k0 + r0 + 16 * i < kend;
+                ra[i] = v ? *(const u32x4*)(pa + offa[i]) : z;
+                rb[i] = v ? *(const u32x4*)(pb + offb[i]) : z;
+            } else {
+                ra[i] = *(const u32x4*)(pa + offa[i]);
+                rb[i] = *(const u32x4*)(pb + offb[i]);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* stage, const u32x4 (&ra)[4], const u32x4 (&rb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { *(u32x4*)(stage + (r0 + 16 * i) * TRP + c * 16) = ra[i]; *(u32x4*)(stage + (64 + r0 + 16 * i) * TRP + c * 16) = rb[i]; }
+    }
+};
+__device__ __forceinline__ bf16x8 tr_frag8(const unsigned char* tile, int sub, int kk, int c, int q) {
+    const unsigned char* a0 = tile + (kk * 32 + q * 4 + (c >> 2)) * TRP + sub * 32 + (c & 3) * 8;
+    const s16x4 lo = lds_read_tr16(a0), hi = lds_read_tr16(a0 + 16 * TRP);
+    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+}  // namespace g8
+
+template <int PIN>
+__global__ __launch_bounds__(512) void gemm8_dw_kernel(DwJobs jobs, int nitems)
+{
+    using namespace g8;
+    SS_DYN_SMEM(lds_raw);
+    unsigned char* lds = (unsigned char*)lds_raw;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
+#if defined(SS_EMU)
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int wm = wave >> 2, wn = wave & 3, G = gridDim.x;
+    StageTR8 st;
+    u32x4 ra[4], rb[4];
+    int it = blockIdx.x, ji = 0, m0, n0, k_begin, k_end, nsteps;
+
+#define G8_SETUP()                                                                                                          \
+    do {                                                                                                                     \
+        ji = 0;                                                                                                              \
+        while (ji + 1 < jobs.n && it >= jobs.job[ji].item0 + jobs.job[ji].nitem) ++ji;                                      \
+        const DwJob& J_ = jobs.job[ji];                                                                                      \
+        const int local = it - J_.item0, z = local / J_.ntiles, tile = local - z * J_.ntiles;                                \
+        const int mt_ = tile / J_.tiles_n, nt_ = tile - mt_ * J_.tiles_n;                                                    \
+        m0 = mt_ * 256; n0 = nt_ * 256;                                                                                      \
+        k_begin = z * J_.k_chunk; k_end = min(J_.K, k_begin + J_.k_chunk);                                                   \
+        nsteps = (k_end - k_begin + BK8 - 1) / BK8;                                                                          \
+        st.init(J_, m0, n0, k_begin, tid);                                                                                   \
+        if (nsteps == 1) st.load<true>(k_begin, k_end, ra, rb); else if (nsteps > 1) st.load<false>(k_begin, k_end, ra, rb); \
+    } while (0)
+
+    G8_SETUP();
+    for (;;) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+        if (nsteps > 0) st.store(lds, ra, rb);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const int cur = s & 1;
+            const bool more = s + 1 < nsteps;
+            if (more) {
+                st.advance();
+                const int k0 = k_begin + (s + 1) * BK8;
+                if (s + 2 == nsteps) st.load<true>(k0, k_end, ra, rb); else st.load<false>(k0, k_end, ra, rb);     // only the last K tile can be ragged
+            }
+            const unsigned char* As = lds + cur * TR_STAGE;
+            const unsigned char* Bs = As + 64 * TRP;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 a[8], b[4];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = tr_frag8(As, wm * 8 + i, kk, c, q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = tr_frag8(Bs, wn * 4 + j, kk, c, q);
+                if (PIN) sched_fence();
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
+                if (PIN) sched_fence();
+            }
+            if (more) st.store(lds + (cur ^ 1) * TR_STAGE, ra, rb);
+            __syncthreads();
+        }
+        // ---- next item: its first global loads fly during this item's epilogue
+        const DwJob& J = jobs.job[ji];
+        float* Cj = J.C; const long long ldc = J.ldc; const int Mj = J.M, Nj = J.N, atomic = J.atomic, cm0 = m0, cn0 = n0;
+        const bool has_next = it + G < nitems;
+        if (has_next) { it += G; G8_SETUP(); }
+        // ---- epilogue: lane holds rows q*4+reg, column c of each 16x16 tile
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = cn0 + wn * 64 + j * 16 + c, row0 = cm0 + (wm * 8 + i) * 16 + q * 4;
+                if (col < Nj) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        if (row0 + reg < Mj) {
+                            float* dst = Cj + (long long)(row0 + reg) * ldc + col;
+                            if (atomic) atomicAdd(dst, acc[i][j][reg]); else *dst += acc[i][j][reg];
+                        }
+                    }
+                }
+            }
+        if (!has_next) break;
+    }
+#undef G8_SETUP
+}
+
+// ---------------------------------------------------------------- host side
+static int g8_cus() {
+#if defined(SS_EMU)
+    return 3;
+#else
+    static int cus = 0;
+    if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+    return cus;
+#endif
+}
+static int g8_grant(const void* fn, size_t smem) {
+#if !defined(SS_EMU)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("gemm8: cannot reserve %zu bytes of LDS", smem); return 1; }
+#endif
+    return 0;
+}
+
+// which == NI (8 or 9).  Legality (bf16 in, K % 64 == 0, 32-bit operand offsets, no transposed second output) is the caller's job.
+template <class TO>
+int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, void* stream)
+{
+    const int bmt = 2 * ni * 16, tiles_m = (M + bmt - 1) / bmt, tiles_n = (N + 255) / 256, nitems = tiles_m * tiles_n;
+    const size_t smem = (size_t)2 * (bmt + 256) * 128;
+    const int cus = g8_cus();
+    dim3 grid(nitems < cus ? nitems : cus), block(512);
+#define G8_CASE(NI_, PIN_, ABL_)                                                                                             \
+    do {                                                                                                                      \
+        static bool granted = false;                                                                                          \
+        if (!granted) { if (g8_grant((const void*)gemm8_kc_kernel<TO, NI_, PIN_, ABL_>, smem)) return 1; granted = true; }    \
+        SS_LAUNCH(SS_KERNEL(gemm8_kc_kernel<TO, NI_, PIN_, ABL_>), grid, block, smem, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, tiles_n, nitems); \
+    } while (0)
+    const int abl = (epi.debug >> 4) & 7;
+    if (abl && sizeof(TO) == 2) {          // tuning builds only (bf16 out): which of MFMA / DMA / fragment reads bounds the loop
+        if (ni == 9) { switch (abl) { case 1: G8_CASE(9, 0, 1); break; case 2: G8_CASE(9, 0, 2); break; case 4: G8_CASE(9, 0, 4); break; case 5: G8_CASE(9, 0, 5); break; case 6: G8_CASE(9, 0, 6); break; default: G8_CASE(9, 0, 7); } }
+        else { switch (abl) { case 1: G8_CASE(8, 0, 1); break; case 2: G8_CASE(8, 0, 2); break; case 4: G8_CASE(8, 0, 4); break; case 5: G8_CASE(8, 0, 5); break; case 6: G8_CASE(8, 0, 6); break; default: G8_CASE(8, 0, 7); } }
+    }
+    else if (ni == 9) { if (pin) G8_CASE(9, 1, 0); else G8_CASE(9, 0, 0); }
+    else { if (pin) G8_CASE(8, 1, 0); else G8_CASE(8, 0, 0); }
+#undef G8_CASE
+    SS_LAUNCH_CHECK("ss_gemm(gemm8)");
+    return 0;
+}
+template int gemm8_launch_kc<bf16_t>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*);
+template int gemm8_launch_kc<float>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*);
+
+static thread_local int g_dw_split_override = 0, g_dw_pin = 1;
+extern "C" int ss_gemm_dw_set_option(int what, int value) {
+    int old = 0;
+    if (what == 0) { old = g_dw_split_override; g_dw_split_override = value; }
+    else if (what == 1) { old = g_dw_pin; g_dw_pin = value; }
+    return old;
+}
+
+extern "C" int ss_gemm_dw_grouped(int n_jobs, const ss_dw_job* jobs, void* stream)
+{
+    SS_CHECK(jobs && n_jobs >= 1 && n_jobs <= DW_MAX_JOBS, "ss_gemm_dw_grouped: 1..%d jobs per launch", DW_MAX_JOBS);
+    DwJobs J; memset(&J, 0, sizeof(J));
+    J.n = n_jobs;
+    long long tiles_total = 0; int kmax = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const ss_dw_job& s = jobs[i];
+        SS_CHECK(s.A && s.B && s.C, "ss_gemm_dw_grouped: null pointer in job %d", i);
+        SS_CHECK(s.M > 0 && s.N > 0 && s.K > 0 && s.M % 8 == 0 && s.N % 8 == 0, "ss_gemm_dw_grouped: job %d: M=%d, N=%d must be positive multiples of 8 (16-byte rows), K=%d > 0", i, s.M, s.N, s.K);
+        SS_CHECK(((uintptr_t)s.A) % 16 == 0 && ((uintptr_t)s.B) % 16 == 0, "ss_gemm_dw_grouped: job %d: operands must be 16-byte aligned", i);
+        const ss_rowmap* maps[2] = {&s.amap, &s.bmap};
+        for (int o = 0; o < 2; ++o)
+            SS_CHECK(maps[o]->base % 8 == 0 && maps[o]->batch_stride % 8 == 0 && maps[o]->row_stride % 8 == 0, "ss_gemm_dw_grouped: job %d operand %d: strides must be multiples of 8 elements", i, o);
+        DwJob& d = J.job[i];
+        d.A = (const bf16_t*)s.A; d.B = (const bf16_t*)s.B; d.C = s.C; d.ldc = s.ldc; d.M = s.M; d.N = s.N; d.K = s.K;
+        d.amap.base = s.amap.base; d.amap.batch_stride = s.amap.batch_stride; d.amap.row_stride = s.amap.row_stride; d.amap.rows_per_batch = s.amap.rows_per_batch > 0 ? s.amap.rows_per_batch : 0x7fffffff;
+        d.bmap.base = s.bmap.base; d.bmap.batch_stride = s.bmap.batch_stride; d.bmap.row_stride = s.bmap.row_stride; d.bmap.rows_per_batch = s.bmap.rows_per_batch > 0 ? s.bmap.rows_per_batch : 0x7fffffff;
+        SS_CHECK(d.amap.rows_per_batch == d.bmap.rows_per_batch, "ss_gemm_dw_grouped: job %d: both operands must split their rows into batches of the same length", i);
+        d.tiles_n = (s.N + 255) / 256; d.ntiles = ((s.M + 255) / 256) * d.tiles_n;
+        tiles_total += d.ntiles; kmax = s.K > kmax ? s.K : kmax;
+    }
+    // one K split for the whole group: the largest that keeps (tiles x split) inside ONE round of the CUs
+    const int cus = g8_cus();
+    int split = (int)(cus / (tiles_total > 0 ? tiles_total : 1)); split = split < 1 ? 1 : split;
+    if (g_dw_split_override > 0) split = g_dw_split_override;
+    int item0 = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        DwJob& d = J.job[i];
+        const int ksteps = (d.K + 63) / 64;
+        int sp = split; if (sp > ksteps / 4) sp = ksteps / 4 > 0 ? ksteps / 4 : 1;          // at least 4 K tiles per item
+        const int per = (ksteps + sp - 1) / sp;
+        d.k_chunk = per * 64; d.split = (ksteps + per - 1) / per;
+        d.atomic = d.split > 1 ? 1 : 0;                     // one item per tile: a plain read-modify-write of C suffices
+        d.item0 = item0; d.nitem = d.ntiles * d.split; item0 += d.nitem;
+    }
+    const int nitems = item0;
+    const size_t smem = 2 * g8::TR_STAGE;
+    dim3 grid(nitems < cus ? nitems : cus), block(512);
+    if (g_dw_pin) {
+        static bool granted = false;
+        if (!granted) { if (g8_grant((const void*)gemm8_dw_kernel<1>, smem)) return 1; granted = true; }
+        SS_LAUNCH(SS_KERNEL(gemm8_dw_kernel<1>), grid, block, smem, stream, J, nitems);
+    } else {
+        static bool granted = false;
+        if (!granted) { if (g8_grant((const void*)gemm8_dw_kernel<0>, smem)) return 1; granted = true; }
+        SS_LAUNCH(SS_KERNEL(gemm8_dw_kernel<0>), grid, block, smem, stream, J, nitems);
+    }
+    SS_LAUNCH_CHECK("ss_gemm_dw_grouped");
+    return 0;
+}

@@ -383,6 +383,27 @@ def _dw_direct(dy, x, grad, N, K, rows, amap, bmap):
     ops.gemm(dy, x, grad, N, K, rows, amap, bmap, RM(K), a_mode=OP_OC, b_mode=OP_OC, mode=2, split_k=_split_k(N, K, rows))
 
 
+class _DwGroup(object):
+    """Weight-gradient GEMMs that become ready at about the same time (the four of an encoder layer, the three of a ResBlock)
+    are launched as ONE grouped kernel (ss_gemm_dw_grouped): the K split that fills the 256 CUs is chosen for the group, which
+    divides the number of f32 atomic accumulations by ~3.5 and lets every workgroup own a 256 x 256 tile.  bf16 only; the exact
+    f32 mode keeps the per-GEMM kernels."""
+
+    def __init__(self, grouped):
+        self.grouped, self.jobs = grouped, []
+
+    def add(self, dy, x, grad, N, K, rows, amap, bmap):
+        if self.grouped:
+            self.jobs.append((dy, x, grad, N, K, rows, amap, bmap, K))
+        else:
+            _dw_direct(dy, x, grad, N, K, rows, amap, bmap)
+
+    def launch(self):
+        if self.jobs:
+            ops.gemm_dw_grouped(self.jobs)
+            self.jobs = []
+
+
 def backward(model, ctx, dhead):
     """Accumulates into .grad of every parameter (except the relative-position embeddings, which get
     no gradient in the reference either, transformer.py:214-218).  dhead: [M][n_head_cols] f32."""
@@ -407,13 +428,14 @@ def backward(model, ctx, dhead):
     gu = grad_unpack(model, dev)
     gu.arena.zero_()                 # staging buffers of the re-laid-out weight gradients (one memset, main stream)
 
-    def head_grads():
-        _dw_direct(dh_t, ctx.x_final, gu.buf['head_w'], nh, d, M, RM(nh), RM(d))
-        ops.colsum(dh_t, M, nh, nh, gu.buf['head_b'])
-    side.run(head_grads, dh_t, dhead)
+    grouped = dt == torch.bfloat16 and os.environ.get('SS_AMD_DW_GROUPED', '1') != '0'
+    grp = _DwGroup(grouped)                      # head + last encoder layer travel together
+    grp.add(dh_t, ctx.x_final, gu.buf['head_w'], nh, d, M, RM(nh), RM(d))
+    side.run(lambda: ops.colsum(dh_t, M, nh, nh, gu.buf['head_b']), dh_t, dhead)
     G = torch.empty(M, d, dtype=dt, device=dev)
     ops.gemm(dh_t, pr.w_head_T, G, M, d, nh, RM(nh), RM(nh), RM(d))
 
+    keep_last = ()
     # ---- encoder layers, last to first (transformer.py:54-59)
     for l in range(len(ctx.layers) - 1, -1, -1):
         layer, w, s = model.transformer.layers[l], pr.layers[l], ctx.layers[l]
@@ -422,26 +444,19 @@ def backward(model, ctx, dhead):
         dF = torch.empty(M, d, dtype=dt, device=dev)
         ops.layernorm_backward(G, s.z2, s.mean2, s.rstd2, layer.norm2.weight.detach(), G, dF, _grad(layer.norm2.weight), _grad(layer.norm2.bias),
                                M, d, p=p_drop, seed=seed, rng_stream=4 * l + 3)
-        def ffn2_grads(dF=dF, s=s, layer=layer):
-            _dw_direct(dF, s.hid, layer.linear2.weight.grad, d, ff, M, RM(d), RM(ff))
-            ops.colsum(dF, M, d, d, layer.linear2.bias.grad)
-        side.run(ffn2_grads, dF)
+        grp.add(dF, s.hid, layer.linear2.weight.grad, d, ff, M, RM(d), RM(ff))
+        side.run(lambda dF=dF, layer=layer: ops.colsum(dF, M, d, d, layer.linear2.bias.grad), dF)
         dHid = torch.empty(M, ff, dtype=dt, device=dev)
         ops.gemm(dF, w['w2T'], dHid, M, ff, d, RM(d), RM(d), RM(ff), gate=s.hid, gate_scale=keep_scale)
 
-        def ffn1_grads(dHid=dHid, s=s, layer=layer):
-            _dw_direct(dHid, s.y1, layer.linear1.weight.grad, ff, d, M, RM(ff), RM(d))
-            ops.colsum(dHid, M, ff, ff, layer.linear1.bias.grad)
-        side.run(ffn1_grads, dHid)
+        grp.add(dHid, s.y1, layer.linear1.weight.grad, ff, d, M, RM(ff), RM(d))
+        side.run(lambda dHid=dHid, layer=layer: ops.colsum(dHid, M, ff, ff, layer.linear1.bias.grad), dHid)
         ops.gemm(dHid, w['w1T'], G, M, d, ff, RM(ff), RM(ff), RM(d), mode=1)
-        del dHid
         dA = torch.empty(M, d, dtype=dt, device=dev)
         ops.layernorm_backward(G, s.z1, s.mean1, s.rstd1, layer.norm1.weight.detach(), G, dA, _grad(layer.norm1.weight), _grad(layer.norm1.bias),
                                M, d, p=p_drop, seed=seed, rng_stream=4 * l + 1)
         # output projection  out[t,b,f] = sum_{h,a} o[b,h,t,a] w_o[h,a,f]   (transformer.py:111)
-        def wo_grads(dA=dA, s=s, l=l):
-            _dw_direct(dA, s.o, gu.buf['wo%d' % l], d, H * dp, M, RM(d), RM(H * dp))
-        side.run(wo_grads, dA)
+        grp.add(dA, s.o, gu.buf['wo%d' % l], d, H * dp, M, RM(d), RM(H * dp))
         dO = torch.empty(M, H * dp, dtype=dt, device=dev)
         if ctx.need_T:
             dOT = torch.empty(B, H * dp, Tp, dtype=dt, device=dev)
@@ -454,17 +469,19 @@ def backward(model, ctx, dhead):
         dsc = torch.empty(B, H, T, dtype=torch.float32, device=dev)
         ops.relpos_attention_backward(s.qkv, s.qkvT, w['E'], w['ET'], s.o, s.lse, dO, dOT, dsc, dqkv, B, H, T, Tp, dp, D, ctx.scale,
                                       p=p_drop, seed=seed, rng_stream=4 * l)
-        def wqkv_grads(dqkv=dqkv, s=s, l=l):
-            _dw_direct(dqkv, s.x, gu.buf['wqkv%d' % l], 3 * H * dp, d, M, RM(3 * H * dp), RM(d))
-        side.run(wqkv_grads, dqkv)
+        grp.add(dqkv, s.x, gu.buf['wqkv%d' % l], 3 * H * dp, d, M, RM(3 * H * dp), RM(d))
         ops.gemm(dqkv, w['wqkvT'], G, M, d, 3 * H * dp, RM(3 * H * dp), RM(3 * H * dp), RM(d), mode=1)
-        del dqkv, dO, dOT, dA, dF
+        if l > 0:                               # layer 0's group waits for w_raw_in's gradient
+            side.run(grp.launch, dF, dHid, dA, dqkv, dh_t)
+            grp = _DwGroup(grouped)
+        keep_last = (dF, dHid, dA, dqkv)
+        del dqkv, dO, dOT, dA, dF, dHid
 
     # ---- w_raw_in (architecture.py:73)
-    def raw_in_grads(G=G):
-        _dw_direct(G, ctx.conv_out, model.w_raw_in.weight.grad, d, d, M, RM(d), RM(d))
-        ops.colsum(G, M, d, d, model.w_raw_in.bias.grad)
-    side.run(raw_in_grads, G)
+    grp.add(G, ctx.conv_out, model.w_raw_in.weight.grad, d, d, M, RM(d), RM(d))
+    side.run(grp.launch, G, dh_t, *keep_last)
+    del keep_last
+    side.run(lambda G=G: ops.colsum(G, M, d, d, model.w_raw_in.bias.grad), G)
     side.run(lambda: gu.encoder_batch.run(dev))                # heads + encoder layers: re-laid-out gradients -> .grad arena, under the conv backward
     dy = torch.empty(M, d, dtype=dt, device=dev)
     ops.gemm(G, pr.w_raw_in_T, dy, M, d, d, RM(d), RM(d), RM(d))
@@ -482,27 +499,21 @@ def backward(model, ctx, dhead):
                         xb=s.cr, pad_xb=0, sb=s.str_, dxb=dcr, pad_dxb=0, dgamma_b=_grad(blk.res_norm.weight), dbeta_b=_grad(blk.res_norm.bias),
                         reduce_fn=bn_reduce)
         # conv2 (k3, stride 1): weight, bias, input gradients
-        def conv2_grads(dc2=dc2, s=s, blk=blk, O=O, Tout=Tout, pbs=pbs, rows=rows, i=i):
-            tmp = gu.buf['c2_%d' % i]
-            ops.gemm(dc2, s.h1, tmp, O, 3 * O, rows, RM(O, Tout, pbs, base=O), RM(O, Tout, pbs), RM(3 * O), a_mode=OP_OC, b_mode=OP_OC, mode=2,
-                     split_k=_split_k(O, 3 * O, rows))
-        side.run(conv2_grads, dc2)
+        cgrp = _DwGroup(grouped)
+        cgrp.add(dc2, s.h1, gu.buf['c2_%d' % i], O, 3 * O, rows, RM(O, Tout, pbs, base=O), RM(O, Tout, pbs))
         # d/d(bias) of a conv feeding training-mode BatchNorm is identically 0 (BN removes the mean): nothing to add
         dh1 = torch.empty(rows, O, dtype=dt, device=dev)
         ops.gemm(dc2, w['w2b'], dh1, rows, O, 3 * O, RM(O, Tout, pbs), RM(3 * O), RM(O))
         dc1 = torch.empty(B, Tout + 2, O, dtype=dt, device=dev)
         ops.bn_backward(dh1, 0, s.h1, 1, s.c1, 0, s.st1, dc1, 1, _grad(blk.bn1.weight), _grad(blk.bn1.bias), s.scratch, B, Tout, O, True,
                         reduce_fn=bn_reduce)
-        del dh1, dc2
+        del dh1
         # conv1 (k3, stride 2) and the 1x1 stride-2 residual path
         in_bs = (Tin + 2) * Cin
-        def conv1_grads(dc1=dc1, dcr=dcr, s=s, blk=blk, O=O, Cin=Cin, Tout=Tout, pbs=pbs, rows=rows, in_bs=in_bs, i=i):
-            tmp = gu.buf['c1_%d' % i]
-            ops.gemm(dc1, s.xin, tmp, O, 3 * Cin, rows, RM(O, Tout, pbs, base=O), RM(2 * Cin, Tout, in_bs), RM(3 * Cin), a_mode=OP_OC, b_mode=OP_OC,
-                     mode=2, split_k=_split_k(O, 3 * Cin, rows))
-            ops.gemm(dcr, s.xin, blk.residual_path.weight.grad, O, Cin, rows, RM(O), RM(2 * Cin, Tout, in_bs, base=Cin), RM(Cin), a_mode=OP_OC,
-                     b_mode=OP_OC, mode=2, split_k=_split_k(O, Cin, rows))
-        side.run(conv1_grads, dc1, dcr)
+        cgrp.add(dc1, s.xin, gu.buf['c1_%d' % i], O, 3 * Cin, rows, RM(O, Tout, pbs, base=O), RM(2 * Cin, Tout, in_bs))
+        cgrp.add(dcr, s.xin, blk.residual_path.weight.grad, O, Cin, rows, RM(O, Tout, Tout * O), RM(2 * Cin, Tout, in_bs, base=Cin))
+        side.run(cgrp.launch, dc2, dc1, dcr)
+        del dc2
         side.run(lambda i=i: gu.conv_batches[i].run(dev))          # this block's conv gradients -> parameter layout
         if i > 0:
             dx = torch.empty(B * Tin, Cin, dtype=dt, device=dev)

@@ -120,6 +120,27 @@ def _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, extras, a_mode=OP_KC, b_mode=
     return C
 
 
+GEMM_OPT_W2, GEMM_OPT_W2_BM, GEMM_OPT_G8, GEMM_OPT_G8_NI, GEMM_OPT_G8_PIN = range(5)
+
+
+def gemm_set_option(what, value):
+    """Kernel-selection knobs of ss_gemm (see include/silent_speech_hip.h); returns the previous value."""
+    return _L().ss_gemm_set_option(int(what), int(value))
+
+
+def gemm_dw_grouped(jobs):
+    """jobs: list of (dY, X, dW, M, N, K, amap, bmap, ldc): dW[m][n] += sum_k dY(k, m) X(k, n) for every job, ONE launch
+    (include/silent_speech_hip.h: ss_gemm_dw_grouped).  Groups of more than 8 jobs are cut into several launches."""
+    for g0 in range(0, len(jobs), 8):
+        grp = jobs[g0:g0 + 8]
+        arr = (_lib.DwJob * len(grp))()
+        for j, (dy, x, dw, M, N, K, amap, bmap, ldc) in zip(arr, grp):
+            assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
+            j.A, j.B, j.C = _p(dy).value, _p(x).value, _p(dw).value
+            j.amap, j.bmap, j.ldc, j.M, j.N, j.K = amap, bmap, int(ldc), int(M), int(N), int(K)
+        _lib.check(_L().ss_gemm_dw_grouped(len(grp), arr, _s(grp[0][2])), 'ss_gemm_dw_grouped')
+
+
 # ------------------------------------------------------------------ BatchNorm / LayerNorm / misc
 def bn_scratch(B, T, C, device):
     return torch.empty(int(_L().ss_bn_scratch_floats(B, T, C)), dtype=torch.float32, device=device)

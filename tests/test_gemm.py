@@ -144,3 +144,102 @@ def test_gemm_transposed_second_output(dev, dt):
     ops.gemm_ex(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), c2=C2, cmap2=ops.rowmap(1, T, N * Tp), col_stride2=Tp)
     assert_close_robust(C, want, _tol(dt), name='C', max_outlier_frac=0)
     assert torch.equal(C2.cpu(), C.cpu().view(Bn, T, N).transpose(1, 2).contiguous())
+
+
+# ------------------------------------------------------------------ 8-wave 256-column-tile kernels (csrc/gemm8.hip)
+@pytest.fixture
+def gemm_opts():
+    """Restores the kernel-selection knobs after a test that forces a variant."""
+    yield ops.gemm_set_option
+    for what in range(5):
+        ops.gemm_set_option(what, -1)
+
+
+@pytest.mark.parametrize('ni', [8, 9])
+@pytest.mark.parametrize('pin', [0, 1])
+def test_gemm8_kc_forced(dev, gemm_opts, ni, pin):
+    """bf16 KC x KC through gemm8_kc_kernel (tile 32*ni x 256): several items per persistent workgroup, ragged M / N
+    (clamped rows), 1 / 2 / 3 K tiles, bias + ReLU, gate + accumulate, f32 output, overlapping conv rows."""
+    from silent_speech_amd import _lib
+    big = not is_emu(dev)
+    gemm_opts(ops.GEMM_OPT_G8, 2); gemm_opts(ops.GEMM_OPT_G8_NI, ni); gemm_opts(ops.GEMM_OPT_G8_PIN, pin)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(100 + ni)
+    for (M, N, K) in ([(3000, 776, 768), (1000, 264, 64), (700, 512, 128)] if big else [(600, 264, 192), (330, 520, 64), (40, 72, 128)]):
+        a = torch.randn(M, K, generator=g).to(dt); b = torch.randn(N, K, generator=g).to(dt)
+        bias = torch.randn(N, generator=g)
+        C = torch.zeros(M, N, dtype=dt, device=dev)
+        ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), bias=bias.to(dev), relu=True)
+        assert _lib.lib().ss_gemm_last_kernel() == (4 if ni == 9 else 3)
+        assert_close_robust(C, torch.relu(a.float() @ b.float().t() + bias), _tol(dt), name='gemm8 %s' % ((M, N, K),), max_outlier_frac=0)
+    M, N, K = (1000, 328, 256) if big else (300, 136, 128)
+    a = torch.randn(M, K, generator=g).to(dt); b = torch.randn(N, K, generator=g).to(dt)
+    gate = (torch.randn(M, N, generator=g) > 0).to(dt); base = torch.randn(M, N, generator=g).to(dt)
+    C2 = base.clone().to(dev)
+    ops.gemm(a.to(dev), b.to(dev), C2, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), gate=gate.to(dev), gate_scale=1.25, mode=1)
+    assert _lib.lib().ss_gemm_last_kernel() in (3, 4)
+    assert_close_robust(C2, base.float() + (a.float() @ b.float().t()) * gate.float() * 1.25, _tol(dt), name='gemm8 gate/acc', max_outlier_frac=0)
+    C3 = torch.zeros(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(a.to(dev), b.to(dev), C3, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N))
+    assert _lib.lib().ss_gemm_last_kernel() in (3, 4)
+    assert_close_robust(C3, a.float() @ b.float().t(), 2e-3, name='gemm8 f32 out', max_outlier_frac=0)
+    # k=3 conv with C_in = 64 (K = 192), stride 2, overlapping rows, output scattered into the odd rows of a (B, 2T, C) buffer
+    Bn, T, Ci, Co = (3, 400, 64, 264) if big else (2, 40, 64, 48)
+    x = torch.randn(Bn, T, Ci, generator=g).to(dt); w = (torch.randn(Co, Ci, 3, generator=g) * 0.2).to(dt)
+    want = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.float(), None, stride=2, padding=1).transpose(1, 2)
+    To = want.shape[1]
+    xpad = torch.zeros(Bn, T + 2, Ci, dtype=dt); xpad[:, 1:-1] = x
+    wg = w.permute(0, 2, 1).reshape(Co, 3 * Ci).contiguous()
+    y = torch.zeros(Bn, 2 * To, Co, dtype=dt, device=dev)
+    ops.gemm(xpad.to(dev), wg.to(dev), y, Bn * To, Co, 3 * Ci, ops.rowmap(2 * Ci, rows_per_batch=To, batch_stride=(T + 2) * Ci), ops.rowmap(3 * Ci),
+             ops.rowmap(2 * Co, To, 2 * To * Co, base=Co))
+    assert _lib.lib().ss_gemm_last_kernel() in (3, 4)
+    assert_close_robust(y[:, 1::2], want, _tol(dt), name='gemm8 conv', max_outlier_frac=0)
+    assert float(y[:, 0::2].float().abs().max()) == 0.0
+
+
+def test_gemm8_dropout_matches_other_kernels(dev, gemm_opts):
+    """The dropout mask is a function of (seed, stream, row, column) only: every kernel variant draws the same one."""
+    M, N, K = (600, 264, 128) if is_emu(dev) else (2000, 776, 256)
+    g = torch.Generator().manual_seed(41)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev); b = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev)
+    outs = []
+    for g8 in (0, 2):
+        gemm_opts(ops.GEMM_OPT_G8, g8)
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(a, b, C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), relu=True, dropout_p=0.2, seed=99, rng_stream=6)
+        outs.append(C.cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('split', [0, 1, 3])
+def test_gemm_dw_grouped(dev, split):
+    """Grouped dW = dY^T X: three problems in one launch (plain maps, a ragged last K tile, conv-style overlapping rows with
+    batches of frames), accumulated onto a non-zero C; automatic / forced K split."""
+    from silent_speech_amd import _lib
+    big = not is_emu(dev)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(77)
+    jobs, wants, outs = [], [], []
+    R = 1000 if big else 200
+    for (N, K) in ([(520, 264), (256, 768)] if big else [(264, 40), (24, 264)]):
+        dy = torch.randn(R, N, generator=g).to(dt); x = torch.randn(R, K, generator=g).to(dt)
+        base = torch.randn(N, K, generator=g)
+        dW = base.clone().to(dev)
+        jobs.append((dy.to(dev), x.to(dev), dW, N, K, R, ops.rowmap(N), ops.rowmap(K), K))
+        wants.append(base + dy.float().t() @ x.float()); outs.append(dW)
+    # conv2-style: dY rows and the 3-tap windows of a zero-padded (B, T+2, C) input, batches of T frames
+    Bn, T, Ci, Co = (4, 200, 64, 264) if big else (3, 24, 16, 40)
+    dyc = torch.randn(Bn, T, Co, generator=g).to(dt)
+    xc = torch.zeros(Bn, T + 2, Ci, dtype=dt); xc[:, 1:-1] = torch.randn(Bn, T, Ci, generator=g).to(dt)
+    dWc = torch.zeros(Co, 3 * Ci, device=dev)
+    jobs.append((dyc.to(dev), xc.to(dev), dWc, Co, 3 * Ci, Bn * T, ops.rowmap(Co, T, T * Co), ops.rowmap(Ci, T, (T + 2) * Ci), 3 * Ci))
+    win = torch.stack([xc[:, k:k + T].float() for k in range(3)], 2).reshape(Bn * T, 3 * Ci)
+    wants.append(dyc.float().reshape(Bn * T, Co).t() @ win); outs.append(dWc)
+    old = _lib.lib().ss_gemm_dw_set_option(0, split)
+    try:
+        ops.gemm_dw_grouped(jobs)
+    finally:
+        _lib.lib().ss_gemm_dw_set_option(0, old)
+    for i, (o, w) in enumerate(zip(outs, wants)):
+        assert_close_robust(o, w, 1.5e-2, name='dw job %d' % i, max_outlier_frac=0)
