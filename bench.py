@@ -11,9 +11,17 @@ reference-size batch per GPU (256 000 raw-sample budget => ~40 utterances, ~22 k
 25 % silent utterances.  Weak scaling: every rank gets its own batch of that size.
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0:
+  value / ms_per_step   the K timed steps (barrier + synchronize on both sides, max over ranks)
+  roofline              the kernel with the largest share of the step + a `kernels` list (MFMA- and HBM-bound ones):
+                        HIP events around every launch on every 5th timed step (those steps run serially: no side stream)
+  cpu_baseline          the oracle (CPU restatement of the reference step) on >= 16 packed rows of the same batch, this node's cores
+  parity                mel-L1 of the HIP model (bf16 and exact-f32 kernels) against the oracle on those rows, same weights
+  dtw / mel             BASELINE configs[2] (64 x 1000^2 DTW, HIP vs the oracle's C twin on 1 core and on all cores) and the
+                        mel-target extraction (frames/s vs the numpy oracle)
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -26,17 +34,24 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0         # HBM3E spec (6.3 TB/s is what a streaming copy reaches)
 
 
-def cpu_baseline(batch_cpu, rows_limit, steps):
-    """The oracle (CPU restatement of the reference step, torch fp32 + compiled C DTW) timed on this node's host
-    cores on a bounded sample of the same workload: the first utterances of the batch up to `rows_limit` rows."""
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cpu_baseline(batch_cpu, rows_limit, warm, timed, model_sd, dev):
+    """The oracle (CPU restatement of the reference step, torch fp32 + compiled C DTW) timed on this node's host cores on a
+    bounded sample of the same workload: the first utterances of the batch up to `rows_limit` packed rows.  Also returns the
+    oracle's eval-free forward (dropout 0, shift 3) on that sample for the parity entry."""
     import subprocess
     subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
     from oracle import loss_ref, model_ref
     # 32 threads is the fastest setting on the GPU node's 2x64-core host for this small-batch fp32 step (probed:
     # 16 thr 0.41 s, 32 thr 0.34 s, 64 thr 0.76 s, 128 thr 1.70 s, 256 thr >100 s per fwd+bwd of 762 frames)
-    torch.set_num_threads(min(32, os.cpu_count()))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     n, frames = 0, 0
     while n < len(batch_cpu['lengths']) and (frames + batch_cpu['lengths'][n] + 199) // 200 <= rows_limit:
         frames += batch_cpu['lengths'][n]
@@ -44,32 +59,140 @@ def cpu_baseline(batch_cpu, rows_limit, steps):
     n = max(n, 1)
     sub = {k: v[:n] for k, v in batch_cpu.items()}
     frames = sum(sub['lengths'])
-    sd = model_ref.init_state_dict(768, 6, 80, 48, seed=0)
+    sd = {k: v.detach().cpu().clone() for k, v in model_sd.items()}
     params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and 'running' not in k and 'relative_positional' not in k]
     opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=1e-7)
     g = torch.Generator().manual_seed(0)
+    x_raw = loss_ref.combine_fixed_length(sub['raw_emg'], 1600)
+    with torch.no_grad():
+        ref_pred, _ = model_ref.model_forward({k: v.detach().clone() for k, v in sd.items()}, x_raw.clone(), training=True, shift_r=3, running_out={})
 
     def step():
         opt.zero_grad()
-        x_raw = loss_ref.combine_fixed_length(sub['raw_emg'], 1600)
-        B, T = x_raw.shape[0], 200
+        xr = loss_ref.combine_fixed_length(sub['raw_emg'], 1600)
+        B, T = xr.shape[0], 200
         masks = []
         for _ in range(6):
             masks.append({'attn': (torch.rand(B, 8, T, T, generator=g) >= 0.2).float(), 'res1': (torch.rand(B, T, 768, generator=g) >= 0.2).float(),
                           'ffn': (torch.rand(B, T, 3072, generator=g) >= 0.2).float(), 'res2': (torch.rand(B, T, 768, generator=g) >= 0.2).float()})
-        pred, aux = model_ref.model_forward(sd, x_raw, training=True, shift_r=3, running_out={}, layer_masks=masks, dropout_p=0.2)
+        pred, aux = model_ref.model_forward(sd, xr, training=True, shift_r=3, running_out={}, layer_masks=masks, dropout_p=0.2)
         loss, _ = loss_ref.dtw_loss_ref(pred, aux, sub)
         loss.backward()
         opt.step()
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(warm):
         step()
-    dt = (time.perf_counter() - t0) / steps
-    return {'value': frames / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d utterances = %d frames (%d packed rows of 200) of the same synthetic batch, full 768-d/6-layer fp32 step '
-                      '(fwd+dtw_loss+bwd+AdamW), %d timed steps after 1 warm-up, %.2f s/step' % (n, frames, (frames + 199) // 200, steps, dt)}
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    dt = _median(ts)
+    rows = (frames + 199) // 200
+    out = {'value': frames / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': '%d utterances = %d frames (%d packed rows of 200) of the same synthetic batch, full 768-d/6-layer fp32 step '
+                     '(fwd+dtw_loss+bwd+AdamW), median of %d timed steps after %d warm-up, %.2f s/step' % (n, frames, rows, timed, warm, dt)}
+    return out, sub, ref_pred
+
+
+def parity_entry(sub, ref_pred, model_sd, dev):
+    """mel-L1 (mean |pred - oracle pred| in normalised log-mel units) of the HIP model on the CPU baseline's sample, same weights,
+    training-mode statistics, dropout 0, shift 3: bf16 kernels (what the bench times) and exact-f32 kernels."""
+    from silent_speech_amd.architecture import Model
+    from silent_speech_amd.data_utils import combine_fixed_length
+
+    class _R(object):
+        @staticmethod
+        def randrange(n):
+            return 3
+    out = {'rows': int(ref_pred.shape[0]), 'reference': 'oracle/model_ref.py (fp32 torch restatement pinned to the reference by tests/golden)'}
+    for name, dt in (('bf16', torch.bfloat16), ('fp32', torch.float32)):
+        m = Model(112, 80, 48, model_size=768, num_layers=6, dropout=0.0, compute_dtype=dt)
+        m.load_state_dict(model_sd, strict=True)
+        m.to(dev)
+        m.shift_rng = _R
+        m.train()
+        X_raw = combine_fixed_length([t.to(dev) for t in sub['raw_emg']], 1600)
+        with torch.no_grad():
+            pred, _ = m(None, X_raw, None)
+        out['mel_l1_%s_vs_oracle' % name] = float((pred.float().cpu() - ref_pred).abs().mean())
+        del m
+    return out
+
+
+def dtw_leg(dev, nb=64, n=1000):
+    """BASELINE configs[2]: a batch of 64 cost matrices of 1000 x 1000 f32: the HIP wavefront kernel (cost skew + recurrence +
+    backtrace, one launch) vs the oracle's C twin of align.py on 1 core (the reference's behaviour) and on all cores."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import dtw_ref
+    from silent_speech_amd import align
+    rng = np.random.default_rng(0)
+    host = rng.random((nb, n, n), dtype=np.float32)
+    flat = torch.from_numpy(host).to(dev)
+    shapes, offs, strides = [(n, n)] * nb, [i * n * n for i in range(nb)], [(n, 1)] * nb
+    res, res_offs = align.dtw_align_batch(flat.view(-1), shapes, offs, strides)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 5
+    a.record()
+    for _ in range(iters):
+        align.dtw_align_batch(flat.view(-1), shapes, offs, strides)
+    b.record()
+    torch.cuda.synchronize()
+    t_gpu = a.elapsed_time(b) * 1e-3 / iters
+    got = res.cpu().numpy()
+    t0 = time.perf_counter()
+    want0 = dtw_ref.align_from_distances_c(host[0])
+    t1 = time.perf_counter() - t0
+    t_1core = t1 * nb
+    ok = bool((got[res_offs[0]:res_offs[0] + n] == np.asarray(want0)).all())
+    cores = min(os.cpu_count() or 1, nb)
+    with ThreadPoolExecutor(cores) as ex:        # ctypes releases the GIL: one matrix per core
+        t0 = time.perf_counter()
+        alls = list(ex.map(dtw_ref.align_from_distances_c, [host[i] for i in range(nb)]))
+        t_all = time.perf_counter() - t0
+    ok = ok and all(bool((got[res_offs[i]:res_offs[i] + n] == np.asarray(alls[i])).all()) for i in range(nb))
+    byts = 8.0 * n * n * nb
+    return {'workload': 'configs[2]: %d cost matrices %d x %d f32' % (nb, n, n), 'hip_ms': t_gpu * 1e3, 'matrices_per_s': nb / t_gpu,
+            'bit_exact_vs_oracle': ok,
+            'roofline': {'bound': 'hbm', 'achieved': byts / t_gpu / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': byts / t_gpu / 1e9 / PEAK_HBM_GBPS,
+                         'algorithmic_bytes': byts, 'note': '8 N M bytes per matrix (f32 cost in + f32 cumulative out, SURVEY 8d); latency-bound: N+M-1 dependent wavefronts'},
+            'cpu_1core_ms': t_1core * 1e3, 'cpu_allcores_ms': t_all * 1e3, 'cpu_cores': cores,
+            'speedup_vs_1core': t_1core / t_gpu, 'speedup_vs_allcores': t_all / t_gpu,
+            'cpu_sample': 'oracle/dtw_ref.c (-O3): 1 core = %d x the time of one matrix; all cores = %d matrices on %d threads' % (nb, nb, cores)}
+
+
+def mel_leg(dev, n_utt=32, seconds=6.0):
+    """Mel-target extraction (data_utils.py:39-62): STFT as two f32-MFMA GEMMs + magnitude + mel GEMM on the device vs the numpy oracle."""
+    import numpy as np
+    from oracle import mel_ref
+    from silent_speech_amd.data_utils import mel_spectrogram
+    L = int(22050 * seconds) // 256 * 256
+    rng = np.random.default_rng(1)
+    y = np.clip(0.1 * rng.standard_normal((n_utt, L)), -1, 1).astype(np.float32)
+    yd = torch.from_numpy(y).to(dev)
+    out = mel_spectrogram(yd, 1024, 80, 22050, 256, 1024, 0, 8000)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 5
+    a.record()
+    for _ in range(iters):
+        mel_spectrogram(yd, 1024, 80, 22050, 256, 1024, 0, 8000)
+    b.record()
+    torch.cuda.synchronize()
+    t_gpu = a.elapsed_time(b) * 1e-3 / iters
+    frames = out.shape[0] * out.shape[2]
+    t0 = time.perf_counter()
+    ref = mel_ref.mel_spectrogram_ref(y[:4])
+    t_cpu = (time.perf_counter() - t0) * n_utt / 4
+    err = float(np.abs(out[:4].cpu().numpy() - ref).mean())
+    byts = frames * (1024.0 + 320.0)          # 1024 B of unique audio in + 320 B out per frame (SURVEY 8d)
+    return {'workload': '%d utterances x %.1f s @ 22.05 kHz -> 80-bin log-mel' % (n_utt, seconds), 'frames': int(frames), 'hip_ms': t_gpu * 1e3,
+            'frames_per_s': frames / t_gpu, 'cpu_frames_per_s': frames / t_cpu, 'cpu_kind': 'oracle/mel_ref.py (numpy rfft, 1 process)',
+            'mean_abs_err_vs_oracle': err,
+            'roofline': {'bound': 'hbm', 'achieved': byts / t_gpu / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': byts / t_gpu / 1e9 / PEAK_HBM_GBPS,
+                         'note': '1344 B per frame algorithmic; the dense-DFT formulation is f32-MFMA-bound (2.1 MFLOP/frame), not HBM-bound'}}
 
 
 def main():
@@ -78,9 +201,11 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
-    ap.add_argument('--cpu-rows', type=int, default=6, help='packed rows of the batch given to the CPU baseline (0 = skip)')
-    ap.add_argument('--cpu-steps', type=int, default=2)
-    ap.add_argument('--no-profile', action='store_true', help='do not bracket GEMM launches with HIP events')
+    ap.add_argument('--cpu-rows', type=int, default=16, help='packed rows of the batch given to the CPU baseline (0 = skip baseline and parity)')
+    ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--cpu-warmup', type=int, default=3)
+    ap.add_argument('--no-profile', action='store_true', help='no per-launch HIP events (roofline entry omitted)')
+    ap.add_argument('--no-legs', action='store_true', help='skip the DTW (configs[2]) and mel legs')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -105,7 +230,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from silent_speech_amd import engine, ops
+    from silent_speech_amd import _lib, engine, ops
     from silent_speech_amd.architecture import Model
     from silent_speech_amd.data_utils import combine_fixed_length
     from silent_speech_amd.distributed import DataParallel
@@ -117,6 +242,7 @@ def main():
     torch.manual_seed(0)
     model = Model(112, 80, 48, model_size=768, num_layers=6, dropout=0.2, compute_dtype=dt).to(dev)
     model.train()
+    init_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     dp = DataParallel() if world > 1 else None
     if dp is not None:
         dp.attach(model)
@@ -137,7 +263,7 @@ def main():
         X_raw = combine_fixed_length(batch['raw_emg'], 1600)
         sess = combine_fixed_length(batch['session_ids'], 200)
         if dp is not None:
-            dp.begin_step(X_raw.shape[0] * 200)
+            dp.begin_step(X_raw.shape[0] * 200, dp.local_target_frames(batch))
         pred, aux = model(X, X_raw, sess)
         total = dp.global_total(batch) if dp is not None else None
         loss, _ = dtw_loss(pred, aux, batch, phoneme_loss_weight=0.5, total_length=total)
@@ -153,23 +279,32 @@ def main():
     torch.cuda.synchronize()
     if not torch.isfinite(loss.detach()).item():
         raise SystemExit('non-finite loss after warm-up')
+    plan = engine.plan_binding(model)
+    L = _lib.lib()
     prof = None
     if not args.no_profile:
-        prof = ops.GemmProfiler()
+        prof = ops.LaunchProfiler()
         ops.PROFILER = prof
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_enqueue = 0.0
     for i in range(args.steps):
+        profiled = prof is not None and i % 5 == 0
         if prof is not None:
-            # every 5th timed step carries the per-launch HIP events (roofline numerator); on those steps the weight-gradient
-            # GEMMs stay on the main stream: a duration taken while a second stream shares the CUs is not a per-kernel quantity
-            prof.enabled = i % 5 == 0
-            engine.SIDE_STREAM_ENABLED = not prof.enabled
+            # every 5th timed step carries the per-launch HIP events (roofline numerator); those steps run serially (no side stream):
+            # a duration taken while a second stream shares the CUs is not a per-kernel quantity
+            prof.enabled = profiled
+            L.ss_plan_profile(plan.handle, int(profiled))
+            engine.SIDE_STREAM_ENABLED = not profiled
+        th = time.perf_counter()
         loss = step()
+        if not profiled:
+            host_enqueue += time.perf_counter() - th
     engine.SIDE_STREAM_ENABLED = True
-    host_enqueue = time.perf_counter() - t0               # host time to ENQUEUE the steps (the GPU runs behind, asynchronously)
+    L.ss_plan_profile(plan.handle, 0)
+    n_plain = args.steps - (len(range(0, args.steps, 5)) if prof is not None else 0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -194,37 +329,69 @@ def main():
                                    '(pack+fwd+dtw_loss incl. on-device DTW+bwd+AdamW), dropout 0.2, synthetic 8-ch EMG',
                        'frames_per_gpu_step': frames, 'rows_per_gpu_step': rows, 'utterances_per_gpu_step': len(batch['lengths']),
                        'silent_utterances': int(sum(batch['silent'])), 'parallelism': 'dp%d' % world, 'final_loss': final_loss,
-                       'host_enqueue_ms_per_step': host_enqueue / args.steps * 1e3},
+                       'host_enqueue_ms_per_step': host_enqueue / max(n_plain, 1) * 1e3,
+                       'host_enqueue_note': 'host time to enqueue one un-profiled step (forward and backward are one native call each)'},
         }
         if prof is not None:
-            summ = prof.summary()
-            psteps = len(range(0, args.steps, 5))                       # steps that carried the per-launch events
-            key = max(summ, key=lambda k: summ[k]['seconds'])
-            d = summ[key]
-            peak = PEAK_BF16_TFLOPS if 'bfloat16' in key[0] else PEAK_F32_TFLOPS
-            ach = d['flops'] / d['seconds'] / 1e12
-            traffic, traffic_src = None, None
-            try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py)
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-                ctype = {'torch.bfloat16': 'unsigned short', 'torch.float32': 'float'}
-                names = {1: ['gemm_glds_kernel<%s, %s>' % (ctype[key[0]], ctype[key[1]])], 2: ['gemm_w2_kernel<%s, 144>' % ctype[key[1]], 'gemm_w2_kernel<%s, 128>' % ctype[key[1]]]}.get(key[4], [])
-                names.append('gemm_kernel<%s, %s, %d, %d>' % (ctype[key[0]], ctype[key[1]], key[2], key[3]))
-                for nm in names:
-                    hit = [v for k, v in pmc.items() if nm in k]
-                    if hit:
-                        traffic, traffic_src = hit[0]['hbm_bytes_per_launch'], 'profiles/r01_pmc_traffic.json: ' + nm
-                        break
-            except Exception:
-                pass
-            out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic,
-                               'traffic_source': traffic_src,
-                               'kernel': '%s<%s,%s,a_mode=%d,b_mode=%d>' % ((('gemm_kernel', 'gemm_glds_kernel', 'gemm_w2_kernel')[key[4]],) + tuple(key[:4])), 'launches_per_step': d['launches'] / psteps, 'event_timed_steps': psteps,
-                               'timing': 'HIP events around every ss_gemm launch on every 5th timed step; those steps keep the dW GEMMs on the main stream (exclusive durations); rocprofv3 counterpart: profiles/*_serial_kernel_stats.txt (SS_AMD_SIDE_STREAM=0)',
-                               'avg_launch_us': d['seconds'] / d['launches'] * 1e6, 'algorithmic_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
-                               'all_gemm_variants': {str(k): {'tflops': v['flops'] / v['seconds'] / 1e12, 'ms_per_step': v['seconds'] / psteps * 1e3,
-                                                              'launches_per_step': v['launches'] / psteps} for k, v in summ.items()}}
+            psteps = len(range(0, args.steps, 5))
+            rows_buf = (_lib.ProfileRow * 64)()
+            nrows = L.ss_plan_profile_read(plan.handle, rows_buf, 64)
+            table = {}
+            for r in rows_buf[:nrows]:
+                table[r.name.decode()] = dict(calls=int(r.calls), flops=float(r.flops), bytes=float(r.bytes), seconds=float(r.seconds))
+            for k, v in prof.summary().items():
+                table[k] = v
+            pmc = {}
+            for fn in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+                try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py)
+                    pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+                    pmc_src = 'profiles/' + fn
+                    break
+                except Exception:
+                    continue
+            hints = {'gemm8_kc_kernel (288x256)': 'gemm8_kc_kernel<unsigned short, 9', 'gemm8_kc_kernel (256x256)': 'gemm8_kc_kernel<unsigned short, 8',
+                     'gemm_dw_grouped': 'gemm8_dw_kernel', 'gemm_w2_kernel (128|144 x 128)': 'gemm_w2_kernel', 'gemm_glds_kernel (128x128)': 'gemm_glds_kernel',
+                     'attn_fwd': 'attn_fwd_res_kernel', 'attn_bwd': 'attn_bwd_kv_res_kernel', 'bn_stats': 'bn_partial_kernel', 'bn_apply': 'bn_apply_kernel',
+                     'bn_bwd_sums': 'bn_bwd_partial_kernel', 'bn_bwd_apply': 'bn_bwd_apply_kernel', 'add_dropout_ln_fwd': 'add_dropout_ln_fwd_kernel',
+                     'ln_bwd': 'ln_bwd_kernel', 'adamw_kernel': 'adamw_kernel', 'dtw_kernel': 'dtw_kernel', 'silent_cost_skewed_kernel': 'silent_cost_skewed_kernel',
+                     'colsum': 'colsum_partial_kernel', 'permute3d_batch (weight re-layout)': 'permute3d_batch_kernel', 'grad_unlayout': 'permute3d_batch_f32_kernel'}
+
+            def traffic_of(name):
+                h = hints.get(name)
+                for k, v in pmc.items():
+                    if h and h in k:
+                        return v.get('hbm_bytes_per_launch')
+                return None
+            kernels = []
+            total_s = sum(v['seconds'] for v in table.values())
+            for name, v in sorted(table.items(), key=lambda kv: -kv[1]['seconds']):
+                if v['seconds'] <= 0 or v['calls'] == 0:
+                    continue
+                mfma = v['flops'] > 0
+                f32_mfma = args.dtype == 'fp32'
+                peak = (PEAK_F32_TFLOPS if f32_mfma else PEAK_BF16_TFLOPS) if mfma else PEAK_HBM_GBPS
+                ach = v['flops'] / v['seconds'] / 1e12 if mfma else v['bytes'] / v['seconds'] / 1e9
+                kernels.append({'kernel': name, 'bound': 'mfma' if mfma else 'hbm', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s' if mfma else 'GB/s',
+                                'frac': ach / peak, 'ms_per_step': v['seconds'] / psteps * 1e3, 'launches_per_step': v['calls'] / psteps,
+                                'avg_launch_us': v['seconds'] / v['calls'] * 1e6,
+                                'algorithmic_per_launch': (v['flops'] if mfma else v['bytes']) / v['calls'], 'traffic': traffic_of(name)})
+            top = kernels[0]
+            out['roofline'] = {'bound': top['bound'], 'achieved': top['achieved'], 'peak': top['peak'], 'unit': top['unit'], 'frac': top['frac'],
+                               'traffic': top['traffic'], 'traffic_source': pmc_src if pmc and top['traffic'] is not None else None, 'kernel': top['kernel'],
+                               'launches_per_step': top['launches_per_step'], 'avg_launch_us': top['avg_launch_us'],
+                               'algorithmic_per_launch': top['algorithmic_per_launch'], 'event_timed_steps': psteps,
+                               'serial_kernel_ms_per_step': total_s / psteps * 1e3,
+                               'timing': 'HIP events around every kernel launch (inside the native plan: ss_plan_profile; Python-launched kernels: '
+                                         'torch events on the launch stream) on every 5th timed step; those steps run without the side stream '
+                                         '(exclusive durations); rocprofv3 counterpart: profiles/r02_serial_kernel_stats.txt',
+                               'kernels': kernels[:16]}
         if world == 1 and args.cpu_rows > 0:
-            out['cpu_baseline'] = cpu_baseline(batch_cpu, args.cpu_rows, args.cpu_steps)
+            base, sub, ref_pred = cpu_baseline(batch_cpu, args.cpu_rows, args.cpu_warmup, args.cpu_steps, init_sd, dev)
+            out['cpu_baseline'] = base
+            out['parity'] = parity_entry(sub, ref_pred, init_sd, dev)
+        if world == 1 and not args.no_legs:
+            out['dtw'] = dtw_leg(dev)
+            out['mel'] = mel_leg(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -265,6 +265,56 @@ int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, c
                                  int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
                                  uint32_t rng_stream, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The execution plan of the transduction model as native code: ONE call enqueues the whole forward pass of Model.forward
+ * (architecture.py:61-84: shift augmentation, 3 ResBlocks :29-40, w_raw_in, the post-norm relative-position encoder layers
+ * transformer.py:43-60,87-112, both heads) and ONE the whole backward pass that loss.backward() (transduction_model.py:209)
+ * triggers through autograd -- ~450 kernel launches per training step without a host-language round trip per kernel.
+ * The plan owns no memory: device pointers (parameters, the GEMM-ready weight copies, gradient buffers, the job tables of the
+ * gradient un-layout launches) are bound to NAMED slots (ss_plan_slot_name lists them; names follow the reference's
+ * state_dict keys), activations live in a caller-provided workspace, the saved-for-backward pointers in a caller-kept host
+ * struct of ss_plan_ctx_bytes() bytes.  dtype: SS_BF16 (MFMA bf16, f32 accumulate) or SS_F32 (exact f32 MFMA). */
+typedef struct ss_model_dims {
+    int32_t d_model, n_layers, n_head, d_qkv, dp /* head dim padded to 32 */, max_rel /* relative_positional_distance */, ff;
+    int32_t n_head_cols /* num_outs + num_aux_outs rounded up to 8: the fused output heads */, dtype;
+    float ln_eps;
+} ss_model_dims;
+typedef struct ss_plan ss_plan;
+/* Data-parallel hook: called between the two phases of every training-mode BatchNorm (forward: n_floats = 2C sums, backward:
+ * 3C) with the device pointer of the per-channel sums and the local row count; must all-reduce the sums in place on `stream`
+ * and return the GLOBAL row count. */
+typedef double (*ss_reduce_hook)(void* user, float* sums_dev, int n_floats, double n_local, void* stream);
+/* Called from ss_plan_backward when a group of parameter gradients is final on `stream` (what = 0: heads + encoder + w_raw_in,
+ * 1..3: ResBlock 2, 1, 0): lets the caller start a bucketed gradient all-reduce while the rest of backward still runs. */
+typedef void (*ss_event_hook)(void* user, int what, void* stream);
+ss_plan* ss_plan_create(const ss_model_dims* dims);                 /* [host] NULL on error */
+void ss_plan_destroy(ss_plan* plan);                                /* [host] */
+int ss_plan_slot_count(const ss_plan* plan);                        /* [host] */
+const char* ss_plan_slot_name(const ss_plan* plan, int slot);       /* [host] */
+int ss_plan_bind(ss_plan* plan, int slot, void* device_ptr_or_value); /* [host] slots named *.total / *.all_f32 / *.bytes take integers */
+int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU */
+int ss_plan_set_reduce_hook(ss_plan* plan, ss_reduce_hook fn, void* user); /* [host] */
+int ss_plan_set_event_hook(ss_plan* plan, ss_event_hook fn, void* user);   /* [host] */
+int64_t ss_plan_ctx_bytes(void);                                    /* [host] */
+int64_t ss_plan_workspace_bytes(ss_plan* plan, int B, int T0, int training); /* [host] forward (+ backward temporaries if training) */
+/* x_raw (B, T0, 8) f32 -> head [B*T0/8][n_head_cols] f32 (pred | aux logits | zero padding).  training: BatchNorm batch statistics
+ * and running-stat updates, dropout (counter-based, keyed by seed), the shift augmentation by shift_r samples, whose result is also
+ * written back to x_raw (the reference mutates its input, architecture.py:67-68; shifted_scratch: B*T0*8 floats, may be NULL when
+ * shift_r == 0).  ctx_out [host, ss_plan_ctx_bytes()] must be kept, with the workspace, until ss_plan_backward has run. */
+int ss_plan_forward(ss_plan* plan, const float* x_raw, float* shifted_scratch, void* workspace, int64_t workspace_bytes, int B, int T0,
+                    int training, int shift_r, float dropout_p, uint64_t seed, float* head, void* ctx_out, void* stream);
+/* Accumulates (+=) the gradient of every bound parameter; dhead [B*T0/8][n_head_cols] f32.  The weight-gradient GEMMs, bias column sums
+ * and gradient un-layouts run on side_stream (may equal stream or be NULL), joined into `stream` before the call returns. */
+int ss_plan_backward(ss_plan* plan, void* ctx, const float* dhead, void* stream, void* side_stream);
+/* Per-launch timing of the plan's kernels (HIP events on the launch stream; use with the side stream switched off so that
+ * durations are exclusive).  ss_plan_profile_read synchronises, aggregates the records gathered since the last read by
+ * kernel, clears them and returns the number of rows written. */
+typedef struct ss_profile_row { char name[64]; int64_t calls; double seconds, flops /* algorithmic */, bytes /* algorithmic HBM traffic */; } ss_profile_row;
+int ss_plan_profile(ss_plan* plan, int enable);                                  /* [host] returns the previous setting */
+int ss_plan_profile_read(ss_plan* plan, ss_profile_row* rows, int max_rows);      /* [host] */
+/* counters[i][0] += delta for n <= 16 device int64 counters (BatchNorm num_batches_tracked, architecture.py:19,21,25) in one launch */
+int ss_counters_add(int n, int64_t** counters /* [host] array of device pointers */, int64_t delta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

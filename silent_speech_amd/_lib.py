@@ -35,6 +35,10 @@ class DwJob(ctypes.Structure):
                 ('ldc', ctypes.c_int64), ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
+class ProfileRow(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char * 64), ('calls', ctypes.c_int64), ('seconds', ctypes.c_double), ('flops', ctypes.c_double), ('bytes', ctypes.c_double)]
+
+
 class PermuteJob(ctypes.Structure):
     _fields_ = [('inp', ctypes.c_void_p), ('out', ctypes.c_void_p), ('s0', ctypes.c_int64), ('s1', ctypes.c_int64), ('s2', ctypes.c_int64),
                 ('o0', ctypes.c_int64), ('o1', ctypes.c_int64), ('d0', ctypes.c_int32), ('d1', ctypes.c_int32), ('d2', ctypes.c_int32),
@@ -85,6 +89,15 @@ _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int6
                'ss_gemm_last_kernel': ([], ctypes.c_int),
                'ss_gemm_set_option': ([_I, _I], ctypes.c_int),
                'ss_gemm_dw_set_option': ([_I, _I], ctypes.c_int),
+               'ss_plan_create': ([_P], _P), 'ss_plan_destroy': ([_P], None), 'ss_plan_slot_count': ([_P], ctypes.c_int),
+               'ss_plan_slot_name': ([_P, _I], ctypes.c_char_p), 'ss_plan_bind': ([_P, _I, _P], ctypes.c_int),
+               'ss_plan_set_option': ([_P, _I, _I], ctypes.c_int), 'ss_plan_set_reduce_hook': ([_P, _P, _P], ctypes.c_int),
+               'ss_plan_set_event_hook': ([_P, _P, _P], ctypes.c_int), 'ss_plan_ctx_bytes': ([], ctypes.c_int64),
+               'ss_plan_workspace_bytes': ([_P, _I, _I, _I], ctypes.c_int64),
+               'ss_plan_forward': ([_P, _P, _P, _P, _L, _I, _I, _I, _I, _F, _U64, _P, _P, _P], ctypes.c_int),
+               'ss_plan_backward': ([_P, _P, _P, _P, _P], ctypes.c_int),
+               'ss_counters_add': ([_I, _P, _L, _P], ctypes.c_int),
+               'ss_plan_profile': ([_P, _I], ctypes.c_int), 'ss_plan_profile_read': ([_P, _P, _I], ctypes.c_int),
                'ss_relpos_attention_needs_transposed': ([_I, _I, _I, _I], ctypes.c_int)}
 _RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}
 

@@ -124,18 +124,39 @@ class Model(nn.Module):
         if self._flat is None or self._flat.device != self.w_out.weight.device or self.w_out.weight.data_ptr() < self._flat.data_ptr() \
                 or self.w_out.weight.data_ptr() >= self._flat.data_ptr() + 4 * self._flat_n:
             self.flatten_parameters()
-        for p in self.optimized_parameters():             # zero_grad(set_to_none=True) detached them: re-attach
-            if p.grad is None:
+        # zero_grad(set_to_none=True) detaches the gradients, and anything that assigned p.grad (a fresh zeros_like, a checkpoint
+        # loader) points them outside the arena: the fused optimiser and the gradient all-reduce would then read a stale arena.
+        lo, hi = self._gflat.data_ptr(), self._gflat.data_ptr() + 4 * self._flat_n
+        for p in self.optimized_parameters():
+            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
                 self._reattach_grads()
                 break
         return self._flat, self._gflat, self._flat_n
 
     def _reattach_grads(self):
-        self._gflat.zero_()
+        """Gradients that live outside the arena are carried over (None counts as zero), then every .grad is a view of it again."""
         off = 0
-        for p in self.optimized_parameters():
-            p.grad = self._gflat[off:off + p.numel()].view(p.shape)
+        lo, hi = self._gflat.data_ptr(), self._gflat.data_ptr() + 4 * self._flat_n
+        with torch.no_grad():
+            for p in self.optimized_parameters():
+                view = self._gflat[off:off + p.numel()].view(p.shape)
+                g = p.grad
+                if g is None:
+                    view.zero_()
+                elif not (lo <= g.data_ptr() < hi):
+                    view.copy_(g.to(torch.float32))
+                p.grad = view
+                off += (p.numel() + 3) // 4 * 4
+
+    def arena_ranges(self):
+        """Parameter name -> (first, one-past-last) float offsets in the flat arenas, in arena order."""
+        out, off = [], 0
+        for n, p in self.named_parameters():
+            if 'relative_positional' in n:
+                continue
+            out.append((n, off, off + p.numel()))
             off += (p.numel() + 3) // 4 * 4
+        return out
 
     def mark_weights_updated(self):
         """Called by optimisers that update the arena through the C ABI (no torch version bump)."""
@@ -159,8 +180,7 @@ class Model(nn.Module):
         r = 0
         if self.training:
             r = self.shift_rng.randrange(8)               # architecture.py:65
-            if x_raw.is_cuda or True:
-                self.flat_arenas()
+            self.flat_arenas()
         xr = x_raw if x_raw.is_contiguous() else x_raw.contiguous()
         self._step += 1
         seed = (self._seed_base * 0x9E3779B1 + self._step) & 0xFFFFFFFFFFFFFFFF

@@ -131,3 +131,17 @@ extern "C" int ss_stft_magnitude(const float* spec, int64_t ld_spec, int n_bins,
     SS_LAUNCH_CHECK("ss_stft_magnitude");
     return 0;
 }
+
+// ---------------------------------------------------------------- ss_counters_add
+struct CounterPtrs { long long* p[16]; };
+__global__ void counters_add_kernel(CounterPtrs c, int n, long long delta) { const int i = threadIdx.x; if (i < n && c.p[i]) c.p[i][0] += delta; }
+extern "C" int ss_counters_add(int n, int64_t** counters, int64_t delta, void* stream)
+{
+    SS_CHECK(counters && n >= 0 && n <= 16, "ss_counters_add: 0..16 counters");
+    if (n == 0) return 0;
+    CounterPtrs c; memset(&c, 0, sizeof(c));
+    for (int i = 0; i < n; ++i) c.p[i] = (long long*)counters[i];
+    SS_LAUNCH(counters_add_kernel, dim3(1), dim3(64), 0, stream, c, n, (long long)delta);
+    SS_LAUNCH_CHECK("ss_counters_add");
+    return 0;
+}

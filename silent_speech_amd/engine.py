@@ -1,17 +1,18 @@
-"""Execution plan of the transduction model on the MI355X: which C-ABI kernel runs when, on which
-buffers.  Pure orchestration -- every FLOP happens in libsilent_speech_hip.so (csrc/*.hip); torch is
-used for device memory, streams and autograd bookkeeping only.
-
-Forward follows reference architecture.py:61-84 (Model.forward), :29-40 (ResBlock.forward) and
-transformer.py:43-60,87-112; backward is the hand-derived reverse pass that
-loss.backward() (transduction_model.py:209) triggers in the reference through autograd.
+"""Host side of the transduction model's execution plan on the MI355X.  The plan itself -- which kernel runs
+when, on which buffers, for the whole forward pass (reference architecture.py:61-84, :29-40, transformer.py:43-60,87-112)
+and the hand-derived backward pass (what loss.backward(), transduction_model.py:209, triggers through autograd) -- is
+native code behind TWO C entry points (csrc/plan.hip: ss_plan_forward / ss_plan_backward), so a training step costs two
+host calls instead of ~450 ctypes round trips.  This module keeps what is host bookkeeping by nature: the GEMM-ready
+copies of the parameters (Prepared), the staging buffers / job tables of the gradient un-layout (GradUnpack), binding
+their device pointers to the plan's named slots, and the per-call workspace.  torch is used for device memory, streams
+and autograd bookkeeping only; every FLOP happens in libsilent_speech_hip.so.
 
 Canonical activation layout: (B, T, C) row-major == a flat [B*T][C] matrix (the reference's
 (B,C,T) / (T,B,C) transposes, architecture.py:70,72,77,79, are layout-only).  Convolution inputs live
 in (B, T+2, C) buffers with a zero halo row at both ends of every sequence, so a k=3 window is one
 contiguous 3C-wide row and conv == GEMM with an overlapping-row RowMap (csrc/gemm.hip).
 """
-import math
+import ctypes
 import os
 
 import torch
@@ -143,140 +144,15 @@ def prepared(model):
     return pr
 
 
-class Ctx(object):
-    pass
-
-
-def _bn(mod):
-    return mod.weight.detach(), mod.bias.detach()
-
-
-def forward(model, x_raw, training, shift_r, seed):
-    """x_raw (B, 8T, 8) f32 on the GPU -> head [B*T][n_head_cols] f32 and the saved context."""
-    pr = prepared(model)
-    dt, dev = model.compute_dtype, x_raw.device
-    B, T0, Cin0 = x_raw.shape
-    if T0 % 8 != 0:
-        raise ValueError('raw EMG length %d must be a multiple of 8 (three stride-2 convolutions)' % T0)
-    d = model.d_model
-    ctx = Ctx()
-    ctx.B, ctx.T0, ctx.training, ctx.seed = B, T0, training, seed
-    p_drop = model.dropout_p if training else 0.0
-    ctx.p_drop = p_drop
-    bn_reduce = model._bn_reduce_fn if training else None
-
-    xin = torch.empty(B, T0 + 2, Cin0, dtype=dt, device=dev)
-    shifted = torch.empty_like(x_raw) if (training and shift_r > 0) else None
-    ops.emg_prepare(x_raw, xin, shifted, B, T0, Cin0, shift_r if training else 0)
-    if shifted is not None:
-        x_raw.copy_(shifted)            # the reference mutates its input in place (architecture.py:67-68)
-
-    ctx.blocks = []
-    Tin, Cin = T0, Cin0
-    nblk = len(model.conv_blocks)
-    for i, (blk, w) in enumerate(zip(model.conv_blocks, pr.blocks)):
-        O = blk.conv1.weight.shape[0]
-        Tout = Tin // 2
-        rows = B * Tout
-        s = Ctx()
-        s.xin, s.Tin, s.Cin, s.Tout, s.O = xin, Tin, Cin, Tout, O
-        scratch = ops.bn_scratch(B, Tout, O, dev)
-        s.scratch = scratch
-        in_bs = (Tin + 2) * Cin
-        c1 = torch.empty(rows, O, dtype=dt, device=dev)
-        ops.gemm(xin, w['w1f'], c1, rows, O, 3 * Cin, RM(2 * Cin, Tout, in_bs), RM(3 * Cin), RM(O), bias=blk.conv1.bias.detach())
-        cr = torch.empty(rows, O, dtype=dt, device=dev)
-        ops.gemm(xin, w['wr'], cr, rows, O, Cin, RM(2 * Cin, Tout, in_bs, base=Cin), RM(Cin), RM(O), bias=blk.residual_path.bias.detach())
-        g1, b1 = _bn(blk.bn1)
-        sh1 = blk.bn1.running_mean if bn_reduce is not None else None
-        m1, i1 = ops.bn_stats(c1, B, Tout, O, 0, scratch, blk.bn1.running_mean, blk.bn1.running_var, training=training, shift=sh1, reduce_fn=bn_reduce)
-        h1 = torch.empty(B, Tout + 2, O, dtype=dt, device=dev)
-        ops.bn_apply(c1, (m1, i1, g1, b1), 0, h1, 1, B, Tout, O, True)
-        c2 = torch.empty(rows, O, dtype=dt, device=dev)
-        ops.gemm(h1, w['w2f'], c2, rows, O, 3 * O, RM(O, Tout, (Tout + 2) * O), RM(3 * O), RM(O), bias=blk.conv2.bias.detach())
-        g2, b2 = _bn(blk.bn2)
-        gr, br = _bn(blk.res_norm)
-        sh2 = blk.bn2.running_mean if bn_reduce is not None else None
-        shr = blk.res_norm.running_mean if bn_reduce is not None else None
-        m2, i2 = ops.bn_stats(c2, B, Tout, O, 0, scratch, blk.bn2.running_mean, blk.bn2.running_var, training=training, shift=sh2, reduce_fn=bn_reduce)
-        mr, ir = ops.bn_stats(cr, B, Tout, O, 0, scratch, blk.res_norm.running_mean, blk.res_norm.running_var, training=training, shift=shr, reduce_fn=bn_reduce)
-        last = i == nblk - 1
-        pad_y = 0 if last else 1
-        y = torch.empty(B, Tout + 2 * pad_y, O, dtype=dt, device=dev)
-        ops.bn_apply(c2, (m2, i2, g2, b2), 0, y, pad_y, B, Tout, O, True, xb=cr, sb=(mr, ir, gr, br), pad_xb=0)
-        if training:
-            for bnm in (blk.bn1, blk.bn2, blk.res_norm):
-                bnm.num_batches_tracked += 1
-        s.c1, s.cr, s.h1, s.c2, s.y, s.pad_y = c1, cr, h1, c2, y, pad_y
-        s.st1, s.st2, s.str_ = (m1, i1, g1), (m2, i2, g2), (mr, ir, gr)
-        ctx.blocks.append(s)
-        xin, Tin, Cin = y, Tout, O
-
-    T = Tin
-    M = B * T
-    ctx.T, ctx.M = T, M
-    conv_out = xin.view(M, d)
-    ctx.conv_out = conv_out
-    x = torch.empty(M, d, dtype=dt, device=dev)
-    ops.gemm(conv_out, pr.w_raw_in, x, M, d, d, RM(d), RM(d), RM(d), bias=model.w_raw_in.bias.detach())
-
-    H, dp, D = model.n_head, model.dp, model.max_rel
-    Tp = _round_up(T, 8)
-    scale = 1.0 / math.sqrt(model.d_qkv)
-    ctx.Tp, ctx.scale = Tp, scale
-    ctx.need_T = bool(_lib.lib().ss_relpos_attention_needs_transposed(_lib.dtype_code(dt), T, dp, D))
-    ctx.layers = []
-    for l, (layer, w) in enumerate(zip(model.transformer.layers, pr.layers)):
-        s = Ctx()
-        s.x = x
-        qkv = torch.empty(M, 3 * H * dp, dtype=dt, device=dev)
-        if ctx.need_T:      # the per-tile attention kernels read a per-sequence transposed copy, written by the same GEMM epilogue
-            qkvT = torch.empty(B, 3 * H * dp, Tp, dtype=dt, device=dev)
-            ops.gemm_ex(x, w['wqkv'], qkv, M, 3 * H * dp, d, RM(d), RM(d), RM(3 * H * dp),
-                        c2=qkvT, cmap2=RM(1, T, 3 * H * dp * Tp), col_stride2=Tp)
-        else:               # LDS-resident attention (bf16 rows of <= 208 frames): row-major operands only
-            qkvT = None
-            ops.gemm(x, w['wqkv'], qkv, M, 3 * H * dp, d, RM(d), RM(d), RM(3 * H * dp))
-        o = torch.empty(M, H * dp, dtype=dt, device=dev)
-        lse = torch.empty(B, H, T, dtype=torch.float32, device=dev)
-        ops.relpos_attention_forward(qkv, qkvT, w['E'], o, lse, B, H, T, Tp, dp, D, scale, p=p_drop, seed=seed, rng_stream=4 * l)
-        a = torch.empty(M, d, dtype=dt, device=dev)
-        ops.gemm(o, w['wo'], a, M, d, H * dp, RM(H * dp), RM(H * dp), RM(d))
-        y1 = torch.empty(M, d, dtype=dt, device=dev)
-        mean1, rstd1 = ops.add_dropout_layernorm(x, a, layer.norm1.weight.detach(), layer.norm1.bias.detach(), y1, M, d,
-                                                 eps=layer.norm1.eps, p=p_drop, seed=seed, rng_stream=4 * l + 1)
-        ff = layer.linear1.weight.shape[0]
-        hid = torch.empty(M, ff, dtype=dt, device=dev)
-        ops.gemm(y1, w['w1'], hid, M, ff, d, RM(d), RM(d), RM(ff), bias=layer.linear1.bias.detach(), relu=True,
-                 dropout_p=p_drop, seed=seed, rng_stream=4 * l + 2)
-        f = torch.empty(M, d, dtype=dt, device=dev)
-        ops.gemm(hid, w['w2'], f, M, d, ff, RM(ff), RM(ff), RM(d), bias=layer.linear2.bias.detach())
-        y2 = torch.empty(M, d, dtype=dt, device=dev)
-        mean2, rstd2 = ops.add_dropout_layernorm(y1, f, layer.norm2.weight.detach(), layer.norm2.bias.detach(), y2, M, d,
-                                                 eps=layer.norm2.eps, p=p_drop, seed=seed, rng_stream=4 * l + 3)
-        s.qkv, s.qkvT, s.o, s.lse, s.z1, s.mean1, s.rstd1, s.y1 = qkv, qkvT, o, lse, a, mean1, rstd1, y1
-        s.hid, s.z2, s.mean2, s.rstd2 = hid, f, mean2, rstd2
-        ctx.layers.append(s)
-        x = y2
-    ctx.x_final = x
-    nh = pr.n_head_cols
-    head = torch.empty(M, nh, dtype=torch.float32, device=dev)
-    ops.gemm(x, pr.w_head, head, M, nh, d, RM(d), RM(d), RM(nh), bias=pr.b_head)
-    if not training:
-        ctx = None
-    return head, ctx
-
-
-def _grad(p):
-    """The (flat-arena backed) gradient buffer of a parameter; accumulated into, as autograd would."""
-    if p.grad is None:
-        p.grad = torch.zeros_like(p)
-    return p.grad
+class ModelDims(ctypes.Structure):
+    _fields_ = [('d_model', ctypes.c_int32), ('n_layers', ctypes.c_int32), ('n_head', ctypes.c_int32), ('d_qkv', ctypes.c_int32),
+                ('dp', ctypes.c_int32), ('max_rel', ctypes.c_int32), ('ff', ctypes.c_int32), ('n_head_cols', ctypes.c_int32),
+                ('dtype', ctypes.c_int32), ('ln_eps', ctypes.c_float)]
 
 
 class GradUnpack(object):
     """f32 staging buffers for the weight gradients whose GEMM layout differs from the parameter layout (conv (O,I,k),
-    per-head attention projections, fused heads) + ONE batched launch that accumulates them into the .grad arena."""
+    per-head attention projections, fused heads) + the batched launches that accumulate them into the .grad arena."""
 
     def __init__(self, model, dev):
         d, H, dh, dp = model.d_model, model.n_head, model.d_qkv, model.dp
@@ -334,194 +210,216 @@ def grad_unpack(model, dev):
     return gu
 
 
-SIDE_STREAM_ENABLED = True      # bench.py clears this on its event-timed steps so that per-launch durations are exclusive
+SIDE_STREAM_ENABLED = True      # tools clear this to measure the serial schedule
 
 
-class _SideStream(object):
-    """Weight-gradient GEMMs (dW = dY^T X), bias column sums and gradient re-layouts do not feed the backward chain,
-    so they run on a second HIP stream: their workgroups fill the CUs that the dependent chain (dX GEMMs, attention,
-    norm kernels) leaves idle in its tail rounds (e.g. a 22 k x 768 GEMM is 1032 tiles = 2.02 rounds of 512 slots).
-    Inputs are kept alive (and never written again on the main stream) until join()."""
+def _split_k(M, N, K):
+    """Split-K factor of a weight-gradient GEMM on the 128-wide transposing-read kernel (exact-f32 mode, tests): the largest one
+    that keeps tiles x split within one round of the 512 persistent workgroup slots (same rule as csrc/plan.hip)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    overlapped = SIDE_STREAM_ENABLED and os.environ.get('SS_AMD_SIDE_STREAM', '1') != '0'
+    s = max(1, min(64, (400 if overlapped else 512) // max(tiles, 1)))
+    return max(1, min(s, K // 512 if K >= 512 else 1))
 
-    def __init__(self, model, dev):
-        self.enabled = dev.type == 'cuda' and SIDE_STREAM_ENABLED and os.environ.get('SS_AMD_SIDE_STREAM', '1') != '0'
-        self.keep = []
-        self.blocks_per_cu = int(os.environ.get('SS_AMD_SIDE_BLOCKS', '2'))
-        if self.enabled:
-            st = getattr(model, '_side_stream', None)
-            if st is None or st.device != dev:
-                st = torch.cuda.Stream(device=dev)
-                model._side_stream = st
-            self.stream = st
 
-    def run(self, fn, *keep):
-        if not self.enabled:
-            fn()
-            return
-        ev = torch.cuda.Event()
-        ev.record()
-        self.stream.wait_event(ev)
-        from . import _lib
-        old = _lib.lib().ss_gemm_set_blocks_per_cu(self.blocks_per_cu)     # leave room on every CU for the main-stream kernels
+_REDUCE_HOOK = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p)
+_EVENT_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
+
+
+class PlanBinding(object):
+    """The native plan (ss_plan) of one model + the binding of its named pointer slots."""
+
+    def __init__(self, model):
+        L = _lib.lib()
+        pr = prepared(model)
+        layer0 = model.transformer.layers[0] if len(model.transformer.layers) else None
+        dims = ModelDims(model.d_model, len(model.transformer.layers), model.n_head, model.d_qkv, model.dp, model.max_rel,
+                         layer0.linear1.weight.shape[0] if layer0 is not None else 0, pr.n_head_cols, _lib.dtype_code(model.compute_dtype),
+                         float(layer0.norm1.eps) if layer0 is not None else 1e-5)
+        self.handle = L.ss_plan_create(ctypes.byref(dims))
+        if not self.handle:
+            raise RuntimeError('ss_plan_create failed: %s' % L.ss_last_error().decode())
+        self.lib = L
+        self.names = [L.ss_plan_slot_name(self.handle, i).decode() for i in range(L.ss_plan_slot_count(self.handle))]
+        self.sig = None
+        self.layout = (model.d_model, len(model.transformer.layers), model.compute_dtype)
+        self.ctx_bytes = int(L.ss_plan_ctx_bytes())
+        self.keep = None
+        self.ws = None                               # workspace of the call in flight (the data-parallel hook maps pointers into it)
+        self._hook = self._hook_fn = None
+        self._event = self._event_fn = None
+
+    def __del__(self):
         try:
-            with torch.cuda.stream(self.stream):
-                fn()
-        finally:
-            _lib.lib().ss_gemm_set_blocks_per_cu(old)
-        self.keep.extend(keep)
+            if self.handle:
+                self.lib.ss_plan_destroy(self.handle)
+        except Exception:
+            pass
 
-    def join(self):
-        if self.enabled:
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            torch.cuda.current_stream().wait_event(ev)
-        self.keep = []
+    # ---- slot table: name -> tensor (device pointer) or int
+    @staticmethod
+    def _table(model, pr, gu, dev):
+        t = {}
+
+        def bn(prefix, m, grads):
+            t[prefix + '.weight'], t[prefix + '.bias'] = m.weight, m.bias
+            t[prefix + '.running_mean'], t[prefix + '.running_var'], t[prefix + '.num_batches_tracked'] = m.running_mean, m.running_var, m.num_batches_tracked
+            if grads:
+                t[prefix + '.weight.grad'], t[prefix + '.bias.grad'] = m.weight.grad, m.bias.grad
+
+        def batch(prefix, pb):
+            jobs, jb, total = pb.device_tables(dev)
+            t[prefix + '.jobs'], t[prefix + '.blocks'], t[prefix + '.total'], t[prefix + '.all_f32'] = jobs, jb, int(total), 1
+
+        g = gu is not None
+        for i, (blk, w) in enumerate(zip(model.conv_blocks, pr.blocks)):
+            p = 'conv_blocks.%d.' % i
+            for k in ('w1f', 'w2f', 'wr', 'wrT', 'w2b', 'w1b_even', 'w1b_odd'):
+                if k in w:
+                    t[p + k] = w[k]
+            t[p + 'conv1.bias'], t[p + 'residual_path.bias'], t[p + 'conv2.bias'] = blk.conv1.bias, blk.residual_path.bias, blk.conv2.bias
+            bn(p + 'bn1', blk.bn1, g); bn(p + 'bn2', blk.bn2, g); bn(p + 'res_norm', blk.res_norm, g)
+            if g:
+                t[p + 'conv2.weight.stage'], t[p + 'conv1.weight.stage'] = gu.buf['c2_%d' % i], gu.buf['c1_%d' % i]
+                t[p + 'residual_path.weight.grad'] = blk.residual_path.weight.grad
+                batch(p + 'unpack', gu.conv_batches[i])
+        t['w_raw_in'], t['w_raw_in_T'], t['w_raw_in.bias'] = pr.w_raw_in, pr.w_raw_in_T, model.w_raw_in.bias
+        if g:
+            t['w_raw_in.weight.grad'], t['w_raw_in.bias.grad'] = model.w_raw_in.weight.grad, model.w_raw_in.bias.grad
+        for l, (layer, w) in enumerate(zip(model.transformer.layers, pr.layers)):
+            p = 'transformer.layers.%d.' % l
+            for k in ('wqkv', 'wqkvT', 'wo', 'woT', 'E', 'ET', 'w1', 'w2', 'w1T', 'w2T'):
+                t[p + k] = w[k]
+            t[p + 'linear1.bias'], t[p + 'linear2.bias'] = layer.linear1.bias, layer.linear2.bias
+            t[p + 'norm1.weight'], t[p + 'norm1.bias'], t[p + 'norm2.weight'], t[p + 'norm2.bias'] = layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias
+            if g:
+                for k in ('norm1.weight', 'norm1.bias', 'norm2.weight', 'norm2.bias', 'linear1.weight', 'linear1.bias', 'linear2.weight', 'linear2.bias'):
+                    mod, attr = k.split('.')
+                    t[p + k + '.grad'] = getattr(getattr(layer, mod), attr).grad
+                t[p + 'w_o.stage'], t[p + 'w_qkv.stage'] = gu.buf['wo%d' % l], gu.buf['wqkv%d' % l]
+        t['w_head'], t['w_head_T'], t['b_head'] = pr.w_head, pr.w_head_T, pr.b_head
+        if g:
+            t['head_w.stage'], t['head_b.stage'] = gu.buf['head_w'], gu.buf['head_b']
+            t['stage_arena'], t['stage_arena.bytes'] = gu.arena, int(gu.arena.numel() * 4)
+            batch('unpack_encoder', gu.encoder_batch)
+        return t
+
+    def ensure_bound(self, model, pr, gu, dev):
+        sig = (pr.layout_sig, gu.sig if gu is not None else None, tuple(b.data_ptr() for b in model.buffers()))
+        if sig == self.sig:
+            return
+        table = self._table(model, pr, gu, dev)
+        for i, n in enumerate(self.names):
+            v = table.get(n)
+            if v is None:
+                val = None
+            elif isinstance(v, int):
+                val = ctypes.c_void_p(v)
+            else:
+                val = _lib.ptr(v.detach() if v.requires_grad else v)
+            _lib.check(self.lib.ss_plan_bind(self.handle, i, val), 'ss_plan_bind')
+        self.keep, self.sig = table, sig
+
+    def set_reduce_hook(self, fn):
+        """fn(sums_tensor, n_local) -> n_total (all-reduces the per-channel BatchNorm sums across data-parallel ranks) or None."""
+        if fn is self._hook_fn:
+            return
+        self._hook_fn = fn
+        if fn is None:
+            self._hook = None
+            self.lib.ss_plan_set_reduce_hook(self.handle, ctypes.cast(None, _REDUCE_HOOK), None)
+            return
+
+        def trampoline(user, sums_ptr, n_floats, n_local, stream):
+            off = int(sums_ptr) - self.ws.data_ptr()
+            sums = self.ws[off:off + 4 * n_floats].view(torch.float32)
+            return float(fn(sums, n_local))
+        self._hook = _REDUCE_HOOK(trampoline)
+        self.lib.ss_plan_set_reduce_hook(self.handle, self._hook, None)
+
+    def set_event_hook(self, fn):
+        """fn(what) is called when a group of parameter gradients is final on the side stream (bucketed all-reduce)."""
+        if fn is self._event_fn:
+            return
+        self._event_fn = fn
+        if fn is None:
+            self._event = None
+            self.lib.ss_plan_set_event_hook(self.handle, ctypes.cast(None, _EVENT_HOOK), None)
+            return
+        self._event = _EVENT_HOOK(lambda user, what, stream: fn(int(what)))
+        self.lib.ss_plan_set_event_hook(self.handle, self._event, None)
 
 
-def _dw_direct(dy, x, grad, N, K, rows, amap, bmap):
-    """grad[N][K] += dy^T x  (both operands outer-contiguous, split-K with f32 atomics)."""
-    ops.gemm(dy, x, grad, N, K, rows, amap, bmap, RM(K), a_mode=OP_OC, b_mode=OP_OC, mode=2, split_k=_split_k(N, K, rows))
+def plan_binding(model):
+    pb = getattr(model, '_plan', None)
+    if pb is None or pb.layout != (model.d_model, len(model.transformer.layers), model.compute_dtype):
+        pb = PlanBinding(model)
+        model._plan = pb
+    return pb
 
 
-class _DwGroup(object):
-    """Weight-gradient GEMMs that become ready at about the same time (the four of an encoder layer, the three of a ResBlock)
-    are launched as ONE grouped kernel (ss_gemm_dw_grouped): the K split that fills the 256 CUs is chosen for the group, which
-    divides the number of f32 atomic accumulations by ~3.5 and lets every workgroup own a 256 x 256 tile.  bf16 only; the exact
-    f32 mode keeps the per-GEMM kernels."""
+def _side_stream(model, dev):
+    if dev.type != 'cuda' or not SIDE_STREAM_ENABLED or os.environ.get('SS_AMD_SIDE_STREAM', '1') == '0':
+        return None
+    st = getattr(model, '_side_stream', None)
+    if st is None or st.device != dev:
+        st = torch.cuda.Stream(device=dev)
+        model._side_stream = st
+    return st
 
-    def __init__(self, grouped):
-        self.grouped, self.jobs = grouped, []
 
-    def add(self, dy, x, grad, N, K, rows, amap, bmap):
-        if self.grouped:
-            self.jobs.append((dy, x, grad, N, K, rows, amap, bmap, K))
-        else:
-            _dw_direct(dy, x, grad, N, K, rows, amap, bmap)
+class Ctx(object):
+    """What backward needs from forward: the plan's host context struct and the workspace its pointers live in."""
 
-    def launch(self):
-        if self.jobs:
-            ops.gemm_dw_grouped(self.jobs)
-            self.jobs = []
+    def __init__(self, buf, ws, M):
+        self.buf, self.ws, self.M = buf, ws, M
+
+
+def forward(model, x_raw, training, shift_r, seed):
+    """x_raw (B, 8T, 8) f32 on the GPU -> head [B*T][n_head_cols] f32 and the saved context (None in eval mode)."""
+    pr = prepared(model)
+    dev = x_raw.device
+    B, T0, Cin0 = x_raw.shape
+    if T0 % 8 != 0:
+        raise ValueError('raw EMG length %d must be a multiple of 8 (three stride-2 convolutions)' % T0)
+    pb = plan_binding(model)
+    gu = None
+    if training:
+        model.flat_arenas()                          # every .grad is (again) a view of the flat gradient arena
+        gu = grad_unpack(model, dev)
+    pb.ensure_bound(model, pr, gu, dev)
+    pb.set_reduce_hook(model._bn_reduce_fn if training else None)
+    L = pb.lib
+    nbytes = int(L.ss_plan_workspace_bytes(pb.handle, B, T0, int(training)))
+    if nbytes < 0:
+        raise RuntimeError('ss_plan_workspace_bytes failed: %s' % L.ss_last_error().decode())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    head = torch.empty(B * (T0 // 8), pr.n_head_cols, dtype=torch.float32, device=dev)
+    shifted = torch.empty_like(x_raw) if (training and shift_r > 0) else None
+    buf = ctypes.create_string_buffer(pb.ctx_bytes)
+    pb.ws = ws
+    p_drop = model.dropout_p if training else 0.0
+    rc = L.ss_plan_forward(pb.handle, _lib.ptr(x_raw), _lib.ptr(shifted), _lib.ptr(ws), nbytes, B, T0, int(training), int(shift_r if training else 0),
+                           float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(head), buf, _lib.stream_of(x_raw))
+    _lib.check(rc, 'ss_plan_forward')
+    return head, (Ctx(buf, ws, B * (T0 // 8)) if training else None)
 
 
 def backward(model, ctx, dhead):
     """Accumulates into .grad of every parameter (except the relative-position embeddings, which get
     no gradient in the reference either, transformer.py:214-218).  dhead: [M][n_head_cols] f32."""
     pr = prepared(model)
-    dt, dev = model.compute_dtype, dhead.device
-    B, T, M, d = ctx.B, ctx.T, ctx.M, model.d_model
-    H, dp, D, dh = model.n_head, model.dp, model.max_rel, model.d_qkv
-    Tp, p_drop, seed = ctx.Tp, ctx.p_drop, ctx.seed
-    keep_scale = 1.0 / (1.0 - p_drop)
-    bn_reduce = model._bn_reduce_fn
-    nh = pr.n_head_cols
-
-    # ---- heads (architecture.py:82)
-    dh_t = dhead if dt == torch.float32 else torch.empty(M, nh, dtype=dt, device=dev)
-    if dt != torch.float32:
-        ops.cast_f32(dhead, dh_t, M * nh)
-    n_out = model.w_out.weight.shape[0]
-    n_aux = model.w_aux.weight.shape[0] if model.has_aux_out else 0
-    side = _SideStream(model, dev)
-    for p_ in model.optimized_parameters():
-        _grad(p_)
+    dev = dhead.device
+    pb = plan_binding(model)
+    model.flat_arenas()                              # a zero_grad(set_to_none=True) between forward and backward lands here
     gu = grad_unpack(model, dev)
-    gu.arena.zero_()                 # staging buffers of the re-laid-out weight gradients (one memset, main stream)
-
-    grouped = dt == torch.bfloat16 and os.environ.get('SS_AMD_DW_GROUPED', '1') != '0'
-    grp = _DwGroup(grouped)                      # head + last encoder layer travel together
-    grp.add(dh_t, ctx.x_final, gu.buf['head_w'], nh, d, M, RM(nh), RM(d))
-    side.run(lambda: ops.colsum(dh_t, M, nh, nh, gu.buf['head_b']), dh_t, dhead)
-    G = torch.empty(M, d, dtype=dt, device=dev)
-    ops.gemm(dh_t, pr.w_head_T, G, M, d, nh, RM(nh), RM(nh), RM(d))
-
-    keep_last = ()
-    # ---- encoder layers, last to first (transformer.py:54-59)
-    for l in range(len(ctx.layers) - 1, -1, -1):
-        layer, w, s = model.transformer.layers[l], pr.layers[l], ctx.layers[l]
-        a = layer.self_attn
-        ff = layer.linear1.weight.shape[0]
-        dF = torch.empty(M, d, dtype=dt, device=dev)
-        ops.layernorm_backward(G, s.z2, s.mean2, s.rstd2, layer.norm2.weight.detach(), G, dF, _grad(layer.norm2.weight), _grad(layer.norm2.bias),
-                               M, d, p=p_drop, seed=seed, rng_stream=4 * l + 3)
-        grp.add(dF, s.hid, layer.linear2.weight.grad, d, ff, M, RM(d), RM(ff))
-        side.run(lambda dF=dF, layer=layer: ops.colsum(dF, M, d, d, layer.linear2.bias.grad), dF)
-        dHid = torch.empty(M, ff, dtype=dt, device=dev)
-        ops.gemm(dF, w['w2T'], dHid, M, ff, d, RM(d), RM(d), RM(ff), gate=s.hid, gate_scale=keep_scale)
-
-        grp.add(dHid, s.y1, layer.linear1.weight.grad, ff, d, M, RM(ff), RM(d))
-        side.run(lambda dHid=dHid, layer=layer: ops.colsum(dHid, M, ff, ff, layer.linear1.bias.grad), dHid)
-        ops.gemm(dHid, w['w1T'], G, M, d, ff, RM(ff), RM(ff), RM(d), mode=1)
-        dA = torch.empty(M, d, dtype=dt, device=dev)
-        ops.layernorm_backward(G, s.z1, s.mean1, s.rstd1, layer.norm1.weight.detach(), G, dA, _grad(layer.norm1.weight), _grad(layer.norm1.bias),
-                               M, d, p=p_drop, seed=seed, rng_stream=4 * l + 1)
-        # output projection  out[t,b,f] = sum_{h,a} o[b,h,t,a] w_o[h,a,f]   (transformer.py:111)
-        grp.add(dA, s.o, gu.buf['wo%d' % l], d, H * dp, M, RM(d), RM(H * dp))
-        dO = torch.empty(M, H * dp, dtype=dt, device=dev)
-        if ctx.need_T:
-            dOT = torch.empty(B, H * dp, Tp, dtype=dt, device=dev)
-            ops.gemm_ex(dA, w['woT'], dO, M, H * dp, d, RM(d), RM(d), RM(H * dp),
-                        c2=dOT, cmap2=RM(1, T, H * dp * Tp), col_stride2=Tp)
-        else:
-            dOT = None
-            ops.gemm(dA, w['woT'], dO, M, H * dp, d, RM(d), RM(d), RM(H * dp))
-        dqkv = torch.empty(M, 3 * H * dp, dtype=dt, device=dev)
-        dsc = torch.empty(B, H, T, dtype=torch.float32, device=dev)
-        ops.relpos_attention_backward(s.qkv, s.qkvT, w['E'], w['ET'], s.o, s.lse, dO, dOT, dsc, dqkv, B, H, T, Tp, dp, D, ctx.scale,
-                                      p=p_drop, seed=seed, rng_stream=4 * l)
-        grp.add(dqkv, s.x, gu.buf['wqkv%d' % l], 3 * H * dp, d, M, RM(3 * H * dp), RM(d))
-        ops.gemm(dqkv, w['wqkvT'], G, M, d, 3 * H * dp, RM(3 * H * dp), RM(3 * H * dp), RM(d), mode=1)
-        if l > 0:                               # layer 0's group waits for w_raw_in's gradient
-            side.run(grp.launch, dF, dHid, dA, dqkv, dh_t)
-            grp = _DwGroup(grouped)
-        keep_last = (dF, dHid, dA, dqkv)
-        del dqkv, dO, dOT, dA, dF, dHid
-
-    # ---- w_raw_in (architecture.py:73)
-    grp.add(G, ctx.conv_out, model.w_raw_in.weight.grad, d, d, M, RM(d), RM(d))
-    side.run(grp.launch, G, dh_t, *keep_last)
-    del keep_last
-    side.run(lambda G=G: ops.colsum(G, M, d, d, model.w_raw_in.bias.grad), G)
-    side.run(lambda: gu.encoder_batch.run(dev))                # heads + encoder layers: re-laid-out gradients -> .grad arena, under the conv backward
-    dy = torch.empty(M, d, dtype=dt, device=dev)
-    ops.gemm(G, pr.w_raw_in_T, dy, M, d, d, RM(d), RM(d), RM(d))
-    del G
-
-    # ---- ResBlocks, last to first (architecture.py:29-40)
-    for i in range(len(ctx.blocks) - 1, -1, -1):
-        blk, w, s = model.conv_blocks[i], pr.blocks[i], ctx.blocks[i]
-        O, Cin, Tin, Tout = s.O, s.Cin, s.Tin, s.Tout
-        rows = B * Tout
-        pbs = (Tout + 2) * O                    # batch stride of a padded (B, Tout+2, O) buffer
-        dc2 = torch.empty(B, Tout + 2, O, dtype=dt, device=dev)
-        dcr = torch.empty(rows, O, dtype=dt, device=dev)
-        ops.bn_backward(dy, 0, s.y, s.pad_y, s.c2, 0, s.st2, dc2, 1, _grad(blk.bn2.weight), _grad(blk.bn2.bias), s.scratch, B, Tout, O, True,
-                        xb=s.cr, pad_xb=0, sb=s.str_, dxb=dcr, pad_dxb=0, dgamma_b=_grad(blk.res_norm.weight), dbeta_b=_grad(blk.res_norm.bias),
-                        reduce_fn=bn_reduce)
-        # conv2 (k3, stride 1): weight, bias, input gradients
-        cgrp = _DwGroup(grouped)
-        cgrp.add(dc2, s.h1, gu.buf['c2_%d' % i], O, 3 * O, rows, RM(O, Tout, pbs, base=O), RM(O, Tout, pbs))
-        # d/d(bias) of a conv feeding training-mode BatchNorm is identically 0 (BN removes the mean): nothing to add
-        dh1 = torch.empty(rows, O, dtype=dt, device=dev)
-        ops.gemm(dc2, w['w2b'], dh1, rows, O, 3 * O, RM(O, Tout, pbs), RM(3 * O), RM(O))
-        dc1 = torch.empty(B, Tout + 2, O, dtype=dt, device=dev)
-        ops.bn_backward(dh1, 0, s.h1, 1, s.c1, 0, s.st1, dc1, 1, _grad(blk.bn1.weight), _grad(blk.bn1.bias), s.scratch, B, Tout, O, True,
-                        reduce_fn=bn_reduce)
-        del dh1
-        # conv1 (k3, stride 2) and the 1x1 stride-2 residual path
-        in_bs = (Tin + 2) * Cin
-        cgrp.add(dc1, s.xin, gu.buf['c1_%d' % i], O, 3 * Cin, rows, RM(O, Tout, pbs, base=O), RM(2 * Cin, Tout, in_bs))
-        cgrp.add(dcr, s.xin, blk.residual_path.weight.grad, O, Cin, rows, RM(O, Tout, Tout * O), RM(2 * Cin, Tout, in_bs, base=Cin))
-        side.run(cgrp.launch, dc2, dc1, dcr)
-        del dc2
-        side.run(lambda i=i: gu.conv_batches[i].run(dev))          # this block's conv gradients -> parameter layout
-        if i > 0:
-            dx = torch.empty(B * Tin, Cin, dtype=dt, device=dev)
-            out_even = RM(2 * Cin, Tout, Tin * Cin)
-            out_odd = RM(2 * Cin, Tout, Tin * Cin, base=Cin)
-            ops.gemm(dc1, w['w1b_even'], dx, rows, Cin, O, RM(O, Tout, pbs, base=O), RM(O), out_even)
-            ops.gemm(dcr, w['wrT'], dx, rows, Cin, O, RM(O), RM(O), out_even, mode=1)
-            ops.gemm(dc1, w['w1b_odd'], dx, rows, Cin, 2 * O, RM(O, Tout, pbs, base=O), RM(2 * O), out_odd)
-            dy = dx
-        del dc1, dcr
-    side.join()
+    pb.ensure_bound(model, pr, gu, dev)
+    pb.set_reduce_hook(model._bn_reduce_fn)
+    pb.set_event_hook(getattr(model, '_grad_ready_fn', None))
+    pb.ws = ctx.ws
+    side = _side_stream(model, dev)
+    L = pb.lib
+    L.ss_plan_set_option(pb.handle, 1, int(os.environ.get('SS_AMD_DW_GROUPED', '1') != '0'))
+    L.ss_plan_set_option(pb.handle, 2, int(os.environ.get('SS_AMD_SIDE_BLOCKS', '2')))
+    rc = L.ss_plan_backward(pb.handle, ctx.buf, _lib.ptr(dhead), _lib.stream_of(dhead), ctypes.c_void_p(side.cuda_stream) if side is not None else None)
+    _lib.check(rc, 'ss_plan_backward')

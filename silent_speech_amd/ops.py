@@ -12,35 +12,46 @@ def rowmap(row_stride, rows_per_batch=0, batch_stride=0, base=0):
     return RowMap(int(base), int(batch_stride), int(row_stride), int(rows_per_batch))
 
 
-PROFILER = None     # bench.py installs a GemmProfiler here to time ss_gemm launches with HIP events on the launch stream
+PROFILER = None     # bench.py installs a LaunchProfiler here: per-launch HIP-event timing of the kernels that are launched from Python
 
 
-class GemmProfiler(object):
-    """Brackets every ss_gemm launch with HIP events on the stream it is launched on (torch's current stream)."""
+class LaunchProfiler(object):
+    """Brackets C-ABI launches made from Python (loss / DTW / AdamW / weight re-layout / stand-alone GEMMs) with HIP events on
+    the stream they are launched on (torch's current stream).  The kernels of the model's forward / backward are timed inside the
+    native plan instead (ss_plan_profile)."""
 
     def __init__(self):
         self.records = []
-        self.enabled = True          # bench.py switches it on for a sample of the timed steps to keep the event overhead small
+        self.enabled = True
 
-    def run(self, key, flops, fn, stream_tensor):
-        if not self.enabled:
+    def run(self, name, flops, nbytes, fn):
+        if not self.enabled or not torch.cuda.is_available():
             return fn()
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
-        fn()
+        r = fn()
         e.record()
-        self.records.append((key + (_lib.lib().ss_gemm_last_kernel(),), flops, s, e))       # + which kernel ran (0 staged, 1 glds, 2 w2)
+        self.records.append((name, float(flops), float(nbytes), s, e))
+        return r
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, flops, s, e in self.records:
-            a = agg.setdefault(key, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += flops
-            a[2] += s.elapsed_time(e) * 1e-3
-        return {k: dict(launches=v[0], flops=v[1], seconds=v[2]) for k, v in agg.items()}
+        for name, flops, nbytes, s, e in self.records:
+            a = agg.setdefault(name, dict(calls=0, flops=0.0, bytes=0.0, seconds=0.0))
+            a['calls'] += 1
+            a['flops'] += flops
+            a['bytes'] += nbytes
+            a['seconds'] += s.elapsed_time(e) * 1e-3
+        self.records = []
+        return agg
+
+
+def timed(name, flops, nbytes, fn):
+    if PROFILER is not None:
+        return PROFILER.run(name, flops, nbytes, fn)
+    return fn()
 
 
 def gemm(A, B, C, M, N, K, amap, bmap, cmap, **kw):
@@ -114,7 +125,7 @@ def _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, extras, a_mode=OP_KC, b_mode=
                           ctypes.byref(cmap), ctypes.byref(epi), split_k, _s(C))
         _lib.check(rc, 'ss_gemm')
     if PROFILER is not None and C.is_cuda:
-        PROFILER.run((str(A.dtype), str(C.dtype), a_mode, b_mode), 2.0 * M * N * K, launch, C)
+        PROFILER.run('ss_gemm (from Python)', 2.0 * M * N * K, (M * K + N * K) * A.element_size() + M * N * C.element_size(), launch)
     else:
         launch()
     return C
@@ -218,8 +229,8 @@ def emg_prepare(x_raw, out_padded, shifted_copy, B, T0, Cin, shift):
 
 
 def adamw_step(p, g, m, v, n, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
-    rc = _L().ss_adamw_step(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, _s(p))
-    _lib.check(rc, 'ss_adamw_step')
+    timed('adamw_kernel', 0, 28.0 * n,
+          lambda: _lib.check(_L().ss_adamw_step(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, _s(p)), 'ss_adamw_step'))
 
 
 def cast_f32(src, dst, n):
@@ -277,6 +288,12 @@ class PermuteBatch(object):
         raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8).clone()
         self._dev = (raw.to(device), torch.tensor(job_of_block, dtype=torch.int32).to(device), first)
 
+    def device_tables(self, device):
+        """(jobs, job_of_block, total_blocks) on the device: what ss_permute3d_batch / a native plan slot takes."""
+        if self._dev is None or self._dev[0].device != device:
+            self._finalize(device)
+        return self._dev
+
     def run(self, device):
         if not self.jobs:
             return
@@ -284,4 +301,6 @@ class PermuteBatch(object):
             self._finalize(device)
         jobs, jb, total = self._dev
         all_f32 = int(all(j.in_dtype == 0 and j.out_dtype == 0 for j in self.jobs))     # f32 -> f32 batches (gradient un-layout) have their own kernel
-        _lib.check(_L().ss_permute3d_batch(_p(jobs), _p(jb), total, all_f32, _s(jobs)), 'ss_permute3d_batch')
+        nbytes = sum(j.d0 * j.d1 * j.d2 * ((4 if j.in_dtype == 0 else 2) + (4 if j.out_dtype == 0 else 2)) for j in self.jobs)
+        timed('permute3d_batch (weight re-layout)', 0, nbytes,
+              lambda: _lib.check(_L().ss_permute3d_batch(_p(jobs), _p(jb), total, all_f32, _s(jobs)), 'ss_permute3d_batch'))

@@ -14,7 +14,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 from .align import _workspace_layout
 from .architecture import Model
 from .data_utils import combine_fixed_length, phoneme_inventory
@@ -93,9 +93,12 @@ class _DtwLossFn(torch.autograd.Function):
             ws = torch.empty(max(plan.ws_bytes, 256), dtype=torch.uint8, device=dev)
             results = torch.empty(max(plan.res_total, 1), dtype=torch.int32, device=dev)
             mx_n, mx_m = max(s[0] for s in plan.shapes), max(s[1] for s in plan.shapes)
-            _lib.check(_L().ss_silent_cost_skewed(_p(head), ld, n_mel, _p(lse), _p(plan.Y), _p(plan.phones), _p(plan.desc), plan.n_silent, mx_n, mx_m,
-                                                  lam, _p(ws), _p(results), st), 'ss_silent_cost_skewed')
-            _lib.check(_L().ss_dtw_align_skewed(_p(plan.desc), plan.n_silent, _p(ws), _p(results), st), 'ss_dtw_align_skewed')
+            cells = float(sum(a * b for a, b in plan.shapes))
+            ops.timed('silent_cost_skewed_kernel', 0, 4.0 * cells + 4.0 * (n_mel + n_ph) * sum(a + b for a, b in plan.shapes),
+                      lambda: _lib.check(_L().ss_silent_cost_skewed(_p(head), ld, n_mel, _p(lse), _p(plan.Y), _p(plan.phones), _p(plan.desc), plan.n_silent, mx_n, mx_m,
+                                                                    lam, _p(ws), _p(results), st), 'ss_silent_cost_skewed'))
+            ops.timed('dtw_kernel', 0, 8.0 * cells,         # 8 N M bytes per matrix (f32 cost in + f32 cumulative out)
+                      lambda: _lib.check(_L().ss_dtw_align_skewed(_p(plan.desc), plan.n_silent, _p(ws), _p(results), st), 'ss_dtw_align_skewed'))
             _lib.check(_L().ss_silent_loss(_p(head), ld, n_mel, n_ph, _p(lse), _p(amax), _p(plan.Y), _p(plan.phones), _p(results), _p(plan.si_tgt),
                                            _p(plan.si_base), _p(plan.si_res), plan.n_silent_frames, lam, inv_total, _p(dhead), _p(loss), _p(correct), st),
                        'ss_silent_loss')

@@ -25,7 +25,8 @@ def make_batch(seed_list):
     return SyntheticEMGDataset.collate_raw(items)
 
 
-UTTS = [(1, 40, False), (2, 80, True), (3, 80, False), (4, 40, True)]      # whole rows of 40 frames -> per-rank rows == global rows
+UTTS = [(1, 40, False), (2, 80, True), (3, 80, False), (4, 40, True), (5, 80, False), (6, 40, True), (7, 40, False), (8, 80, True)]
+# whole rows of 40 frames -> per-rank rows == global rows; 8 utterances deal evenly to 1, 2 and 4 ranks
 
 
 def run_step(model, batch, dp, seq_len=40):
@@ -34,12 +35,16 @@ def run_step(model, batch, dp, seq_len=40):
     X_raw = combine_fixed_length(batch['raw_emg'], seq_len * 8)
     X = combine_fixed_length(batch['emg'], seq_len)
     sess = combine_fixed_length(batch['session_ids'], seq_len)
+    zero_late = os.environ.get('SS_DP_ZERO_LATE') == '1'
+    if not zero_late:
+        model.zero_grad(set_to_none=True)
     if dp is not None:
-        dp.begin_step(X_raw.shape[0] * seq_len)
+        dp.begin_step(X_raw.shape[0] * seq_len, dp.local_target_frames(batch))
     pred, aux = model(X, X_raw, sess)
     total = dp.global_total(batch) if dp is not None else None
     loss, _ = dtw_loss(pred, aux, batch, phoneme_loss_weight=0.5, total_length=total)
-    model.zero_grad(set_to_none=True)
+    if zero_late:
+        model.zero_grad(set_to_none=True)       # between forward and backward: .grad must be re-homed in the flat arena, not silently dropped
     loss.backward()
     if dp is not None:
         dp.sync_gradients(model)
@@ -76,15 +81,21 @@ def main():
     model = build_model().to(dev)
     dp = None
     if world > 1:
-        dp = DataParallel()
+        torch.manual_seed(1000 + rank)               # ranks start from DIFFERENT weights / embeddings: attach() must make them equal to rank 0's
+        with torch.no_grad():
+            for prm in model.parameters():
+                if rank > 0:
+                    prm.add_(torch.randn(prm.shape, device=prm.device) * 0.01)
+        dp = DataParallel(bucketed=os.environ.get('SS_DP_BUCKETED', '1') == '1')
         dp.attach(model)
         batch = make_batch(UTTS[rank::world])
     else:
-        batch = make_batch(UTTS[0::2] + UTTS[1::2])
+        batch = make_batch([u for r in range(int(os.environ.get('SS_DP_ORDER_OF', '2'))) for u in UTTS[r::int(os.environ.get('SS_DP_ORDER_OF', '2'))]])
     batch = {k: ([t.to(dev) for t in v] if isinstance(v, list) and len(v) and torch.is_tensor(v[0]) else v) for k, v in batch.items()}
     loss = run_step(model, batch, dp)
     _, gflat, n = model.flat_arenas()
-    res = {'loss': float(loss), 'grads': gflat.clone().cpu(), 'rm': model.conv_blocks[0].bn1.running_mean.clone().cpu(), 'rv': model.conv_blocks[2].bn2.running_var.clone().cpu()}
+    emb = model.transformer.layers[0].self_attn.relative_positional.embeddings.detach().clone().cpu()
+    res = {'loss': float(loss), 'grads': gflat.clone().cpu(), 'emb': emb, 'rm': model.conv_blocks[0].bn1.running_mean.clone().cpu(), 'rv': model.conv_blocks[2].bn2.running_var.clone().cpu()}
     if rank == 0:
         torch.save(res, out)
     if world > 1:

@@ -19,31 +19,49 @@ def _free_port():
     return p
 
 
-def _two_rank_vs_single(tmp_path, extra_env):
+def _ranks_vs_single(tmp_path, extra_env, world=2):
     worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
-    env = dict(os.environ, OMP_NUM_THREADS='1', **extra_env)
+    env = dict(os.environ, OMP_NUM_THREADS='1', SS_DP_ORDER_OF=str(world), **extra_env)
     single = str(tmp_path / 'single.pt')
     p0 = subprocess.Popen([sys.executable, worker, single], env=dict(env, WORLD_SIZE='1', RANK='0'))
     port = str(_free_port())
     multi = str(tmp_path / 'multi.pt')
-    procs = [subprocess.Popen([sys.executable, worker, multi], env=dict(env, WORLD_SIZE='2', RANK=str(r), MASTER_PORT=port, MASTER_ADDR='127.0.0.1'))
-             for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, multi], env=dict(env, WORLD_SIZE=str(world), RANK=str(r), MASTER_PORT=port, MASTER_ADDR='127.0.0.1'))
+             for r in range(world)]
     for p in [p0] + procs:
-        assert p.wait(timeout=600) == 0
+        assert p.wait(timeout=900) == 0
     a, b = torch.load(single), torch.load(multi)
     # loss: each rank reports sum(local losses)/global frames; the single-process loss is the sum over ranks
     assert abs(b['loss']) < abs(a['loss'])
     ga, gb = a['grads'], b['grads']
     assert ga.shape == gb.shape
+    assert float(ga.abs().max()) > 1e-3 and float(gb.abs().max()) > 1e-3, 'vacuous comparison: the gradient arena is empty'
     err = float((ga - gb).abs().max()) / (float(ga.abs().max()) + 1e-12)
     assert err < 2e-4, err
     assert torch.allclose(a['rm'], b['rm'], rtol=1e-4, atol=1e-6)
     assert torch.allclose(a['rv'], b['rv'], rtol=1e-4, atol=1e-6)
+    assert torch.equal(a['emb'], b['emb'])      # the never-trained relative-position embeddings were broadcast from rank 0 too
+
+
+def _two_rank_vs_single(tmp_path, extra_env):
+    _ranks_vs_single(tmp_path, extra_env, 2)
 
 
 def test_two_rank_step_equals_single_process(tmp_path):
     _ensure_emu()
     _two_rank_vs_single(tmp_path, {})
+
+
+def test_zero_grad_between_forward_and_backward_keeps_the_arena(tmp_path):
+    """model.zero_grad(set_to_none=True) after the forward pass used to leave the fused optimiser / the all-reduce with a stale,
+    all-zero arena: gradients are re-homed instead."""
+    _ensure_emu()
+    _two_rank_vs_single(tmp_path, {'SS_DP_ZERO_LATE': '1'})
+
+
+def test_four_rank_step_equals_single_process_unbucketed(tmp_path):
+    _ensure_emu()
+    _ranks_vs_single(tmp_path, {'SS_DP_BUCKETED': '0'}, 4)
 
 
 @pytest.mark.gpu
