@@ -27,30 +27,42 @@ def _workspace_layout(shapes):
     return rows, off
 
 
+class DtwBatch(object):
+    """Device-side descriptors, workspace and result buffer of one batch of DTW problems (shapes / offsets / strides as for
+    dtw_align_batch).  Building it is host work (descriptor table, one H2D copy); run() only enqueues the two kernels, so a
+    caller that aligns batches of the same shapes repeatedly (benchmarks, evaluation loops) pays the host part once."""
+
+    def __init__(self, shapes, offsets, strides, device):
+        n = len(shapes)
+        for N, M in shapes:
+            if N < 1 or M < 1:
+                raise ValueError('DTW cost matrix must be non-empty, got %dx%d' % (N, M))
+        layout, ws_bytes = _workspace_layout(shapes)
+        self.res_offs, tot = [], 0
+        desc = np.zeros((n, _DESC), dtype=np.int64)
+        for b, ((N, M), off, st, (sk, dr, bd)) in enumerate(zip(shapes, offsets, strides, layout)):
+            desc[b] = [N, M, off, st[0], st[1], sk, dr, bd, tot, 0]
+            self.res_offs.append(tot)
+            tot += N
+        self.n, self.max_n, self.max_m = n, max(s[0] for s in shapes), max(s[1] for s in shapes)
+        self.desc = torch.from_numpy(desc).to(device, non_blocking=True)
+        self.ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=device)
+        self.results = torch.empty(max(tot, 1), dtype=torch.int32, device=device)
+        self.cells = float(sum(N * M for N, M in shapes))
+
+    def run(self, costs):
+        assert costs.dtype == torch.float32
+        rc = _lib.lib().ss_dtw_align(_lib.ptr(costs), _lib.ptr(self.desc), self.n, self.max_n, self.max_m,
+                                     _lib.ptr(self.ws), _lib.ptr(self.results), _lib.stream_of(costs))
+        _lib.check(rc, 'ss_dtw_align')
+        return self.results, self.res_offs
+
+
 def dtw_align_batch(costs, shapes, offsets, strides):
     """costs: one f32 device tensor holding every matrix; matrix b has logical shape shapes[b] = (N, M),
     starts at element offsets[b] and element (i, j) sits at offsets[b] + i*strides[b][0] + j*strides[b][1].
     Returns (results int32 device tensor, list of per-matrix offsets into it).  No host sync."""
-    assert costs.dtype == torch.float32
-    n = len(shapes)
-    for N, M in shapes:
-        if N < 1 or M < 1:
-            raise ValueError('DTW cost matrix must be non-empty, got %dx%d' % (N, M))
-    dev = costs.device
-    layout, ws_bytes = _workspace_layout(shapes)
-    res_offs, tot = [], 0
-    desc = np.zeros((n, _DESC), dtype=np.int64)
-    for b, ((N, M), off, st, (sk, dr, bd)) in enumerate(zip(shapes, offsets, strides, layout)):
-        desc[b] = [N, M, off, st[0], st[1], sk, dr, bd, tot, 0]
-        res_offs.append(tot)
-        tot += N
-    desc_dev = torch.from_numpy(desc).to(dev, non_blocking=True)
-    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
-    results = torch.empty(max(tot, 1), dtype=torch.int32, device=dev)
-    rc = _lib.lib().ss_dtw_align(_lib.ptr(costs), _lib.ptr(desc_dev), n, max(s[0] for s in shapes), max(s[1] for s in shapes),
-                                 _lib.ptr(ws), _lib.ptr(results), _lib.stream_of(costs))
-    _lib.check(rc, 'ss_dtw_align')
-    return results, res_offs
+    return DtwBatch(shapes, offsets, strides, costs.device).run(costs)
 
 
 def align_from_distances(distance_matrix, debug=False, device=None):

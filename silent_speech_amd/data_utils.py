@@ -84,8 +84,6 @@ def _mel_basis(sampling_rate, n_fft, num_mels, fmin, fmax, device, ld):
 def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False):
     """y: (B, L) float32 in [-1, 1] on the GPU -> (B, num_mels, F) float32 log-mel, F = 1 + (L + n_fft - hop - n_fft)//hop.
     (The reference's min/max range warnings (:40-43) would force a device sync and are omitted.)"""
-    if center:
-        raise NotImplementedError('the reference always calls mel_spectrogram with center=False (data_utils.py:79)')
     if y.dim() != 2 or y.dtype != torch.float32:
         raise ValueError('y must be a float32 (B, L) tensor')
     if hop_size % 4 or n_fft % 4:
@@ -94,13 +92,23 @@ def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin,
     B, L = y.shape
     pad = int((n_fft - hop_size) / 2)
     Lp = L + 2 * pad
-    if Lp < n_fft:
-        raise ValueError('signal too short for one frame')
-    F = 1 + (Lp - n_fft) // hop_size
     dev = y.device
     ldp = (Lp + 3) // 4 * 4
     ypad = torch.zeros(B, ldp, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().ss_reflect_pad(_lib.ptr(y), _lib.ptr(ypad), B, L, pad, ldp, _lib.stream_of(y)), 'ss_reflect_pad')
+    if center:          # torch.stft(center=True, pad_mode='reflect') (data_utils.py:54): n_fft//2 more samples, reflected off the PADDED signal
+        pad2 = n_fft // 2
+        if pad2 >= Lp:
+            raise ValueError('signal too short for centred frames')
+        Lp2 = Lp + 2 * pad2
+        ldp2 = (Lp2 + 3) // 4 * 4
+        ypad2 = torch.zeros(B, ldp2, dtype=torch.float32, device=dev)
+        src = ypad if ldp == Lp else ypad[:, :Lp].contiguous()
+        _lib.check(_lib.lib().ss_reflect_pad(_lib.ptr(src), _lib.ptr(ypad2), B, Lp, pad2, ldp2, _lib.stream_of(y)), 'ss_reflect_pad')
+        ypad, Lp, ldp = ypad2, Lp2, ldp2
+    if Lp < n_fft:
+        raise ValueError('signal too short for one frame')
+    F = 1 + (Lp - n_fft) // hop_size
     nb = n_fft // 2 + 1
     W = _windowed_dft(n_fft, win_size, dev)
     ld_spec = (2 * nb + 7) // 8 * 8

@@ -14,6 +14,27 @@ class FusedAdamW(torch.optim.Optimizer):
         self._m = self._v = None
         self._t = 0
 
+    def state_dict(self):
+        """torch.optim.Optimizer.state_dict() plus the fused state (first / second moments over the flat arena, step count):
+        the moments live outside Optimizer.state, so the base class alone would silently drop them."""
+        sd = super().state_dict()
+        sd['fused'] = {'step': self._t, 'exp_avg': None if self._m is None else self._m.detach().cpu().clone(),
+                       'exp_avg_sq': None if self._v is None else self._v.detach().cpu().clone()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        fused = state_dict.pop('fused', None)
+        super().load_state_dict(state_dict)
+        if fused is not None:
+            flat, _, n = self.model.flat_arenas()
+            self._t = int(fused['step'])
+            if fused['exp_avg'] is not None:
+                if fused['exp_avg'].numel() != n:
+                    raise ValueError('optimizer state of %d parameters, model has %d' % (fused['exp_avg'].numel(), n))
+                self._m = fused['exp_avg'].to(flat.device, torch.float32).clone()
+                self._v = fused['exp_avg_sq'].to(flat.device, torch.float32).clone()
+
     def zero_grad(self, set_to_none=False):
         flat, gflat, n = self.model.flat_arenas()
         gflat.zero_()
@@ -24,6 +45,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._m is None or self._m.device != flat.device or self._m.numel() != n:
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
+        if len(self.param_groups) != 1:
+            raise ValueError('FusedAdamW updates the whole flat arena with one set of hyper-parameters: exactly one param group')
         g = self.param_groups[0]
         self._t += 1
         ops.adamw_step(flat, gflat, self._m, self._v, n, float(g['lr']), self._t, beta1=g['betas'][0], beta2=g['betas'][1], eps=g['eps'],

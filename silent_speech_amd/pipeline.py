@@ -58,6 +58,63 @@ def mel_targets(audio, normalizer=None, max_frames=None):
     return normalize_features(mspec, normalizer) if normalizer is not None else mspec
 
 
+class SizeAwareSampler(torch.utils.data.Sampler):
+    """Drop-in for read_emg.py:115-140 -- same constructor (emg_dataset, max_len), same greedy packing under a budget of raw 1 kHz
+    EMG samples, reshuffled on every __iter__ with Python's `random`, text-less utterances skipped (:129-130), the incomplete
+    last batch dropped (:140).  Works on the reference's EMGDataset protocol (example_indices -> <idx>_info.json with 'text' and
+    'chunks') and on datasets that answer example_length(idx) directly (synthetic.SyntheticEMGDataset; None = skip).
+    rank / world / seed (keyword-only extras): data-parallel training deals batch i to rank i % world from a shuffle that every
+    rank derives from the shared seed and epoch (equal step counts, no communication)."""
+
+    def __init__(self, emg_dataset, max_len, *, rank=0, world=1, seed=None):
+        self.dataset, self.max_len, self.rank, self.world, self.seed, self.epoch = emg_dataset, max_len, rank, world, seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def _length(self, idx):
+        ds = self.dataset
+        if hasattr(ds, 'example_length'):
+            return ds.example_length(idx)
+        import json
+        import os
+        import string
+        directory_info, file_idx = ds.example_indices[idx]
+        with open(os.path.join(directory_info.directory, f'{file_idx}_info.json')) as f:
+            info = json.load(f)
+        if not np.any([l in string.ascii_letters for l in info['text']]):
+            return None
+        return sum([emg_len for emg_len, _, _ in info['chunks']])
+
+    def _batches(self):
+        import logging
+        indices = list(range(len(self.dataset)))
+        if self.world > 1 or self.seed is not None:
+            random.Random((self.seed or 0) * 1000003 + self.epoch).shuffle(indices)
+        else:
+            random.shuffle(indices)                         # read_emg.py:122
+        batch, batch_length = [], 0
+        for idx in indices:
+            length = self._length(idx)
+            if length is None:
+                continue
+            if length > self.max_len:
+                logging.warning(f'Warning: example {idx} cannot fit within desired batch length')
+            if length + batch_length > self.max_len:
+                yield batch
+                batch, batch_length = [], 0
+            batch.append(idx)
+            batch_length += length
+        # dropping last incomplete batch
+
+    def __iter__(self):
+        if self.world == 1:
+            return self._batches()
+        batches = [b for b in self._batches() if b]
+        usable = len(batches) - len(batches) % self.world    # equal step counts on every rank
+        return iter(batches[self.rank:usable:self.world])
+
+
 class ShardedSizeAwareSampler(torch.utils.data.Sampler):
     """read_emg.py:115-140 for data-parallel training: the same greedy packing under a budget of 1 kHz samples (shuffled
     order, the incomplete last batch dropped), with batch i going to rank i % world.  Every rank builds the identical list

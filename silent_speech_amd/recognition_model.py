@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .pipeline import SizeAwareSampler
 from .architecture import Model
 from .flags import FLAGS
 from .optim import FusedAdamW
@@ -165,7 +166,7 @@ def test(model, testset, device, *, batch_size=32):
 def train_model(trainset, devset, device, n_epochs=200, *, compute_dtype=torch.bfloat16, max_steps=None):
     """:61-117 on the MI355X: batches under a 128 000-sample budget, AdamW (lr 3e-4 in the reference's flags), linear
     warm-up, an optimiser step every SECOND batch (gradients accumulate in the flat .grad arena), MultiStepLR."""
-    dataloader = torch.utils.data.DataLoader(trainset, collate_fn=devset.collate_raw, num_workers=0, batch_sampler=trainset.size_aware_sampler(128000))
+    dataloader = torch.utils.data.DataLoader(trainset, collate_fn=devset.collate_raw, num_workers=0, batch_sampler=SizeAwareSampler(trainset, 128000))
     n_chars = len(devset.text_transform.chars)
     model = Model(devset.num_features, n_chars + 1, compute_dtype=compute_dtype).to(device)
     # flag defaults of recognition_model.py:20-28 (they differ from the transduction trainer's)

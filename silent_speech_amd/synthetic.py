@@ -46,6 +46,10 @@ class SyntheticEMGDataset(torch.utils.data.Dataset):
     def __getitem__(self, i):
         return self.items[i]
 
+    def example_length(self, i):
+        """Raw 1 kHz samples of utterance i: what read_emg.py:131 sums from the chunk table (SizeAwareSampler protocol)."""
+        return self.items[i]['length_1k']
+
     def subset(self, fraction):
         out = SyntheticEMGDataset(0)
         out.items = self.items[:max(1, int(fraction * len(self.items)))]

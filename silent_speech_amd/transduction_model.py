@@ -245,16 +245,20 @@ def train_model(trainset, devset, device, save_sound_outputs=True, *, compute_dt
     signature compatibility and ignored with a warning."""
     if save_sound_outputs:
         logging.warning('save_sound_outputs: HiFi-GAN vocoding / DeepSpeech evaluation are outside the MI355X hot path; skipped')
+    from .pipeline import SizeAwareSampler
     n_epochs = FLAGS.epochs
     training_subset = trainset if FLAGS.data_size_fraction >= 1 else trainset.subset(FLAGS.data_size_fraction)
-    dataloader = torch.utils.data.DataLoader(training_subset, collate_fn=devset.collate_raw, num_workers=0,
-                                             batch_sampler=training_subset.size_aware_sampler(256000))
+    dp = data_parallel if (data_parallel is not None and data_parallel.world > 1) else None
+    # transduction_model.py:166: SizeAwareSampler(training_subset, 256000); data-parallel ranks take every world-th batch of one shared shuffle
+    sampler = SizeAwareSampler(training_subset, 256000, rank=dp.rank, world=dp.world, seed=0) if dp is not None else SizeAwareSampler(training_subset, 256000)
+    dataloader = torch.utils.data.DataLoader(training_subset, collate_fn=devset.collate_raw, num_workers=0, batch_sampler=sampler)
     n_phones = len(phoneme_inventory)
     model = Model(devset.num_features, devset.num_speech_features, n_phones, compute_dtype=compute_dtype).to(device)
     if FLAGS.start_training_from is not None:
         model.load_state_dict(torch.load(FLAGS.start_training_from), strict=False)
     if data_parallel is not None:
         data_parallel.attach(model)
+    main_rank = dp is None or dp.rank == 0
     optim = FusedAdamW(model, weight_decay=FLAGS.l2)
     lr_sched = torch.optim.lr_scheduler.ReduceLROnPlateau(optim, 'min', 0.5, patience=FLAGS.learning_rate_patience)
 
@@ -272,10 +276,13 @@ def train_model(trainset, devset, device, save_sound_outputs=True, *, compute_dt
     batch_idx = 0
     for epoch_idx in range(n_epochs):
         losses = []
+        sampler.set_epoch(epoch_idx)
         for batch in dataloader:
             optim.zero_grad()
             schedule_lr(batch_idx)
             X, X_raw, sess = _pack_batch(batch, device)
+            if data_parallel is not None:
+                data_parallel.begin_step(X_raw.shape[0] * (X_raw.shape[1] // 8), data_parallel.local_target_frames(batch))
             pred, phoneme_pred = model(X, X_raw, sess)
             total = data_parallel.global_total(batch) if data_parallel is not None else None
             loss, _ = dtw_loss(pred, phoneme_pred, batch, total_length=total)
@@ -288,12 +295,13 @@ def train_model(trainset, devset, device, save_sound_outputs=True, *, compute_dt
             if max_steps is not None and batch_idx >= max_steps:
                 break
         train_loss = float(torch.stack(losses).mean()) if losses else float('nan')      # one sync per epoch instead of per step (:207)
-        val, phoneme_acc, _ = test(model, devset, device)
+        val, phoneme_acc, _ = test(model, devset, device)                                 # every rank evaluates (identical weights): the plateau scheduler stays in step
         lr_sched.step(val)
-        logging.info(f'finished epoch {epoch_idx+1} - validation loss: {val:.4f} training loss: {train_loss:.4f} phoneme accuracy: {phoneme_acc*100:.2f}')
-        out_dir = FLAGS.output_directory
-        os.makedirs(out_dir, exist_ok=True)
-        torch.save(model.state_dict(), os.path.join(out_dir, 'model.pt'))                 # :217
+        if main_rank:
+            logging.info(f'finished epoch {epoch_idx+1} - validation loss: {val:.4f} training loss: {train_loss:.4f} phoneme accuracy: {phoneme_acc*100:.2f}')
+            out_dir = FLAGS.output_directory
+            os.makedirs(out_dir, exist_ok=True)
+            torch.save(model.state_dict(), os.path.join(out_dir, 'model.pt'))             # :217
         if max_steps is not None and batch_idx >= max_steps:
             break
     return model

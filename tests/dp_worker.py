@@ -64,6 +64,31 @@ def build_model():
     return m
 
 
+def train_model_mode(out, dev, world, rank):
+    """Two steps of the drop-in train_model() with data_parallel=...: begin_step per batch, rank-sharded batches of one shared
+    shuffle, checkpoint written by rank 0 only."""
+    from silent_speech_amd import transduction_model as tm
+    from silent_speech_amd.distributed import DataParallel
+    from silent_speech_amd.flags import FLAGS
+    from silent_speech_amd.synthetic import SyntheticEMGDataset
+    FLAGS.model_size, FLAGS.num_layers, FLAGS.epochs, FLAGS.dropout = 16, 1, 1, 0.0
+    FLAGS.output_directory = os.path.join(os.path.dirname(out), 'ckpt_rank%d' % rank)
+    train = SyntheticEMGDataset(12, seed=1, min_frames=40, max_frames=80)
+    devset = SyntheticEMGDataset(3, seed=2, min_frames=40, max_frames=60)
+    for it in train.items:
+        it['length_1k'] = 1000                                           # 4 utterances per batch of 4000 "samples"
+    import silent_speech_amd.pipeline as pl
+    orig = pl.SizeAwareSampler.__init__
+
+    def small_budget(self, ds, max_len, **kw):
+        orig(self, ds, 4000, **kw)
+    pl.SizeAwareSampler.__init__ = small_budget
+    dp = DataParallel() if world > 1 else None
+    model = tm.train_model(train, devset, dev, save_sound_outputs=False, compute_dtype=torch.float32, max_steps=2, data_parallel=dp)
+    flat, _, n = model.flat_arenas()
+    torch.save({'flat': flat.clone().cpu(), 'saved': os.path.exists(os.path.join(FLAGS.output_directory, 'model.pt'))}, out + '.rank%d' % rank)
+
+
 def main():
     out = sys.argv[1]
     from silent_speech_amd import _lib
@@ -78,6 +103,12 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     if world > 1:
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % os.environ['MASTER_PORT'], rank=rank, world_size=world)
+    if os.environ.get('SS_DP_TRAIN_MODEL') == '1':
+        train_model_mode(out, dev, world, rank)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     model = build_model().to(dev)
     dp = None
     if world > 1:

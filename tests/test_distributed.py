@@ -64,6 +64,22 @@ def test_four_rank_step_equals_single_process_unbucketed(tmp_path):
     _ranks_vs_single(tmp_path, {'SS_DP_BUCKETED': '0'}, 4)
 
 
+def test_train_model_data_parallel_two_ranks(tmp_path):
+    """train_model(..., data_parallel=DataParallel()) end to end on 2 ranks: it used to die in the first BatchNorm reduction (no
+    begin_step) and every rank saw the same batches; now the ranks stay bit-identical and only rank 0 writes the checkpoint."""
+    _ensure_emu()
+    worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
+    port = str(_free_port())
+    out = str(tmp_path / 'tm.pt')
+    env = dict(os.environ, OMP_NUM_THREADS='1', SS_DP_TRAIN_MODEL='1')
+    procs = [subprocess.Popen([sys.executable, worker, out], env=dict(env, WORLD_SIZE='2', RANK=str(r), MASTER_PORT=port, MASTER_ADDR='127.0.0.1')) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    a, b = torch.load(out + '.rank0'), torch.load(out + '.rank1')
+    assert torch.equal(a['flat'], b['flat']) and torch.isfinite(a['flat']).all()
+    assert a['saved'] and not b['saved']
+
+
 @pytest.mark.gpu
 def test_two_rank_step_equals_single_process_on_the_gpu(tmp_path):
     """The same contract through the HIP kernels: two gloo ranks share the one MI355X of the test box (RCCL itself needs one

@@ -70,3 +70,53 @@ def test_sharded_sampler_partitions_the_reference_packing():
     assert dealt == batches[:len(dealt)]
     ep1 = pipeline.ShardedSizeAwareSampler(lengths, 128000, 0, 1, seed=3); ep1.set_epoch(1)
     assert ep1.all_batches() != batches
+
+
+def test_size_aware_sampler_on_the_reference_dataset_protocol(tmp_path):
+    """SizeAwareSampler(emg_dataset, max_len) exactly as transduction_model.py:166 constructs it, on an object that only offers
+    what the reference's EMGDataset offers: example_indices -> (directory_info, file_idx) and <file_idx>_info.json on disk."""
+    import json
+    import random
+
+    class _Dir(object):
+        def __init__(self, d):
+            self.directory = d
+    rng = np.random.default_rng(5)
+    d = str(tmp_path)
+    lengths = {}
+    for i in range(60):
+        chunks = [[int(v), 0, 0] for v in rng.integers(500, 3000, 3)]
+        text = '' if i % 13 == 5 else 'utterance %d' % i                  # text-less utterances are skipped (read_emg.py:129-130)
+        with open(os.path.join(d, '%d_info.json' % i), 'w') as f:
+            json.dump({'text': text, 'chunks': chunks}, f)
+        lengths[i] = None if not text else sum(c[0] for c in chunks)
+
+    class _DS(object):
+        example_indices = [(_Dir(d), i) for i in range(60)]
+
+        def __len__(self):
+            return 60
+    random.seed(11)
+    batches = list(pipeline.SizeAwareSampler(_DS(), 20000))
+    flat = [i for b in batches for i in b]
+    assert len(set(flat)) == len(flat) and all(lengths[i] is not None for i in flat)
+    assert all(sum(lengths[i] for i in b) <= 20000 for b in batches) and len(batches) >= 3
+    random.seed(12)
+    assert list(pipeline.SizeAwareSampler(_DS(), 20000)) != batches         # reshuffled on every __iter__ (read_emg.py:122)
+    # data-parallel extras: every rank gets the same number of batches of one shared shuffle
+    shards = [list(pipeline.SizeAwareSampler(_DS(), 20000, rank=r, world=2, seed=4)) for r in range(2)]
+    assert len(shards[0]) == len(shards[1]) and not (set(map(tuple, shards[0])) & set(map(tuple, shards[1])))
+
+
+def test_mel_spectrogram_center_true_matches_torch_stft(dev):
+    """center=True is forwarded to torch.stft by the reference (data_utils.py:54): n_fft // 2 extra samples reflected off the padded signal."""
+    from silent_speech_amd.data_utils import mel_spectrogram, slaney_mel_filterbank
+    g = torch.Generator().manual_seed(3)
+    y = (torch.rand(2, 256 * 8, generator=g) * 2 - 1) * 0.5
+    got = mel_spectrogram(y.to(dev), 1024, 80, 22050, 256, 1024, 0, 8000, center=True).cpu()
+    pad = (1024 - 256) // 2
+    yp = torch.nn.functional.pad(y.unsqueeze(1), (pad, pad), mode='reflect').squeeze(1)
+    spec = torch.stft(yp, 1024, hop_length=256, win_length=1024, window=torch.hann_window(1024), center=True, pad_mode='reflect', normalized=False,
+                      onesided=True, return_complex=True)
+    want = torch.log(torch.clamp(torch.from_numpy(slaney_mel_filterbank(22050, 1024, 80, 0, 8000)) @ torch.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9), min=1e-5))
+    assert got.shape == want.shape and float((got - want).abs().mean()) < 1e-4

@@ -61,3 +61,33 @@ def test_recognition_train_model_runs_and_learns(tiny_flags):
     assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], losses
     wer = rm.test(model, train, 'cuda')
     assert 0.0 <= wer
+
+
+def test_fused_adamw_state_dict_round_trip():
+    """state_dict() / load_state_dict() carry the fused moments and the step count (they live outside Optimizer.state)."""
+    from tests import backend
+    backend._ensure_emu()
+    _lib.use_library_for_testing(backend.EMU)
+    from silent_speech_amd.architecture import Model
+    from silent_speech_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    m = Model(112, 80, 48, model_size=8, num_layers=1, dropout=0.0, compute_dtype=torch.float32)
+    opt = FusedAdamW(m, lr=1e-2, weight_decay=0.0)
+    _, gflat, n = m.flat_arenas()
+    for _ in range(2):
+        gflat.copy_(torch.randn(n))
+        opt.step()
+    sd = opt.state_dict()
+    assert sd['fused']['step'] == 2 and sd['fused']['exp_avg'].numel() == n and float(sd['fused']['exp_avg'].abs().max()) > 0
+    m2 = Model(112, 80, 48, model_size=8, num_layers=1, dropout=0.0, compute_dtype=torch.float32)
+    m2.load_state_dict(m.state_dict())
+    opt2 = FusedAdamW(m2, lr=1e-2, weight_decay=0.0)
+    opt2.load_state_dict(sd)
+    g = torch.randn(n)
+    for mm, oo in ((m, opt), (m2, opt2)):
+        mm.flat_arenas()[1].copy_(g)
+        oo.step()
+    assert torch.equal(m.flat_arenas()[0], m2.flat_arenas()[0])
+    with pytest.raises(ValueError, match='one param group'):
+        opt.add_param_group({'params': [torch.nn.Parameter(torch.zeros(1))]})
+        opt.step()
