@@ -62,6 +62,14 @@ typedef struct ss_gemm_epilogue {
                                the attention kernels read as MFMA B operands                          */
     ss_rowmap cmap2;
     int64_t col_stride2;
+    /* optional per-column statistics of the STORED result (f32, accumulated with atomics; the caller zeroes them):
+       col_sum[n] += sum_m (C[m][n] - shift[n]),  col_sumsq[n] += sum_m (C[m][n] - shift[n])^2   (shift NULL = 0, col_sumsq may be NULL).
+       Serves nn.Linear bias gradients (column sums of dY) and the BatchNorm batch statistics of a convolution output
+       (architecture.py:19,21,25) without a separate pass over the tensor.  Only the 8-wave kernel computes them: ask
+       ss_gemm_fuses_column_stats() first and fall back to ss_colsum / ss_bn_stats_sums when it answers 0. */
+    float* col_sum;
+    float* col_sumsq;
+    const float* col_shift;
 } ss_gemm_epilogue;
 
 #define SS_OP_KC 0   /* reduction index contiguous:  elem(o, r) = p[rowmap(o) + r] */
@@ -84,6 +92,10 @@ int ss_gemm_set_blocks_per_cu(int n); /* [host] */
  * 2 gemm_w2_kernel, 3 / 4 gemm8_kc_kernel with 256 / 288-row tiles (so that a profiler can attribute per-launch timings to
  * the kernel names rocprofv3 reports, and tests can assert which variant they exercised). */
 int ss_gemm_last_kernel(void); /* [host] */
+/* 1 if ss_gemm with these arguments runs the 8-wave kernel, which honours epilogue.col_sum / col_sumsq; 0 otherwise (the call then fails
+ * with those fields set).  Same decision procedure as ss_gemm itself (legality + cost model + knobs). */
+int ss_gemm_fuses_column_stats(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* C, int M, int N, int K, const ss_rowmap* amap,
+                               const ss_rowmap* bmap, const ss_rowmap* cmap, const ss_gemm_epilogue* epilogue, int split_k); /* [host] */
 /* Kernel-selection knobs of ss_gemm (process-wide): what = 0 two-wave kernel (0 never / 1 cost model / 2 whenever legal),
  * 1 its tile height (128 / 144, 0 = cost model), 2 eight-wave kernel (0 / 1 / 2 as above), 3 its tile height in 16-row units
  * per M-wave (8 / 9, 0 = cost model), 4 its LDS reads / DMA pieces spread between MFMA groups (0 / 1, 2 = per tile height), 5 ablation mask for kernel tuning (results are
@@ -160,6 +172,10 @@ int64_t ss_bn_scratch_floats(int B, int T, int C); /* [host] */
 int ss_bn_stats_sums(int dtype, const void* x, int B, int T, int C, int pad, float* scratch, const float* shift, float* sums, void* stream);
 int ss_bn_finalize(const float* sums, double n_total, int C, float* mean, float* invstd, float* running_mean, float* running_var,
                    float momentum, float eps, int training, void* stream);
+/* The same with the shift vector passed separately (sums = [2][C]): for sums produced by a GEMM epilogue (ss_gemm_epilogue.col_sum /
+ * col_sumsq with col_shift = shift, e.g. the running mean BEFORE this update; shift may alias running_mean). */
+int ss_bn_finalize_shift(const float* sums, const float* shift, double n_total, int C, float* mean, float* invstd, float* running_mean,
+                         float* running_var, float momentum, float eps, int training, void* stream);
 /* y = act( bn_a(xa) [+ bn_b(xb)] ),  act = ReLU if relu */
 int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const float* invstd_a, const float* gamma_a, const float* beta_a, int pad_xa,
                 const void* xb, const float* mean_b, const float* invstd_b, const float* gamma_b, const float* beta_b, int pad_xb,
@@ -192,6 +208,12 @@ int ss_add_dropout_layernorm_forward(int dtype, const void* x, void* branch_inou
 int ss_layernorm_backward(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                           void* dres, void* dbranch, float* dgamma, float* dbeta, int rows, int C, float dropout_p, uint64_t seed,
                           uint32_t rng_stream, void* stream);
+
+/* The same, also accumulating dbranch_colsum[c] += sum_rows dbranch[row][c] (as stored, i.e. rounded to dtype): the bias gradient of
+ * the nn.Linear that produced the branch (linear2 of transformer.py:58), without a separate pass over dbranch. */
+int ss_layernorm_backward_bias(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                               void* dres, void* dbranch, float* dgamma, float* dbeta, float* dbranch_colsum, int rows, int C, float dropout_p,
+                               uint64_t seed, uint32_t rng_stream, void* stream);
 
 /* EMG input conditioning: training-time shift augmentation (architecture.py:64-68: x[:, :-r] = x[:, r:],
  * x[:, -r:] = 0), cast to the compute dtype and zero halo rows: x_raw (B,T0,Cin) f32 ->
@@ -292,7 +314,7 @@ void ss_plan_destroy(ss_plan* plan);                                /* [host] */
 int ss_plan_slot_count(const ss_plan* plan);                        /* [host] */
 const char* ss_plan_slot_name(const ss_plan* plan, int slot);       /* [host] */
 int ss_plan_bind(ss_plan* plan, int slot, void* device_ptr_or_value); /* [host] slots named *.total / *.all_f32 / *.bytes take integers */
-int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU */
+int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off */
 int ss_plan_set_reduce_hook(ss_plan* plan, ss_reduce_hook fn, void* user); /* [host] */
 int ss_plan_set_event_hook(ss_plan* plan, ss_event_hook fn, void* user);   /* [host] */
 int64_t ss_plan_ctx_bytes(void);                                    /* [host] */

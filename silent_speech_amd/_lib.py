@@ -27,7 +27,8 @@ class GemmEpilogue(ctypes.Structure):
                 ('alpha', ctypes.c_float), ('relu', ctypes.c_int32), ('dropout_p', ctypes.c_float),
                 ('seed', ctypes.c_uint64), ('rng_stream', ctypes.c_uint32), ('mode', ctypes.c_int32),
                 ('col_mod', ctypes.c_int32), ('col_mul', ctypes.c_int32), ('col_div_mul', ctypes.c_int32),
-                ('log_clamp', ctypes.c_float), ('c2', ctypes.c_void_p), ('cmap2', RowMap), ('col_stride2', ctypes.c_int64)]
+                ('log_clamp', ctypes.c_float), ('c2', ctypes.c_void_p), ('cmap2', RowMap), ('col_stride2', ctypes.c_int64),
+                ('col_sum', ctypes.c_void_p), ('col_sumsq', ctypes.c_void_p), ('col_shift', ctypes.c_void_p)]
 
 
 class DwJob(ctypes.Structure):
@@ -63,12 +64,14 @@ SIGNATURES = {
     'ss_relpos_attention_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_bn_stats_sums': [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     'ss_bn_finalize': [_P, ctypes.c_double, _I, _P, _P, _P, _P, _F, _F, _I, _P],
+    'ss_bn_finalize_shift': [_P, _P, ctypes.c_double, _I, _P, _P, _P, _P, _F, _F, _I, _P],
     'ss_bn_apply': [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'ss_bn_backward_sums': [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'ss_bn_backward_apply': [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, ctypes.c_double, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'ss_colsum': [_I, _P, _I, _I, _L, _P, _P, _P],
     'ss_add_dropout_layernorm_forward': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_layernorm_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _P],
+    'ss_layernorm_backward_bias': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _P],
     'ss_emg_prepare': [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     'ss_frame_lse': [_P, _L, _I, _I, _I, _P, _P, _P],
     'ss_voiced_loss': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],
@@ -88,6 +91,8 @@ _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int6
                'ss_gemm_set_blocks_per_cu': ([_I], ctypes.c_int),
                'ss_gemm_last_kernel': ([], ctypes.c_int),
                'ss_gemm_set_option': ([_I, _I], ctypes.c_int),
+               'ss_gemm_fuses_column_stats': ([_I, _I, _I, _I, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), ctypes.POINTER(RowMap),
+                                               ctypes.POINTER(GemmEpilogue), _I], ctypes.c_int),
                'ss_gemm_dw_set_option': ([_I, _I], ctypes.c_int),
                'ss_plan_create': ([_P], _P), 'ss_plan_destroy': ([_P], None), 'ss_plan_slot_count': ([_P], ctypes.c_int),
                'ss_plan_slot_name': ([_P, _I], ctypes.c_char_p), 'ss_plan_bind': ([_P, _I, _P], ctypes.c_int),

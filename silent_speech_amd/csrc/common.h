@@ -87,11 +87,45 @@ template <> struct Vec8<bf16_t> {
     }
 };
 
+// raw (unconverted) 8-element chunks: load now, convert at the use -> the load stays in flight across unrelated work
+template <class T> struct RawVec8;
+template <> struct RawVec8<bf16_t> {
+    typedef u32x4 type;
+    static __device__ __forceinline__ type load(const bf16_t* p) { return *(const u32x4*)p; }
+    static __device__ __forceinline__ type zero() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
+    static __device__ __forceinline__ void unpack(const type& r, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(r[i] << 16); v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+    }
+};
+struct f32x8_raw { f32x4 a, b; };
+template <> struct RawVec8<float> {
+    typedef f32x8_raw type;
+    static __device__ __forceinline__ type load(const float* p) { type r; r.a = *(const f32x4*)p; r.b = *(const f32x4*)(p + 4); return r; }
+    static __device__ __forceinline__ type zero() { type r; f32x4 z = {0.f, 0.f, 0.f, 0.f}; r.a = z; r.b = z; return r; }
+    static __device__ __forceinline__ void unpack(const type& r, float (&v)[8]) { v[0] = r.a[0]; v[1] = r.a[1]; v[2] = r.a[2]; v[3] = r.a[3]; v[4] = r.b[0]; v[5] = r.b[1]; v[6] = r.b[2]; v[7] = r.b[3]; }
+};
+
 // ------------------------------------------------------------------ wave helpers (wave = 64)
+// Sum over the 64 lanes, returned in every lane.  DPP adds (quad swaps, row half-mirror / mirror, row broadcasts) + one readlane: six
+// full-rate VALU ops instead of six ds_bpermute round trips through the LDS crossbar (their latency sat on the critical path of every
+// LayerNorm row).
 __device__ __forceinline__ float wave_sum(float v) {
+#if defined(SS_EMU)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
+#else
+#define SS_DPP_ADD(CTRL, ROWMASK) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xf, true))
+    SS_DPP_ADD(0xB1, 0xf);        // quad_perm [1,0,3,2]
+    SS_DPP_ADD(0x4E, 0xf);        // quad_perm [2,3,0,1]
+    SS_DPP_ADD(0x141, 0xf);       // row_half_mirror: lanes of 8
+    SS_DPP_ADD(0x140, 0xf);       // row_mirror: every lane of a 16-lane row holds the row sum
+    SS_DPP_ADD(0x142, 0xa);       // row_bcast:15 into rows 1 and 3
+    SS_DPP_ADD(0x143, 0xc);       // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef SS_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -673,6 +673,43 @@ static int gemm_slots() {
 #endif
 }
 
+// Does this problem run the 8-wave 256 / 288 x 256 kernel (gemm8.hip: one workgroup per CU, fragment reads travelling under the MFMAs)?
+// Legality (bf16, both operands K-contiguous, K % 64 == 0, LDS-staged epilogue, 32-bit operand offsets) + a measured cost model
+// (tools/gemm_bench.cpp, 22 000 .. 88 000 rows, us): a tile costs 13 + 0.0245 K (256 rows) or 13 + 0.0295 K (288 rows) while the whole chip
+// streams; a last round of `rem` tiles runs faster (0.55 + 0.45 rem / CUs of a tile).  The 128-wide kernels sustain ~560 TFLOP/s at
+// K <= 1024 and ~680 beyond, plus ~6 us.
+static bool pick_gemm8(bool bf16_in, int a_mode, int b_mode, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, int split_k, int* ni_out, int* pin_out)
+{
+    if (!(bf16_in && gemm_opt(OPT_G8) && a_mode == OP_KC && b_mode == OP_KC && epi.fast && !epi.c2 && split_k == 1 && K % 64 == 0 && K > 0)) return false;
+    const int cus = gemm_slots() / g_blocks_per_cu;
+    auto max_off = [](const RowMap& m, int rows, int K_) {     // largest element offset the kernel forms for this operand
+        const long long nb = m.rows_per_batch == 0x7fffffff ? 0 : (rows - 1) / m.rows_per_batch;
+        const long long rr = m.rows_per_batch == 0x7fffffff ? rows - 1 : m.rows_per_batch - 1;
+        return m.base + nb * (m.batch_stride > 0 ? m.batch_stride : 0) + rr * (m.row_stride > 0 ? m.row_stride : 0) + K_;
+    };
+    const bool fits = am.base >= 0 && bm.base >= 0 && am.row_stride >= 0 && bm.row_stride >= 0 && am.batch_stride >= 0 && bm.batch_stride >= 0 &&
+                      max_off(am, M, K) * 2 < 0xffffffffLL && max_off(bm, N, K) * 2 < 0xffffffffLL;
+    if (!fits) return false;
+    const int ni_force = gemm_opt(OPT_G8_NI);
+    double best8 = 0; int ni = 0;
+    for (int cand = 8; cand <= 9; ++cand) {
+        if (ni_force && cand != ni_force) continue;
+        const int bmt = 32 * cand;
+        const long long t = (long long)((M + bmt - 1) / bmt) * ((N + 255) / 256);
+        const double tile = 13.0 + (cand == 9 ? 0.0295 : 0.0245) * K;
+        const long long full = t / cus, rem = t % cus;
+        const double cost = 5.0 + full * tile + (rem ? tile * (0.55 + 0.45 * (double)rem / cus) : 0.0);
+        if (!ni || cost < best8) { best8 = cost; ni = cand; }
+    }
+    const double cost_old = 6.0 + 2.0 * M * N * K / ((K <= 1024 ? 560.0 : 680.0) * 1e6);
+    if (!ni || !(gemm_opt(OPT_G8) == 2 || best8 < cost_old)) return false;
+    // spreading the fragment reads / DMA pieces between the MFMA groups pays on the 256-row tiles (+12 %); the 288-row variant of it
+    // spills (144 accumulator registers) and loses on multi-tile shapes
+    *ni_out = ni;
+    *pin_out = gemm_opt(OPT_G8_PIN) >= 0 && gemm_opt(OPT_G8_PIN) <= 1 ? gemm_opt(OPT_G8_PIN) : (ni == 8 ? 1 : 0);
+    return true;
+}
+
 template <class T, class TO>
 static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, void* C, int M, int N, int K,
                        const RowMap& am, const RowMap& bm, const GemmEpi& epi, int split_k, void* stream)
@@ -687,43 +724,14 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     const int nitems = tiles_m * tiles_n * split_k;
     const int slots = gemm_slots();
     dim3 grid(nitems < slots ? nitems : slots), block(256);
-    // 8-wave 256 / 288 x 256 kernel (gemm8.hip): one workgroup per CU, fragment reads travelling under the MFMAs.
-    // Cost model in MACs a CU works through: ceil(tiles / CUs) whole tiles of (rows x 256 x (K + fixed)), against the 128-wide
-    // kernels' own round model below at their measured relative rate.
-    if (sizeof(T) == 2 && gemm_opt(OPT_G8) && a_mode == OP_KC && b_mode == OP_KC && epi.fast && !epi.c2 && split_k == 1 && K % 64 == 0) {
-        const int cus = slots / g_blocks_per_cu;
-        auto max_off = [](const RowMap& m, int rows, int K_) {     // largest element offset the kernel forms for this operand
-            const long long nb = m.rows_per_batch == 0x7fffffff ? 0 : (rows - 1) / m.rows_per_batch;
-            const long long rr = m.rows_per_batch == 0x7fffffff ? rows - 1 : m.rows_per_batch - 1;
-            return m.base + nb * (m.batch_stride > 0 ? m.batch_stride : 0) + rr * (m.row_stride > 0 ? m.row_stride : 0) + K_;
-        };
-        const bool fits = am.base >= 0 && bm.base >= 0 && am.row_stride >= 0 && bm.row_stride >= 0 && am.batch_stride >= 0 && bm.batch_stride >= 0 &&
-                          max_off(am, M, K) * 2 < 0xffffffffLL && max_off(bm, N, K) * 2 < 0xffffffffLL;
-        if (fits) {
-            // Measured model (tools/gemm_bench.cpp, 22 000 .. 88 000 rows, us): a tile costs 13 + 0.0245 K (256 rows) or 13 + 0.0295 K
-            // (288 rows) while the whole chip streams; a last round of `rem` tiles runs faster (0.55 + 0.45 rem / CUs of a tile).
-            // The 128-wide kernels sustain ~560 TFLOP/s at K <= 1024 and ~680 beyond, plus ~6 us.
-            const int ni_force = gemm_opt(OPT_G8_NI);
-            double best8 = 0; int ni = 0;
-            for (int cand = 8; cand <= 9; ++cand) {
-                if (ni_force && cand != ni_force) continue;
-                const int bmt = 32 * cand;
-                const long long t = (long long)((M + bmt - 1) / bmt) * ((N + 255) / 256);
-                const double tile = 13.0 + (cand == 9 ? 0.0295 : 0.0245) * K;
-                const long long full = t / cus, rem = t % cus;
-                const double cost = 5.0 + full * tile + (rem ? tile * (0.55 + 0.45 * (double)rem / cus) : 0.0);
-                if (!ni || cost < best8) { best8 = cost; ni = cand; }
-            }
-            const double cost_old = 6.0 + 2.0 * M * N * K / ((K <= 1024 ? 560.0 : 680.0) * 1e6);
-            if (ni && (gemm_opt(OPT_G8) == 2 || best8 < cost_old)) {
-                // spreading the fragment reads / DMA pieces between the MFMA groups pays on the 256-row tiles (+12 %); the 288-row
-                // variant of it spills (144 accumulator registers) and loses on multi-tile shapes
-                const int pin = gemm_opt(OPT_G8_PIN) >= 0 && gemm_opt(OPT_G8_PIN) <= 1 ? gemm_opt(OPT_G8_PIN) : (ni == 8 ? 1 : 0);
-                if (gemm8_launch_kc<TO>(ni, pin, A, B, C, M, N, K, am, bm, epi, stream)) return 1;
-                g_last_kernel = ni == 9 ? 4 : 3;
-                return 0;
-            }
+    {   // 8-wave 256 / 288 x 256 kernel (gemm8.hip)
+        int ni = 0, pin = 0;
+        if (pick_gemm8(sizeof(T) == 2, a_mode, b_mode, M, N, K, am, bm, epi, split_k, &ni, &pin)) {
+            if (gemm8_launch_kc<TO>(ni, pin, A, B, C, M, N, K, am, bm, epi, stream)) return 1;
+            g_last_kernel = ni == 9 ? 4 : 3;
+            return 0;
         }
+        if (epi.col_sum) { ss_set_error("ss_gemm: epilogue column statistics need the 8-wave kernel for this shape (ask ss_gemm_fuses_column_stats first)"); return 1; }
     }
     {   // 2-wave kernel: bf16 KC x KC with the plain LDS-staged epilogue (no transposed second output)
         const int w2_on = gemm_opt(OPT_W2);                                                  // 0 never, 1 heuristic, 2 whenever possible
@@ -781,6 +789,46 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     return 0;
 }
 
+static int build_epi(GemmEpi& epi, int dtype_out, const void* C, int M, int N, const ss_rowmap* cmap, const ss_gemm_epilogue* e, int split_k)
+{
+    memset(&epi, 0, sizeof(epi));
+    epi.alpha = 1.f; epi.gate_scale = 1.f; epi.drop_scale = 1.f;
+    epi.cmap = to_rowmap(cmap);
+    if (e) {
+        epi.bias = e->bias; epi.gate = e->gate; epi.gate_scale = e->gate_scale; epi.alpha = e->alpha; epi.relu = e->relu;
+        if (e->dropout_p > 0.f) { epi.drop_thresh = dropout_threshold(e->dropout_p); epi.drop_scale = 1.f / (1.f - e->dropout_p); }
+        epi.seed = e->seed; epi.stream = e->rng_stream; epi.mode = e->mode;
+        epi.col_mod = e->col_mod; epi.col_mul = e->col_mul; epi.col_div_mul = e->col_div_mul;
+        epi.log_clamp = e->log_clamp;
+        if (e->c2) { epi.c2 = e->c2; epi.cmap2 = to_rowmap(&e->cmap2); epi.col_stride2 = e->col_stride2; }
+        epi.col_sum = e->col_sum; epi.col_sumsq = e->col_sumsq; epi.col_shift = e->col_shift;
+        SS_CHECK(!(e->col_sumsq && !e->col_sum), "ss_gemm: col_sumsq needs col_sum");
+        SS_CHECK(e->mode >= 0 && e->mode <= 2, "ss_gemm: bad output mode %d", e->mode);
+        SS_CHECK(!(e->mode == 2 && dtype_out != SS_F32), "ss_gemm: atomic accumulation needs f32 output");
+        SS_CHECK(!(split_k > 1 && e->mode != 2), "ss_gemm: split_k > 1 needs mode 2 (atomic accumulate)");
+    } else {
+        SS_CHECK(split_k <= 1, "ss_gemm: split_k > 1 needs mode 2 (atomic accumulate)");
+    }
+    epi.debug = gemm_opt(OPT_DEBUG);
+    {
+        const int ev = dtype_out == SS_BF16 ? 8 : 4;
+        const RowMap& cm = epi.cmap;
+        epi.general = epi.drop_thresh != 0 ? 1 : (epi.log_clamp > 0.f ? 2 : 0);
+        epi.fast = !(epi.drop_thresh != 0 && epi.log_clamp > 0.f) && epi.mode != 2 && epi.col_mod == 0 && N % ev == 0 && cm.base % ev == 0 && cm.batch_stride % ev == 0 && cm.row_stride % ev == 0 &&
+                   ((uintptr_t)C) % 16 == 0 && (!epi.gate || ((uintptr_t)epi.gate) % 16 == 0);
+        if (epi.c2) {
+            const int pk = 4;      // rows per lane
+            const size_t osz = dtype_out == SS_BF16 ? 2 : 4;
+            const RowMap& c2m = epi.cmap2;
+            epi.c2_lds = dtype_out == SS_BF16 && !epi.general && c2m.row_stride == 1 && c2m.rows_per_batch % 8 == 0 && M % 8 == 0 && c2m.base % 8 == 0 &&
+                         c2m.batch_stride % 8 == 0 && epi.col_stride2 % 8 == 0 && ((uintptr_t)epi.c2) % 16 == 0;
+            epi.c2_pack = c2m.row_stride == 1 && c2m.rows_per_batch % pk == 0 && c2m.base % pk == 0 && c2m.batch_stride % pk == 0 && epi.col_stride2 % pk == 0 &&
+                          ((uintptr_t)epi.c2) % (pk * osz) == 0;
+        }
+    }
+    return 0;
+}
+
 extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, const void* B, void* C,
                        int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap,
                        const ss_gemm_epilogue* e, int split_k, void* stream)
@@ -807,41 +855,19 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
     }
     (void)esz;
     GemmEpi epi;
-    memset(&epi, 0, sizeof(epi));
-    epi.alpha = 1.f; epi.gate_scale = 1.f; epi.drop_scale = 1.f;
-    epi.cmap = to_rowmap(cmap);
-    if (e) {
-        epi.bias = e->bias; epi.gate = e->gate; epi.gate_scale = e->gate_scale; epi.alpha = e->alpha; epi.relu = e->relu;
-        if (e->dropout_p > 0.f) { epi.drop_thresh = dropout_threshold(e->dropout_p); epi.drop_scale = 1.f / (1.f - e->dropout_p); }
-        epi.seed = e->seed; epi.stream = e->rng_stream; epi.mode = e->mode;
-        epi.col_mod = e->col_mod; epi.col_mul = e->col_mul; epi.col_div_mul = e->col_div_mul;
-        epi.log_clamp = e->log_clamp;
-        if (e->c2) { epi.c2 = e->c2; epi.cmap2 = to_rowmap(&e->cmap2); epi.col_stride2 = e->col_stride2; }
-        SS_CHECK(e->mode >= 0 && e->mode <= 2, "ss_gemm: bad output mode %d", e->mode);
-        SS_CHECK(!(e->mode == 2 && dtype_out != SS_F32), "ss_gemm: atomic accumulation needs f32 output");
-        SS_CHECK(!(split_k > 1 && e->mode != 2), "ss_gemm: split_k > 1 needs mode 2 (atomic accumulate)");
-    } else {
-        SS_CHECK(split_k <= 1, "ss_gemm: split_k > 1 needs mode 2 (atomic accumulate)");
-    }
+    if (build_epi(epi, dtype_out, C, M, N, cmap, e, split_k)) return 1;
     RowMap am = to_rowmap(amap), bm = to_rowmap(bmap);
-    epi.debug = gemm_opt(OPT_DEBUG);
-    {
-        const int ev = dtype_out == SS_BF16 ? 8 : 4;
-        const RowMap& cm = epi.cmap;
-        epi.general = epi.drop_thresh != 0 ? 1 : (epi.log_clamp > 0.f ? 2 : 0);
-        epi.fast = !(epi.drop_thresh != 0 && epi.log_clamp > 0.f) && epi.mode != 2 && epi.col_mod == 0 && N % ev == 0 && cm.base % ev == 0 && cm.batch_stride % ev == 0 && cm.row_stride % ev == 0 &&
-                   ((uintptr_t)C) % 16 == 0 && (!epi.gate || ((uintptr_t)epi.gate) % 16 == 0);
-        if (epi.c2) {
-            const int pk = 4;      // rows per lane
-            const size_t osz = dtype_out == SS_BF16 ? 2 : 4;
-            const RowMap& c2m = epi.cmap2;
-            epi.c2_lds = dtype_out == SS_BF16 && !epi.general && c2m.row_stride == 1 && c2m.rows_per_batch % 8 == 0 && M % 8 == 0 && c2m.base % 8 == 0 &&
-                         c2m.batch_stride % 8 == 0 && epi.col_stride2 % 8 == 0 && ((uintptr_t)epi.c2) % 16 == 0;
-            epi.c2_pack = c2m.row_stride == 1 && c2m.rows_per_batch % pk == 0 && c2m.base % pk == 0 && c2m.batch_stride % pk == 0 && epi.col_stride2 % pk == 0 &&
-                          ((uintptr_t)epi.c2) % (pk * osz) == 0;
-        }
-    }
     if (dtype_in == SS_BF16 && dtype_out == SS_BF16) return launch_gemm<bf16_t, bf16_t>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
     if (dtype_in == SS_BF16 && dtype_out == SS_F32) return launch_gemm<bf16_t, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
     return launch_gemm<float, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
+}
+
+extern "C" int ss_gemm_fuses_column_stats(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* C, int M, int N, int K, const ss_rowmap* amap,
+                                          const ss_rowmap* bmap, const ss_rowmap* cmap, const ss_gemm_epilogue* e, int split_k)
+{
+    if (!amap || !bmap || !cmap || dtype_in != SS_BF16 || (dtype_out != SS_BF16 && dtype_out != SS_F32) || M <= 0 || N <= 0) return 0;
+    GemmEpi epi;
+    if (build_epi(epi, dtype_out, C, M, N, cmap, e, split_k)) return 0;
+    int ni = 0, pin = 0;
+    return pick_gemm8(true, a_mode, b_mode, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, split_k, &ni, &pin) ? 1 : 0;
 }

@@ -112,8 +112,11 @@ __device__ __forceinline__ void lds_wait_pin(bf16x8 (&f)[N]) {
 }
 
 // flush of an epilogue pass: the LDS piece holds IPP*16 rows of each of the two M halves of the tile
-template <class TO, int NI, int IPP>
-__device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* __restrict__ C, const GemmEpi& epi, int m0, int n0, int pass, int M, int N, int tid)
+// A thread always handles the same 16-byte column chunk (512 % CPR == 0), so the optional column statistics accumulate in registers
+// (cs / cq) over all rows the thread stores, across the passes of a tile.
+template <class TO, int NI, int IPP, bool STATS>
+__device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* __restrict__ C, const GemmEpi& epi, int m0, int n0, int pass, int M, int N, int tid,
+                                       float (&cs)[OutVec<TO>::N], float (&cq)[OutVec<TO>::N], const float (&sh)[OutVec<TO>::N])
 {
     constexpr int EV = OutVec<TO>::N, CPR = TBN / EV, R = IPP * 16, TOTAL = 2 * R * CPR;
     for (int idx = tid; idx < TOTAL; idx += 512) {
@@ -136,13 +139,18 @@ __device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* _
                 for (int e = 0; e < EV; ++e) v[e] += o[e];
             }
             outvec_store(C + off, v);
+            if (STATS) {
+#pragma unroll
+                for (int e = 0; e < EV; ++e) { const float x = rnd<TO>(v[e]) - sh[e]; cs[e] += x; cq[e] += x * x; }
+            }
         }
     }
 }
 
-template <class TO, int GEN, int NI, int IPP, int P, int NPASS>
+template <class TO, int GEN, int NI, int IPP, int P, int NPASS, bool STATS>
 struct Passes8 {
-    static __device__ __forceinline__ void run(const f32x4 (&acc)[NI][4], TO* ct, int ldc, TO* C, const GemmEpi& epi, int m0, int n0, int M, int N, int tid, int wm, int wn, int r, int q) {
+    static __device__ __forceinline__ void run(const f32x4 (&acc)[NI][4], TO* ct, int ldc, TO* C, const GemmEpi& epi, int m0, int n0, int M, int N, int tid, int wm, int wn, int r, int q,
+                                               float (&cs)[OutVec<TO>::N], float (&cq)[OutVec<TO>::N], const float (&sh)[OutVec<TO>::N]) {
 #pragma unroll
         for (int ii = 0; ii < IPP; ++ii) {
             constexpr int I0 = P * IPP;
@@ -154,22 +162,25 @@ struct Passes8 {
             }
         }
         barrier_keep_vm();
-        flush8<TO, NI, IPP>(ct, ldc, C, epi, m0, n0, P, M, N, tid);
+        flush8<TO, NI, IPP, STATS>(ct, ldc, C, epi, m0, n0, P, M, N, tid, cs, cq, sh);
         if (P + 1 < NPASS) barrier_keep_vm();
-        Passes8<TO, GEN, NI, IPP, P + 1, NPASS>::run(acc, ct, ldc, C, epi, m0, n0, M, N, tid, wm, wn, r, q);
+        Passes8<TO, GEN, NI, IPP, P + 1, NPASS, STATS>::run(acc, ct, ldc, C, epi, m0, n0, M, N, tid, wm, wn, r, q, cs, cq, sh);
     }
 };
-template <class TO, int GEN, int NI, int IPP, int NPASS>
-struct Passes8<TO, GEN, NI, IPP, NPASS, NPASS> {
-    static __device__ __forceinline__ void run(const f32x4 (&)[NI][4], TO*, int, TO*, const GemmEpi&, int, int, int, int, int, int, int, int, int) {}
+template <class TO, int GEN, int NI, int IPP, int NPASS, bool STATS>
+struct Passes8<TO, GEN, NI, IPP, NPASS, NPASS, STATS> {
+    static __device__ __forceinline__ void run(const f32x4 (&)[NI][4], TO*, int, TO*, const GemmEpi&, int, int, int, int, int, int, int, int, int,
+                                               float (&)[OutVec<TO>::N], float (&)[OutVec<TO>::N], const float (&)[OutVec<TO>::N]) {}
 };
 
 }  // namespace g8
 
 // ================================================================ KC x KC
 // PIN: 1 = fragment reads and DMA pieces spread between the MFMA groups of a phase, 0 = issued in a burst at the phase start.
+// STATS: the epilogue also accumulates per-column sums / sums of squares of the stored tile (a separate instantiation: the extra live
+// registers of that path would otherwise spill in the main loop of every launch).
 // ABL: compile-time ablation mask for tuning (results are wrong): 1 no MFMA, 2 no in-loop global->LDS copies, 4 no in-loop fragment reads.
-template <class TO, int NI, int PIN, int ABL>
+template <class TO, int NI, int PIN, int ABL, bool STATS>
 __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
                                                        int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi, int tiles_n, int nitems)
 {
@@ -305,9 +316,50 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
         constexpr int IPP = sizeof(TO) == 2 ? (NI % 3 == 0 ? 3 : 2) : 1;
         constexpr int NPASS = (NI + IPP - 1) / IPP;
         static_assert((size_t)2 * IPP * 16 * LDC * sizeof(TO) <= (size_t)STAGE, "C piece does not fit the free stage");
-        if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q);
-        else if (epi.general == 2) Passes8<TO, 2, NI, IPP, 0, NPASS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q);
-        else Passes8<TO, 0, NI, IPP, 0, NPASS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q);
+        constexpr int EV = OutVec<TO>::N, CPR = TBN / EV;
+        float cs[EV], cq[EV], sh[EV];
+#pragma unroll
+        for (int e = 0; e < EV; ++e) { cs[e] = 0.f; cq[e] = 0.f; sh[e] = 0.f; }
+        if constexpr (STATS) {
+            // column statistics of the stored tile: registers (per thread: one 16-byte column chunk, all its rows) -> per-wave LDS bins
+            // (plain stores: every wave covers all 256 columns) -> 512 threads add the 8 waves' bins -> one global atomic per column and
+            // tile.  The bins sit behind the C piece in the free stage.
+            constexpr int BINS_OFF = NI % 3 == 0 ? 51200 : 40960;
+            float* bins = (float*)(lds + (cur ^ 1) * STAGE + BINS_OFF);
+            static_assert((size_t)2 * IPP * 16 * LDC * sizeof(TO) <= BINS_OFF && BINS_OFF + 8 * 2 * TBN * 4 <= STAGE, "column-statistics bins overlap the C piece");
+            const int ch = tid % CPR;
+            if (epi.col_shift) {
+#pragma unroll
+                for (int e = 0; e < EV; ++e) { const int col = cn0 + ch * EV + e; sh[e] = col < N ? epi.col_shift[col] : 0.f; }
+            }
+            if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS, true>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
+            else if (epi.general == 2) Passes8<TO, 2, NI, IPP, 0, NPASS, true>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
+            else Passes8<TO, 0, NI, IPP, 0, NPASS, true>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
+            if (CPR == 32) {                  // bf16 out: lanes l and l + 32 of a wave hold the same column chunk
+#pragma unroll
+                for (int e = 0; e < EV; ++e) { cs[e] += __shfl_xor(cs[e], 32); cq[e] += __shfl_xor(cq[e], 32); }
+            }
+            if (CPR == 64 || lane < 32) {
+                float* wb = bins + wave * 2 * TBN;
+#pragma unroll
+                for (int e = 0; e < EV; ++e) { wb[ch * EV + e] = cs[e]; wb[TBN + ch * EV + e] = cq[e]; }
+            }
+            barrier_keep_vm();
+            {
+                float t = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) t += bins[w8 * 2 * TBN + tid];
+                const int col = cn0 + (tid & (TBN - 1));
+                if (col < N) {
+                    if (tid < TBN) atomicAdd(epi.col_sum + col, t);
+                    else if (epi.col_sumsq) atomicAdd(epi.col_sumsq + col, t);
+                }
+            }
+        } else {
+            if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS, false>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
+            else if (epi.general == 2) Passes8<TO, 2, NI, IPP, 0, NPASS, false>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
+            else Passes8<TO, 0, NI, IPP, 0, NPASS, false>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
+        }
         if (!has_next) break;
     }
 }
@@ -510,19 +562,22 @@ int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int 
     const size_t smem = (size_t)2 * (bmt + 256) * 128;
     const int cus = g8_cus();
     dim3 grid(nitems < cus ? nitems : cus), block(512);
-#define G8_CASE(NI_, PIN_, ABL_)                                                                                             \
+#define G8_CASE(NI_, PIN_, ABL_, ST_)                                                                                        \
     do {                                                                                                                      \
         static bool granted = false;                                                                                          \
-        if (!granted) { if (g8_grant((const void*)gemm8_kc_kernel<TO, NI_, PIN_, ABL_>, smem)) return 1; granted = true; }    \
-        SS_LAUNCH(SS_KERNEL(gemm8_kc_kernel<TO, NI_, PIN_, ABL_>), grid, block, smem, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, tiles_n, nitems); \
+        if (!granted) { if (g8_grant((const void*)gemm8_kc_kernel<TO, NI_, PIN_, ABL_, ST_>, smem)) return 1; granted = true; } \
+        SS_LAUNCH(SS_KERNEL(gemm8_kc_kernel<TO, NI_, PIN_, ABL_, ST_>), grid, block, smem, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, tiles_n, nitems); \
     } while (0)
     const int abl = (epi.debug >> 4) & 7;
-    if (abl && sizeof(TO) == 2) {          // tuning builds only (bf16 out): which of MFMA / DMA / fragment reads bounds the loop
-        if (ni == 9) { switch (abl) { case 1: G8_CASE(9, 0, 1); break; case 2: G8_CASE(9, 0, 2); break; case 4: G8_CASE(9, 0, 4); break; case 5: G8_CASE(9, 0, 5); break; case 6: G8_CASE(9, 0, 6); break; default: G8_CASE(9, 0, 7); } }
-        else { switch (abl) { case 1: G8_CASE(8, 0, 1); break; case 2: G8_CASE(8, 0, 2); break; case 4: G8_CASE(8, 0, 4); break; case 5: G8_CASE(8, 0, 5); break; case 6: G8_CASE(8, 0, 6); break; default: G8_CASE(8, 0, 7); } }
+    if (epi.col_sum) {                      // column statistics: the burst schedule (fewest live registers) of either tile height
+        if (ni == 9) G8_CASE(9, 0, 0, true); else G8_CASE(8, 0, 0, true);
     }
-    else if (ni == 9) { if (pin) G8_CASE(9, 1, 0); else G8_CASE(9, 0, 0); }
-    else { if (pin) G8_CASE(8, 1, 0); else G8_CASE(8, 0, 0); }
+    else if (abl && sizeof(TO) == 2) {      // tuning builds only (bf16 out): which of MFMA / DMA / fragment reads bounds the loop
+        if (ni == 9) { switch (abl) { case 1: G8_CASE(9, 0, 1, false); break; case 2: G8_CASE(9, 0, 2, false); break; case 4: G8_CASE(9, 0, 4, false); break; case 5: G8_CASE(9, 0, 5, false); break; case 6: G8_CASE(9, 0, 6, false); break; default: G8_CASE(9, 0, 7, false); } }
+        else { switch (abl) { case 1: G8_CASE(8, 0, 1, false); break; case 2: G8_CASE(8, 0, 2, false); break; case 4: G8_CASE(8, 0, 4, false); break; case 5: G8_CASE(8, 0, 5, false); break; case 6: G8_CASE(8, 0, 6, false); break; default: G8_CASE(8, 0, 7, false); } }
+    }
+    else if (ni == 9) { if (pin) G8_CASE(9, 1, 0, false); else G8_CASE(9, 0, 0, false); }
+    else { if (pin) G8_CASE(8, 1, 0, false); else G8_CASE(8, 0, 0, false); }
 #undef G8_CASE
     SS_LAUNCH_CHECK("ss_gemm(gemm8)");
     return 0;

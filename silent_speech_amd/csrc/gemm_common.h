@@ -31,6 +31,9 @@ struct GemmEpi {
     int c2_pack;             // 1: the 4 rows a lane holds are consecutive, aligned elements of c2 -> one packed store
     int general;             // 1: dropout or log-clamp in the epilogue
     int c2_lds;              // 1: the transposed copy can leave through LDS as 16-byte stores (bf16, 8-row aligned sequences)
+    float* col_sum;          // optional column statistics of the stored result (8-wave kernel only): += sum_m (C - shift), += sum_m (C - shift)^2
+    float* col_sumsq;
+    const float* col_shift;
     int debug;               // tuning experiments only (SS_GEMM_DEBUG): 1 skip flush stores, 2 skip stage, 4 skip MFMA
 };
 

@@ -122,13 +122,13 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, S
     sums[c] = t[0]; sums[C + c] = t[1]; sums[2 * C + c] = shift ? shift[c] : ldf(x + sx.row(0) * C + c);
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, float n, int C, float* mean, float* invstd, float* running_mean, float* running_var,
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* shift, float n, int C, float* mean, float* invstd, float* running_mean, float* running_var,
                                    float momentum, float eps, int training)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (!training) { mean[c] = running_mean[c]; invstd[c] = rsqrtf(running_var[c] + eps); return; }
-    const float d = sums[c] / n, mu = sums[2 * C + c] + d;
+    const float d = sums[c] / n, mu = (shift ? shift[c] : sums[2 * C + c]) + d;      // shift may alias running_mean: read before the update below
     float var = sums[C + c] / n - d * d; var = var < 0.f ? 0.f : var;
     mean[c] = mu; invstd[c] = rsqrtf(var + eps);
     if (running_mean) {   // torch: running = (1-m)*running + m*stat, unbiased variance for the running estimate
@@ -164,8 +164,17 @@ extern "C" int ss_bn_finalize(const float* sums, double n_total, int C, float* m
 {
     SS_CHECK(mean && invstd && C > 0, "ss_bn_finalize: null pointer");
     SS_CHECK(training ? (sums != nullptr && n_total >= 1.0) : (running_mean && running_var), "ss_bn_finalize: missing sums (training) or running statistics (eval)");
-    SS_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, (float)n_total, C, mean, invstd, running_mean, running_var, momentum, eps, training);
+    SS_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, (const float*)nullptr, (float)n_total, C, mean, invstd, running_mean, running_var, momentum, eps, training);
     SS_LAUNCH_CHECK("ss_bn_finalize");
+    return 0;
+}
+extern "C" int ss_bn_finalize_shift(const float* sums, const float* shift, double n_total, int C, float* mean, float* invstd, float* running_mean, float* running_var,
+                                    float momentum, float eps, int training, void* stream)
+{
+    SS_CHECK(mean && invstd && C > 0, "ss_bn_finalize_shift: null pointer");
+    SS_CHECK(training ? (sums != nullptr && shift != nullptr && n_total >= 1.0) : (running_mean && running_var), "ss_bn_finalize_shift: missing sums / shift (training) or running statistics (eval)");
+    SS_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, shift, (float)n_total, C, mean, invstd, running_mean, running_var, momentum, eps, training);
+    SS_LAUNCH_CHECK("ss_bn_finalize_shift");
     return 0;
 }
 
@@ -500,39 +509,60 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __rest
     }
 }
 
-template <class T, int NV>
+// Backward of z = x + dropout(branch); y = LN(z): one wave per row.  The loads of the NEXT row of a wave (dy, z: 2 x NV 16-byte
+// loads per lane) are issued before the current row's reductions and stores: a wave otherwise has only those 4 loads in flight and the
+// kernel is latency-bound (2.3 TB/s); optional dbsum accumulates the column sums of dbranch (the bias gradient of the nn.Linear that
+// produced the branch, transformer.py:58), which saves a separate pass over dbranch.
+template <class T, int NV, bool BS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, T* __restrict__ dres, T* __restrict__ dbranch, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     int rows, int C, unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id)
+                                                     float* __restrict__ dbsum, int rows, int C, unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id)
 {
-    __shared__ float red[2][4][NV * 64 * 8];
+    __shared__ float red[4][NV * 64 * 8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6, CV = C >> 3;
-    float dg[NV][8], db[NV][8];
+    float dg[NV][8], db[NV][8], dbs[BS ? NV : 1][8];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
-    for (int r = blockIdx.x * wpb + w; r < rows; r += gridDim.x * wpb) {
-        const float mu = mean[r], rs = rstd[r];
+        for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; if (BS) dbs[BS ? i : 0][e] = 0.f; }
+    float gm[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gm[i][e] = lane + 64 * i < CV ? gamma[(lane + 64 * i) * 8 + e] : 0.f;
+    const int stride = gridDim.x * wpb;
+    int r = blockIdx.x * wpb + w;
+    // raw 16-byte (bf16) / 2 x 16-byte (f32) chunks: the conversion to float happens at the USE, so the loads of the next row stay in flight
+    typedef typename RawVec8<T>::type Raw;
+    Raw dcur[NV], zcur[NV];
+    auto load_row = [&](int rr, Raw (&d)[NV], Raw (&zz)[NV]) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int cx = lane + 64 * i;
+            if (cx < CV) { d[i] = RawVec8<T>::load(dy + (long long)rr * C + cx * 8); zz[i] = RawVec8<T>::load(z + (long long)rr * C + cx * 8); }
+            else { d[i] = RawVec8<T>::zero(); zz[i] = RawVec8<T>::zero(); }
+        }
+    };
+    float mu = 0.f, rs = 0.f;
+    if (r < rows) { load_row(r, dcur, zcur); mu = mean[r]; rs = rstd[r]; }
+    for (; r < rows; r += stride) {
+        Raw dnx[NV], znx[NV]; float mun = 0.f, rsn = 0.f;
+        const bool more = r + stride < rows;
+        if (more) { load_row(r + stride, dnx, znx); mun = mean[r + stride]; rsn = rstd[r + stride]; }   // in flight during this row's reductions and stores
+        float dc[NV][8], zc[NV][8];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { RawVec8<T>::unpack(dcur[i], dc[i]); RawVec8<T>::unpack(zcur[i], zc[i]); }
         float gy[NV][8], xh[NV][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int cx = lane + 64 * i;
-            if (cx < CV) {
-                float d[8], zz[8];
-                Vec8<T>::load(dy + (long long)r * C + cx * 8, d);
-                Vec8<T>::load(z + (long long)r * C + cx * 8, zz);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    xh[i][e] = (zz[e] - mu) * rs;
-                    dg[i][e] += d[e] * xh[i][e]; db[i][e] += d[e];
-                    gy[i][e] = d[e] * gamma[cx * 8 + e];
-                    s1 += gy[i][e]; s2 += gy[i][e] * xh[i][e];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { gy[i][e] = 0.f; xh[i][e] = 0.f; }
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = lane + 64 * i < CV;
+                xh[i][e] = ok ? (zc[i][e] - mu) * rs : 0.f;
+                dg[i][e] += dc[i][e] * xh[i][e]; db[i][e] += dc[i][e];
+                gy[i][e] = dc[i][e] * gm[i][e];
+                s1 += gy[i][e]; s2 += gy[i][e] * xh[i][e];
             }
         }
         s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
@@ -555,25 +585,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 for (int e = 0; e < 8; ++e) {
                     o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
                     ob[e] = (thresh && !kp[e]) ? 0.f : (thresh ? o[e] * keep_scale : o[e]);
+                    if (BS) dbs[BS ? i : 0][e] += rnd<T>(ob[e]);  // what the consumers of dbranch read (stored in T)
                 }
                 Vec8<T>::store(dres + (long long)r * C + cx * 8, o);
                 if (dbranch) Vec8<T>::store(dbranch + (long long)r * C + cx * 8, ob);
             }
         }
-    }
-    // block-level reduction of the affine gradients, then one atomic per channel per block
+        if (more) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { red[0][w][(i * 64 + lane) * 8 + e] = dg[i][e]; red[1][w][(i * 64 + lane) * 8 + e] = db[i][e]; }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < NV * 64 * 8; idx += blockDim.x) {
-        const int i = idx / 512, l = (idx / 8) & 63, e = idx & 7, cx = l + 64 * i;
-        if (cx < CV) {
-            float a = 0.f, b = 0.f;
-            for (int ww = 0; ww < wpb; ++ww) { a += red[0][ww][idx]; b += red[1][ww][idx]; }
-            atomicAdd(dgamma + cx * 8 + e, a); atomicAdd(dbeta + cx * 8 + e, b);
+            for (int i = 0; i < NV; ++i) { dcur[i] = dnx[i]; zcur[i] = znx[i]; }
+            mu = mun; rs = rsn;
         }
+    }
+    // block-level reduction of the affine gradients (and the branch column sums), then one atomic per channel per block
+#pragma unroll
+    for (int qn = 0; qn < 3; ++qn) {
+        float* const dst = qn == 0 ? dgamma : (qn == 1 ? dbeta : dbsum);
+        if (!dst || (qn == 2 && !BS)) continue;               // uniform
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[w][(i * 64 + lane) * 8 + e] = qn == 0 ? dg[i][e] : (qn == 1 ? db[i][e] : dbs[BS ? i : 0][e]);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < NV * 64 * 8; idx += blockDim.x) {
+            const int i = idx / 512, l = (idx / 8) & 63, e = idx & 7, cx = l + 64 * i;
+            if (cx < CV) {
+                float a = 0.f;
+                for (int ww = 0; ww < wpb; ++ww) a += red[ww][idx];
+                atomicAdd(dst + cx * 8 + e, a);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -597,12 +639,23 @@ extern "C" int ss_add_dropout_layernorm_forward(int dtype, const void* x, void* 
 extern "C" int ss_layernorm_backward(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                                      void* dres, void* dbranch, float* dgamma, float* dbeta, int rows, int C, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
+    return ss_layernorm_backward_bias(dtype, dy, z, mean, rstd, gamma, dres, dbranch, dgamma, dbeta, nullptr, rows, C, dropout_p, seed, rng_stream, stream);
+}
+
+extern "C" int ss_layernorm_backward_bias(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                          void* dres, void* dbranch, float* dgamma, float* dbeta, float* dbranch_colsum, int rows, int C, float dropout_p,
+                                          uint64_t seed, uint32_t rng_stream, void* stream)
+{
     SS_CHECK(dy && z && mean && rstd && gamma && dres && dgamma && dbeta, "ss_layernorm_backward: null pointer");
+    SS_CHECK(!dbranch_colsum || dbranch, "ss_layernorm_backward_bias: the column sums are those of dbranch");
     SS_CHECK(C % 8 == 0 && C > 0 && C <= 4096, "ss_layernorm_backward: C=%d must be a multiple of 8 and <= 4096", C);
     if (rows <= 0) return 0;
     const unsigned th = dropout_threshold(dropout_p); const float ks = 1.f / (1.f - dropout_p);
-    int blocks = (rows + 15) / 16; if (blocks > 512) blocks = 512;       // 2 blocks per CU: fewer same-address atomics on dgamma/dbeta than 1024 (measured 42 vs 47 us)
-#define SS_LNB(TT, NV) SS_LAUNCH(SS_KERNEL(ln_bwd_kernel<TT, NV>), dim3(blocks), dim3(256), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, dgamma, dbeta, rows, C, th, ks, (unsigned long long)seed, rng_stream)
+    // 2 blocks per CU (~200 registers).  On gfx9 a wait for the prefetched loads also drains the previous row's stores (one vmcnt for both),
+    // so consecutive rows of one wave overlap only partly; forcing 3 waves per SIMD (168 registers) spills the column accumulators.
+    int blocks = (rows + 15) / 16; if (blocks > 512) blocks = 512;
+#define SS_LNB(TT, NV) do { if (dbranch_colsum) SS_LAUNCH(SS_KERNEL(ln_bwd_kernel<TT, NV, true>), dim3(blocks), dim3(256), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, dgamma, dbeta, dbranch_colsum, rows, C, th, ks, (unsigned long long)seed, rng_stream); \
+                            else SS_LAUNCH(SS_KERNEL(ln_bwd_kernel<TT, NV, false>), dim3(blocks), dim3(256), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, dgamma, dbeta, dbranch_colsum, rows, C, th, ks, (unsigned long long)seed, rng_stream); } while (0)
     if (dtype == SS_BF16) { if (C <= 1024) SS_LNB(bf16_t, 2); else SS_LNB(bf16_t, 8); }
     else { if (C <= 1024) SS_LNB(float, 2); else SS_LNB(float, 8); }
 #undef SS_LNB

@@ -75,7 +75,7 @@ struct Plan {
     PermB unpack_enc;
     reduce_fn hook = 0; void* hook_user = 0;
     event_fn on_event = 0; void* event_user = 0;
-    int side_enabled = 1, dw_grouped = 1, side_blocks = 2;
+    int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1;
     hipEvent_t ev_fork = 0, ev_join = 0;
     size_t esz() const { return D.dtype == SS_BF16 ? 2 : 4; }
 
@@ -164,16 +164,30 @@ struct Plan {
         if (X.dry || !b.jobs || b.total <= 0) return 0;
         return timed(X, "grad_unlayout", 0, 0, stream, [&] { return ss_permute3d_batch(b.jobs, (const int32_t*)b.blocks, (int)b.total, (int)b.all_f32, stream); });
     }
-    int bn_stats(Exec& X, const void* x, int B, int T, int C, float* scratch, BnP& bn, bool training, float** mean, float** invstd) {
+    // fused != null: [2][C] sums already accumulated by the producing GEMM's epilogue (shift = the running mean before this update)
+    int bn_stats(Exec& X, const void* x, int B, int T, int C, float* scratch, BnP& bn, bool training, float** mean, float** invstd, float* fused = nullptr) {
         *mean = (float*)X.alloc((size_t)C * 4); *invstd = (float*)X.alloc((size_t)C * 4);
-        float* sums = training ? (float*)X.alloc((size_t)3 * C * 4) : nullptr;
+        float* sums = (training && !fused) ? (float*)X.alloc((size_t)3 * C * 4) : fused;
         if (X.dry) return 0;
         double n_total = (double)B * T;
         if (training) {
-            if (timed(X, "bn_stats", 0, (double)B * T * C * esz(), X.stream, [&] { return ss_bn_stats_sums(D.dtype, x, B, T, C, 0, scratch, hook ? bn.rmean : nullptr, sums, X.stream); })) return 1;
+            if (!fused && timed(X, "bn_stats", 0, (double)B * T * C * esz(), X.stream, [&] { return ss_bn_stats_sums(D.dtype, x, B, T, C, 0, scratch, hook ? bn.rmean : nullptr, sums, X.stream); })) return 1;
             if (hook) n_total = hook(hook_user, sums, 2 * C, n_total, X.stream);
         }
+        if (fused) return timed(X, "bn_finalize", 0, 0, X.stream, [&] { return ss_bn_finalize_shift(sums, bn.rmean, n_total, C, *mean, *invstd, bn.rmean, bn.rvar, 0.1f, 1e-5f, 1, X.stream); });
         return timed(X, "bn_finalize", 0, 0, X.stream, [&] { return ss_bn_finalize(sums, n_total, C, *mean, *invstd, bn.rmean, bn.rvar, 0.1f, 1e-5f, training ? 1 : 0, X.stream); });
+    }
+    // a forward convolution whose output feeds a training-mode BatchNorm: the batch statistics leave with the GEMM epilogue when the
+    // 8-wave kernel runs this shape (returns the [2][C] sums then, else null -> the stand-alone statistics pass)
+    float* conv_gemm(Exec& X, const void* A, const void* Bw, void* C, int M, int N, int K, ss_rowmap am, ss_rowmap bm, const float* bias, BnP& bn, float* stat_slot, int* rc) {
+        ss_gemm_epilogue e = EPI(); e.bias = bias;
+        ss_rowmap cm = RM(N);
+        float* fused = nullptr;
+        if (!X.dry && stat_slot && fuse_stats && ss_gemm_fuses_column_stats(D.dtype, D.dtype, SS_OP_KC, SS_OP_KC, C, M, N, K, &am, &bm, &cm, &e, 1)) {
+            fused = stat_slot; e.col_sum = fused; e.col_sumsq = fused + N; e.col_shift = bn.rmean;
+        }
+        *rc = gemm(X, D.dtype, A, Bw, C, M, N, K, am, bm, cm, &e);
+        return fused;
     }
     // side stream: the weight-gradient GEMMs, bias column sums and gradient un-layouts do not feed the backward chain
     void fork(Exec& X) {
@@ -251,6 +265,15 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         if (training && shift_r > 0 && shifted) memcpy((void*)x_raw, shifted, (size_t)B * T0 * Cin0 * 4);
 #endif
     }
+    // [9][2][C] per-channel sums of the nine BatchNorms, zeroed once: filled by the conv GEMM epilogues where the 8-wave kernel runs
+    float* bnsums = training ? (float*)X.alloc((size_t)9 * 2 * d * 4) : nullptr;
+    if (bnsums && !X.dry) {
+#if !defined(SS_EMU)
+        if (hipMemsetAsync(bnsums, 0, (size_t)9 * 2 * d * 4, (hipStream_t)stream) != hipSuccess) { ss_set_error("forward: memset failed"); return 1; }
+#else
+        memset(bnsums, 0, (size_t)9 * 2 * d * 4);
+#endif
+    }
     int Tin = T0, Cin = Cin0;
     for (int i = 0; i < 3; ++i) {
         BlockP& w = blk[i]; BlockCtx& s = c->blk[i];
@@ -258,17 +281,19 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         s.xin = xin; s.Tin = Tin; s.Cin = Cin; s.Tout = Tout; s.O = O;
         s.scratch = (float*)X.alloc((size_t)ss_bn_scratch_floats(B, Tout, O) * 4);
         const long long in_bs = (long long)(Tin + 2) * Cin;
+        int rc = 0;
+        float* slot = bnsums ? bnsums + (size_t)i * 3 * 2 * d : nullptr;
         void* c1 = X.alloc((size_t)rows * O * es);
-        { ss_gemm_epilogue e = EPI(); e.bias = w.b1; L_(gemm(X, dt, xin, w.w1f, c1, rows, O, 3 * Cin, RM(2 * Cin, Tout, in_bs), RM(3 * Cin), RM(O), &e)); }
+        float* f1 = conv_gemm(X, xin, w.w1f, c1, rows, O, 3 * Cin, RM(2 * Cin, Tout, in_bs), RM(3 * Cin), w.b1, w.bn1, slot, &rc); L_(rc);
         void* cr = X.alloc((size_t)rows * O * es);
-        { ss_gemm_epilogue e = EPI(); e.bias = w.br; L_(gemm(X, dt, xin, w.wr, cr, rows, O, Cin, RM(2 * Cin, Tout, in_bs, Cin), RM(Cin), RM(O), &e)); }
-        L_(bn_stats(X, c1, B, Tout, O, s.scratch, w.bn1, training, &s.m1, &s.i1));
+        float* fr = conv_gemm(X, xin, w.wr, cr, rows, O, Cin, RM(2 * Cin, Tout, in_bs, Cin), RM(Cin), w.br, w.bnr, slot ? slot + 2 * d : nullptr, &rc); L_(rc);
+        L_(bn_stats(X, c1, B, Tout, O, s.scratch, w.bn1, training, &s.m1, &s.i1, f1));
         void* h1 = X.alloc((size_t)B * (Tout + 2) * O * es);
         if (!X.dry) L_(timed(X, "bn_apply", 0, (double)B * Tout * O * es * 3, stream, [&] { return ss_bn_apply(dt, c1, s.m1, s.i1, w.bn1.gamma, w.bn1.beta, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h1, 1, B, Tout, O, 1, stream); }));
         void* c2 = X.alloc((size_t)rows * O * es);
-        { ss_gemm_epilogue e = EPI(); e.bias = w.b2; L_(gemm(X, dt, h1, w.w2f, c2, rows, O, 3 * O, RM(O, Tout, (long long)(Tout + 2) * O), RM(3 * O), RM(O), &e)); }
-        L_(bn_stats(X, c2, B, Tout, O, s.scratch, w.bn2, training, &s.m2, &s.i2));
-        L_(bn_stats(X, cr, B, Tout, O, s.scratch, w.bnr, training, &s.mr, &s.ir));
+        float* f2 = conv_gemm(X, h1, w.w2f, c2, rows, O, 3 * O, RM(O, Tout, (long long)(Tout + 2) * O), RM(3 * O), w.b2, w.bn2, slot ? slot + 4 * d : nullptr, &rc); L_(rc);
+        L_(bn_stats(X, c2, B, Tout, O, s.scratch, w.bn2, training, &s.m2, &s.i2, f2));
+        L_(bn_stats(X, cr, B, Tout, O, s.scratch, w.bnr, training, &s.mr, &s.ir, fr));
         const int pad_y = i == 2 ? 0 : 1;
         void* y = X.alloc((size_t)B * (Tout + 2 * pad_y) * O * es);
         if (!X.dry) L_(timed(X, "bn_apply", 0, (double)B * Tout * O * es * 3, stream, [&] { return ss_bn_apply(dt, c2, s.m2, s.i2, w.bn2.gamma, w.bn2.beta, 0, cr, s.mr, s.ir, w.bnr.gamma, w.bnr.beta, 0, y, pad_y, B, Tout, O, 1, stream); }));
@@ -368,13 +393,18 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         // every layer gets its own temporaries (~340 MB at the reference batch): the side stream reads dF / dHid / dA / dqkv of a layer
         // (its grouped weight-gradient launch) while the main stream is already inside the next layer, so nothing is recycled before join()
         void* dF = X.alloc((size_t)M * d * es);
-        if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward(dt, G, s.z2, s.mean2, s.rstd2, w.g2, G, dF, w.dg2, w.dbe2, M, d, p_drop, seed, 4 * l + 3, stream); }));
+        // linear2.bias.grad = column sums of dF: accumulated by the LayerNorm backward kernel itself
+        if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward_bias(dt, G, s.z2, s.mean2, s.rstd2, w.g2, G, dF, w.dg2, w.dbe2, w.db2, M, d, p_drop, seed, 4 * l + 3, stream); }));
         L_(grp.add(dF, s.hid, w.dw2, d, ff, M, RM(d), RM(ff), side));
-        SIDE_BEGIN(); L_(colsum(X, dF, M, d, w.db2, side)); SIDE_END();
         void* dHid = X.alloc((size_t)M * ff * es);
-        { ss_gemm_epilogue e = EPI(); e.gate = s.hid; e.gate_scale = keep_scale; L_(gemm(X, dt, dF, w.w2T, dHid, M, ff, d, RM(d), RM(d), RM(ff), &e)); }
+        bool db1_fused = false;
+        { ss_gemm_epilogue e = EPI(); e.gate = s.hid; e.gate_scale = keep_scale;
+          ss_rowmap am_ = RM(d), bm_ = RM(d), cm_ = RM(ff);
+          // linear1.bias.grad = column sums of dHid: accumulated by this GEMM's epilogue when the 8-wave kernel runs the shape
+          if (!X.dry && fuse_stats && ss_gemm_fuses_column_stats(dt, dt, SS_OP_KC, SS_OP_KC, dHid, M, ff, d, &am_, &bm_, &cm_, &e, 1)) { e.col_sum = w.db1; db1_fused = true; }
+          L_(gemm(X, dt, dF, w.w2T, dHid, M, ff, d, am_, bm_, cm_, &e)); }
         L_(grp.add(dHid, s.y1, w.dw1, ff, d, M, RM(ff), RM(d), side));
-        SIDE_BEGIN(); L_(colsum(X, dHid, M, ff, w.db1, side)); SIDE_END();
+        if (!db1_fused) { SIDE_BEGIN(); L_(colsum(X, dHid, M, ff, w.db1, side)); SIDE_END(); }
         { ss_gemm_epilogue e = EPI(); e.mode = 1; L_(gemm(X, dt, dHid, w.w1T, G, M, d, ff, RM(ff), RM(ff), RM(d), &e)); }
         void* dA = X.alloc((size_t)M * d * es);
         if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward(dt, G, s.z1, s.mean1, s.rstd1, w.g1, G, dA, w.dg1, w.dbe1, M, d, p_drop, seed, 4 * l + 1, stream); }));
@@ -490,6 +520,7 @@ extern "C" int ss_plan_set_option(ss_plan* h, int what, int value)
     if (what == 0) { old = h->p->side_enabled; h->p->side_enabled = value; }
     else if (what == 1) { old = h->p->dw_grouped; h->p->dw_grouped = value; }
     else if (what == 2) { old = h->p->side_blocks; h->p->side_blocks = value >= 1 && value <= 2 ? value : 2; }
+    else if (what == 3) { old = h->p->fuse_stats; h->p->fuse_stats = value; }
     return old;
 }
 extern "C" int ss_plan_set_reduce_hook(ss_plan* h, ss_reduce_hook fn, void* user) { SS_CHECK(h, "null plan"); h->p->hook = (reduce_fn)fn; h->p->hook_user = user; return 0; }

@@ -99,8 +99,13 @@ def gemm_ex(A, B, C, M, N, K, amap, bmap, cmap, **kw):
 
 
 def _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, extras, a_mode=OP_KC, b_mode=OP_KC, bias=None, relu=False, gate=None,
-               gate_scale=1.0, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0, mode=0, split_k=1, col_perm=None):
+               gate_scale=1.0, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0, mode=0, split_k=1, col_perm=None, col_stats=None):
+    """col_stats = (col_sum, col_sumsq or None, col_shift or None): f32 [N] tensors accumulated by the 8-wave kernel's epilogue
+    (RuntimeError when another kernel would run: ask ss_gemm_fuses_column_stats first)."""
     epi = GemmEpilogue()
+    if col_stats is not None:
+        cs, cq, sh = col_stats
+        epi.col_sum, epi.col_sumsq, epi.col_shift = _p(cs).value, (_p(cq).value if cq is not None else None), (_p(sh).value if sh is not None else None)
     epi.bias = _p(bias).value if bias is not None else None
     epi.gate = _p(gate).value if gate is not None else None
     epi.gate_scale, epi.alpha, epi.relu, epi.dropout_p = gate_scale, alpha, int(bool(relu)), float(dropout_p)

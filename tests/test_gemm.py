@@ -243,3 +243,35 @@ def test_gemm_dw_grouped(dev, split):
         _lib.lib().ss_gemm_dw_set_option(0, old)
     for i, (o, w) in enumerate(zip(outs, wants)):
         assert_close_robust(o, w, 1.5e-2, name='dw job %d' % i, max_outlier_frac=0)
+
+
+@pytest.mark.parametrize('ni', [8, 9])
+@pytest.mark.parametrize('out_dt', [torch.bfloat16, torch.float32])
+def test_gemm8_column_statistics(dev, gemm_opts, ni, out_dt):
+    """Epilogue column statistics of the 8-wave kernel: col_sum += sum_m (C - shift), col_sumsq += sum_m (C - shift)^2 over the STORED
+    values (BatchNorm batch statistics of a conv output / bias gradients), several tiles per column, ragged M and N, gate epilogue."""
+    from silent_speech_amd import _lib
+    gemm_opts(ops.GEMM_OPT_G8, 2); gemm_opts(ops.GEMM_OPT_G8_NI, ni)
+    M, N, K = (700, 328, 128) if is_emu(dev) else (5000, 776, 256)
+    g = torch.Generator().manual_seed(9 + ni)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16); b = (torch.randn(N, K, generator=g) * 0.2).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g); shift = torch.randn(N, generator=g) * 0.3
+    gate = (torch.randn(M, N, generator=g) > 0).to(out_dt)
+    for use_gate in (False, True):
+        C = torch.zeros(M, N, dtype=out_dt, device=dev)
+        cs = torch.full((N,), 2.0, device=dev); cq = torch.full((N,), 3.0, device=dev)          # accumulated into, not overwritten
+        kw = dict(gate=gate.to(dev), gate_scale=1.5) if use_gate else dict(bias=bias.to(dev))
+        ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), col_stats=(cs, cq, shift.to(dev)), **kw)
+        assert _lib.lib().ss_gemm_last_kernel() == (4 if ni == 9 else 3)
+        stored = C.float().cpu()
+        want = a.float() @ b.float().t()
+        want = want * gate.float() * 1.5 if use_gate else want + bias
+        assert_close_robust(stored, want, 1.5e-2 if out_dt == torch.bfloat16 else 2e-3, name='C', max_outlier_frac=0)
+        x = stored - shift
+        assert_close_robust(cs.cpu() - 2.0, x.sum(0), 2e-5, name='col_sum', max_outlier_frac=0)
+        assert_close_robust(cq.cpu() - 3.0, (x * x).sum(0), 2e-5, name='col_sumsq', max_outlier_frac=0)
+    # a shape the cost model leaves to the 128-wide kernels refuses the request instead of silently skipping the statistics
+    gemm_opts(ops.GEMM_OPT_G8, 0)
+    assert _lib.lib().ss_gemm_last_kernel() in (3, 4)
+    with pytest.raises(RuntimeError, match='8-wave kernel'):
+        ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), col_stats=(cs, None, None))
