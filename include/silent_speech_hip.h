@@ -288,6 +288,16 @@ int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, c
                                  uint32_t rng_stream, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Offline EMG conditioning ("next" row N4): the zero-phase IIR cascade of read_emg.py:27-38 (7 x filtfilt(iirnotch(60 h, 30)) then
+ * filtfilt(butter(3, 2 Hz, 'highpass')), scipy.signal.filtfilt defaults: odd extension of 3 max(len a, len b) samples, lfilter_zi
+ * initial conditions) and the np.interp resampling of read_emg.py:40-44, in f64 like numpy.  x, y: (T, C) f64, time-major.
+ * coef [host]: per filter 13 doubles { b[4], a[4] (a[0] = 1, zero padded), zi[3] (scipy.signal.lfilter_zi), order n, padlen }. */
+int64_t ss_iir_filtfilt_workspace_bytes(int T, int C, int max_padlen); /* [host] */
+int ss_iir_filtfilt(const double* x, double* y, int T, int C, int n_filt, const double* coef, void* workspace, int64_t workspace_bytes, void* stream);
+/* y[i] = np.interp(i / new_freq, arange(T) / old_freq, x[:, c]) for i < T_out (the caller sizes T_out = len(arange(0, (T-1)/old_freq, 1/new_freq))) */
+int ss_linear_resample(const double* x, double* y, int T, int C, double old_freq, double new_freq, int T_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The execution plan of the transduction model as native code: ONE call enqueues the whole forward pass of Model.forward
  * (architecture.py:61-84: shift augmentation, 3 ResBlocks :29-40, w_raw_in, the post-norm relative-position encoder layers
  * transformer.py:43-60,87-112, both heads) and ONE the whole backward pass that loss.backward() (transduction_model.py:209)

@@ -176,7 +176,7 @@ struct Passes8<TO, GEN, NI, IPP, NPASS, NPASS, STATS> {
 }  // namespace g8
 
 // ================================================================ KC x KC
-// PIN: 1 = fragment reads and DMA pieces spread between the MFMA groups of a phase, 0 = issued in a burst at the phase start.
+// PIN: bit 0 = fragment reads, bit 1 = DMA pieces spread between the MFMA groups of a phase (else issued in a burst at the phase start).
 // STATS: the epilogue also accumulates per-column sums / sums of squares of the stored tile (a separate instantiation: the extra live
 // registers of that path would otherwise spill in the main loop of every launch).
 // ABL: compile-time ablation mask for tuning (results are wrong): 1 no MFMA, 2 no in-loop global->LDS copies, 4 no in-loop fragment reads.
@@ -221,7 +221,8 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
     sa.issue((const unsigned char*)A, lds, wave); sb.issue((const unsigned char*)B, lds + BMT * RB, wave);
 
     constexpr int SA_NP = Stage<BMT>::NP, NPW = SA_NP + Stage<TBN>::NP;     // global->LDS pieces per wave and K tile
-    constexpr int NCH = PIN ? NPH / 2 : 1, CS = (NPW + NCH - 1) / NCH;     // the copy of a K tile is issued in NCH chunks of CS pieces
+    constexpr bool SPR = (PIN & 1) != 0, SPD = (PIN & 2) != 0;              // spread the fragment reads / the DMA pieces between the MFMA groups
+    constexpr int NCH = SPD ? NPH / 2 : 1, CS = (NPW + NCH - 1) / NCH;     // the copy of a K tile is issued in NCH chunks of CS pieces
 
     for (;;) {
         f32x4 acc[NI][4];
@@ -273,13 +274,14 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             if (ABL & 4) rd = false;
             static_for<0, HR>([&](auto xc) {
                 constexpr int x = xc;
-                constexpr int x0 = PIN ? x : 0, x1 = PIN ? x + 1 : (x == 0 ? HR : 0);           // shares issued in front of MFMA group x
+                constexpr int x0 = SPR ? x : 0, x1 = SPR ? x + 1 : (x == 0 ? HR : 0);           // read shares issued in front of MFMA group x
+                constexpr int y0 = SPD ? x : 0, y1 = SPD ? x + 1 : (x == 0 ? HR : 0);           // DMA shares
                 if (rd) {
                     static_for<x0, x1>([&](auto xr) { read_a(std::integral_constant<int, nx>{}, xr, rst); });
                     if constexpr (nx % NPK == 0) static_for<x0 * 4 / HR, x1 * 4 / HR>([&](auto j) { read_b(std::integral_constant<int, nx>{}, j, rst); });
                 }
                 if constexpr (chunk < NCH) {
-                    if (dm) static_for<chunk * CS + x0 * CS / HR, chunk * CS + x1 * CS / HR>([&](auto k) { dma(k, kb, dst); });
+                    if (dm) static_for<chunk * CS + y0 * CS / HR, chunk * CS + y1 * CS / HR>([&](auto k) { dma(k, kb, dst); });
                 }
                 sched_fence();
                 if (!(ABL & 1)) mfma_row(phc, xc);
@@ -576,8 +578,8 @@ int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int 
         if (ni == 9) { switch (abl) { case 1: G8_CASE(9, 0, 1, false); break; case 2: G8_CASE(9, 0, 2, false); break; case 4: G8_CASE(9, 0, 4, false); break; case 5: G8_CASE(9, 0, 5, false); break; case 6: G8_CASE(9, 0, 6, false); break; default: G8_CASE(9, 0, 7, false); } }
         else { switch (abl) { case 1: G8_CASE(8, 0, 1, false); break; case 2: G8_CASE(8, 0, 2, false); break; case 4: G8_CASE(8, 0, 4, false); break; case 5: G8_CASE(8, 0, 5, false); break; case 6: G8_CASE(8, 0, 6, false); break; default: G8_CASE(8, 0, 7, false); } }
     }
-    else if (ni == 9) { if (pin) G8_CASE(9, 1, 0, false); else G8_CASE(9, 0, 0, false); }
-    else { if (pin) G8_CASE(8, 1, 0, false); else G8_CASE(8, 0, 0, false); }
+    else if (ni == 9) { switch (pin) { case 1: G8_CASE(9, 1, 0, false); break; case 2: G8_CASE(9, 2, 0, false); break; case 3: G8_CASE(9, 3, 0, false); break; default: G8_CASE(9, 0, 0, false); } }
+    else { switch (pin) { case 1: G8_CASE(8, 1, 0, false); break; case 2: G8_CASE(8, 2, 0, false); break; case 3: G8_CASE(8, 3, 0, false); break; default: G8_CASE(8, 0, 0, false); } }
 #undef G8_CASE
     SS_LAUNCH_CHECK("ss_gemm(gemm8)");
     return 0;

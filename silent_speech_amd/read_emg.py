@@ -1,0 +1,177 @@
+"""Offline EMG conditioning on the MI355X -- drop-in for the signal-processing helpers of the reference's read_emg.py
+("next" row N4 of SURVEY section 8f):
+
+    remove_drift(signal, fs)                      read_emg.py:27-29   filtfilt(butter(3, 2, 'highpass', fs=fs))
+    notch(signal, freq, sample_frequency)         read_emg.py:31-33   filtfilt(iirnotch(freq, 30, sample_frequency))
+    notch_harmonics(signal, freq, sample_freq)    read_emg.py:35-38   7 harmonics
+    subsample(signal, new_freq, old_freq)         read_emg.py:40-44   np.interp onto the new grid
+    apply_to_all(function, signal_array, ...)     read_emg.py:46-50   per-channel application
+    condition_raw_emg_recording(x)                read_emg.py:65-70   the whole chain of load_utterance on a (T, 8) recording
+
+The filters are designed here (closed forms of scipy.signal.iirnotch / butter / lfilter_zi, f64) and run by csrc/filters.hip; all
+channels of a recording go through ONE cascade launch, so `apply_to_all(notch_harmonics, x, 60, 1000)` costs the same as one channel.
+Inputs may be numpy arrays or tensors; the arithmetic is f64 on the device and results come back in the input's container.
+File I/O, text alignment, the 112-d hand-crafted features (unused by the model) and dataset bookkeeping stay out of scope.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+# ------------------------------------------------------------------ filter design (f64, closed forms of the scipy routines)
+def iirnotch_coeffs(w0, Q, fs):
+    """scipy.signal.iirnotch(w0, Q, fs): second-order notch, -3 dB bandwidth w0 / Q."""
+    w0 = 2.0 * float(w0) / float(fs)
+    bw = w0 / float(Q) * math.pi
+    w0 = w0 * math.pi
+    gb = 1.0 / math.sqrt(2.0)
+    beta = (math.sqrt(1.0 - gb ** 2.0) / gb) * math.tan(bw / 2.0)
+    gain = 1.0 / (1.0 + beta)
+    b = gain * np.array([1.0, -2.0 * math.cos(w0), 1.0])
+    a = np.array([1.0, -2.0 * gain * math.cos(w0), 2.0 * gain - 1.0])
+    return b, a
+
+
+def butter_highpass_coeffs(order, cutoff, fs):
+    """scipy.signal.butter(order, cutoff, 'highpass', fs=fs): analog prototype -> frequency pre-warping -> lp2hp -> bilinear -> tf."""
+    N = int(order)
+    wn = 2.0 * float(cutoff) / float(fs)
+    m = np.arange(-N + 1, N, 2)
+    p = -np.exp(1j * math.pi * m / (2 * N))               # buttap
+    k = 1.0
+    fs2 = 2.0
+    warped = 2.0 * fs2 * math.tan(math.pi * wn / fs2)
+    # lp2hp_zpk
+    z_hp = np.zeros(N, dtype=complex)
+    p_hp = warped / p
+    k_hp = k * np.real(1.0 / np.prod(-p))
+    # bilinear_zpk
+    fs4 = 2.0 * fs2
+    z_d = (fs4 + z_hp) / (fs4 - z_hp)
+    p_d = (fs4 + p_hp) / (fs4 - p_hp)
+    k_d = k_hp * np.real(np.prod(fs4 - z_hp) / np.prod(fs4 - p_hp))
+    b = k_d * np.real(np.poly(z_d))
+    a = np.real(np.poly(p_d))
+    return b, a
+
+
+def lfilter_zi(b, a):
+    """scipy.signal.lfilter_zi: the state of the transposed direct form II in steady state for a unit step input,
+    zi = (I - A)^-1 B with A the transposed companion matrix of a."""
+    b = np.atleast_1d(np.asarray(b, dtype=np.float64)); a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+    if a[0] != 1.0:
+        b, a = b / a[0], a / a[0]
+    n = max(len(a), len(b))
+    a = np.r_[a, np.zeros(n - len(a))]; b = np.r_[b, np.zeros(n - len(b))]
+    comp = np.zeros((n - 1, n - 1))
+    comp[0, :] = -a[1:]
+    comp[1:, :-1] = np.eye(n - 2)
+    IminusA = np.eye(n - 1) - comp.T
+    B = b[1:] - a[1:] * b[0]
+    zi = np.linalg.solve(IminusA, B)                      # the LAPACK solve scipy uses: the drift filter's I - A is ill-conditioned (poles at
+                                                          # 0.99), and its closed form differs from this in the 10th digit
+    return zi
+
+
+def _pack_filters(filters):
+    rows = []
+    for b, a in filters:
+        b = np.asarray(b, dtype=np.float64); a = np.asarray(a, dtype=np.float64)
+        b, a = b / a[0], a / a[0]
+        n = max(len(a), len(b)) - 1
+        if not 1 <= n <= 3:
+            raise ValueError('filter order 1..3 supported, got %d' % n)
+        zi = lfilter_zi(b, a)
+        row = np.zeros(13)
+        row[:len(b)] = b; row[4:4 + len(a)] = a; row[8:8 + n] = zi; row[11] = n; row[12] = 3 * max(len(a), len(b))
+        rows.append(row)
+    return np.ascontiguousarray(np.stack(rows, 0))
+
+
+# ------------------------------------------------------------------ device entry points
+def _to_device_2d(signal):
+    """-> (tensor (T, C) f64 on the kernel device, restore function)"""
+    is_np = not torch.is_tensor(signal)
+    t = torch.from_numpy(np.ascontiguousarray(signal, dtype=np.float64)) if is_np else signal.to(torch.float64)
+    one_d = t.dim() == 1
+    if one_d:
+        t = t.unsqueeze(1)
+    if t.dim() != 2:
+        raise ValueError('signal must be (T,) or (T, channels)')
+    dev = t.device if (t.is_cuda or _lib.is_emulator()) else torch.device('cuda')
+    t = t.to(dev).contiguous()
+
+    def restore(y):
+        y = y[:, 0] if one_d else y
+        return y.cpu().numpy() if is_np else y
+    return t, restore
+
+
+def filtfilt_cascade(filters, signal):
+    """scipy.signal.filtfilt(b, a, signal, axis=0) for every (b, a) of `filters` in turn, all channels at once."""
+    x, restore = _to_device_2d(signal)
+    T, C = x.shape
+    coef = _pack_filters(filters)
+    maxpad = int(coef[:, 12].max())
+    if T <= maxpad:
+        raise ValueError('The length of the input vector x must be greater than padlen, which is %d.' % maxpad)      # scipy's message
+    L = _lib.lib()
+    nbytes = int(L.ss_iir_filtfilt_workspace_bytes(T, C, maxpad))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    y = torch.empty_like(x)
+    rc = L.ss_iir_filtfilt(_lib.ptr(x), _lib.ptr(y), T, C, coef.shape[0], coef.ctypes.data_as(ctypes.c_void_p), _lib.ptr(ws), nbytes, _lib.stream_of(x))
+    _lib.check(rc, 'ss_iir_filtfilt')
+    return restore(y)
+
+
+def remove_drift(signal, fs):
+    return filtfilt_cascade([butter_highpass_coeffs(3, 2, fs)], signal)
+
+
+def notch(signal, freq, sample_frequency):
+    return filtfilt_cascade([iirnotch_coeffs(freq, 30, sample_frequency)], signal)
+
+
+def notch_harmonics(signal, freq, sample_frequency):
+    return filtfilt_cascade([iirnotch_coeffs(freq * harmonic, 30, sample_frequency) for harmonic in range(1, 8)], signal)
+
+
+def subsample(signal, new_freq, old_freq):
+    x, restore = _to_device_2d(signal)
+    T, C = x.shape
+    times_last = (T - 1) / old_freq
+    T_out = len(np.arange(0, times_last, 1 / new_freq))
+    y = torch.empty(T_out, C, dtype=torch.float64, device=x.device)
+    rc = _lib.lib().ss_linear_resample(_lib.ptr(x), _lib.ptr(y), T, C, float(old_freq), float(new_freq), T_out, _lib.stream_of(x))
+    _lib.check(rc, 'ss_linear_resample')
+    return restore(y)
+
+
+def apply_to_all(function, signal_array, *args, **kwargs):
+    """read_emg.py:46-50.  The device functions above already process every column of a (T, C) array in one launch, so for them this
+    is a single call; any other callable is applied column by column like the reference does."""
+    if function in (remove_drift, notch, notch_harmonics, subsample):
+        return function(signal_array, *args, **kwargs)
+    results = []
+    for i in range(signal_array.shape[1]):
+        results.append(function(signal_array[:, i], *args, **kwargs))
+    return np.stack(results, 1)
+
+
+def condition_raw_emg_recording(raw_emg, raw_emg_before=None, raw_emg_after=None):
+    """The signal chain of load_utterance (read_emg.py:52-70) on in-memory recordings: context concatenation, notch harmonics, drift
+    removal, context removal, resampling to 689.06 Hz (model input, `emg_orig`) and 516.79 Hz (feature rate).  Returns (emg_orig, emg)."""
+    raw_emg = np.asarray(raw_emg)
+    before = np.zeros([0, raw_emg.shape[1]]) if raw_emg_before is None else np.asarray(raw_emg_before)
+    after = np.zeros([0, raw_emg.shape[1]]) if raw_emg_after is None else np.asarray(raw_emg_after)
+    x = np.concatenate([before, raw_emg, after], 0)
+    filters = [iirnotch_coeffs(60 * h, 30, 1000) for h in range(1, 8)] + [butter_highpass_coeffs(3, 2, 1000)]
+    x = filtfilt_cascade(filters, x)                               # notch_harmonics then remove_drift, ONE launch sequence for all 8 channels
+    x = x[before.shape[0]:x.shape[0] - after.shape[0], :]
+    emg_orig = subsample(x, 689.06, 1000)
+    emg = subsample(x, 516.79, 1000)
+    return emg_orig, emg

@@ -347,6 +347,36 @@ def gen_recog():
     save('recog_d16_L1_T40', **arrs)
 
 
+def gen_filters():
+    """Offline EMG conditioning (row N4): the reference's own read_emg.py functions on synthetic 1 kHz recordings."""
+    import read_emg as ref_emg                        # noqa: E402  (imports the reference; its FLAGS are the absl stub's)
+    rng = np.random.default_rng(11)
+    arrs = {}
+    for tag, T, C in (('short', 37, 8), ('mid', 400, 8), ('long', 2500, 3)):     # long spans three 1024-sample chunks of the drift filter
+        t = np.arange(T) / 1000.0
+        x = rng.standard_normal((T, C)) * 40.0 + rng.uniform(-300, 300, (1, C)) + 25.0 * np.sin(2 * np.pi * 60 * t)[:, None] \
+            + 8.0 * np.sin(2 * np.pi * 180 * t + 0.3)[:, None] + 60.0 * t[:, None]           # offset + mains + harmonic + drift
+        arrs[tag + '/x'] = x
+        arrs[tag + '/notch_harmonics'] = ref_emg.apply_to_all(ref_emg.notch_harmonics, x, 60, 1000)
+        if tag != 'long':
+            arrs[tag + '/notch60'] = ref_emg.apply_to_all(ref_emg.notch, x, 60, 1000)
+            arrs[tag + '/remove_drift'] = ref_emg.apply_to_all(ref_emg.remove_drift, x, 1000)
+        y = ref_emg.apply_to_all(ref_emg.remove_drift, arrs[tag + '/notch_harmonics'], 1000)
+        arrs[tag + '/chain'] = y
+        arrs[tag + '/emg_orig'] = ref_emg.apply_to_all(ref_emg.subsample, y, 689.06, 1000)
+        arrs[tag + '/emg'] = ref_emg.apply_to_all(ref_emg.subsample, y, 516.79, 1000)
+    # load_utterance's context handling (read_emg.py:54-68): neighbours concatenated, filtered, cut away again
+    x = arrs['mid/x']; before = arrs['short/x']; after = arrs['mid/x'][::-1][:150].copy()
+    z = np.concatenate([before, x, after], 0)
+    z = ref_emg.apply_to_all(ref_emg.notch_harmonics, z, 60, 1000)
+    z = ref_emg.apply_to_all(ref_emg.remove_drift, z, 1000)
+    z = z[before.shape[0]:z.shape[0] - after.shape[0], :]
+    arrs['context/after'] = after
+    arrs['context/emg_orig'] = ref_emg.apply_to_all(ref_emg.subsample, z, 689.06, 1000)
+    arrs['context/emg'] = ref_emg.apply_to_all(ref_emg.subsample, z, 516.79, 1000)
+    save('filters', **arrs)
+
+
 if __name__ == '__main__':
     random.seed(0)
     # architecture.py:67 copies x_raw[:, r:] onto x_raw[:, :-r] IN PLACE (overlapping views); with a
@@ -371,3 +401,4 @@ if __name__ == '__main__':
     gen_adamw()
     gen_ctc()
     gen_recog()
+    gen_filters()
