@@ -23,6 +23,8 @@
 #include "common.h"
 #include "silent_speech_hip.h"
 #include <math.h>
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -40,9 +42,11 @@ struct AttnP {
     const void* qkv; const void* qkvT; const void* E; const void* ET;
     void* out; float* lse;
     const void* dO; const void* dOT; const float* Dv; void* dqkv;
+    void* pimg;     // saved probabilities of the resident kernels (see the P image below), or null
     int B, H, T, Tp, dp, D, MPt, gx;
     float scale;
     unsigned drop_thresh; float drop_scale; unsigned long long seed; unsigned stream;
+    int debug;      // SS_ATTN_DEBUG (measurement only): bit 0 skips the operand staging, bit 1 the tile loop of the hand-scheduled forward
 };
 
 constexpr int NB_MAX = 16;      // 16-key blocks per query tile: ceil((31 + 16 + 2*99)/16)
@@ -574,6 +578,45 @@ __device__ __forceinline__ void store_tile_rows(RT* tile, const f32x4 (&acc)[2 *
         wave_lds_sync();
     }
 }
+// Dropout of the resident kernels: probability (q, k) of pair bh draws 16 bits of a hash of (row group q / 4, k); slot q & 3.
+// The per-tile part (a full mix of the row group) is hoisted; a block costs one add, a short multiply-xorshift and one derived word.
+__device__ __forceinline__ unsigned res_drop_key(const AttnP& p, int bh, int q0, int g) {
+    const unsigned row = (unsigned)bh * (unsigned)p.T + (unsigned)((q0 >> 2) + g);
+    const unsigned sd = (unsigned)p.seed ^ ((unsigned)(p.seed >> 32) * 0x9E3779B9u) ^ (p.stream * 0x85EBCA6Bu);
+    return mix32(row * 0x9E3779B1u ^ sd) + sd;
+}
+// two 32-bit words of 16-bit draws for the 4 rows of a lane: word 0 = rows (1, 0), word 1 = rows (3, 2)
+__device__ __forceinline__ void res_drop_words(unsigned key, int k, unsigned& a, unsigned& b) {
+    a = (key + 2u * (unsigned)k) * 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+    b = (a ^ 0x68E31DA4u) * 0x9E3779B1u; b ^= b >> 15;
+}
+// an entry is dropped iff the low 15 bits of its draw are below t15 = round(p * 2^15)  (p exact to 2^-15)
+__device__ __forceinline__ void res_drop_keep4(unsigned key, int k, unsigned t15, bool (&keep)[4]) {
+    unsigned a, b; res_drop_words(key, k, a, b);
+    keep[0] = (a & 0x7fffu) >= t15; keep[1] = ((a >> 16) & 0x7fffu) >= t15; keep[2] = (b & 0x7fffu) >= t15; keep[3] = ((b >> 16) & 0x7fffu) >= t15;
+}
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// packed form: bit 15 of each half of the result is set iff that entry is dropped
+__device__ __forceinline__ unsigned res_drop_sign2(unsigned draws, unsigned t15x2) {
+    const s16x2 d = __builtin_bit_cast(s16x2, draws & 0x7fff7fffu) - __builtin_bit_cast(s16x2, t15x2);
+    return __builtin_bit_cast(unsigned, d);
+}
+__device__ __forceinline__ unsigned res_sign_fill2(unsigned signs) {            // 0xffff in every half whose bit 15 is set
+    const s16x2 m = __builtin_bit_cast(s16x2, signs) >> 15;
+    return __builtin_bit_cast(unsigned, m);
+}
+
+// ---- the P image: what the resident forward leaves for the backward kernels.
+// For every (pair, 16-query tile, 16-key block) the 64 lanes store the 4 probabilities they own (rows 4g..4g+3 of column c, the
+// MFMA accumulator layout all three kernels compute in) as 4 bf16: normalised, BEFORE dropout, with bit 15 (the sign: P >= 0)
+// set iff dropout removed the entry.  512 B per block, written and read as one 8-byte word per lane.  With it the backward
+// kernels skip the recomputation of both logit products, the skew, the exponentials and the dropout draws (2/3 of their VALU
+// work and 6 resp. 9 of their 15 resp. 18 MFMAs per block).  Slots per tile: nb + 5 (the fixed-size tile bodies of the forward
+// also store the all-zero blocks just past the band).
+__device__ __host__ __forceinline__ int pimg_slots(int nb) { return nb + 5; }
+__device__ __forceinline__ u32x2* pimg_block(void* base, int pair, int nb, int tile, int block, int lane) {
+    return (u32x2*)base + (((long long)pair * nb + tile) * pimg_slots(nb) + block) * 64 + lane;
+}
 // tile index of the i-th work item: centre of the sequence (full band, most key blocks) first
 __device__ __forceinline__ int res_tile_of(int i, int nb) { const int mid = nb >> 1; return (i & 1) ? mid - ((i + 1) >> 1) : mid + (i >> 1); }
 __device__ __forceinline__ int res_split_index(int i, int half) { return half < 0 ? i : 2 * i + half; }
@@ -665,7 +708,7 @@ __device__ __forceinline__ void fwd_res_tile(const AttnP& p, const unsigned char
                 for (int reg = 0; reg < 4; ++reg) pv[reg] = lg[i < NBLK ? i : 0][reg] * inv[reg];
                 if (DROP) {
                     bool kp[4];
-                    dropout_keep4(p.seed, p.stream, (((unsigned long long)b * H + h) * Tn + ((q0 >> 2) + g)) * Tn + (16 * (jlo + i) + c), p.drop_thresh, kp);
+                    res_drop_keep4(res_drop_key(p, b * H + h, q0, g), 16 * (jlo + i) + c, p.drop_thresh >> 17, kp);
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) pv[reg] = kp[reg] ? pv[reg] : 0.f;
                 }
@@ -730,6 +773,309 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res_kernel(AttnP p)
     }
 }
 
+// =========================================================================== resident forward, hand-scheduled
+// Same data flow as attn_fwd_res_kernel (one workgroup per (sequence, head), K / V / E rows resident in LDS, one wave per 16-row
+// tile).  What changes is WHO schedules the tile: hipcc placed every fragment read directly in front of its MFMA and waited for it
+// there (87 s_waitcnt in the logits block of one tile, each exposing the LDS latency to a wave that has only one partner on its
+// SIMD), which left the kernel at 9 % of the MFMA rate.  Here
+//   * every LDS access of the tile body is issued from inline asm with compile-time offsets off four per-tile base addresses
+//     (no address arithmetic per block), one block AHEAD of its use, and ONE s_waitcnt per block closes them;
+//   * the blocks form a static software pipeline: fragment reads of block i+1 | relative->absolute skew of block i-1 |
+//     MFMAs of block i | logit arithmetic of block i-2, then for the P~V product: P~ of chunk c+2 | reads of chunk c+1 | MFMAs of c;
+//   * the skew takes ONE ds_bpermute per value (the SOURCE lane knows which half of the 32-wide window its reader wants);
+//     band and sequence limits are one add + compare against per-row constants; row maxima / sums are DPP reductions;
+//   * dropout is packed 16-bit arithmetic on the bf16 pairs (sign of draw - threshold -> and-mask), its scale moves to the outputs;
+//   * the normalised probabilities are also stored for the backward pass (the P image, above).
+// LDS: [V rows | K rows | E rows | per-wave P~ chunk buffers].  Reads that run past a table (key blocks beyond the band, relative
+// positions outside [0, 2D-2]) land in the NEXT region: for K and E they only feed logits that the band test replaces, and V rows
+// past the sequence are met by P~ = 0 and hold finite K values.
+namespace {
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+__device__ __forceinline__ void afence() {
+#if !defined(SS_EMU)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ void ard128(bf16x8& d, const unsigned char* lds, unsigned a) {
+#if defined(SS_EMU)
+    d = *(const bf16x8*)(lds + a + OFF);
+#else
+    (void)lds;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ void ard64tr(s16x4& d, const unsigned char* lds, unsigned a) {
+#if defined(SS_EMU)
+    d = lds_read_tr16(lds + a + OFF);
+#else
+    (void)lds;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ void awr64(unsigned char* lds, unsigned a, u32x2 v) {
+#if defined(SS_EMU)
+    *(u32x2*)(lds + a + OFF) = v;
+#else
+    (void)lds;
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(a), "v"(v), "n"(OFF) : "memory");
+#endif
+}
+__device__ __forceinline__ void abperm(float& d, unsigned src_byte, float v) {
+#if defined(SS_EMU)
+    d = __shfl(v, (int)(src_byte >> 2));
+#else
+    asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(d) : "v"(src_byte), "v"(v));
+#endif
+}
+// every LDS operation this wave has issued is complete (and, on the emulator, visible to its other lanes)
+__device__ __forceinline__ void await0() {
+#if defined(SS_EMU)
+    hipemu::sync_wave();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+// ties later uses of x to this point of the asm stream (registers written by the asm reads above are not read before the wait)
+template <class T> __device__ __forceinline__ void apin(T& x) {
+#if !defined(SS_EMU)
+    asm volatile("" : "+v"(x));
+#endif
+}
+__device__ __forceinline__ bf16x8 join8(const s16x4& lo, const s16x4& hi) { bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; return f; }
+
+#if defined(SS_EMU)
+__device__ __forceinline__ float row16_max(float v) { return group16_max(v); }
+__device__ __forceinline__ float row16_sum(float v) { return group16_sum(v); }
+#else
+#define SS_DPP_F(v, CTRL) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true))
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, SS_DPP_F(v, 0xB1)); v = fmaxf(v, SS_DPP_F(v, 0x4E)); v = fmaxf(v, SS_DPP_F(v, 0x141)); v = fmaxf(v, SS_DPP_F(v, 0x140));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += SS_DPP_F(v, 0xB1); v += SS_DPP_F(v, 0x4E); v += SS_DPP_F(v, 0x141); v += SS_DPP_F(v, 0x140);
+    return v;
+}
+#endif
+
+constexpr int F2_PTB = 32 * 20 * 2;       // bytes of one P~ chunk buffer: [32 keys][16 queries + 4] bf16
+constexpr float MASKED_NAT = -1e8f;       // transformer.py:256-261
+
+template <int DPK, int NBLK, bool DROP>
+__device__ __forceinline__ void fwd2_tile(const AttnP& p, unsigned char* lds, unsigned kaddr, unsigned eaddr, unsigned vaddr, unsigned ptw, unsigned ptr_,
+                                          const bf16x8 (&qf)[DPK], const unsigned (&srcb)[4], const bool (&sel)[4],
+                                          int bh, int q0, int jlo, int lane, f32x4 (&o)[2 * DPK], float (&lse)[4])
+{
+    constexpr int PK = DPK * 64 + 16, BLK = 16 * PK, NCH = (NBLK + 1) / 2;
+    const int c = lane & 15, g = lane >> 4, Tn = p.T, D = p.D;
+    const float scale = p.scale;
+    int t0[4]; unsigned lim[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int r = g * 4 + reg;
+        t0[reg] = 16 * jlo - q0 + c - r + (D - 1);                            // relative position (+ D-1) of this lane's column in block 0
+        int l = Tn - 1 - (q0 + r) + (D - 1); l = l < 2 * (D - 1) ? l : 2 * (D - 1);
+        lim[reg] = (unsigned)l;                                               // rows past the sequence (l < 0) are never stored
+    }
+    float lg[NBLK][4], mrun[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    bf16x8 F[2][2 * DPK];
+    f32x4 sacc[3], racc[3];
+    float bp[2][4];
+
+    auto reads = [&](auto ic) {                                               // K rows of block i, E rows of window block i+1
+        constexpr int i = ic;
+        sfor<0, DPK>([&](auto kk) { ard128<i * BLK + kk * 64>(F[i & 1][kk], lds, kaddr); ard128<(i + 1) * BLK + kk * 64>(F[i & 1][DPK + kk], lds, eaddr); });
+    };
+    auto mfmas = [&](auto ic) {
+        constexpr int i = ic;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DPK; ++kk) { s = mfma_bf16_16x16x32(qf[kk], F[i & 1][kk], s); r = mfma_bf16_16x16x32(qf[kk], F[i & 1][DPK + kk], r); }
+        sacc[i % 3] = s; racc[(i + 1) % 3] = r;
+    };
+    auto skew_issue = [&](auto jc) {
+        constexpr int j = jc;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) abperm(bp[j & 1][reg], srcb[reg], sel[reg] ? racc[j % 3][reg] : racc[(j + 1) % 3][reg]);
+    };
+    auto logits = [&](auto jc) {
+        constexpr int j = jc;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float l = fmaf(sacc[j % 3][reg], scale, bp[j & 1][reg]);
+            const bool in = (unsigned)(t0[reg] + 16 * j) <= lim[reg];
+            const float v = in ? l : MASKED_NAT;                              // select AFTER the fma: masked entries may come from rows of another table
+            lg[j][reg] = v; mrun[reg] = fmaxf(mrun[reg], v);
+        }
+    };
+    // ---- logits
+    sfor<0, DPK>([&](auto kk) { ard128<kk * 64>(F[1][DPK + kk], lds, eaddr); });
+    reads(std::integral_constant<int, 0>{});
+    await0();
+    sfor<0, 2 * DPK>([&](auto x) { apin(F[0][x]); });
+    sfor<0, DPK>([&](auto kk) { apin(F[1][DPK + kk]); });
+    {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DPK; ++kk) r = mfma_bf16_16x16x32(qf[kk], F[1][DPK + kk], r);
+        racc[0] = r;
+    }
+    afence();
+    sfor<0, NBLK + 2>([&](auto ic) {
+        constexpr int i = ic;
+        if constexpr (i + 1 < NBLK) reads(std::integral_constant<int, i + 1>{});
+        if constexpr (i >= 1 && i - 1 < NBLK) skew_issue(std::integral_constant<int, i - 1>{});
+        afence();
+        if constexpr (i < NBLK) mfmas(ic);
+        if constexpr (i >= 2) logits(std::integral_constant<int, i - 2>{});
+        afence();
+        await0();
+        if constexpr (i + 1 < NBLK) sfor<0, 2 * DPK>([&](auto x) { apin(F[(i + 1) & 1][x]); });
+        if constexpr (i >= 1 && i - 1 < NBLK) sfor<0, 4>([&](auto x) { apin(bp[(i - 1) & 1][x]); });
+        afence();
+    });
+    // ---- probabilities (normalised, f32 in place), their image for the backward pass, and O = P~ V
+    float nm2[4], sum[4] = {0.f, 0.f, 0.f, 0.f}, inv[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) { mrun[reg] = row16_max(mrun[reg]); nm2[reg] = -mrun[reg] * LOG2E; }
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) { const float e = fast_exp2(fmaf(lg[j][reg], LOG2E, nm2[reg])); lg[j][reg] = e; sum[reg] += e; }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) { const float sm = row16_sum(sum[reg]); inv[reg] = fast_rcp(sm); lse[reg] = mrun[reg] + logf(sm); }
+    unsigned dkey = 0;
+    if (DROP) dkey = res_drop_key(p, bh, q0, g);
+    const unsigned t15 = p.drop_thresh >> 17, t15x2 = t15 | (t15 << 16);
+    u32x2* img = p.pimg ? pimg_block(p.pimg, bh, (Tn + 15) >> 4, q0 >> 4, jlo, lane) : (u32x2*)0;
+    s16x4 palo[2], pahi[2], vlo[2][2 * DPK], vhi[2][2 * DPK];
+    auto pchunk = [&](auto kcc) {
+        constexpr int kc = kcc;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int j = 2 * kc + half;
+            u32x2 pk = {0u, 0u};
+            if (j < NBLK) {
+                const int jj = j < NBLK ? j : 0;
+                pk[0] = pack_bf16(lg[jj][0] * inv[0], lg[jj][1] * inv[1]); pk[1] = pack_bf16(lg[jj][2] * inv[2], lg[jj][3] * inv[3]);
+                u32x2 im = pk;
+                if (DROP) {
+                    unsigned a, b; res_drop_words(dkey, 16 * (jlo + j) + c, a, b);
+                    const unsigned d0 = res_drop_sign2(a, t15x2), d1 = res_drop_sign2(b, t15x2);
+                    im[0] = (d0 & 0x80008000u) | pk[0]; im[1] = (d1 & 0x80008000u) | pk[1];
+                    pk[0] &= ~res_sign_fill2(d0); pk[1] &= ~res_sign_fill2(d1);
+                }
+                if (img) img[j * 64] = im;
+            }
+            if (half == 0) awr64<(kc & 1) * F2_PTB>(lds, ptw, pk); else awr64<(kc & 1) * F2_PTB + 16 * 40>(lds, ptw, pk);
+        }
+    };
+    auto chunk_reads = [&](auto kcc) {
+        constexpr int kc = kcc;
+        ard64tr<(kc & 1) * F2_PTB>(palo[kc & 1], lds, ptr_); ard64tr<(kc & 1) * F2_PTB + 16 * 40>(pahi[kc & 1], lds, ptr_);
+        sfor<0, 2 * DPK>([&](auto n) { ard64tr<kc * 32 * PK + n * 32>(vlo[kc & 1][n], lds, vaddr); ard64tr<kc * 32 * PK + 16 * PK + n * 32>(vhi[kc & 1][n], lds, vaddr); });
+    };
+    auto chunk_pin = [&](auto kcc) {
+        constexpr int kc = kcc;
+        apin(palo[kc & 1]); apin(pahi[kc & 1]);
+        sfor<0, 2 * DPK>([&](auto n) { apin(vlo[kc & 1][n]); apin(vhi[kc & 1][n]); });
+    };
+#pragma unroll
+    for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; o[n] = z; }
+    pchunk(std::integral_constant<int, 0>{});
+    if constexpr (NCH > 1) pchunk(std::integral_constant<int, 1>{});
+    afence();
+    await0();                                                                  // emulator: the chunk-0 stores are visible to the other lanes
+    chunk_reads(std::integral_constant<int, 0>{});
+    await0();
+    chunk_pin(std::integral_constant<int, 0>{});
+    afence();
+    sfor<0, NCH>([&](auto kcc) {
+        constexpr int kc = kcc;
+        if constexpr (kc + 1 < NCH) chunk_reads(std::integral_constant<int, kc + 1>{});
+        afence();
+        {
+            const bf16x8 pa = join8(palo[kc & 1], pahi[kc & 1]);
+#pragma unroll
+            for (int n = 0; n < 2 * DPK; ++n) o[n] = mfma_bf16_16x16x32(pa, join8(vlo[kc & 1][n], vhi[kc & 1][n]), o[n]);
+        }
+        if constexpr (kc + 2 < NCH) pchunk(std::integral_constant<int, kc + 2>{});       // into the buffer chunk kc was read from (those reads completed last step)
+        afence();
+        await0();
+        if constexpr (kc + 1 < NCH) chunk_pin(std::integral_constant<int, kc + 1>{});
+        afence();
+    });
+    if (DROP) {
+#pragma unroll
+        for (int n = 0; n < 2 * DPK; ++n) o[n] = o[n] * p.drop_scale;
+    }
+}
+}  // namespace
+
+template <int DPK, bool DROP>
+__global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res2_kernel(AttnP p)
+{
+    SS_DYN_SMEM(smem);
+    constexpr int dp = DPK * 32, PK = dp * 2 + 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
+    const int H = p.H, h = pair % H, b = pair / H;
+    const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1;
+    unsigned char* lds = (unsigned char*)smem;
+    const unsigned VS = 0, KS = VS + Tr * PK, ES = KS + Tr * PK, PT = ES + NE * PK, CT = PT + RES_W_FWD * 2 * F2_PTB;
+    int* ctr = (int*)(lds + CT);
+    const long long ldq = 3LL * H * dp;
+    const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
+    if (!(p.debug & 1)) {
+        stage_rows<DPK>(lds + KS, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W_FWD * 64);
+        stage_rows<DPK>(lds + VS, PK, Q + 2 * H * dp, ldq, Tn, Tr, tid, RES_W_FWD * 64);
+        stage_rows<DPK>(lds + ES, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE, tid, RES_W_FWD * 64);
+    }
+    if (tid == 0) *ctr = (p.debug & 2) ? nb : 0;
+    __syncthreads();
+#if defined(SS_EMU)
+    const unsigned lbase = 0;
+#else
+    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+#endif
+    unsigned srcb[4]; bool sel[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) { const int r = g * 4 + reg; srcb[reg] = (unsigned)((((c - r + 15) & 15) + 16 * g) * 4); sel[reg] = c + r >= 15; }
+    const unsigned ptw = lbase + PT + w * 2 * F2_PTB + (c * 20 + g * 4) * 2, ptr_ = lbase + PT + w * 2 * F2_PTB + (g * 4 + (c >> 2)) * 40 + (c & 3) * 8;
+    int it = res_split_index(res_next(ctr, lane), half);
+    bf16x8 qf[DPK], qn[DPK];
+    if (it < nb) { int qr = res_tile_of(it, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1; glb_row_frags<DPK>(qf, Q + (long long)qr * ldq, true, g); }
+    while (it < nb) {
+        const int q0 = res_tile_of(it, nb) * 16;
+        int jlo = q0 - (D - 1); jlo = jlo < 0 ? 0 : jlo >> 4;
+        int jhi = (q0 + 15 + D - 1) >> 4; jhi = jhi > nb - 1 ? nb - 1 : jhi;
+        const int nblk = jhi - jlo + 1;
+        const int itn = res_split_index(res_next(ctr, lane), half);
+        if (itn < nb) { int qr = res_tile_of(itn, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1; glb_row_frags<DPK>(qn, Q + (long long)qr * ldq, true, g); }
+        const unsigned kaddr = lbase + KS + (16 * jlo + c) * PK + g * 16;
+        const unsigned eaddr = lbase + ES + (unsigned)((16 * jlo - q0 - 15 + (D - 1) + c) * PK) + g * 16;        // rows below the table: the last K rows (band test)
+        const unsigned vaddr = lbase + VS + (16 * jlo + g * 4 + (c >> 2)) * PK + (c & 3) * 8;
+        f32x4 o[2 * DPK]; float lse[4];
+        if (nblk <= 4) fwd2_tile<DPK, 4, DROP>(p, lds, kaddr, eaddr, vaddr, ptw, ptr_, qf, srcb, sel, b * H + h, q0, jlo, lane, o, lse);
+        else if (nblk <= 10) fwd2_tile<DPK, 10, DROP>(p, lds, kaddr, eaddr, vaddr, ptw, ptr_, qf, srcb, sel, b * H + h, q0, jlo, lane, o, lse);
+        else fwd2_tile<DPK, RES_NB, DROP>(p, lds, kaddr, eaddr, vaddr, ptw, ptr_, qf, srcb, sel, b * H + h, q0, jlo, lane, o, lse);
+        if (c == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) { const int q = q0 + g * 4 + reg; if (q < Tn) p.lse[((long long)b * H + h) * Tn + q] = lse[reg]; }
+        }
+        store_tile_rows<DPK>((RT*)(lds + PT + w * 2 * F2_PTB), o, 1.f, (RT*)p.out + (long long)b * Tn * (H * dp) + h * dp, (long long)H * dp, q0, Tn, lane);
+        it = itn;
+#pragma unroll
+        for (int kk = 0; kk < DPK; ++kk) qf[kk] = qn[kk];
+    }
+}
+
 // probability and dS of one block from log2-domain logits:  p = 2^(l2 - lse2);  dS = p * (keep ? dP/(1-pd) : 0  -  D).
 // Masked entries carry l2 = -1e8*log2(e), so p is exactly 0 there; rows past the sequence are cut by rowok.
 template <bool DROP>
@@ -738,7 +1084,7 @@ __device__ __forceinline__ void res_prob_ds(const float (&l2)[4], const f32x4& d
 {
     const int c = lane & 15, g = lane >> 4;
     bool kp[4] = {true, true, true, true};
-    if (DROP) dropout_keep4(p.seed, p.stream, (((unsigned long long)b * p.H + h) * p.T + ((q0 >> 2) + g)) * p.T + (k0 + c), p.drop_thresh, kp);
+    if (DROP) res_drop_keep4(res_drop_key(p, b * p.H + h, q0, g), k0 + c, p.drop_thresh >> 17, kp);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const float pr = rowok[reg] ? fast_exp2(l2[reg] - lse2[reg]) : 0.f;
@@ -997,6 +1343,7 @@ static void attn_fill(AttnP& p, int B, int H, int T, int Tp, int dp, int D, floa
     p.B = B; p.H = H; p.T = T; p.Tp = Tp; p.dp = dp; p.D = D; p.MPt = (2 * D - 1 + 31) / 32 * 32; p.scale = scale;
     if (dropout_p > 0.f) { p.drop_thresh = dropout_threshold(dropout_p); p.drop_scale = 1.f / (1.f - dropout_p); } else { p.drop_scale = 1.f; }
     p.seed = seed; p.stream = rng_stream;
+    { const char* e = getenv("SS_ATTN_DEBUG"); p.debug = e ? atoi(e) : 0; }
 }
 
 #define SS_ATTN_DISPATCH(KERNEL, grid, BLK, smem)                                                              \
@@ -1022,11 +1369,16 @@ static size_t res_smem(int which, int T, int dp, int D) {
     const size_t PK = (size_t)dp * 2 + 16, nb = (size_t)(T + 15) / 16, Tr = nb * 16, NE = 2 * (size_t)D - 1, TQ = (nb + 1) / 2 * 32, tile = 16 * RT_LD * 2;
     if (which == 0) return 2 * Tr * PK + (NE + 2 * RES_PL) * PK + RES_W_FWD * tile + 16;
     if (which == 1) return 2 * Tr * PK + (NE + 96) * PK + RES_W_BQ * tile + 16;
+    if (which == 3) { const size_t tail = RES_W_FWD * 2 * (size_t)F2_PTB + 16, over = 128 * PK + 16; return 2 * Tr * PK + NE * PK + (tail > over ? tail : over); }   // hand-scheduled forward: reads past the E table stay inside the allocation
     return 2 * TQ * PK + NE * PK + RES_W_BKV * 2 * tile + 8 * TQ + 16;
 }
 static bool res_enabled(int dtype, int T) {
     if (dtype != SS_BF16 || (T + 15) / 16 > RES_NB) return false;
     const char* e = getenv("SS_ATTN_RESIDENT");           // "0" forces the per-tile kernels (A/B measurements, tests of both paths)
+    return !(e && e[0] == '0');
+}
+static bool fwd2_enabled() {
+    const char* e = getenv("SS_ATTN_FWD2");               // "0" keeps the compiler-scheduled resident forward (A/B measurements, tests of both)
     return !(e && e[0] == '0');
 }
 typedef void (*ResKernel)(AttnP);
@@ -1045,7 +1397,7 @@ static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, 
     p.gx = split ? pairs - rem : pairs;
     const int blocks = split ? pairs + rem : pairs;
 #if !defined(SS_EMU)
-    static size_t granted[24] = {0};
+    static size_t granted[32] = {0};
     if (granted[slot] < smem) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("attention: cannot reserve %zu bytes of LDS", smem); return 1; }
         granted[slot] = smem;
@@ -1056,6 +1408,9 @@ static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, 
 }
 static ResKernel res_pick(int which, int dpk, bool drop = false) {
     static const ResKernel fwd_drop[3] = {attn_fwd_res_kernel<1, true>, attn_fwd_res_kernel<2, true>, attn_fwd_res_kernel<3, true>};
+    static const ResKernel fwd2[2][3] = {{attn_fwd_res2_kernel<1, false>, attn_fwd_res2_kernel<2, false>, attn_fwd_res2_kernel<3, false>},
+                                         {attn_fwd_res2_kernel<1, true>, attn_fwd_res2_kernel<2, true>, attn_fwd_res2_kernel<3, true>}};
+    if (which == 3) return dpk >= 1 && dpk <= 3 ? fwd2[drop ? 1 : 0][dpk - 1] : (ResKernel)0;
     if (which == 0 && drop && dpk >= 1 && dpk <= 3) return fwd_drop[dpk - 1];
     static const ResKernel tab[3][3] = {
         {attn_fwd_res_kernel<1, false>, attn_fwd_res_kernel<2, false>, attn_fwd_res_kernel<3, false>},
@@ -1086,7 +1441,9 @@ extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const voi
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
     p.qkv = qkv; p.qkvT = qkvT; p.E = E; p.out = out; p.lse = lse;
     if (!ss_relpos_attention_needs_transposed(dtype, T, dp, D)) {
-        if (res_launch(res_pick(0, dp / 32, p.drop_thresh != 0), dp / 32 + (p.drop_thresh ? 12 : 0), B * H, RES_W_FWD, res_smem(0, T, dp, D), stream, p)) return 1;
+        if (fwd2_enabled() && res_smem(3, T, dp, D) <= RES_LDS_MAX) {
+            if (res_launch(res_pick(3, dp / 32, p.drop_thresh != 0), 24 + dp / 32 + (p.drop_thresh ? 4 : 0), B * H, RES_W_FWD, res_smem(3, T, dp, D), stream, p)) return 1;
+        } else if (res_launch(res_pick(0, dp / 32, p.drop_thresh != 0), dp / 32 + (p.drop_thresh ? 12 : 0), B * H, RES_W_FWD, res_smem(0, T, dp, D), stream, p)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_forward");
         return 0;
     }

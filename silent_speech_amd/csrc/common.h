@@ -161,7 +161,16 @@ __device__ __forceinline__ float fast_rcp(float x) {
 #endif
 }
 // two floats -> packed bf16 pair (lo in bits 0..15)
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+#if defined(SS_EMU)
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+#else
+    typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+    const f32x2_hw v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_hw));      // ONE v_cvt_pk_bf16_f32 (two separate conversions + shift/or otherwise)
+#endif
+}
 
 // ------------------------------------------------------------------ MFMA wrappers
 __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {

@@ -15,6 +15,10 @@
 #include "silent_speech_hip.h"
 #include <math.h>
 
+// numpy / scipy evaluate these expressions with separate multiplies and adds (x86-64 baseline, no FMA); contraction into f64 FMAs
+// would move results by an ulp -- and np.interp parity is checked bit for bit
+#pragma clang fp contract(off)
+
 namespace {
 constexpr int FL_MIN = 256, FL_MAX = 4096;   // samples per chunk: chosen per filter, see ss_iir_filtfilt
 constexpr int FN = 3;              // maximum state dimension (order-3 Butterworth)
