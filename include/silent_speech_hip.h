@@ -287,6 +287,19 @@ int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, c
                                  int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
                                  uint32_t rng_stream, void* stream);
 
+/* The same with SAVED PROBABILITIES: the LDS-resident forward can leave its normalised probabilities (bf16, accumulator layout,
+ * dropout decision in the sign bit; csrc/attention.hip "the P image") in `pimg`, ss_relpos_attention_saved_bytes() bytes; the
+ * backward then reads them instead of recomputing both logit products, the skew, the exponentials and the dropout draws.
+ * saved_bytes is 0 for shapes that run the per-tile kernels; pimg may be NULL in both calls (= the functions above). */
+int64_t ss_relpos_attention_saved_bytes(int dtype, int B, int H, int T, int dp, int D); /* [host] */
+int ss_relpos_attention_forward_p(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse, void* pimg,
+                                  int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
+                                  uint32_t rng_stream, void* stream);
+int ss_relpos_attention_backward_p(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* out,
+                                   const float* lse, const void* dO, const void* dOT, float* Dscratch, void* dqkv, const void* pimg,
+                                   int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
+                                   uint32_t rng_stream, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Offline EMG conditioning ("next" row N4): the zero-phase IIR cascade of read_emg.py:27-38 (7 x filtfilt(iirnotch(60 h, 30)) then
  * filtfilt(butter(3, 2 Hz, 'highpass')), scipy.signal.filtfilt defaults: odd extension of 3 max(len a, len b) samples, lfilter_zi

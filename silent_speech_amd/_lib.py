@@ -62,6 +62,8 @@ SIGNATURES = {
     'ss_dtw_align_skewed': [_P, _I, _P, _P, _P],
     'ss_relpos_attention_forward': [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_relpos_attention_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_relpos_attention_forward_p': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_relpos_attention_backward_p': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_bn_stats_sums': [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     'ss_bn_finalize': [_P, ctypes.c_double, _I, _P, _P, _P, _P, _F, _F, _I, _P],
     'ss_bn_finalize_shift': [_P, _P, ctypes.c_double, _I, _P, _P, _P, _P, _F, _F, _I, _P],
@@ -106,7 +108,8 @@ _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int6
                'ss_plan_backward': ([_P, _P, _P, _P, _P], ctypes.c_int),
                'ss_counters_add': ([_I, _P, _L, _P], ctypes.c_int),
                'ss_plan_profile': ([_P, _I], ctypes.c_int), 'ss_plan_profile_read': ([_P, _P, _I], ctypes.c_int),
-               'ss_relpos_attention_needs_transposed': ([_I, _I, _I, _I], ctypes.c_int)}
+               'ss_relpos_attention_needs_transposed': ([_I, _I, _I, _I], ctypes.c_int),
+               'ss_relpos_attention_saved_bytes': ([_I, _I, _I, _I, _I, _I], ctypes.c_int64)}
 _RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}
 
 _lib = None

@@ -799,10 +799,11 @@ __device__ __forceinline__ void afence() {
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
-template <int OFF>
-__device__ __forceinline__ void ard128(bf16x8& d, const unsigned char* lds, unsigned a) {
+template <int OFF, class V16>
+__device__ __forceinline__ void ard128(V16& d, const unsigned char* lds, unsigned a) {
+    static_assert(sizeof(V16) == 16, "128-bit destination");
 #if defined(SS_EMU)
-    d = *(const bf16x8*)(lds + a + OFF);
+    d = *(const V16*)(lds + a + OFF);
 #else
     (void)lds;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
@@ -815,6 +816,15 @@ __device__ __forceinline__ void ard64tr(s16x4& d, const unsigned char* lds, unsi
 #else
     (void)lds;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ void ard64(s16x4& d, const unsigned char* lds, unsigned a) {
+#if defined(SS_EMU)
+    d = *(const s16x4*)(lds + a + OFF);
+#else
+    (void)lds;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
 #endif
 }
 template <int OFF>
@@ -839,6 +849,14 @@ __device__ __forceinline__ void await0() {
     hipemu::sync_wave();
 #else
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+// all but the N most recently issued LDS operations are complete
+template <int N> __device__ __forceinline__ void await_but() {
+#if defined(SS_EMU)
+    hipemu::sync_wave();
+#else
+    asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory");
 #endif
 }
 // ties later uses of x to this point of the asm stream (registers written by the asm reads above are not read before the wait)
@@ -879,9 +897,10 @@ __device__ __forceinline__ void fwd2_tile(const AttnP& p, unsigned char* lds, un
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int r = g * 4 + reg;
-        t0[reg] = 16 * jlo - q0 + c - r + (D - 1);                            // relative position (+ D-1) of this lane's column in block 0
         int l = Tn - 1 - (q0 + r) + (D - 1); l = l < 2 * (D - 1) ? l : 2 * (D - 1);
-        lim[reg] = (unsigned)l;                                               // rows past the sequence (l < 0) are never stored
+        // relative position (+ D-1) of this lane's column in block 0; rows past the sequence fail every test (their P is 0 in the image)
+        t0[reg] = q0 + r < Tn ? 16 * jlo - q0 + c - r + (D - 1) : (1 << 30);
+        lim[reg] = (unsigned)(l < 0 ? 0 : l);
     }
     float lg[NBLK][4], mrun[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
     bf16x8 F[2][2 * DPK];
@@ -949,7 +968,9 @@ __device__ __forceinline__ void fwd2_tile(const AttnP& p, unsigned char* lds, un
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) { const float e = fast_exp2(fmaf(lg[j][reg], LOG2E, nm2[reg])); lg[j][reg] = e; sum[reg] += e; }
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) { const float sm = row16_sum(sum[reg]); inv[reg] = fast_rcp(sm); lse[reg] = mrun[reg] + logf(sm); }
+    for (int reg = 0; reg < 4; ++reg) {                                        // rows past the sequence: P = 0 (their image entries are read by the key-major backward)
+        const float sm = row16_sum(sum[reg]); inv[reg] = q0 + g * 4 + reg < Tn ? fast_rcp(sm) : 0.f; lse[reg] = mrun[reg] + logf(sm);
+    }
     unsigned dkey = 0;
     if (DROP) dkey = res_drop_key(p, bh, q0, g);
     const unsigned t15 = p.drop_thresh >> 17, t15x2 = t15 | (t15 << 16);
@@ -1073,6 +1094,385 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res2_kernel(AttnP p)
         it = itn;
 #pragma unroll
         for (int kk = 0; kk < DPK; ++kk) qf[kk] = qn[kk];
+    }
+}
+
+// =========================================================================== resident backward on the saved probabilities
+// Both kernels read the P image of the forward instead of recomputing the logits.  With pf = the stored value as a float (negative
+// iff dropout removed the entry), s = 1 / (1 - p_drop) and D' = D / s the scaled-down score gradient is
+//     dS' = max(pf, 0) * dP - |pf| * D'          (dS = s * dS',  P~ = s * max(pf, 0),  dP = dO . V)
+// i.e. 1.5 unpack + 3 arithmetic instructions per entry; the factor s is applied to the 16 x dp results.
+namespace {
+// the 4 stored probabilities of a lane: (signed) f32
+__device__ __forceinline__ void pimg_unpack(const u32x2& w, float (&pf)[4]) {
+    pf[0] = __uint_as_float(w[0] << 16); pf[1] = __uint_as_float(w[0] & 0xffff0000u);
+    pf[2] = __uint_as_float(w[1] << 16); pf[3] = __uint_as_float(w[1] & 0xffff0000u);
+}
+
+// acc[n] += A B with A[q][k] handed over as packed bf16 column pairs (src(j) = this lane's 4 rows of 16-key block j, zero for
+// blocks the caller does not have) and B = 32-row chunks of a row-major LDS table starting at baddr (per-lane transposing-read
+// address): blocks go through the per-wave chunk buffers ([32 keys][16 queries + 4]) two chunks ahead of their MFMAs.
+template <int DPK, int NC, class SRC>
+__device__ __forceinline__ void chunk_mma(unsigned char* lds, unsigned ptw, unsigned ptr_, unsigned baddr, SRC&& src, f32x4 (&acc)[2 * DPK])
+{
+    constexpr int PK = DPK * 64 + 16;
+    s16x4 alo[2], ahi[2], blo[2][2 * DPK], bhi[2][2 * DPK];
+    auto put = [&](auto kcc) {
+        constexpr int kc = kcc;
+        awr64<(kc & 1) * F2_PTB>(lds, ptw, src(std::integral_constant<int, 2 * kc>{}));
+        awr64<(kc & 1) * F2_PTB + 16 * 40>(lds, ptw, src(std::integral_constant<int, 2 * kc + 1>{}));
+    };
+    auto get = [&](auto kcc) {
+        constexpr int kc = kcc;
+        ard64tr<(kc & 1) * F2_PTB>(alo[kc & 1], lds, ptr_); ard64tr<(kc & 1) * F2_PTB + 16 * 40>(ahi[kc & 1], lds, ptr_);
+        sfor<0, 2 * DPK>([&](auto n) { ard64tr<kc * 32 * PK + n * 32>(blo[kc & 1][n], lds, baddr); ard64tr<kc * 32 * PK + 16 * PK + n * 32>(bhi[kc & 1][n], lds, baddr); });
+    };
+    auto pin = [&](auto kcc) {
+        constexpr int kc = kcc;
+        apin(alo[kc & 1]); apin(ahi[kc & 1]);
+        sfor<0, 2 * DPK>([&](auto n) { apin(blo[kc & 1][n]); apin(bhi[kc & 1][n]); });
+    };
+    put(std::integral_constant<int, 0>{});
+    if constexpr (NC > 1) put(std::integral_constant<int, 1>{});
+    afence();
+    await0();
+    get(std::integral_constant<int, 0>{});
+    await0();
+    pin(std::integral_constant<int, 0>{});
+    afence();
+    sfor<0, NC>([&](auto kcc) {
+        constexpr int kc = kcc;
+        if constexpr (kc + 1 < NC) get(std::integral_constant<int, kc + 1>{});
+        afence();
+        {
+            const bf16x8 a = join8(alo[kc & 1], ahi[kc & 1]);
+#pragma unroll
+            for (int n = 0; n < 2 * DPK; ++n) acc[n] = mfma_bf16_16x16x32(a, join8(blo[kc & 1][n], bhi[kc & 1][n]), acc[n]);
+        }
+        if constexpr (kc + 2 < NC) put(std::integral_constant<int, kc + 2>{});
+        afence();
+        await0();
+        if constexpr (kc + 1 < NC) pin(std::integral_constant<int, kc + 1>{});
+        afence();
+    });
+}
+
+// one query tile of the query-major backward: dQ = s * (scale * dS' K + dR' E)
+template <int DPK, int NBLK>
+__device__ __forceinline__ void bq2_tile(const AttnP& p, unsigned char* lds, unsigned vfaddr, unsigned kaddr_tr, unsigned eaddr_tr, unsigned ptw, unsigned ptr_,
+                                         const bf16x8 (&dof)[DPK], const float (&dprime)[4], const u32x2* img, const unsigned (&srcb)[4], const bool (&sel)[4],
+                                         f32x4 (&acc)[2 * DPK])
+{
+    constexpr int PK = DPK * 64 + 16, BLK = 16 * PK, NCH = (NBLK + 1) / 2, NCHM = (NBLK + 2) / 2;
+    u32x2 im[NBLK];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) im[j] = img[j * 64];
+    float ds[NBLK][4];
+    bf16x8 F[2][DPK];
+    f32x4 dpa[2];
+    auto reads = [&](auto ic) { constexpr int i = ic; sfor<0, DPK>([&](auto kk) { ard128<i * BLK + kk * 64>(F[i & 1][kk], lds, vfaddr); }); };
+    auto mfmas = [&](auto ic) {
+        constexpr int i = ic;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < DPK; ++kk) d = mfma_bf16_16x16x32(dof[kk], F[i & 1][kk], d);
+        dpa[i & 1] = d;
+    };
+    auto grads = [&](auto jc) {
+        constexpr int j = jc;
+        float pf[4]; pimg_unpack(im[j], pf);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) ds[j][reg] = fmaf(fmaxf(pf[reg], 0.f), dpa[j & 1][reg], -(fabsf(pf[reg]) * dprime[reg]));
+    };
+    reads(std::integral_constant<int, 0>{});
+    await0();
+    sfor<0, DPK>([&](auto x) { apin(F[0][x]); });
+    afence();
+    sfor<0, NBLK + 1>([&](auto ic) {
+        constexpr int i = ic;
+        if constexpr (i + 1 < NBLK) reads(std::integral_constant<int, i + 1>{});
+        afence();
+        if constexpr (i < NBLK) mfmas(ic);
+        if constexpr (i >= 1) grads(std::integral_constant<int, i - 1>{});
+        afence();
+        await0();
+        if constexpr (i + 1 < NBLK) sfor<0, DPK>([&](auto x) { apin(F[(i + 1) & 1][x]); });
+        afence();
+    });
+#pragma unroll
+    for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[n] = z; }
+    // content term
+    chunk_mma<DPK, NCH>(lds, ptw, ptr_, kaddr_tr, [&](auto jc) {
+        constexpr int j = jc;
+        u32x2 pk = {0u, 0u};
+        if constexpr (j < NBLK) { pk[0] = pack_bf16(ds[j][0], ds[j][1]); pk[1] = pack_bf16(ds[j][2], ds[j][3]); }
+        return pk;
+    }, acc);
+#pragma unroll
+    for (int n = 0; n < 2 * DPK; ++n) acc[n] = acc[n] * p.scale;
+    // positional term: window block u of dR holds, for row r, column (col + r - 15) of key block u (col + r >= 15) or u - 1; the SOURCE lane
+    // (column s) is read for block u iff s <= r, so it selects before the one ds_bpermute
+    float dr[NBLK + 1][4];
+    sfor<0, NBLK + 1>([&](auto uc) {
+        constexpr int u = uc;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float hi = u < NBLK ? ds[u < NBLK ? u : 0][reg] : 0.f, lo = u >= 1 ? ds[u >= 1 ? u - 1 : 0][reg] : 0.f;
+            abperm(dr[u][reg], srcb[reg], sel[reg] ? hi : lo);
+        }
+    });
+    await0();
+    sfor<0, NBLK + 1>([&](auto uc) { constexpr int u = uc; sfor<0, 4>([&](auto x) { apin(dr[u][x]); }); });
+    afence();
+    chunk_mma<DPK, NCHM>(lds, ptw, ptr_, eaddr_tr, [&](auto uc) {
+        constexpr int u = uc;
+        u32x2 pk = {0u, 0u};
+        if constexpr (u < NBLK + 1) { pk[0] = pack_bf16(dr[u][0], dr[u][1]); pk[1] = pack_bf16(dr[u][2], dr[u][3]); }
+        return pk;
+    }, acc);
+}
+}  // namespace
+
+template <int DPK>
+__global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q2_kernel(AttnP p)
+{
+    SS_DYN_SMEM(smem);
+    constexpr int dp = DPK * 32, PK = dp * 2 + 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
+    const int H = p.H, h = pair % H, b = pair / H;
+    const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1;
+    unsigned char* lds = (unsigned char*)smem;
+    // [K | V | E | chunk buffers]: V rows past the band continue into E, E rows outside the table into V resp. the (zeroed) buffers: always finite, always met by dS' = 0
+    const unsigned KS = 0, VS = KS + Tr * PK, ES = VS + Tr * PK, PT = ES + NE * PK, PTE = PT + RES_W_BQ * 2 * F2_PTB, TAIL = PT + 160 * PK;
+    const unsigned CT = (PTE > TAIL ? PTE : TAIL);
+    int* ctr = (int*)(lds + CT);
+    const long long ldq = 3LL * H * dp;
+    const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
+    const RT* dO = (const RT*)p.dO + (long long)b * Tn * (H * dp) + h * dp;
+    {
+        stage_rows<DPK>(lds + KS, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W_BQ * 64);
+        stage_rows<DPK>(lds + VS, PK, Q + 2 * H * dp, ldq, Tn, Tr, tid, RES_W_BQ * 64);
+        stage_rows<DPK>(lds + ES, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE, tid, RES_W_BQ * 64);
+        for (unsigned i = PT + tid * 16; i < CT; i += RES_W_BQ * 64 * 16) { u32x4 z = {0u, 0u, 0u, 0u}; *(u32x4*)(lds + i) = z; }
+        if (tid == 0) *ctr = 0;
+    }
+    __syncthreads();
+#if defined(SS_EMU)
+    const unsigned lbase = 0;
+#else
+    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+#endif
+    unsigned srcb[4]; bool sel[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) { const int r = g * 4 + reg; srcb[reg] = (unsigned)((((c + r + 1) & 15) + 16 * g) * 4); sel[reg] = c <= r; }
+    const unsigned ptw = lbase + PT + w * 2 * F2_PTB + (c * 20 + g * 4) * 2, ptr_ = lbase + PT + w * 2 * F2_PTB + (g * 4 + (c >> 2)) * 40 + (c & 3) * 8;
+    const float sdrop = p.drop_scale, inv_s = 1.f / sdrop;
+    int it = res_split_index(res_next(ctr, lane), half);
+    bf16x8 dof[DPK], don[DPK];
+    if (it < nb) { int qr = res_tile_of(it, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1; glb_row_frags<DPK>(dof, dO + (long long)qr * (H * dp), true, g); }
+    while (it < nb) {
+        const int q0 = res_tile_of(it, nb) * 16;
+        int jlo = q0 - (D - 1); jlo = jlo < 0 ? 0 : jlo >> 4;
+        int jhi = (q0 + 15 + D - 1) >> 4; jhi = jhi > nb - 1 ? nb - 1 : jhi;
+        const int nblk = jhi - jlo + 1;
+        float dprime[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) { const int q = q0 + g * 4 + reg; dprime[reg] = p.Dv[((long long)b * H + h) * Tn + (q < Tn ? q : Tn - 1)] * inv_s; }
+        const int itn = res_split_index(res_next(ctr, lane), half);
+        if (itn < nb) { int qr = res_tile_of(itn, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1; glb_row_frags<DPK>(don, dO + (long long)qr * (H * dp), true, g); }
+        const unsigned vfaddr = lbase + VS + (16 * jlo + c) * PK + g * 16;
+        const unsigned kaddr_tr = lbase + KS + (16 * jlo + g * 4 + (c >> 2)) * PK + (c & 3) * 8;
+        const unsigned eaddr_tr = lbase + ES + (unsigned)((16 * jlo - q0 - 15 + (D - 1) + g * 4 + (c >> 2)) * PK) + (c & 3) * 8;
+        const u32x2* img = pimg_block(p.pimg, pair, nb, q0 >> 4, jlo, lane);
+        f32x4 acc[2 * DPK];
+        if (nblk <= 4) bq2_tile<DPK, 4>(p, lds, vfaddr, kaddr_tr, eaddr_tr, ptw, ptr_, dof, dprime, img, srcb, sel, acc);
+        else if (nblk <= 10) bq2_tile<DPK, 10>(p, lds, vfaddr, kaddr_tr, eaddr_tr, ptw, ptr_, dof, dprime, img, srcb, sel, acc);
+        else bq2_tile<DPK, RES_NB>(p, lds, vfaddr, kaddr_tr, eaddr_tr, ptw, ptr_, dof, dprime, img, srcb, sel, acc);
+        store_tile_rows<DPK>((RT*)(lds + PT + w * 2 * F2_PTB), acc, sdrop, (RT*)p.dqkv + (long long)b * Tn * ldq + h * dp, ldq, q0, Tn, lane);
+        it = itn;
+#pragma unroll
+        for (int kk = 0; kk < DPK; ++kk) dof[kk] = don[kk];
+    }
+}
+
+// one key tile of the key-major backward: dV = s P~'^T dO, dK = s scale dS'^T Q over NCK 32-query chunks starting at chunk c0
+namespace {
+constexpr int KV_TILE = 16 * RT_LD * 2;            // bytes of one [16 keys][32 queries + 8] bf16 hand-over tile
+template <int DPK, int NCK>
+__device__ __forceinline__ void bkv2_tile(unsigned char* lds, unsigned dofaddr, unsigned dvaddr, unsigned qtr, unsigned dotr, unsigned tpa,
+                                          const bf16x8 (&vf)[DPK], const u32x2* img_tile0, long long img_stride, int c0, int ilo, int ihi,
+                                          f32x4 (&dk)[2 * DPK], f32x4 (&dvv)[2 * DPK])
+{
+    constexpr int PK = DPK * 64 + 16, BLK = 16 * PK;
+    // this lane's image words of the 2 NCK (tile, key tile) blocks; tiles outside [ilo, ihi] (never written by the forward) read a valid neighbour and are zeroed
+    u32x2 im[2 * NCK];
+#pragma unroll
+    for (int x = 0; x < 2 * NCK; ++x) {
+        const int i = 2 * c0 + x, ic = i < ilo ? ilo : (i > ihi ? ihi : i);
+        const unsigned vm = (i >= ilo && i <= ihi) ? 0xffffffffu : 0u;
+        u32x2 w = img_tile0[(long long)(ic - 2 * c0) * img_stride];
+        w[0] &= vm; w[1] &= vm; im[x] = w;
+    }
+    bf16x8 dof[2][DPK];                             // dO rows (A operand of dP) of the two 16-query blocks of one chunk
+    f32x4 dpr[2][2];                                // D' of those rows: ring of 2 chunks
+    f32x4 dpa[2];
+    s16x4 pal, pah, sal, sah, blo[2][2 * DPK], bhi[2][2 * DPK];          // [0] = dO columns (for dV), [1] = Q columns (for dK)
+    auto rows_issue = [&](auto tc) {
+        constexpr int t = tc;
+        sfor<0, 2>([&](auto hc) { constexpr int hh = hc; sfor<0, DPK>([&](auto kk) { ard128<(2 * t + hh) * BLK + kk * 64>(dof[hh][kk], lds, dofaddr); }); });
+        ard128<(2 * t) * 64>(dpr[t & 1][0], lds, dvaddr); ard128<(2 * t + 1) * 64>(dpr[t & 1][1], lds, dvaddr);
+    };
+    auto rows_pin = [&](auto tc) {
+        constexpr int t = tc;
+        sfor<0, 2>([&](auto hc) { constexpr int hh = hc; sfor<0, DPK>([&](auto kk) { apin(dof[hh][kk]); }); });
+        apin(dpr[t & 1][0]); apin(dpr[t & 1][1]);
+    };
+    auto dp_mfma = [&]() {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < DPK; ++kk) d = mfma_bf16_16x16x32(dof[hh][kk], vf[kk], d);
+            dpa[hh] = d;
+        }
+    };
+    auto grads_put = [&](auto tc) {                 // dS', P~' of chunk t -> hand-over tiles of buffer t & 1
+        constexpr int t = tc;
+        sfor<0, 2>([&](auto hc) {
+            constexpr int hh = hc;
+            float pf[4], us[4], ds[4]; pimg_unpack(im[2 * t + hh], pf);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) { us[reg] = fmaxf(pf[reg], 0.f); ds[reg] = fmaf(us[reg], dpa[hh][reg], -(fabsf(pf[reg]) * dpr[t & 1][hh][reg])); }
+            const u32x2 pp = {pack_bf16(us[0], us[1]), pack_bf16(us[2], us[3])}, ss = {pack_bf16(ds[0], ds[1]), pack_bf16(ds[2], ds[3])};
+            awr64<(t & 1) * 2 * KV_TILE + hh * 32>(lds, tpa, pp);
+            awr64<(t & 1) * 2 * KV_TILE + KV_TILE + hh * 32>(lds, tpa, ss);
+        });
+    };
+    // a wave holds at most 15 LDS operations in flight (4-bit lgkmcnt): the operands of one chunk are requested in two batches of 2 + 4 DPK
+    auto issue_v = [&](auto tc) {
+        constexpr int t = tc;
+        ard64<(t & 1) * 2 * KV_TILE>(pal, lds, tpa); ard64<(t & 1) * 2 * KV_TILE + 32>(pah, lds, tpa);
+        sfor<0, 2 * DPK>([&](auto n) { ard64tr<t * 32 * PK + n * 32>(blo[0][n], lds, dotr); ard64tr<t * 32 * PK + 16 * PK + n * 32>(bhi[0][n], lds, dotr); });
+    };
+    auto issue_k = [&](auto tc) {
+        constexpr int t = tc;
+        ard64<(t & 1) * 2 * KV_TILE + KV_TILE>(sal, lds, tpa); ard64<(t & 1) * 2 * KV_TILE + KV_TILE + 32>(sah, lds, tpa);
+        sfor<0, 2 * DPK>([&](auto n) { ard64tr<t * 32 * PK + n * 32>(blo[1][n], lds, qtr); ard64tr<t * 32 * PK + 16 * PK + n * 32>(bhi[1][n], lds, qtr); });
+    };
+    auto pin_v = [&]() { apin(pal); apin(pah); sfor<0, 2 * DPK>([&](auto n) { apin(blo[0][n]); apin(bhi[0][n]); }); };
+    auto pin_k = [&]() { apin(sal); apin(sah); sfor<0, 2 * DPK>([&](auto n) { apin(blo[1][n]); apin(bhi[1][n]); }); };
+    // prologue: rows of chunk 0 -> dP(0) -> rows of chunk 1 in flight -> tiles(0)
+    rows_issue(std::integral_constant<int, 0>{});
+    await0();
+    rows_pin(std::integral_constant<int, 0>{});
+    afence();
+    dp_mfma();
+    afence();
+    if constexpr (NCK > 1) rows_issue(std::integral_constant<int, 1>{});
+    grads_put(std::integral_constant<int, 0>{});
+    afence();
+    await0();
+    if constexpr (NCK > 1) rows_pin(std::integral_constant<int, 1>{});
+    afence();
+    sfor<0, NCK>([&](auto tc) {
+        constexpr int t = tc;
+        issue_v(tc);                                                         // P~' tile + dO columns of chunk t
+        afence();
+        if constexpr (t + 1 < NCK) dp_mfma();                                // dP of chunk t+1 (its rows landed during the previous step)
+        afence();
+        await0();
+        pin_v();
+        afence();
+        issue_k(tc);                                                         // dS' tile + Q columns
+        afence();
+        {
+            const bf16x8 pa = join8(pal, pah);
+#pragma unroll
+            for (int n = 0; n < 2 * DPK; ++n) dvv[n] = mfma_bf16_16x16x32(pa, join8(blo[0][n], bhi[0][n]), dvv[n]);
+        }
+        afence();
+        await0();
+        pin_k();
+        afence();
+        if constexpr (t + 2 < NCK) rows_issue(std::integral_constant<int, t + 2>{});
+        afence();
+        {
+            const bf16x8 sa = join8(sal, sah);
+#pragma unroll
+            for (int n = 0; n < 2 * DPK; ++n) dk[n] = mfma_bf16_16x16x32(sa, join8(blo[1][n], bhi[1][n]), dk[n]);
+        }
+        if constexpr (t + 1 < NCK) grads_put(std::integral_constant<int, t + 1>{});
+        afence();
+        await0();
+        if constexpr (t + 2 < NCK) rows_pin(std::integral_constant<int, t + 2>{});
+        afence();
+    });
+}
+}  // namespace
+
+template <int DPK>
+__global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv2_kernel(AttnP p)
+{
+    SS_DYN_SMEM(smem);
+    constexpr int dp = DPK * 32, PK = dp * 2 + 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
+    const int H = p.H, h = pair % H, b = pair / H;
+    const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4;
+    const int TQ = ((nb + 1) >> 1) * 32;                               // whole 32-query chunks
+    unsigned char* lds = (unsigned char*)smem;
+    // [Q rows | dO rows | hand-over tiles (zeroed) | D' (zeroed past the sequence)]: chunk slots past the band read on into the next region, always finite, always met by P = 0
+    const unsigned QS = 0, DOS = QS + TQ * PK, TP = DOS + TQ * PK, DV = TP + RES_W_BKV * 4 * KV_TILE, CT = DV + (TQ + 7 * 32) * 4;
+    int* ctr = (int*)(lds + CT);
+    const long long ldq = 3LL * H * dp;
+    const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
+    const RT* K = Q + H * dp;
+    const RT* V = Q + 2 * H * dp;
+    const float sdrop = p.drop_scale, inv_s = 1.f / sdrop;
+    {
+        stage_rows<DPK>(lds + QS, PK, Q, ldq, Tn, TQ, tid, RES_W_BKV * 64);
+        stage_rows<DPK>(lds + DOS, PK, (const RT*)p.dO + (long long)b * Tn * (H * dp) + h * dp, (long long)H * dp, Tn, TQ, tid, RES_W_BKV * 64);
+        for (unsigned i = TP + tid * 16; i < CT; i += RES_W_BKV * 64 * 16) { u32x4 z = {0u, 0u, 0u, 0u}; *(u32x4*)(lds + i) = z; }
+    }
+    __syncthreads();
+    for (int i = tid; i < Tn; i += RES_W_BKV * 64) ((float*)(lds + DV))[i] = p.Dv[((long long)b * H + h) * Tn + i] * inv_s;
+    if (tid == 0) *ctr = 0;
+    __syncthreads();
+#if defined(SS_EMU)
+    const unsigned lbase = 0;
+#else
+    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
+#endif
+    const unsigned tpa = lbase + TP + w * 4 * KV_TILE + (c * RT_LD + g * 4) * 2;
+    int it = res_split_index(res_next(ctr, lane), half);
+    bf16x8 vf[DPK], vn[DPK];
+    if (it < nb) { int kr = res_tile_of(it, nb) * 16 + c; const bool ok = kr < Tn; kr = ok ? kr : Tn - 1; glb_row_frags<DPK>(vf, V + (long long)kr * ldq, ok, g); }
+    while (it < nb) {
+        const int jt = res_tile_of(it, nb), k0 = jt * 16;
+        int ilo = k0 - (D - 1); ilo = ilo < 0 ? 0 : ilo >> 4;
+        int ihi = (k0 + 15 + D - 1) >> 4; ihi = ihi > nb - 1 ? nb - 1 : ihi;
+        const int c0 = ilo >> 1, nck = (ihi >> 1) - c0 + 1;
+        const int itn = res_split_index(res_next(ctr, lane), half);
+        if (itn < nb) { int kr = res_tile_of(itn, nb) * 16 + c; const bool ok = kr < Tn; kr = ok ? kr : Tn - 1; glb_row_frags<DPK>(vn, V + (long long)kr * ldq, ok, g); }
+        const unsigned dofaddr = lbase + DOS + (32 * c0 + c) * PK + g * 16;
+        const unsigned dvaddr = lbase + DV + (32 * c0 + g * 4) * 4;
+        const unsigned qtr = lbase + QS + (32 * c0 + g * 4 + (c >> 2)) * PK + (c & 3) * 8, dotr = qtr + (DOS - QS);
+        const u32x2* img0 = pimg_block(p.pimg, pair, nb, 2 * c0, jt, lane);
+        const long long istride = (long long)pimg_slots(nb) * 64;
+        f32x4 dk[2 * DPK], dvv[2 * DPK];
+#pragma unroll
+        for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; dk[n] = z; dvv[n] = z; }
+        if (nck <= 2) bkv2_tile<DPK, 2>(lds, dofaddr, dvaddr, qtr, dotr, tpa, vf, img0, istride, c0, ilo, ihi, dk, dvv);
+        else if (nck <= 5) bkv2_tile<DPK, 5>(lds, dofaddr, dvaddr, qtr, dotr, tpa, vf, img0, istride, c0, ilo, ihi, dk, dvv);
+        else bkv2_tile<DPK, 7>(lds, dofaddr, dvaddr, qtr, dotr, tpa, vf, img0, istride, c0, ilo, ihi, dk, dvv);
+        RT* dK = (RT*)p.dqkv + (long long)b * Tn * ldq + H * dp + h * dp;
+        RT* tl = (RT*)(lds + TP + w * 4 * KV_TILE);
+        store_tile_rows<DPK>(tl, dk, p.scale * sdrop, dK, ldq, k0, Tn, lane);
+        store_tile_rows<DPK>(tl + 16 * RT_LD, dvv, sdrop, dK + H * dp, ldq, k0, Tn, lane);
+        it = itn;
+#pragma unroll
+        for (int kk = 0; kk < DPK; ++kk) vf[kk] = vn[kk];
     }
 }
 
@@ -1369,6 +1769,8 @@ static size_t res_smem(int which, int T, int dp, int D) {
     const size_t PK = (size_t)dp * 2 + 16, nb = (size_t)(T + 15) / 16, Tr = nb * 16, NE = 2 * (size_t)D - 1, TQ = (nb + 1) / 2 * 32, tile = 16 * RT_LD * 2;
     if (which == 0) return 2 * Tr * PK + (NE + 2 * RES_PL) * PK + RES_W_FWD * tile + 16;
     if (which == 1) return 2 * Tr * PK + (NE + 96) * PK + RES_W_BQ * tile + 16;
+    if (which == 4) { const size_t PT = 2 * Tr * PK + NE * PK, e1 = PT + RES_W_BQ * 2 * (size_t)F2_PTB, e2 = PT + 160 * PK; return (e1 > e2 ? e1 : e2) + 16; }       // query-major backward on the P image
+    if (which == 5) return 2 * TQ * PK + RES_W_BKV * 4 * (size_t)KV_TILE + (TQ + 7 * 32) * 4 + 16;                                                      // key-major backward on the P image
     if (which == 3) { const size_t tail = RES_W_FWD * 2 * (size_t)F2_PTB + 16, over = 128 * PK + 16; return 2 * Tr * PK + NE * PK + (tail > over ? tail : over); }   // hand-scheduled forward: reads past the E table stay inside the allocation
     return 2 * TQ * PK + NE * PK + RES_W_BKV * 2 * tile + 8 * TQ + 16;
 }
@@ -1397,7 +1799,7 @@ static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, 
     p.gx = split ? pairs - rem : pairs;
     const int blocks = split ? pairs + rem : pairs;
 #if !defined(SS_EMU)
-    static size_t granted[32] = {0};
+    static size_t granted[48] = {0};
     if (granted[slot] < smem) {
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("attention: cannot reserve %zu bytes of LDS", smem); return 1; }
         granted[slot] = smem;
@@ -1411,6 +1813,8 @@ static ResKernel res_pick(int which, int dpk, bool drop = false) {
     static const ResKernel fwd2[2][3] = {{attn_fwd_res2_kernel<1, false>, attn_fwd_res2_kernel<2, false>, attn_fwd_res2_kernel<3, false>},
                                          {attn_fwd_res2_kernel<1, true>, attn_fwd_res2_kernel<2, true>, attn_fwd_res2_kernel<3, true>}};
     if (which == 3) return dpk >= 1 && dpk <= 3 ? fwd2[drop ? 1 : 0][dpk - 1] : (ResKernel)0;
+    static const ResKernel bq2[3] = {attn_bwd_q2_kernel<1>, attn_bwd_q2_kernel<2>, attn_bwd_q2_kernel<3>}, bkv2[3] = {attn_bwd_kv2_kernel<1>, attn_bwd_kv2_kernel<2>, attn_bwd_kv2_kernel<3>};
+    if (which == 4 || which == 5) return dpk >= 1 && dpk <= 3 ? (which == 4 ? bq2 : bkv2)[dpk - 1] : (ResKernel)0;
     if (which == 0 && drop && dpk >= 1 && dpk <= 3) return fwd_drop[dpk - 1];
     static const ResKernel tab[3][3] = {
         {attn_fwd_res_kernel<1, false>, attn_fwd_res_kernel<2, false>, attn_fwd_res_kernel<3, false>},
@@ -1432,7 +1836,19 @@ extern "C" int ss_relpos_attention_needs_transposed(int dtype, int T, int dp, in
     return resident ? 0 : 1;
 }
 
-extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse,
+// bytes of the P image (see above) the forward can leave for the backward, 0 if this shape does not run the kernels that use one
+extern "C" int64_t ss_relpos_attention_saved_bytes(int dtype, int B, int H, int T, int dp, int D)
+{
+    if (B <= 0 || H <= 0 || T <= 0 || dp % 32 != 0 || dp < 32 || dp > 96 || D < 1 || D > 100) return 0;
+    if (ss_relpos_attention_needs_transposed(dtype, T, dp, D) || !fwd2_enabled()) return 0;
+    if (res_smem(3, T, dp, D) > RES_LDS_MAX || res_smem(4, T, dp, D) > RES_LDS_MAX || res_smem(5, T, dp, D) > RES_LDS_MAX) return 0;
+    const char* e = getenv("SS_ATTN_SAVE_P");             // "0": backward recomputes the probabilities (A/B measurements, tests of both paths)
+    if (e && e[0] == '0') return 0;
+    const int64_t nb = (T + 15) / 16;
+    return (int64_t)B * H * nb * pimg_slots((int)nb) * 512;
+}
+
+extern "C" int ss_relpos_attention_forward_p(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse, void* pimg,
                                            int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
     if (attn_check("ss_relpos_attention_forward", dtype, B, H, T, Tp, dp, D, dropout_p)) return 1;
@@ -1440,6 +1856,8 @@ extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const voi
     SS_CHECK(qkvT || !ss_relpos_attention_needs_transposed(dtype, T, dp, D), "ss_relpos_attention_forward: this shape runs the per-tile kernels, which need the transposed copy qkvT");
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
     p.qkv = qkv; p.qkvT = qkvT; p.E = E; p.out = out; p.lse = lse;
+    SS_CHECK(!pimg || ss_relpos_attention_saved_bytes(dtype, B, H, T, dp, D) > 0, "ss_relpos_attention_forward_p: this shape does not save probabilities (ss_relpos_attention_saved_bytes is 0)");
+    p.pimg = pimg;
     if (!ss_relpos_attention_needs_transposed(dtype, T, dp, D)) {
         if (fwd2_enabled() && res_smem(3, T, dp, D) <= RES_LDS_MAX) {
             if (res_launch(res_pick(3, dp / 32, p.drop_thresh != 0), 24 + dp / 32 + (p.drop_thresh ? 4 : 0), B * H, RES_W_FWD, res_smem(3, T, dp, D), stream, p)) return 1;
@@ -1454,8 +1872,14 @@ extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const voi
     return 0;
 }
 
-extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* out, const float* lse,
-                                            const void* dO, const void* dOT, float* Dscratch, void* dqkv,
+extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse,
+                                           int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
+{
+    return ss_relpos_attention_forward_p(dtype, qkv, qkvT, E, out, lse, nullptr, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream, stream);
+}
+
+extern "C" int ss_relpos_attention_backward_p(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* out, const float* lse,
+                                            const void* dO, const void* dOT, float* Dscratch, void* dqkv, const void* pimg,
                                             int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
     if (attn_check("ss_relpos_attention_backward", dtype, B, H, T, Tp, dp, D, dropout_p)) return 1;
@@ -1467,6 +1891,14 @@ extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const vo
         long long blocks = ((long long)B * T + 3) / 4; if (blocks > 8192) blocks = 8192;
         if (dtype == SS_BF16) SS_LAUNCH(attn_dsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dO, (const bf16_t*)out, Dscratch, B, H, T, dp);
         else SS_LAUNCH(attn_dsum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)dO, (const float*)out, Dscratch, B, H, T, dp);
+    }
+    if (pimg) {
+        SS_CHECK(ss_relpos_attention_saved_bytes(dtype, B, H, T, dp, D) > 0, "ss_relpos_attention_backward_p: this shape has no saved probabilities");
+        p.pimg = (void*)pimg;
+        if (res_launch(res_pick(4, dp / 32), 32 + dp / 32, B * H, RES_W_BQ, res_smem(4, T, dp, D), stream, p)) return 1;
+        if (res_launch(res_pick(5, dp / 32), 36 + dp / 32, B * H, RES_W_BKV, res_smem(5, T, dp, D), stream, p)) return 1;
+        SS_LAUNCH_CHECK("ss_relpos_attention_backward_p");
+        return 0;
     }
     if (!ss_relpos_attention_needs_transposed(dtype, T, dp, D)) {
         const bool drop = p.drop_thresh != 0;
@@ -1486,4 +1918,11 @@ extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const vo
     SS_ATTN_DISPATCH(attn_bwd_kv_kernel, grid, 256, 0);
     SS_LAUNCH_CHECK("ss_relpos_attention_backward");
     return 0;
+}
+
+extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* out, const float* lse,
+                                            const void* dO, const void* dOT, float* Dscratch, void* dqkv,
+                                            int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
+{
+    return ss_relpos_attention_backward_p(dtype, qkv, qkvT, E, ET, out, lse, dO, dOT, Dscratch, dqkv, nullptr, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream, stream);
 }

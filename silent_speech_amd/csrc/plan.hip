@@ -39,7 +39,7 @@ struct LayerP {
 
 // pointers saved by forward for backward (all into the caller's workspace)
 struct BlockCtx { void *xin, *c1, *cr, *h1, *c2, *y; float *m1, *i1, *m2, *i2, *mr, *ir, *scratch; int Tin, Cin, Tout, O, pad_y; };
-struct LayerCtx { void *x, *qkv, *qkvT, *o, *z1, *y1, *hid, *z2; float *lse, *mean1, *rstd1, *mean2, *rstd2; };
+struct LayerCtx { void *x, *qkv, *qkvT, *o, *z1, *y1, *hid, *z2, *pimg; float *lse, *mean1, *rstd1, *mean2, *rstd2; };
 constexpr int MAX_LAYERS = 16;
 struct Ctx {
     int B, T0, T, M, Tp, need_T, n_layers;
@@ -327,7 +327,11 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         } else L_(gemm(X, dt, x, w.wqkv, qkv, M, 3 * HD, d, RM(d), RM(d), RM(3 * HD)));
         void* o = X.alloc((size_t)M * HD * es);
         float* lse = (float*)X.alloc((size_t)B * H * T * 4);
-        if (!X.dry) L_(timed(X, "attn_fwd", 4.0 * B * H * T * (2.0 * Dr - 1 < T ? 2.0 * Dr - 1 : T) * dp * 1.5, (double)M * 4 * HD * es, stream, [&] { return ss_relpos_attention_forward(dt, qkv, qkvT, w.E, o, lse, B, H, T, Tp, dp, Dr, scale, p_drop, seed, 4 * l, stream); }));
+        // training: the resident forward leaves its probabilities for the backward kernels (no recomputation of the logits there)
+        const size_t pimg_bytes = training ? (size_t)ss_relpos_attention_saved_bytes(dt, B, H, T, dp, Dr) : 0;
+        void* pimg = pimg_bytes ? X.alloc(pimg_bytes) : nullptr;
+        if (!X.dry) L_(timed(X, "attn_fwd", 4.0 * B * H * T * (2.0 * Dr - 1 < T ? 2.0 * Dr - 1 : T) * dp * 1.5, (double)M * 4 * HD * es, stream, [&] { return ss_relpos_attention_forward_p(dt, qkv, qkvT, w.E, o, lse, pimg, B, H, T, Tp, dp, Dr, scale, p_drop, seed, 4 * l, stream); }));
+        s.pimg = pimg;
         void* a = X.alloc((size_t)M * d * es);
         L_(gemm(X, dt, o, w.wo, a, M, d, HD, RM(HD), RM(HD), RM(d)));
         void* y1 = X.alloc((size_t)M * d * es);
@@ -419,7 +423,7 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         } else L_(gemm(X, dt, dA, w.woT, dO, M, HD, d, RM(d), RM(d), RM(HD)));
         void* dqkv = X.alloc((size_t)M * 3 * HD * es);
         float* dsc = (float*)X.alloc((size_t)B * H * T * 4);
-        if (!X.dry) L_(timed(X, "attn_bwd", 4.0 * B * H * T * (2.0 * Dr - 1 < T ? 2.0 * Dr - 1 : T) * dp * 3.75, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_backward(dt, s.qkv, s.qkvT, w.E, w.ET, s.o, s.lse, dO, dOT, dsc, dqkv, B, H, T, Tp, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
+        if (!X.dry) L_(timed(X, "attn_bwd", 4.0 * B * H * T * (2.0 * Dr - 1 < T ? 2.0 * Dr - 1 : T) * dp * 3.75, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_backward_p(dt, s.qkv, s.qkvT, w.E, w.ET, s.o, s.lse, dO, dOT, dsc, dqkv, s.pimg, B, H, T, Tp, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
         L_(grp.add(dqkv, s.x, w.wqkv_stage, 3 * HD, d, M, RM(3 * HD), RM(d), side));
         { ss_gemm_epilogue e = EPI(); e.mode = 1; L_(gemm(X, dt, dqkv, w.wqkvT, G, M, d, 3 * HD, RM(3 * HD), RM(3 * HD), RM(d), &e)); }
         if (l > 0) { SIDE_BEGIN(); L_(grp.launch(side)); SIDE_END(); }          // layer 0's group waits for w_raw_in's gradient

@@ -243,15 +243,20 @@ def cast_f32(src, dst, n):
 
 
 # ------------------------------------------------------------------ attention
-def relpos_attention_forward(qkv, qkvT, E, out, lse, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0):
-    rc = _L().ss_relpos_attention_forward(_dt(qkv), _p(qkv), _p(qkvT), _p(E), _p(out), _p(lse), B, H, T, Tp, dp, D, scale, p,
-                                          int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
+def relpos_attention_saved_bytes(dtype, B, H, T, dp, D):
+    """bytes of the probability image the forward can save for the backward (0: this shape recomputes)"""
+    return int(_L().ss_relpos_attention_saved_bytes(dtype if isinstance(dtype, int) else _lib.dtype_code(dtype), B, H, T, dp, D))
+
+
+def relpos_attention_forward(qkv, qkvT, E, out, lse, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0, saved=None):
+    rc = _L().ss_relpos_attention_forward_p(_dt(qkv), _p(qkv), _p(qkvT), _p(E), _p(out), _p(lse), _p(saved), B, H, T, Tp, dp, D, scale, p,
+                                            int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
     _lib.check(rc, 'ss_relpos_attention_forward')
 
 
-def relpos_attention_backward(qkv, qkvT, E, ET, out, lse, dO, dOT, dscratch, dqkv, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0):
-    rc = _L().ss_relpos_attention_backward(_dt(qkv), _p(qkv), _p(qkvT), _p(E), _p(ET), _p(out), _p(lse), _p(dO), _p(dOT), _p(dscratch),
-                                           _p(dqkv), B, H, T, Tp, dp, D, scale, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
+def relpos_attention_backward(qkv, qkvT, E, ET, out, lse, dO, dOT, dscratch, dqkv, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0, saved=None):
+    rc = _L().ss_relpos_attention_backward_p(_dt(qkv), _p(qkv), _p(qkvT), _p(E), _p(ET), _p(out), _p(lse), _p(dO), _p(dOT), _p(dscratch),
+                                             _p(dqkv), _p(saved), B, H, T, Tp, dp, D, scale, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
     _lib.check(rc, 'ss_relpos_attention_backward')
 
 

@@ -48,7 +48,9 @@ def _run(dev, dt, B, H, T, dh, D, seed, tol_f, tol_b):
     lse = torch.zeros(B, H, T, device=dev)
     qkv_d, qkvT_d, E_d, ET_d = qkv.to(dev), qkvT.to(dev), Ed.to(dev), ETd.to(dev)
     scale = 1.0 / math.sqrt(dh)
-    ops.relpos_attention_forward(qkv_d, qkvT_d, E_d, out, lse, B, H, T, Tp, dp, D, scale)
+    nsaved = ops.relpos_attention_saved_bytes(dt, B, H, T, dp, D)
+    saved = torch.empty(nsaved, dtype=torch.uint8, device=dev) if nsaved else None             # the probability image of the resident kernels
+    ops.relpos_attention_forward(qkv_d, qkvT_d, E_d, out, lse, B, H, T, Tp, dp, D, scale, saved=saved)
     O = out.view(B, T, H, dp)[..., :dh].permute(0, 2, 1, 3)
     assert_close_robust(O, O_ref, tol_f, name='O', max_outlier_frac=0)
     assert_close_robust(lse, lse_ref, 1e-5 if dt == torch.float32 else 2e-2, name='lse', max_outlier_frac=0)
@@ -59,11 +61,16 @@ def _run(dev, dt, B, H, T, dh, D, seed, tol_f, tol_b):
     dOT = torch.zeros(B, H * dp, Tp, dtype=dt); dOT[:, :, :T] = dOd.view(B, T, H * dp).transpose(1, 2)
     dqkv = torch.full((B * T, 3 * H * dp), 7.0, dtype=dt, device=dev)
     dsc = torch.empty(B, H, T, device=dev)
-    ops.relpos_attention_backward(qkv_d, qkvT_d, E_d, ET_d, out, lse, dOd.to(dev), dOT.to(dev), dsc, dqkv, B, H, T, Tp, dp, D, scale)
-    dq, dk, dv = [dqkv.view(B, T, 3, H, dp)[:, :, i, :, :dh].permute(0, 2, 1, 3) for i in range(3)]
-    assert_close_robust(dv, v.grad, tol_b, name='dV', max_outlier_frac=0)
-    assert_close_robust(dk, k.grad, tol_b, name='dK', max_outlier_frac=0)
-    assert_close_robust(dq, q.grad, tol_b, name='dQ', max_outlier_frac=0)
+    for sv in ([saved, None] if saved is not None else [None]):              # backward from the saved probabilities, and recomputing them
+        dqkv.fill_(7.0)
+        ops.relpos_attention_backward(qkv_d, qkvT_d, E_d, ET_d, out, lse, dOd.to(dev), dOT.to(dev), dsc, dqkv, B, H, T, Tp, dp, D, scale, saved=sv)
+        dq, dk, dv = [dqkv.view(B, T, 3, H, dp)[:, :, i, :, :dh].permute(0, 2, 1, 3) for i in range(3)]
+        tag = ' (saved P)' if sv is not None else ''
+        assert_close_robust(dv, v.grad, tol_b, name='dV' + tag, max_outlier_frac=0)
+        assert_close_robust(dk, k.grad, tol_b, name='dK' + tag, max_outlier_frac=0)
+        assert_close_robust(dq, q.grad, tol_b, name='dQ' + tag, max_outlier_frac=0)
+        if dp > dh:
+            assert float(dqkv.view(B, T, 3, H, dp)[..., dh:].float().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
@@ -126,7 +133,9 @@ def test_attention_backward_uses_the_forward_dropout_mask(dev, dt):
     ETd = torch.zeros(H, dp, MPt, dtype=dt); ETd[:, :, :2 * D - 1] = E.transpose(1, 2).to(dt)
     out = torch.zeros(B * T, H * dp, dtype=dt, device=dev); lse = torch.zeros(B, H, T, device=dev)
     qkv_d, qkvT_d, E_d, ET_d = qkv.to(dev), qkvT.to(dev), Ed.to(dev), ETd.to(dev)
-    ops.relpos_attention_forward(qkv_d, qkvT_d, E_d, out, lse, B, H, T, Tp, dp, D, scale, p=p, seed=99, rng_stream=4)
+    nsaved = ops.relpos_attention_saved_bytes(dt, B, H, T, dp, D)
+    saved = torch.empty(nsaved, dtype=torch.uint8, device=dev) if nsaved else None
+    ops.relpos_attention_forward(qkv_d, qkvT_d, E_d, out, lse, B, H, T, Tp, dp, D, scale, p=p, seed=99, rng_stream=4, saved=saved)
     Pd = out.cpu().float().view(B, T, H, dp).permute(0, 2, 1, 3)                        # (B,H,q,k) = P~
     band = (torch.arange(T)[None, :] - torch.arange(T)[:, None]).abs() <= D - 1
     keep = (Pd != 0).float()
@@ -139,11 +148,14 @@ def test_attention_backward_uses_the_forward_dropout_mask(dev, dt):
     dOd = _pack(dO, dp).reshape(B * T, H * dp).to(dt).contiguous()
     dOT = dOd.view(B, T, H * dp).transpose(1, 2).contiguous()
     dqkv = torch.zeros(B * T, 3 * H * dp, dtype=dt, device=dev); dsc = torch.empty(B, H, T, device=dev)
-    ops.relpos_attention_backward(qkv_d, qkvT_d, E_d, ET_d, out, lse, dOd.to(dev), dOT.to(dev), dsc, dqkv, B, H, T, Tp, dp, D, scale, p=p, seed=99, rng_stream=4)
-    dq, dk, dv = [dqkv.view(B, T, 3, H, dp)[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
-    assert_close_robust(dv, v.grad, tolG, name='dV', max_outlier_frac=0)
-    assert_close_robust(dk, k.grad, tolG, name='dK', max_outlier_frac=0)
-    assert_close_robust(dq, q.grad, tolG, name='dQ', max_outlier_frac=0)
+    assert (saved is not None) == bf
+    for sv in ([saved, None] if saved is not None else [None]):
+        dqkv.zero_()
+        ops.relpos_attention_backward(qkv_d, qkvT_d, E_d, ET_d, out, lse, dOd.to(dev), dOT.to(dev), dsc, dqkv, B, H, T, Tp, dp, D, scale, p=p, seed=99, rng_stream=4, saved=sv)
+        dq, dk, dv = [dqkv.float().view(B, T, 3, H, dp)[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+        assert_close_robust(dv, v.grad, tolG, name='dV', max_outlier_frac=0)
+        assert_close_robust(dk, k.grad, tolG, name='dK', max_outlier_frac=0)
+        assert_close_robust(dq, q.grad, tolG, name='dQ', max_outlier_frac=0)
 
 
 @pytest.mark.parametrize('T,D,dh,p', [(40, 9, 32, 0.0), (72, 30, 64, 0.25), (200, 100, 96, 0.2)])

@@ -32,11 +32,14 @@ int main(int argc, char** argv)
     CK(hipMemcpy(qkv, h.data(), nqkv * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(E, hE.data(), nE * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(ET, hET.data(), nET * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dO, hdO.data(), nO * 2, hipMemcpyHostToDevice));
     if (ss_relpos_attention_needs_transposed(SS_BF16, T, dp, D)) { fprintf(stderr, "shape runs the per-tile kernels (needs transposed copies): not benchmarked here\n"); return 2; }
+    const int64_t nsaved = ss_relpos_attention_saved_bytes(SS_BF16, B, H, T, dp, D);          // 0 with SS_ATTN_SAVE_P=0: backward recomputes the probabilities
+    void* pimg = nullptr; if (nsaved) CK(hipMalloc(&pimg, (size_t)nsaved));
+    printf("saved probabilities: %.1f MB\n", nsaved / 1e6);
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const float scale = 1.0f / sqrtf((float)dp);
-    auto fwd = [&]() { return ss_relpos_attention_forward(SS_BF16, qkv, nullptr, E, out, lse, B, H, T, Tp, dp, D, scale, pdrop, 77, 3, st); };
-    auto bwd = [&]() { return ss_relpos_attention_backward(SS_BF16, qkv, nullptr, E, ET, out, lse, dO, nullptr, dsc, dqkv, B, H, T, Tp, dp, D, scale, pdrop, 77, 3, st); };
+    auto fwd = [&]() { return ss_relpos_attention_forward_p(SS_BF16, qkv, nullptr, E, out, lse, pimg, B, H, T, Tp, dp, D, scale, pdrop, 77, 3, st); };
+    auto bwd = [&]() { return ss_relpos_attention_backward_p(SS_BF16, qkv, nullptr, E, ET, out, lse, dO, nullptr, dsc, dqkv, pimg, B, H, T, Tp, dp, D, scale, pdrop, 77, 3, st); };
     for (int pass = 0; pass < 2; ++pass) {
         for (int i = 0; i < 3; ++i) if ((pass ? bwd() : fwd())) { fprintf(stderr, "launch failed: %s\n", ss_last_error()); return 1; }
         CK(hipStreamSynchronize(st));
