@@ -214,6 +214,13 @@ int ss_layernorm_backward(int dtype, const void* dy, const void* z, const float*
 int ss_layernorm_backward_bias(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                                void* dres, void* dbranch, float* dgamma, float* dbeta, float* dbranch_colsum, int rows, int C, float dropout_p,
                                uint64_t seed, uint32_t rng_stream, void* stream);
+/* The same with a scratch buffer of ss_layernorm_backward_scratch_floats(rows, C) floats: the per-workgroup column sums go there
+ * instead of through atomics and a second small kernel adds them into dgamma / dbeta / dbranch_colsum (16 waves per CU, C = 256,
+ * 512 or 768; scratch_floats returns 0 for other widths, and scratch == NULL runs the atomic form). */
+int64_t ss_layernorm_backward_scratch_floats(int rows, int C); /* [host] */
+int ss_layernorm_backward_ws(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                             void* dres, void* dbranch, float* dgamma, float* dbeta, float* dbranch_colsum, float* scratch, int64_t scratch_floats,
+                             int rows, int C, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream);
 
 /* EMG input conditioning: training-time shift augmentation (architecture.py:64-68: x[:, :-r] = x[:, r:],
  * x[:, -r:] = 0), cast to the compute dtype and zero halo rows: x_raw (B,T0,Cin) f32 ->

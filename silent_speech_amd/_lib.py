@@ -74,6 +74,7 @@ SIGNATURES = {
     'ss_add_dropout_layernorm_forward': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_layernorm_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _P],
     'ss_layernorm_backward_bias': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _P],
+    'ss_layernorm_backward_ws': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _U64, _U32, _P],
     'ss_emg_prepare': [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     'ss_frame_lse': [_P, _L, _I, _I, _I, _P, _P, _P],
     'ss_voiced_loss': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],
@@ -109,7 +110,8 @@ _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int6
                'ss_counters_add': ([_I, _P, _L, _P], ctypes.c_int),
                'ss_plan_profile': ([_P, _I], ctypes.c_int), 'ss_plan_profile_read': ([_P, _P, _I], ctypes.c_int),
                'ss_relpos_attention_needs_transposed': ([_I, _I, _I, _I], ctypes.c_int),
-               'ss_relpos_attention_saved_bytes': ([_I, _I, _I, _I, _I, _I], ctypes.c_int64)}
+               'ss_relpos_attention_saved_bytes': ([_I, _I, _I, _I, _I, _I], ctypes.c_int64),
+               'ss_layernorm_backward_scratch_floats': ([_I, _I], ctypes.c_int64)}
 _RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}
 
 _lib = None

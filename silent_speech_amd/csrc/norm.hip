@@ -7,6 +7,7 @@
 // (bf16) / 2x16 bytes (f32) channels, statistics are f32.  Padded buffers carry one zero row on each
 // side of every sequence so the k=3 convolutions read their taps as one contiguous 3C row (gemm.hip).
 #include "common.h"
+#include <stdlib.h>
 #include "silent_speech_hip.h"
 
 namespace {
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __rest
 template <class T, int NV, bool BS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, T* __restrict__ dres, T* __restrict__ dbranch, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     float* __restrict__ dbsum, int rows, int C, unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id)
+                                                     float* __restrict__ dbsum, int rows, int C, unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id, int dbg)
 {
     __shared__ float red[4][NV * 64 * 8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpb = blockDim.x >> 6, CV = C >> 3;
@@ -612,11 +613,153 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             if (cx < CV) {
                 float a = 0.f;
                 for (int ww = 0; ww < wpb; ++ww) a += red[ww][idx];
-                atomicAdd(dst + cx * 8 + e, a);
+                if (!(dbg & 1)) atomicAdd(dst + cx * 8 + e, a);
             }
         }
         __syncthreads();
     }
+}
+
+// ---- LayerNorm backward, second form: 16 waves per workgroup (<= 128 registers), partial column sums to a scratch buffer.
+// The kernel above keeps one row per wave in 64 x 16-byte chunks: for C = 768 the second chunk round uses half the lanes, the column
+// accumulators of both rounds plus a prefetched row cost ~200 registers (2 waves per SIMD, ~32 KB of loads in flight per CU) and every
+// workgroup ends with 3 C atomics onto the same 3 C addresses (8.5 us of the 44 us measured alone).  Here a lane owns C / 256 pieces of
+// 4 consecutive elements (no idle lanes, 8-byte bf16 loads / stores), the second pass recomputes from the raw row instead of keeping
+// floats, which fits 16 waves per CU, and the per-workgroup sums go to scratch[workgroup][3][C], added up by a second tiny kernel.
+template <class T> struct Piece4;
+template <> struct Piece4<bf16_t> {
+    typedef u32x2 raw;
+    static __device__ __forceinline__ raw load(const bf16_t* p) { return *(const u32x2*)p; }
+    static __device__ __forceinline__ void unpack(const raw& r, float (&v)[4]) {
+        v[0] = __uint_as_float(r[0] << 16); v[1] = __uint_as_float(r[0] & 0xffff0000u); v[2] = __uint_as_float(r[1] << 16); v[3] = __uint_as_float(r[1] & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) { u32x2 r = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])}; *(u32x2*)p = r; }
+};
+template <> struct Piece4<float> {
+    typedef f32x4 raw;
+    static __device__ __forceinline__ raw load(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ void unpack(const raw& r, float (&v)[4]) { v[0] = r[0]; v[1] = r[1]; v[2] = r[2]; v[3] = r[3]; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { f32x4 r = {v[0], v[1], v[2], v[3]}; *(f32x4*)p = r; }
+};
+constexpr int LNB2_WAVES = 16;
+
+template <class T, int P, bool BS>
+__global__ __launch_bounds__(LNB2_WAVES * 64) void ln_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gamma, T* __restrict__ dres, T* __restrict__ dbranch, float* __restrict__ partial,
+                                                                  int rows, unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id)
+{
+    constexpr int C = P * 256;
+    __shared__ float red[LNB2_WAVES][C];
+    typedef typename Piece4<T>::raw Raw;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float dg[P][4], db[P][4], dbs[BS ? P : 1][4], gm[P][4];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dg[p][e] = 0.f; db[p][e] = 0.f; if (BS) dbs[BS ? p : 0][e] = 0.f; gm[p][e] = gamma[(p * 64 + lane) * 4 + e]; }
+    const int stride = gridDim.x * LNB2_WAVES;
+    int r = blockIdx.x * LNB2_WAVES + w;
+    Raw dcur[P], zcur[P];
+    float mu = 0.f, rs = 0.f;
+    auto load_row = [&](int rr, Raw (&d)[P], Raw (&zz)[P]) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) { d[p] = Piece4<T>::load(dy + (long long)rr * C + (p * 64 + lane) * 4); zz[p] = Piece4<T>::load(z + (long long)rr * C + (p * 64 + lane) * 4); }
+    };
+    if (r < rows) { load_row(r, dcur, zcur); mu = mean[r]; rs = rstd[r]; }
+    for (; r < rows; r += stride) {
+        Raw dnx[P], znx[P]; float mun = 0.f, rsn = 0.f;
+        const bool more = r + stride < rows;
+        if (more) { load_row(r + stride, dnx, znx); mun = mean[r + stride]; rsn = rstd[r + stride]; }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float dc[4], zc[4]; Piece4<T>::unpack(dcur[p], dc); Piece4<T>::unpack(zcur[p], zc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (zc[e] - mu) * rs, gy = dc[e] * gm[p][e];
+                dg[p][e] += dc[e] * xh; db[p][e] += dc[e];
+                s1 += gy; s2 += gy * xh;
+            }
+        }
+        s1 = wave_sum(s1) * (1.f / (float)C); s2 = wave_sum(s2) * (1.f / (float)C);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float dc[4], zc[4], o[4], ob[4]; Piece4<T>::unpack(dcur[p], dc); Piece4<T>::unpack(zcur[p], zc);
+            bool kp[4] = {true, true, true, true};
+            const long long col = (p * 64 + lane) * 4;
+            if (thresh && dbranch) dropout_keep4(seed, stream_id, ((unsigned long long)r * C + col) >> 2, thresh, kp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (zc[e] - mu) * rs;
+                o[e] = rs * (dc[e] * gm[p][e] - s1 - xh * s2);
+                ob[e] = (thresh && !kp[e]) ? 0.f : (thresh ? o[e] * keep_scale : o[e]);
+                if (BS) dbs[BS ? p : 0][e] += rnd<T>(ob[e]);
+            }
+            Piece4<T>::store(dres + (long long)r * C + col, o);
+            if (dbranch) Piece4<T>::store(dbranch + (long long)r * C + col, ob);
+        }
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) { dcur[p] = dnx[p]; zcur[p] = znx[p]; }
+            mu = mun; rs = rsn;
+        }
+    }
+#pragma unroll
+    for (int qn = 0; qn < 3; ++qn) {
+        if (qn == 2 && !BS) continue;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[w][(p * 64 + lane) * 4 + e] = qn == 0 ? dg[p][e] : (qn == 1 ? db[p][e] : dbs[BS ? p : 0][e]);
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += LNB2_WAVES * 64) {
+            float a = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < LNB2_WAVES; ++ww) a += red[ww][c];
+            partial[((long long)blockIdx.x * 3 + qn) * C + c] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// 64 columns x 16 slices of the workgroup range per block: 16 independent loads per thread instead of one thread walking all partials
+__global__ __launch_bounds__(1024) void ln_bwd2_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* dgamma, float* dbeta, float* dbsum)
+{
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;                        // 3 C is a multiple of 64
+    const int qn = i / C, c = i - qn * C;
+    float a = 0.f;
+    for (int b = sl; b < nblocks; b += 16) a += partial[((long long)b * 3 + qn) * C + c];
+    red[sl][lane] = a;
+    __syncthreads();
+    if (sl == 0) {
+        float* const dst = qn == 0 ? dgamma : (qn == 1 ? dbeta : dbsum);
+        if (dst) {
+#pragma unroll
+            for (int k = 1; k < 16; ++k) a += red[k][lane];
+            dst[c] += a;
+        }
+    }
+}
+
+static int lnb2_blocks(int rows) {
+    static int cus = 0;
+    if (!cus) {
+#if defined(SS_EMU)
+        cus = 2;
+#else
+        int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+#endif
+    }
+    const int need = (rows + LNB2_WAVES - 1) / LNB2_WAVES;
+    return need < cus ? need : cus;
+}
+// floats of scratch ss_layernorm_backward_ws wants for (rows, C); 0 if this shape runs the atomic form (C not 256, 512 or 768)
+extern "C" int64_t ss_layernorm_backward_scratch_floats(int rows, int C)
+{
+    if (rows <= 0 || (C != 256 && C != 512 && C != 768)) return 0;
+    return (int64_t)lnb2_blocks(rows) * 3 * C;
 }
 
 extern "C" int ss_add_dropout_layernorm_forward(int dtype, const void* x, void* branch_inout, const float* gamma, const float* beta, void* y,
@@ -646,16 +789,39 @@ extern "C" int ss_layernorm_backward_bias(int dtype, const void* dy, const void*
                                           void* dres, void* dbranch, float* dgamma, float* dbeta, float* dbranch_colsum, int rows, int C, float dropout_p,
                                           uint64_t seed, uint32_t rng_stream, void* stream)
 {
+    return ss_layernorm_backward_ws(dtype, dy, z, mean, rstd, gamma, dres, dbranch, dgamma, dbeta, dbranch_colsum, nullptr, 0, rows, C, dropout_p, seed, rng_stream, stream);
+}
+
+extern "C" int ss_layernorm_backward_ws(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                        void* dres, void* dbranch, float* dgamma, float* dbeta, float* dbranch_colsum, float* scratch, int64_t scratch_floats,
+                                        int rows, int C, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
+{
     SS_CHECK(dy && z && mean && rstd && gamma && dres && dgamma && dbeta, "ss_layernorm_backward: null pointer");
     SS_CHECK(!dbranch_colsum || dbranch, "ss_layernorm_backward_bias: the column sums are those of dbranch");
     SS_CHECK(C % 8 == 0 && C > 0 && C <= 4096, "ss_layernorm_backward: C=%d must be a multiple of 8 and <= 4096", C);
     if (rows <= 0) return 0;
     const unsigned th = dropout_threshold(dropout_p); const float ks = 1.f / (1.f - dropout_p);
+    {
+        const int64_t want = ss_layernorm_backward_scratch_floats(rows, C);
+        const char* e = getenv("SS_LN_BWD2");                 // "0": the atomic form (A/B measurements, tests of both)
+        if (scratch && want > 0 && scratch_floats >= want && !(e && e[0] == '0')) {
+            const int nb = lnb2_blocks(rows);
+#define SS_LNB2(TT, PP) do { if (dbranch_colsum) SS_LAUNCH(SS_KERNEL(ln_bwd2_kernel<TT, PP, true>), dim3(nb), dim3(LNB2_WAVES * 64), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, scratch, rows, th, ks, (unsigned long long)seed, rng_stream); \
+                             else SS_LAUNCH(SS_KERNEL(ln_bwd2_kernel<TT, PP, false>), dim3(nb), dim3(LNB2_WAVES * 64), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, scratch, rows, th, ks, (unsigned long long)seed, rng_stream); } while (0)
+            if (dtype == SS_BF16) { if (C == 256) SS_LNB2(bf16_t, 1); else if (C == 512) SS_LNB2(bf16_t, 2); else SS_LNB2(bf16_t, 3); }
+            else { if (C == 256) SS_LNB2(float, 1); else if (C == 512) SS_LNB2(float, 2); else SS_LNB2(float, 3); }
+#undef SS_LNB2
+            SS_LAUNCH(ln_bwd2_finalize_kernel, dim3(3 * C / 64), dim3(1024), 0, stream, (const float*)scratch, nb, C, dgamma, dbeta, dbranch_colsum);
+            SS_LAUNCH_CHECK("ss_layernorm_backward_ws");
+            return 0;
+        }
+    }
     // 2 blocks per CU (~200 registers).  On gfx9 a wait for the prefetched loads also drains the previous row's stores (one vmcnt for both),
     // so consecutive rows of one wave overlap only partly; forcing 3 waves per SIMD (168 registers) spills the column accumulators.
     int blocks = (rows + 15) / 16; if (blocks > 512) blocks = 512;
-#define SS_LNB(TT, NV) do { if (dbranch_colsum) SS_LAUNCH(SS_KERNEL(ln_bwd_kernel<TT, NV, true>), dim3(blocks), dim3(256), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, dgamma, dbeta, dbranch_colsum, rows, C, th, ks, (unsigned long long)seed, rng_stream); \
-                            else SS_LAUNCH(SS_KERNEL(ln_bwd_kernel<TT, NV, false>), dim3(blocks), dim3(256), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, dgamma, dbeta, dbranch_colsum, rows, C, th, ks, (unsigned long long)seed, rng_stream); } while (0)
+    int dbg = 0; { const char* e = getenv("SS_LN_DEBUG"); if (e) dbg = atoi(e); const char* b = getenv("SS_LN_BLOCKS"); if (b) blocks = atoi(b); }
+#define SS_LNB(TT, NV) do { if (dbranch_colsum) SS_LAUNCH(SS_KERNEL(ln_bwd_kernel<TT, NV, true>), dim3(blocks), dim3(256), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, dgamma, dbeta, dbranch_colsum, rows, C, th, ks, (unsigned long long)seed, rng_stream, dbg); \
+                            else SS_LAUNCH(SS_KERNEL(ln_bwd_kernel<TT, NV, false>), dim3(blocks), dim3(256), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, dgamma, dbeta, dbranch_colsum, rows, C, th, ks, (unsigned long long)seed, rng_stream, dbg); } while (0)
     if (dtype == SS_BF16) { if (C <= 1024) SS_LNB(bf16_t, 2); else SS_LNB(bf16_t, 8); }
     else { if (C <= 1024) SS_LNB(float, 2); else SS_LNB(float, 8); }
 #undef SS_LNB

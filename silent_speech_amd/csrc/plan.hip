@@ -391,6 +391,9 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
     void* G = X.alloc((size_t)M * d * es);
     L_(gemm(X, dt, dh_t, w_head_T, G, M, d, nh, RM(nh), RM(nh), RM(d)));
 
+    // scratch of the LayerNorm backward (per-workgroup column sums): one buffer, the launches are stream-ordered
+    const int64_t ln_floats = ss_layernorm_backward_scratch_floats(M, d);
+    float* ln_scratch = ln_floats ? (float*)X.alloc((size_t)ln_floats * 4) : nullptr;
     // ---- encoder layers, last to first (transformer.py:54-59)
     for (int l = c->n_layers - 1; l >= 0; --l) {
         LayerP& w = layers[l]; LayerCtx& s = c->layer[l];
@@ -398,7 +401,7 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         // (its grouped weight-gradient launch) while the main stream is already inside the next layer, so nothing is recycled before join()
         void* dF = X.alloc((size_t)M * d * es);
         // linear2.bias.grad = column sums of dF: accumulated by the LayerNorm backward kernel itself
-        if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward_bias(dt, G, s.z2, s.mean2, s.rstd2, w.g2, G, dF, w.dg2, w.dbe2, w.db2, M, d, p_drop, seed, 4 * l + 3, stream); }));
+        if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward_ws(dt, G, s.z2, s.mean2, s.rstd2, w.g2, G, dF, w.dg2, w.dbe2, w.db2, ln_scratch, ln_floats, M, d, p_drop, seed, 4 * l + 3, stream); }));
         L_(grp.add(dF, s.hid, w.dw2, d, ff, M, RM(d), RM(ff), side));
         void* dHid = X.alloc((size_t)M * ff * es);
         bool db1_fused = false;
@@ -411,7 +414,7 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         if (!db1_fused) { SIDE_BEGIN(); L_(colsum(X, dHid, M, ff, w.db1, side)); SIDE_END(); }
         { ss_gemm_epilogue e = EPI(); e.mode = 1; L_(gemm(X, dt, dHid, w.w1T, G, M, d, ff, RM(ff), RM(ff), RM(d), &e)); }
         void* dA = X.alloc((size_t)M * d * es);
-        if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward(dt, G, s.z1, s.mean1, s.rstd1, w.g1, G, dA, w.dg1, w.dbe1, M, d, p_drop, seed, 4 * l + 1, stream); }));
+        if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward_ws(dt, G, s.z1, s.mean1, s.rstd1, w.g1, G, dA, w.dg1, w.dbe1, nullptr, ln_scratch, ln_floats, M, d, p_drop, seed, 4 * l + 1, stream); }));
         // output projection  out[t,b,f] = sum_{h,a} o[b,h,t,a] w_o[h,a,f]   (transformer.py:111)
         L_(grp.add(dA, s.o, w.wo_stage, d, HD, M, RM(d), RM(HD), side));
         void* dO = X.alloc((size_t)M * HD * es);

@@ -222,9 +222,21 @@ def add_dropout_layernorm(x, branch_inout, gamma, beta, y, rows, C, eps=1e-5, p=
     return mean, rstd
 
 
-def layernorm_backward(dy, z, mean, rstd, gamma, dres, dbranch, dgamma, dbeta, rows, C, p=0.0, seed=0, rng_stream=0):
-    rc = _L().ss_layernorm_backward(_dt(dy), _p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dbranch), _p(dgamma), _p(dbeta),
-                                    rows, C, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(dy))
+_ln_scratch = {}
+
+
+def layernorm_backward(dy, z, mean, rstd, gamma, dres, dbranch, dgamma, dbeta, rows, C, p=0.0, seed=0, rng_stream=0, dbranch_colsum=None):
+    """dres / dbranch / (+=) dgamma, dbeta [, dbranch_colsum]; the per-workgroup column sums go through a cached scratch buffer when the
+    width has the 16-wave form (ss_layernorm_backward_scratch_floats > 0), through atomics otherwise."""
+    n = int(_L().ss_layernorm_backward_scratch_floats(rows, C))
+    scratch = None
+    if n:
+        key = (str(dy.device), n)
+        scratch = _ln_scratch.get(key)
+        if scratch is None:
+            scratch = _ln_scratch[key] = torch.empty(n, dtype=torch.float32, device=dy.device)
+    rc = _L().ss_layernorm_backward_ws(_dt(dy), _p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dbranch), _p(dgamma), _p(dbeta),
+                                       _p(dbranch_colsum), _p(scratch), n, rows, C, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(dy))
     _lib.check(rc, 'ss_layernorm_backward')
 
 

@@ -5,7 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import adamw_ref
-from silent_speech_amd import ops
+from silent_speech_amd import _lib, ops
 from tests.backend import dev, is_emu  # noqa: F401
 from tests.util import assert_close_robust
 
@@ -124,6 +124,33 @@ def test_layernorm_dropout_mask_consistency(dev):
     dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     ops.layernorm_backward(dy.to(dev), ad, mean, rstd, torch.ones(C, device=dev), dres, dbr, dg, db, rows, C, p=p, seed=77, rng_stream=5)
     assert torch.allclose(dbr.cpu(), dres.cpu() * kept.float() * 1.25, atol=1e-6)
+
+
+@pytest.mark.parametrize('dt', DTS)
+@pytest.mark.parametrize('C', [256, 768])
+def test_layernorm_backward_forms_agree(dev, dt, C, monkeypatch):
+    """The 16-wave scratch form (C = 256 / 512 / 768) and the atomic form (SS_LN_BWD2=0) of the LayerNorm backward: same dres / dbranch
+    (same dropout mask) and dgamma / dbeta / branch column sums up to summation order; the sums ACCUMULATE into their destinations."""
+    rows, p = (41 if is_emu(dev) else 3001), 0.25
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(rows, C, generator=g).to(dt); dy = torch.randn(rows, C, generator=g).to(dt)
+    gamma = torch.rand(C, generator=g) + 0.5
+    zf = z.float(); mean = zf.mean(1); rstd = (zf.var(1, unbiased=False) + 1e-5).rsqrt()
+    assert int(_lib.lib().ss_layernorm_backward_scratch_floats(rows, C)) > 0
+    res = {}
+    for form in ('1', '0'):
+        monkeypatch.setenv('SS_LN_BWD2', form)
+        dres = torch.empty(rows, C, dtype=dt, device=dev); dbr = torch.empty(rows, C, dtype=dt, device=dev)
+        dg, db, dbs = [torch.full((C,), 3.0, device=dev) for _ in range(3)]
+        ops.layernorm_backward(dy.to(dev), z.to(dev), mean.to(dev), rstd.to(dev), gamma.to(dev), dres, dbr, dg, db, rows, C, p=p, seed=5, rng_stream=9, dbranch_colsum=dbs)
+        res[form] = [t.float().cpu() for t in (dres, dbr, dg, db, dbs)]
+    tol = 2e-6 if dt == torch.float32 else 1e-2                              # the row sums are taken in a different lane order
+    assert_close_robust(res['1'][0], res['0'][0], tol, name='dres', max_outlier_frac=0)
+    assert_close_robust(res['1'][1], res['0'][1], tol, name='dbranch', max_outlier_frac=0)
+    assert torch.equal(res['1'][1] == 0, res['0'][1] == 0)                     # the same dropped set
+    for i, name in ((2, 'dgamma'), (3, 'dbeta'), (4, 'dbranch_colsum')):
+        assert_close_robust(res['1'][i], res['0'][i], 2e-5 if dt == torch.float32 else 1e-3, name=name, max_outlier_frac=0)   # bf16: a dbranch entry may round the other way
+    assert_close_robust(res['1'][4], 3.0 + res['1'][1].sum(0), 1e-4, name='colsum of dbranch', max_outlier_frac=0)
 
 
 @pytest.mark.parametrize('dt', DTS)
