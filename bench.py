@@ -352,17 +352,24 @@ def main():
                     continue
             hints = {'gemm8_kc_kernel (288x256)': 'gemm8_kc_kernel<unsigned short, 9', 'gemm8_kc_kernel (256x256)': 'gemm8_kc_kernel<unsigned short, 8',
                      'gemm_dw_grouped': 'gemm8_dw_kernel', 'gemm_w2_kernel (128|144 x 128)': 'gemm_w2_kernel', 'gemm_glds_kernel (128x128)': 'gemm_glds_kernel',
-                     'attn_fwd': 'attn_fwd_res_kernel', 'attn_bwd': 'attn_bwd_kv_res_kernel', 'bn_stats': 'bn_partial_kernel', 'bn_apply': 'bn_apply_kernel',
+                     'attn_fwd': 'attn_fwd_res2_kernel', 'attn_bwd': ('attn_bwd_kv2_kernel', 'attn_bwd_q2_kernel', 'attn_dsum_kernel'), 'bn_stats': 'bn_partial_kernel', 'bn_apply': 'bn_apply_kernel',
                      'bn_bwd_sums': 'bn_bwd_partial_kernel', 'bn_bwd_apply': 'bn_bwd_apply_kernel', 'add_dropout_ln_fwd': 'add_dropout_ln_fwd_kernel',
-                     'ln_bwd': 'ln_bwd_kernel', 'adamw_kernel': 'adamw_kernel', 'dtw_kernel': 'dtw_kernel', 'silent_cost_skewed_kernel': 'silent_cost_skewed_kernel',
+                     'ln_bwd': ('ln_bwd2_kernel<', 'ln_bwd2_finalize_kernel'), 'adamw_kernel': 'adamw_kernel', 'dtw_kernel': 'dtw_kernel', 'silent_cost_skewed_kernel': 'silent_cost_skewed_kernel',
                      'colsum': 'colsum_partial_kernel', 'permute3d_batch (weight re-layout)': 'permute3d_batch_kernel', 'grad_unlayout': 'permute3d_batch_f32_kernel'}
 
-            def traffic_of(name):
-                h = hints.get(name)
-                for k, v in pmc.items():
-                    if h and h in k:
-                        return v.get('hbm_bytes_per_launch')
-                return None
+            def traffic_of(name):              # a logical launch may be several kernels (attention backward = 3): their HBM bytes add up
+                hs = hints.get(name)
+                if not hs:
+                    return None
+                hs = (hs,) if isinstance(hs, str) else hs
+                tot, hit = 0.0, False
+                for h in hs:
+                    for k, v in pmc.items():
+                        if h in k:
+                            tot += v.get('hbm_bytes_per_launch') or 0.0
+                            hit = True
+                            break
+                return tot if hit else None
             kernels = []
             total_s = sum(v['seconds'] for v in table.values())
             for name, v in sorted(table.items(), key=lambda kv: -kv[1]['seconds']):

@@ -245,6 +245,10 @@ struct Plan {
 
 #define L_(call) do { if (call) return 1; } while (0)
 
+// (query, key) pairs inside the relative-position band |k - q| <= D - 1 of one sequence: the attention kernels' algorithmic work is
+// 2 dp flops per pair and product -- 3 products forward (QK, QE, PV), 5 backward (dP, dS K, dR E, P^T dO, dS^T Q)
+static double band_pairs(int T, int D) { double n = 0; for (int q = 0; q < T; ++q) { const int lo = q - (D - 1) < 0 ? 0 : q - (D - 1), hi = q + (D - 1) > T - 1 ? T - 1 : q + (D - 1); n += hi - lo + 1; } return n; }
+
 int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, int training, int shift_r, float p_drop, unsigned long long seed, float* head, Ctx* c)
 {
     const int dt = D.dtype, d = D.d_model; const size_t es = esz();
@@ -330,7 +334,7 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         // training: the resident forward leaves its probabilities for the backward kernels (no recomputation of the logits there)
         const size_t pimg_bytes = training ? (size_t)ss_relpos_attention_saved_bytes(dt, B, H, T, dp, Dr) : 0;
         void* pimg = pimg_bytes ? X.alloc(pimg_bytes) : nullptr;
-        if (!X.dry) L_(timed(X, "attn_fwd", 4.0 * B * H * T * (2.0 * Dr - 1 < T ? 2.0 * Dr - 1 : T) * dp * 1.5, (double)M * 4 * HD * es, stream, [&] { return ss_relpos_attention_forward_p(dt, qkv, qkvT, w.E, o, lse, pimg, B, H, T, Tp, dp, Dr, scale, p_drop, seed, 4 * l, stream); }));
+        if (!X.dry) L_(timed(X, "attn_fwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 3.0, (double)M * 4 * HD * es, stream, [&] { return ss_relpos_attention_forward_p(dt, qkv, qkvT, w.E, o, lse, pimg, B, H, T, Tp, dp, Dr, scale, p_drop, seed, 4 * l, stream); }));
         s.pimg = pimg;
         void* a = X.alloc((size_t)M * d * es);
         L_(gemm(X, dt, o, w.wo, a, M, d, HD, RM(HD), RM(HD), RM(d)));
@@ -426,7 +430,7 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         } else L_(gemm(X, dt, dA, w.woT, dO, M, HD, d, RM(d), RM(d), RM(HD)));
         void* dqkv = X.alloc((size_t)M * 3 * HD * es);
         float* dsc = (float*)X.alloc((size_t)B * H * T * 4);
-        if (!X.dry) L_(timed(X, "attn_bwd", 4.0 * B * H * T * (2.0 * Dr - 1 < T ? 2.0 * Dr - 1 : T) * dp * 3.75, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_backward_p(dt, s.qkv, s.qkvT, w.E, w.ET, s.o, s.lse, dO, dOT, dsc, dqkv, s.pimg, B, H, T, Tp, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
+        if (!X.dry) L_(timed(X, "attn_bwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 5.0, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_backward_p(dt, s.qkv, s.qkvT, w.E, w.ET, s.o, s.lse, dO, dOT, dsc, dqkv, s.pimg, B, H, T, Tp, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
         L_(grp.add(dqkv, s.x, w.wqkv_stage, 3 * HD, d, M, RM(3 * HD), RM(d), side));
         { ss_gemm_epilogue e = EPI(); e.mode = 1; L_(gemm(X, dt, dqkv, w.wqkvT, G, M, d, 3 * HD, RM(3 * HD), RM(3 * HD), RM(d), &e)); }
         if (l > 0) { SIDE_BEGIN(); L_(grp.launch(side)); SIDE_END(); }          // layer 0's group waits for w_raw_in's gradient

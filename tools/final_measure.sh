@@ -1,13 +1,21 @@
-export TMPDIR=/tmp
-O=gpurun_out/final; mkdir -p $O
+#!/bin/bash
+# Round-end measurement on the GPU box: GPU tests, the default bench line, rocprofv3 kernel traces (overlapped and serial), the HBM
+# traffic counters (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, kernel trace only) and the SQ counters of the attention kernels.
+# Everything lands in gpurun_out/final/; copy what is to be judged into profiles/ (tracked).
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+O=gpurun_out/final; rm -rf $O; mkdir -p $O
 python -m pytest tests -m gpu -q -x 2>&1 | tail -3 > $O/pytest_gpu.log
 python bench.py > $O/bench.json.log 2>$O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --steps 6 --warmup 2 --cpu-rows 0 > $O/kt_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --steps 6 --warmup 2 --cpu-rows 0 --no-legs --no-profile > $O/kt_bench.log 2>&1
 python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -1) 8 > $O/kernel_stats.txt
-SS_AMD_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -d $O/ks -o ks -- python bench.py --steps 6 --warmup 2 --cpu-rows 0 --no-profile > $O/ks_bench.log 2>&1
+SS_AMD_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -d $O/ks -o ks -- python bench.py --steps 6 --warmup 2 --cpu-rows 0 --no-legs --no-profile > $O/ks_bench.log 2>&1
 python tools/rocprof_summary.py $(find $O/ks -name "*.db" | head -1) 8 > $O/serial_kernel_stats.txt
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o pf -- python bench.py --steps 2 --warmup 1 --cpu-rows 0 --no-profile > $O/pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o pw -- python bench.py --steps 2 --warmup 1 --cpu-rows 0 --no-profile > $O/pw.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o pf -- python bench.py --steps 2 --warmup 1 --cpu-rows 0 --no-legs --no-profile > $O/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o pw -- python bench.py --steps 2 --warmup 1 --cpu-rows 0 --no-legs --no-profile > $O/pw.log 2>&1
 python tools/pmc_summary.py $(find $O/pf -name "*.db" | head -1) $(find $O/pw -name "*.db" | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt
 rm -rf $O/kt $O/ks $O/pf $O/pw
-cat $O/pytest_gpu.log; tail -1 $O/bench.json.log | cut -c1-400; head -6 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -5 $O/pmc_traffic.txt
+bash tools/attn_trace.sh > /dev/null 2>&1; cp gpurun_out/attn_trace/kernel_stats.txt $O/attention_kernel_stats.txt
+bash tools/attn_pmc.sh > /dev/null 2>&1; cp gpurun_out/attn_pmc/table.txt $O/attention_sq_counters.txt
+./tools/bin/attn_bench > $O/attention_bench.txt 2>&1
+cat $O/pytest_gpu.log; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/attention_bench.txt
