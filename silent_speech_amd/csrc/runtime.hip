@@ -87,6 +87,61 @@ __device__ __forceinline__ void permute_job(const PermuteJob& j, int lb, int nth
     const bool c0 = j.d0 > 1 && as0 >= 1 && as0 <= 4, c1 = j.d1 > 1 && as1 >= 1 && as1 <= 4;
     const bool fx1 = c1 && (!c0 || j.d1 >= j.d0), fx0 = c0 && !fx1;
     const int dXq = fx1 ? j.d1 : j.d0;
+    const bool al16 = ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
+    // ---- cast path: the same dense layout on both sides (the plain [N][K] weights, more than half of the parameters): one linear
+    // index, 8 elements per thread, no index arithmetic at all (the row path below spends two 64-bit divisions per 4 elements)
+    if (!GROUPED_RMW && !j.accumulate && j.s2 == 1 && j.s1 == j.d2 && j.o1 == j.d2 && (j.d0 == 1 || (j.s0 == (long long)j.d1 * j.d2 && j.o0 == j.s0)) &&
+        j.valid1 >= j.d1 && j.valid2 >= j.d2 && (total & 7) == 0 && al16 && total < (1LL << 34)) {
+        const unsigned n8 = (unsigned)(total >> 3), step = (unsigned)j.nblocks * nthreads;
+        for (unsigned i = (unsigned)lb * nthreads + tid; i < n8; i += step) {
+            float v[8]; Vec8<TI>::load(in + (size_t)i * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= j.scale;
+            Vec8<TO>::store(out + (size_t)i * 8, v);
+        }
+        return;
+    }
+    // ---- vector transpose path (16-bit output): input unit-stride along X, output along c, everything in multiples of 8 elements.
+    // 64 (X) x 64 (c) tiles: 16/32-byte loads along X, a 16-bit LDS tile, 16-byte stores along c -- the scalar transpose path below
+    // moves 2 bytes per lane and instruction on both sides.
+    if (!GROUPED_RMW && sizeof(TO) == 2 && !j.accumulate && as2 >= 8 && (fx0 || fx1) && nthreads == 256 && al16) {
+        const int dX = fx1 ? j.d1 : j.d0, dO = fx1 ? j.d0 : j.d1;
+        const long long sX = fx1 ? j.s1 : j.s0, sO = fx1 ? j.s0 : j.s1, oX = fx1 ? j.o1 : j.o0, oO = fx1 ? j.o0 : j.o1;
+        const int vX = fx1 ? (j.valid1 < j.d1 ? j.valid1 : j.d1) : dX, vO = fx1 ? dO : (j.valid1 < j.d1 ? j.valid1 : j.d1), vC = j.valid2 < j.d2 ? j.valid2 : j.d2;
+        if (sX == 1 && !(dX & 7) && !(j.d2 & 7) && !(sO & 7) && !(j.s2 & 7) && !(oX & 7) && !(oO & 7) && !(vX & 7) && !(vC & 7) && dX >= 64 && j.d2 >= 64) {
+            unsigned short* t16 = (unsigned short*)tile;                    // [64 c][66]
+            const int tiles_x = (dX + 63) >> 6, tiles_c = (j.d2 + 63) >> 6;
+            const long long ntiles = (long long)dO * tiles_x * tiles_c;
+            for (long long t = lb; t < ntiles; t += j.nblocks) {
+                const int oi = (int)(t / (tiles_x * tiles_c)), rem = (int)(t - (long long)oi * (tiles_x * tiles_c));
+                const int tx = rem / tiles_c, tc = rem - tx * tiles_c;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int f = k * 256 + tid, cc = f >> 3, x0 = (f & 7) * 8, gx = tx * 64 + x0, gc = tc * 64 + cc;
+                    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (gx < vX && gc < vC && oi < vO) { Vec8<TI>::load(in + oi * sO + gx + (long long)gc * j.s2, v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= j.scale; }
+                    unsigned* d = (unsigned*)(t16 + cc * 66 + x0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = pack_bf16(v[2 * e], v[2 * e + 1]);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int f = k * 256 + tid, x = f >> 3, c0 = (f & 7) * 8, gx = tx * 64 + x, gc = tc * 64 + c0;
+                    if (gx < dX && gc < j.d2) {
+                        u32x4 r;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] = (unsigned)t16[(c0 + 2 * e) * 66 + x] | ((unsigned)t16[(c0 + 2 * e + 1) * 66 + x] << 16);
+                        *(u32x4*)(out + oi * oO + gx * oX + gc) = r;
+                    }
+                }
+                __syncthreads();
+            }
+            return;
+        }
+    }
     // (a 4096-element tile must be reasonably full: an (O, 8, 3) conv weight would put 24 elements in each and its few
     //  workgroups would walk hundreds of almost empty tiles -- the generic path is faster there)
     if (as2 > 4 && (fx0 || fx1) && nthreads == 256 && total >= 4096 && (long long)(dXq < 64 ? dXq : 64) * (j.d2 < 64 ? j.d2 : 64) >= 192) {

@@ -1,5 +1,5 @@
 """ss_permute3d_batch (weight re-layout / gradient un-layout) against an index gather on every code path of the kernel:
-vector rows, LDS-tiled transposes (short X, short c, negative / near-contiguous strides), generic gather."""
+linear casts, vector rows, vector and scalar LDS-tiled transposes (short X, short c, negative / near-contiguous strides), generic gather."""
 import numpy as np
 import pytest
 import torch
@@ -17,6 +17,11 @@ CASES = [
     ((4, 32, 72), (72 * 20, 1, 20), 0, 20, None, False, torch.float32, torch.bfloat16),      # per-head projection, zero-padded head dim
     ((5, 7, 11), (77, 11, 1), 0, None, 9, False, torch.float32, torch.float32),              # small generic job with column padding
     ((2, 130, 70), (130 * 70, 1, 130), 0, None, None, True, torch.bfloat16, torch.float32),  # ragged tiles, bf16 in, accumulate
+    ((1, 96, 160), (0, 160, 1), 0, None, None, False, torch.float32, torch.float32),         # dense copy: linear cast path, f32 out
+    ((3, 40, 64), (2560, 64, 1), 0, None, None, False, torch.bfloat16, torch.bfloat16),      # dense 3-d copy (cast path)
+    ((136, 1, 200), (1, 0, 136), 0, None, None, False, torch.bfloat16, torch.bfloat16),      # [n][k] -> [k][n], vector transpose path, ragged tiles
+    ((3, 72, 128), (128 * 88, 1, 88), 0, 64, None, False, torch.float32, torch.bfloat16),    # per-head projection (vector transpose, f32 in, head dim padded 64 -> 72)
+    ((192, 2, 80), (1, 80 * 192, 192), 0, None, 72, False, torch.float32, torch.bfloat16),   # W_o form: X = dim 0, columns beyond 72 zero
 ]
 
 
