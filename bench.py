@@ -351,7 +351,7 @@ def main():
                 except Exception:
                     continue
             hints = {'gemm8_kc_kernel (288x256)': 'gemm8_kc_kernel<unsigned short, 9', 'gemm8_kc_kernel (256x256)': 'gemm8_kc_kernel<unsigned short, 8',
-                     'gemm_dw_grouped': 'gemm8_dw_kernel', 'gemm_w2_kernel (128|144 x 128)': 'gemm_w2_kernel', 'gemm_glds_kernel (128x128)': 'gemm_glds_kernel',
+                     'gemm_dw_grouped': 'gemm8_dw_kernel', 'gemm_smallk_kernel (K <= 32, first conv)': 'gemm_smallk_kernel', 'gemm_w2_kernel (128|144 x 128)': 'gemm_w2_kernel', 'gemm_glds_kernel (128x128)': 'gemm_glds_kernel',
                      'attn_fwd': 'attn_fwd_res2_kernel', 'attn_bwd': ('attn_bwd_kv2_kernel', 'attn_bwd_q2_kernel', 'attn_dsum_kernel'), 'bn_stats': 'bn_partial_kernel', 'bn_apply': 'bn_apply_kernel',
                      'bn_bwd_sums': 'bn_bwd_partial_kernel', 'bn_bwd_apply': 'bn_bwd_apply_kernel', 'add_dropout_ln_fwd': 'add_dropout_ln_fwd_kernel',
                      'ln_bwd': ('ln_bwd2_kernel<', 'ln_bwd2_finalize_kernel'), 'adamw_kernel': 'adamw_kernel', 'dtw_kernel': 'dtw_kernel', 'silent_cost_skewed_kernel': 'silent_cost_skewed_kernel',

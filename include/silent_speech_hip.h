@@ -89,17 +89,17 @@ int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, 
  * run on a side stream use 1 so that the dependent chain on the main stream can co-reside on every CU.  Returns the old value. */
 int ss_gemm_set_blocks_per_cu(int n); /* [host] */
 /* Which kernel the calling thread's last ss_gemm launch used: 0 register-staged gemm_kernel, 1 gemm_glds_kernel,
- * 2 gemm_w2_kernel, 3 / 4 gemm8_kc_kernel with 256 / 288-row tiles (so that a profiler can attribute per-launch timings to
+ * 2 gemm_w2_kernel, 3 / 4 gemm8_kc_kernel with 256 / 288-row tiles, 5 gemm_smallk_kernel (K <= 32, no LDS) (so that a profiler can attribute per-launch timings to
  * the kernel names rocprofv3 reports, and tests can assert which variant they exercised). */
 int ss_gemm_last_kernel(void); /* [host] */
-/* 1 if ss_gemm with these arguments runs the 8-wave kernel, which honours epilogue.col_sum / col_sumsq; 0 otherwise (the call then fails
+/* 1 if ss_gemm with these arguments runs a kernel that honours epilogue.col_sum / col_sumsq (the 8-wave kernel, the K <= 32 kernel); 0 otherwise (the call then fails
  * with those fields set).  Same decision procedure as ss_gemm itself (legality + cost model + knobs). */
 int ss_gemm_fuses_column_stats(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* C, int M, int N, int K, const ss_rowmap* amap,
                                const ss_rowmap* bmap, const ss_rowmap* cmap, const ss_gemm_epilogue* epilogue, int split_k); /* [host] */
 /* Kernel-selection knobs of ss_gemm (process-wide): what = 0 two-wave kernel (0 never / 1 cost model / 2 whenever legal),
  * 1 its tile height (128 / 144, 0 = cost model), 2 eight-wave kernel (0 / 1 / 2 as above), 3 its tile height in 16-row units
  * per M-wave (8 / 9, 0 = cost model), 4 its LDS reads / DMA pieces spread between MFMA groups (0 / 1, 2 = per tile height), 5 ablation mask for kernel tuning (results are
- * wrong when non-zero).  value < 0 restores the default (environment SS_GEMM_W2, SS_GEMM_W2_BM, SS_GEMM8, SS_GEMM8_NI, SS_GEMM8_PIN,
+ * wrong when non-zero), 6 the LDS-free K <= 32 kernel on / off (SS_GEMM_SMALLK).  value < 0 restores the default (environment SS_GEMM_W2, SS_GEMM_W2_BM, SS_GEMM8, SS_GEMM8_NI, SS_GEMM8_PIN,
  * SS_GEMM_DEBUG).  Returns the previous value, -1 for a bad `what`. */
 int ss_gemm_set_option(int what, int value); /* [host] */
 

@@ -644,11 +644,12 @@ extern "C" int ss_gemm_set_blocks_per_cu(int n) { int old = g_blocks_per_cu; if 
 //   4 SS_GEMM8_PIN   bit 0: its fragment reads, bit 1: its DMA pieces spread between the MFMA groups (else a burst per phase); 4 = per tile height
 //   5 SS_GEMM_DEBUG  ablation mask for tuning (results are then wrong): 1 no flush stores, 2 no epilogue staging, 4 no MFMA (128-wide
 //                    kernels); 16 no MFMA, 32 no in-loop global->LDS copies, 64 no in-loop fragment reads, 128 no C flush (8-wave kernel)
-enum { OPT_W2 = 0, OPT_W2_BM, OPT_G8, OPT_G8_NI, OPT_G8_PIN, OPT_DEBUG, OPT_COUNT };
-static int g_opt[OPT_COUNT] = {-1, -1, -1, -1, -1, -1};
+//   6 SS_GEMM_SMALLK the LDS-free K <= 32 kernel (gemm_smallk.hip): 0 never, 1 whenever legal
+enum { OPT_W2 = 0, OPT_W2_BM, OPT_G8, OPT_G8_NI, OPT_G8_PIN, OPT_DEBUG, OPT_SMALLK, OPT_COUNT };
+static int g_opt[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1};
 static int gemm_opt(int what) {
-    static const char* names[OPT_COUNT] = {"SS_GEMM_W2", "SS_GEMM_W2_BM", "SS_GEMM8", "SS_GEMM8_NI", "SS_GEMM8_PIN", "SS_GEMM_DEBUG"};
-    static const int defaults[OPT_COUNT] = {1, 0, 1, 0, 4, 0};
+    static const char* names[OPT_COUNT] = {"SS_GEMM_W2", "SS_GEMM_W2_BM", "SS_GEMM8", "SS_GEMM8_NI", "SS_GEMM8_PIN", "SS_GEMM_DEBUG", "SS_GEMM_SMALLK"};
+    static const int defaults[OPT_COUNT] = {1, 0, 1, 0, 4, 0, 1};
     if (g_opt[what] < 0) { const char* e = getenv(names[what]); g_opt[what] = e ? atoi(e) : defaults[what]; }
     return g_opt[what];
 }
@@ -724,6 +725,11 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     const int nitems = tiles_m * tiles_n * split_k;
     const int slots = gemm_slots();
     dim3 grid(nitems < slots ? nitems : slots), block(256);
+    if (gemm_opt(OPT_SMALLK) && gemm_smallk_ok(sizeof(T) == 2 ? SS_BF16 : SS_F32, sizeof(TO) == 2 ? SS_BF16 : SS_F32, a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k)) {
+        if (gemm_smallk_launch(A, B, C, M, N, K, am, bm, epi, stream)) return 1;       // K <= 32: register-resident weights, no LDS (gemm_smallk.hip)
+        g_last_kernel = 5;
+        return 0;
+    }
     {   // 8-wave 256 / 288 x 256 kernel (gemm8.hip)
         int ni = 0, pin = 0;
         if (pick_gemm8(sizeof(T) == 2, a_mode, b_mode, M, N, K, am, bm, epi, split_k, &ni, &pin)) {
@@ -868,6 +874,7 @@ extern "C" int ss_gemm_fuses_column_stats(int dtype_in, int dtype_out, int a_mod
     if (!amap || !bmap || !cmap || dtype_in != SS_BF16 || (dtype_out != SS_BF16 && dtype_out != SS_F32) || M <= 0 || N <= 0) return 0;
     GemmEpi epi;
     if (build_epi(epi, dtype_out, C, M, N, cmap, e, split_k)) return 0;
+    if (gemm_opt(OPT_SMALLK) && gemm_smallk_ok(dtype_in, dtype_out, a_mode, b_mode, (const void*)16, (const void*)16, C, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, split_k)) return 1;
     int ni = 0, pin = 0;
     return pick_gemm8(true, a_mode, b_mode, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, split_k, &ni, &pin) ? 1 : 0;
 }

@@ -557,12 +557,14 @@ extern "C" int ss_plan_profile_read(ss_plan* h, ss_profile_row* rows, int max_ro
         hipEventSynchronize(r.e1);
         float ms = 0.f; hipEventElapsedTime(&ms, r.e0, r.e1);
         const char* name = r.tag;
+        double flops = r.flops;
         if (!strcmp(r.tag, "gemm") && r.sub >= 0 && r.sub < 5) name = gemm_names[r.sub];
+        else if (!strcmp(r.tag, "gemm") && r.sub == 5) { name = "gemm_smallk_kernel (K <= 32, first conv)"; flops = 0; }      // an HBM-bound write of C: reported by its bytes
         else if (!strcmp(r.tag, "gemm_dw")) name = "gemm_kernel<OC,OC> (128x128 dW, split-K atomics)";
         int k = 0;
         for (; k < n; ++k) if (!strcmp(rows[k].name, name)) break;
         if (k == n) { if (n == max_rows) continue; memset(&rows[n], 0, sizeof(rows[n])); strncpy(rows[n].name, name, sizeof(rows[n].name) - 1); ++n; }
-        rows[k].calls += 1; rows[k].seconds += ms * 1e-3; rows[k].flops += r.flops; rows[k].bytes += r.bytes;
+        rows[k].calls += 1; rows[k].seconds += ms * 1e-3; rows[k].flops += flops; rows[k].bytes += r.bytes;
     }
     P->recs.clear(); P->ev_used = 0;
 #else

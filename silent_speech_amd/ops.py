@@ -136,7 +136,7 @@ def _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, extras, a_mode=OP_KC, b_mode=
     return C
 
 
-GEMM_OPT_W2, GEMM_OPT_W2_BM, GEMM_OPT_G8, GEMM_OPT_G8_NI, GEMM_OPT_G8_PIN = range(5)
+GEMM_OPT_W2, GEMM_OPT_W2_BM, GEMM_OPT_G8, GEMM_OPT_G8_NI, GEMM_OPT_G8_PIN, GEMM_OPT_DEBUG, GEMM_OPT_SMALLK = range(7)
 
 
 def gemm_set_option(what, value):

@@ -4,7 +4,7 @@ import torch
 
 from silent_speech_amd import ops
 from silent_speech_amd._lib import OP_KC, OP_OC
-from tests.backend import dev, is_emu  # noqa: F401
+from tests.backend import dev, is_emu as backend_is_emu, is_emu  # noqa: F401
 from tests.util import assert_close_robust
 
 
@@ -151,7 +151,7 @@ def test_gemm_transposed_second_output(dev, dt):
 def gemm_opts():
     """Restores the kernel-selection knobs after a test that forces a variant."""
     yield ops.gemm_set_option
-    for what in range(5):
+    for what in range(7):
         ops.gemm_set_option(what, -1)
 
 
@@ -275,3 +275,41 @@ def test_gemm8_column_statistics(dev, gemm_opts, ni, out_dt):
     assert _lib.lib().ss_gemm_last_kernel() in (3, 4)
     with pytest.raises(RuntimeError, match='8-wave kernel'):
         ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), col_stats=(cs, None, None))
+
+
+# ------------------------------------------------------------------ K <= 32: the LDS-free kernel of the first convolution (csrc/gemm_smallk.hip)
+@pytest.mark.parametrize('ktaps', [3, 1])
+@pytest.mark.parametrize('stats', [False, True])
+def test_gemm_smallk_first_conv(dev, gemm_opts, ktaps, stats):
+    """The model's first convolution (8 channels x 3 taps, stride 2, overlapping rows of the padded input) and its 1x1 residual projection
+    (K = 8, centre tap), bias and BatchNorm column statistics in the epilogue, against conv1d -- and against the tiled kernel it replaces."""
+    from silent_speech_amd import _lib
+    Bn, T, Ci, Co = (2, 40, 8, 64) if backend_is_emu(dev) else (7, 800, 8, 768)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(Bn, T, Ci, generator=g).to(dt)
+    w = (torch.randn(Co, Ci, ktaps, generator=g) * 0.3).to(dt)
+    bias = torch.randn(Co, generator=g); shift = torch.randn(Co, generator=g) * 0.1
+    want = torch.nn.functional.conv1d(x.float().transpose(1, 2), w.float(), bias, stride=2, padding=ktaps // 2).transpose(1, 2)
+    To = want.shape[1]
+    xpad = torch.zeros(Bn, T + 2, Ci, dtype=dt); xpad[:, 1:-1] = x
+    wg = w.permute(0, 2, 1).reshape(Co, ktaps * Ci).contiguous()
+    amap = ops.rowmap(2 * Ci, rows_per_batch=To, batch_stride=(T + 2) * Ci, base=(0 if ktaps == 3 else Ci))
+    res = {}
+    for on in (1, 0):
+        gemm_opts(ops.GEMM_OPT_SMALLK, on)
+        y = torch.zeros(Bn, To, Co, dtype=dt, device=dev)
+        cs, cq = torch.full((Co,), 2.0, device=dev), torch.full((Co,), 3.0, device=dev)
+        if stats and not on:
+            continue                                                   # the tiled kernels have no statistics for this K
+        kw = dict(col_stats=(cs, cq, shift.to(dev))) if stats else {}
+        ops.gemm(xpad.to(dev), wg.to(dev), y, Bn * To, Co, ktaps * Ci, amap, ops.rowmap(ktaps * Ci), ops.rowmap(Co), bias=bias.to(dev), **kw)
+        assert int(_lib.lib().ss_gemm_last_kernel()) == (5 if on else 0)
+        res[on] = y.float().cpu()
+        assert_close_robust(y, want, rtol=_tol(dt), name='conv K=%d' % (ktaps * Ci), max_outlier_frac=0)
+        if stats:
+            v = y.float().cpu().reshape(-1, Co) - shift
+            assert_close_robust(cs, 2.0 + v.sum(0), 1e-4, name='col_sum', max_outlier_frac=0)
+            assert_close_robust(cq, 3.0 + (v * v).sum(0), 1e-4, name='col_sumsq', max_outlier_frac=0)
+    if 0 in res:
+        assert torch.equal(res[1], res[0])                              # same products, same f32 accumulation order inside one MFMA
