@@ -120,7 +120,8 @@ typedef struct ss_dw_job {
     int32_t reserved;
 } ss_dw_job;
 int ss_gemm_dw_grouped(int n_jobs, const ss_dw_job* jobs /* [host] */, void* stream);
-/* Tuning knobs of ss_gemm_dw_grouped for the calling thread: what = 0 K split override (0 = automatic), 1 scheduling fences. */
+/* Tuning knobs of ss_gemm_dw_grouped for the calling thread: what = 0 K split override (0 = automatic), 1 scheduling fences,
+ * 2 XCD-contiguous item order on / off (default on: neighbouring tiles of one problem share an L2). */
 int ss_gemm_dw_set_option(int what, int value); /* [host] */
 
 /* out[a][b][c] (contiguous, dims d0 x d1 x d2) (+)= scale * in[a*s0 + b*s1 + c*s2] for b < valid1 and
