@@ -144,6 +144,54 @@ __device__ __forceinline__ void permute_job(const PermuteJob& j, int lb, int nth
     }
     // (a 4096-element tile must be reasonably full: an (O, 8, 3) conv weight would put 24 elements in each and its few
     //  workgroups would walk hundreds of almost empty tiles -- the generic path is faster there)
+    // ---- vector transpose path, f32 -> f32 (the gradient un-layout: GEMM-layout weight gradients accumulated into the parameter-layout
+    // .grad arena): 64 x 64 tiles, 16-byte loads along X, 16-byte read-modify-write along c
+    if (sizeof(TI) == 4 && sizeof(TO) == 4 && as2 >= 4 && (fx0 || fx1) && nthreads == 256 && al16) {
+        const int dX = fx1 ? j.d1 : j.d0, dO = fx1 ? j.d0 : j.d1;
+        const long long sX = fx1 ? j.s1 : j.s0, sO = fx1 ? j.s0 : j.s1, oX = fx1 ? j.o1 : j.o0, oO = fx1 ? j.o0 : j.o1;
+        const int vX = fx1 ? (j.valid1 < j.d1 ? j.valid1 : j.d1) : dX, vO = fx1 ? dO : (j.valid1 < j.d1 ? j.valid1 : j.d1), vC = j.valid2 < j.d2 ? j.valid2 : j.d2;
+        if (sX == 1 && !(dX & 3) && !(j.d2 & 3) && !(sO & 3) && !(j.s2 & 3) && !(oX & 3) && !(oO & 3) && !(vX & 3) && !(vC & 3) && dX >= 32 && j.d2 >= 32) {
+            const int tiles_x = (dX + 63) >> 6, tiles_c = (j.d2 + 63) >> 6;
+            const long long ntiles = (long long)dO * tiles_x * tiles_c;
+            for (long long t = lb; t < ntiles; t += j.nblocks) {
+                const int oi = (int)(t / (tiles_x * tiles_c)), rem = (int)(t - (long long)oi * (tiles_x * tiles_c));
+                const int tx = rem / tiles_c, tc = rem - tx * tiles_c;
+                f32x4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = k * 256 + tid, cc = f >> 4, x0 = (f & 15) * 4, gx = tx * 64 + x0, gc = tc * 64 + cc;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    v[k] = (gx < vX && gc < vC && oi < vO) ? *(const f32x4*)((const float*)in + oi * sO + gx + (long long)gc * j.s2) : z;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = k * 256 + tid, cc = f >> 4, x0 = (f & 15) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tile[cc * 65 + x0 + e] = v[k][e] * j.scale;
+                }
+                __syncthreads();
+                f32x4 w[4]; float* op[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = k * 256 + tid, x = f >> 4, c0 = (f & 15) * 4, gx = tx * 64 + x, gc = tc * 64 + c0;
+                    op[k] = (gx < dX && gc < j.d2) ? (float*)out + oi * oO + gx * oX + gc : nullptr;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    w[k] = (op[k] && j.accumulate) ? *(const f32x4*)op[k] : z;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = k * 256 + tid, x = f >> 4, c0 = (f & 15) * 4;
+                    if (op[k]) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[k][e] += tile[(c0 + e) * 65 + x];
+                        *(f32x4*)op[k] = w[k];
+                    }
+                }
+                __syncthreads();
+            }
+            return;
+        }
+    }
     if (as2 > 4 && (fx0 || fx1) && nthreads == 256 && total >= 4096 && (long long)(dXq < 64 ? dXq : 64) * (j.d2 < 64 ? j.d2 : 64) >= 192) {
         // ---- transpose path: X as above, O = the other outer dimension.  Tile = TX (along X) x TC (along c) = 4096 elements;
         // the shape follows the short side (3 conv taps along X on the way in, along c on the way out).

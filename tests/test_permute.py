@@ -22,6 +22,8 @@ CASES = [
     ((136, 1, 200), (1, 0, 136), 0, None, None, False, torch.bfloat16, torch.bfloat16),      # [n][k] -> [k][n], vector transpose path, ragged tiles
     ((3, 72, 128), (128 * 88, 1, 88), 0, 64, None, False, torch.float32, torch.bfloat16),    # per-head projection (vector transpose, f32 in, head dim padded 64 -> 72)
     ((192, 2, 80), (1, 80 * 192, 192), 0, None, 72, False, torch.float32, torch.bfloat16),   # W_o form: X = dim 0, columns beyond 72 zero
+    ((3, 68, 132), (132 * 72, 1, 72), 0, None, None, True, torch.float32, torch.float32),    # gradient un-layout of a per-head projection: f32 vector transpose, accumulate, ragged tiles
+    ((100, 1, 36), (1, 0, 100), 0, None, None, True, torch.float32, torch.float32),          # [n][k] -> [k][n] f32 accumulate
 ]
 
 
