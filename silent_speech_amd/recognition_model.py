@@ -144,21 +144,33 @@ def wer(references, predictions):
     return errs / max(words, 1)
 
 
-def test(model, testset, device, *, batch_size=32):
-    """:30-58.  Eval-mode forward on packed batches (the reference decodes one utterance at a time; packing changes
-    nothing for the utterances because eval-mode BatchNorm is per-frame -- but attention is per 200-frame row, as in training)."""
+def test(model, testset, device, *, batch_size=1):
+    """:30-58.  Default (batch_size=1) = the reference: eval-mode forward of ONE WHOLE utterance at a time (:37-43), so the convolutions
+    and the +-99-frame attention band span the utterance (the banded attention kernels take any T).  batch_size > 1 packs the utterances
+    into 200-frame rows like training does -- faster, but context is cut at the row boundaries, so its WER is not the reference's number.
+    Decoding is greedy best-path in both cases (the reference's KenLM beam search is third-party C++ needing lm.binary: out of scope)."""
     model.eval()
     tt = testset.text_transform
     blank = len(tt.chars)
-    dataloader = torch.utils.data.DataLoader(testset, batch_size=batch_size, collate_fn=testset.collate_raw)
     references, predictions = [], []
     with torch.no_grad():
-        for batch in dataloader:
-            X, X_raw, sess = _pack_batch(batch, device)
-            pred = model(X, X_raw, sess)
-            for ints, tgt in zip(greedy_decode(pred, batch['lengths'], blank), batch['text_int']):
-                predictions.append(tt.int_to_text(ints))
-                references.append(tt.int_to_text(tgt.tolist()))
+        if batch_size == 1:
+            for i in range(len(testset)):
+                ex = testset[i]
+                X = ex['emg'].to(device=device, dtype=torch.float32).unsqueeze(0)
+                X_raw = ex['raw_emg'].to(device=device, dtype=torch.float32).unsqueeze(0)
+                sess = ex['session_ids'].to(device=device).unsqueeze(0)
+                pred = model(X, X_raw, sess)                                   # (1, T, V) logits
+                predictions.append(tt.int_to_text(greedy_decode(pred, [pred.shape[1]], blank)[0]))
+                references.append(tt.int_to_text(torch.as_tensor(ex['text_int']).tolist()))
+        else:
+            dataloader = torch.utils.data.DataLoader(testset, batch_size=batch_size, collate_fn=testset.collate_raw)
+            for batch in dataloader:
+                X, X_raw, sess = _pack_batch(batch, device)
+                pred = model(X, X_raw, sess)
+                for ints, tgt in zip(greedy_decode(pred, batch['lengths'], blank), batch['text_int']):
+                    predictions.append(tt.int_to_text(ints))
+                    references.append(tt.int_to_text(tgt.tolist()))
     model.train()
     return wer(references, predictions)
 
