@@ -1297,6 +1297,13 @@ __global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q2_kernel(AttnP p)
 }
 
 // one key tile of the key-major backward: dV = s P~'^T dO, dK = s scale dS'^T Q over NCK 32-query chunks starting at chunk c0
+// Row pitch of the Q / dO tables of the key-major kernel: dp*2 + 32 bytes (224 at dp = 96).  The transposing reads of a 32-lane group touch
+// 8 rows x 32 bytes, conflict-free iff the pitch is an odd multiple of 32 bytes: with the 208-byte pitch of the other kernels 42 % of the
+// LDS cycles of this kernel were bank conflicts (SQ_LDS_BANK_CONFLICT 7.0e6 -> 1.9e6, 78.8 -> 75.3 us).  The forward and the query-major
+// kernel keep 208 (three tables do not fit with 224).
+#ifndef KV2_PAD
+#define KV2_PAD 32
+#endif
 namespace {
 constexpr int KV_TILE = 16 * RT_LD * 2;            // bytes of one [16 keys][32 queries + 8] bf16 hand-over tile
 template <int DPK, int NCK>
@@ -1304,7 +1311,7 @@ __device__ __forceinline__ void bkv2_tile(unsigned char* lds, unsigned dofaddr, 
                                           const bf16x8 (&vf)[DPK], const u32x2* img_tile0, long long img_stride, int c0, int ilo, int ihi,
                                           f32x4 (&dk)[2 * DPK], f32x4 (&dvv)[2 * DPK])
 {
-    constexpr int PK = DPK * 64 + 16, BLK = 16 * PK;
+    constexpr int PK = DPK * 64 + KV2_PAD, BLK = 16 * PK;
     // this lane's image words of the 2 NCK (tile, key tile) blocks; tiles outside [ilo, ihi] (never written by the forward) read a valid neighbour and are zeroed
     u32x2 im[2 * NCK];
 #pragma unroll
@@ -1415,7 +1422,7 @@ template <int DPK>
 __global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv2_kernel(AttnP p)
 {
     SS_DYN_SMEM(smem);
-    constexpr int dp = DPK * 32, PK = dp * 2 + 16;
+    constexpr int dp = DPK * 32, PK = dp * 2 + KV2_PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
     const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
     const int H = p.H, h = pair % H, b = pair / H;
@@ -1770,7 +1777,7 @@ static size_t res_smem(int which, int T, int dp, int D) {
     if (which == 0) return 2 * Tr * PK + (NE + 2 * RES_PL) * PK + RES_W_FWD * tile + 16;
     if (which == 1) return 2 * Tr * PK + (NE + 96) * PK + RES_W_BQ * tile + 16;
     if (which == 4) { const size_t PT = 2 * Tr * PK + NE * PK, e1 = PT + RES_W_BQ * 2 * (size_t)F2_PTB, e2 = PT + 160 * PK; return (e1 > e2 ? e1 : e2) + 16; }       // query-major backward on the P image
-    if (which == 5) return 2 * TQ * PK + RES_W_BKV * 4 * (size_t)KV_TILE + (TQ + 7 * 32) * 4 + 16;                                                      // key-major backward on the P image
+    if (which == 5) return 2 * TQ * ((size_t)dp * 2 + KV2_PAD) + RES_W_BKV * 4 * (size_t)KV_TILE + (TQ + 7 * 32) * 4 + 16;                                                      // key-major backward on the P image
     if (which == 3) { const size_t tail = RES_W_FWD * 2 * (size_t)F2_PTB + 16, over = 128 * PK + 16; return 2 * Tr * PK + NE * PK + (tail > over ? tail : over); }   // hand-scheduled forward: reads past the E table stay inside the allocation
     return 2 * TQ * PK + NE * PK + RES_W_BKV * 2 * tile + 8 * TQ + 16;
 }
