@@ -46,6 +46,7 @@ struct AttnP {
     int B, H, T, Tp, dp, D, MPt, gx;
     float scale;
     unsigned drop_thresh; float drop_scale; unsigned long long seed; unsigned stream;
+    int tail;       // hand-scheduled kernels: bytes behind the last table (chunk buffers / room for reads that run past the E table)
     int debug;      // SS_ATTN_DEBUG (measurement only): bit 0 skips the operand staging, bit 1 the tile loop of the hand-scheduled forward
 };
 
@@ -882,6 +883,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 #endif
 
+// Row pitch of the resident tables of the hand-scheduled kernels: dp*2 + 32 bytes (224 at dp = 96).  The transposing reads of a 32-lane
+// group touch 8 rows x 32 bytes -- conflict-free iff the pitch is an odd multiple of 32 bytes -- and the 16-byte fragment reads of a
+// 16-lane service group stay conflict-free as well (even slots for its g = 0 lanes, odd for g = 1).  With the 208-byte pitch of the
+// compiler-scheduled kernels 42 % of the LDS cycles of the key-major kernel were bank conflicts (SQ_LDS_BANK_CONFLICT 7.0e6 -> 1.9e6).
+#define RES2_PAD 32
 constexpr int F2_PTB = 32 * 20 * 2;       // bytes of one P~ chunk buffer: [32 keys][16 queries + 4] bf16
 constexpr float MASKED_NAT = -1e8f;       // transformer.py:256-261
 
@@ -890,7 +896,7 @@ __device__ __forceinline__ void fwd2_tile(const AttnP& p, unsigned char* lds, un
                                           const bf16x8 (&qf)[DPK], const unsigned (&srcb)[4], const bool (&sel)[4],
                                           int bh, int q0, int jlo, int lane, f32x4 (&o)[2 * DPK], float (&lse)[4])
 {
-    constexpr int PK = DPK * 64 + 16, BLK = 16 * PK, NCH = (NBLK + 1) / 2;
+    constexpr int PK = DPK * 64 + RES2_PAD, BLK = 16 * PK, NCH = (NBLK + 1) / 2;
     const int c = lane & 15, g = lane >> 4, Tn = p.T, D = p.D;
     const float scale = p.scale;
     int t0[4]; unsigned lim[4];
@@ -1043,13 +1049,13 @@ template <int DPK, bool DROP>
 __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res2_kernel(AttnP p)
 {
     SS_DYN_SMEM(smem);
-    constexpr int dp = DPK * 32, PK = dp * 2 + 16;
+    constexpr int dp = DPK * 32, PK = dp * 2 + RES2_PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
     const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
     const int H = p.H, h = pair % H, b = pair / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1;
     unsigned char* lds = (unsigned char*)smem;
-    const unsigned VS = 0, KS = VS + Tr * PK, ES = KS + Tr * PK, PT = ES + NE * PK, CT = PT + RES_W_FWD * 2 * F2_PTB;
+    const unsigned VS = 0, KS = VS + Tr * PK, ES = KS + Tr * PK, PT = ES + NE * PK, CT = PT + (unsigned)p.tail;      // tail: chunk buffers, and room for reads past the E table
     int* ctr = (int*)(lds + CT);
     const long long ldq = 3LL * H * dp;
     const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
@@ -1115,7 +1121,7 @@ __device__ __forceinline__ void pimg_unpack(const u32x2& w, float (&pf)[4]) {
 template <int DPK, int NC, class SRC>
 __device__ __forceinline__ void chunk_mma(unsigned char* lds, unsigned ptw, unsigned ptr_, unsigned baddr, SRC&& src, f32x4 (&acc)[2 * DPK])
 {
-    constexpr int PK = DPK * 64 + 16;
+    constexpr int PK = DPK * 64 + RES2_PAD;
     s16x4 alo[2], ahi[2], blo[2][2 * DPK], bhi[2][2 * DPK];
     auto put = [&](auto kcc) {
         constexpr int kc = kcc;
@@ -1163,7 +1169,7 @@ __device__ __forceinline__ void bq2_tile(const AttnP& p, unsigned char* lds, uns
                                          const bf16x8 (&dof)[DPK], const float (&dprime)[4], const u32x2* img, const unsigned (&srcb)[4], const bool (&sel)[4],
                                          f32x4 (&acc)[2 * DPK])
 {
-    constexpr int PK = DPK * 64 + 16, BLK = 16 * PK, NCH = (NBLK + 1) / 2, NCHM = (NBLK + 2) / 2;
+    constexpr int PK = DPK * 64 + RES2_PAD, BLK = 16 * PK, NCH = (NBLK + 1) / 2, NCHM = (NBLK + 2) / 2;
     u32x2 im[NBLK];
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) im[j] = img[j * 64];
@@ -1237,15 +1243,14 @@ template <int DPK>
 __global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q2_kernel(AttnP p)
 {
     SS_DYN_SMEM(smem);
-    constexpr int dp = DPK * 32, PK = dp * 2 + 16;
+    constexpr int dp = DPK * 32, PK = dp * 2 + RES2_PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
     const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
     const int H = p.H, h = pair % H, b = pair / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1;
     unsigned char* lds = (unsigned char*)smem;
     // [K | V | E | chunk buffers]: V rows past the band continue into E, E rows outside the table into V resp. the (zeroed) buffers: always finite, always met by dS' = 0
-    const unsigned KS = 0, VS = KS + Tr * PK, ES = VS + Tr * PK, PT = ES + NE * PK, PTE = PT + RES_W_BQ * 2 * F2_PTB, TAIL = PT + 160 * PK;
-    const unsigned CT = (PTE > TAIL ? PTE : TAIL);
+    const unsigned KS = 0, VS = KS + Tr * PK, ES = VS + Tr * PK, PT = ES + NE * PK, CT = PT + (unsigned)p.tail;
     int* ctr = (int*)(lds + CT);
     const long long ldq = 3LL * H * dp;
     const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
@@ -1297,13 +1302,6 @@ __global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q2_kernel(AttnP p)
 }
 
 // one key tile of the key-major backward: dV = s P~'^T dO, dK = s scale dS'^T Q over NCK 32-query chunks starting at chunk c0
-// Row pitch of the Q / dO tables of the key-major kernel: dp*2 + 32 bytes (224 at dp = 96).  The transposing reads of a 32-lane group touch
-// 8 rows x 32 bytes, conflict-free iff the pitch is an odd multiple of 32 bytes: with the 208-byte pitch of the other kernels 42 % of the
-// LDS cycles of this kernel were bank conflicts (SQ_LDS_BANK_CONFLICT 7.0e6 -> 1.9e6, 78.8 -> 75.3 us).  The forward and the query-major
-// kernel keep 208 (three tables do not fit with 224).
-#ifndef KV2_PAD
-#define KV2_PAD 32
-#endif
 namespace {
 constexpr int KV_TILE = 16 * RT_LD * 2;            // bytes of one [16 keys][32 queries + 8] bf16 hand-over tile
 template <int DPK, int NCK>
@@ -1311,7 +1309,7 @@ __device__ __forceinline__ void bkv2_tile(unsigned char* lds, unsigned dofaddr, 
                                           const bf16x8 (&vf)[DPK], const u32x2* img_tile0, long long img_stride, int c0, int ilo, int ihi,
                                           f32x4 (&dk)[2 * DPK], f32x4 (&dvv)[2 * DPK])
 {
-    constexpr int PK = DPK * 64 + KV2_PAD, BLK = 16 * PK;
+    constexpr int PK = DPK * 64 + RES2_PAD, BLK = 16 * PK;
     // this lane's image words of the 2 NCK (tile, key tile) blocks; tiles outside [ilo, ihi] (never written by the forward) read a valid neighbour and are zeroed
     u32x2 im[2 * NCK];
 #pragma unroll
@@ -1422,7 +1420,7 @@ template <int DPK>
 __global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv2_kernel(AttnP p)
 {
     SS_DYN_SMEM(smem);
-    constexpr int dp = DPK * 32, PK = dp * 2 + KV2_PAD;
+    constexpr int dp = DPK * 32, PK = dp * 2 + RES2_PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
     const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
     const int H = p.H, h = pair % H, b = pair / H;
@@ -1772,13 +1770,32 @@ static void attn_fill(AttnP& p, int B, int H, int T, int Tp, int dp, int D, floa
 // ---- resident-path dispatch
 #include <stdlib.h>
 static const size_t RES_LDS_MAX = 160 * 1024;
+// bytes behind the E table of the hand-scheduled forward (which = 3) / query-major backward (4): the per-wave chunk buffers, or the
+// farthest read past the table over all tiles of this (T, D) if that is more (those reads only meet masked logits resp. dS = 0)
+static size_t res2_tail(int which, int T, int dp, int D) {
+    const int nb = (T + 15) / 16, NE = 2 * D - 1;
+    int over = 0;
+    for (int t = 0; t < nb; ++t) {
+        const int q0 = 16 * t;
+        const int jlo = q0 - (D - 1) < 0 ? 0 : (q0 - (D - 1)) >> 4;
+        int jhi = (q0 + 15 + D - 1) >> 4; jhi = jhi > nb - 1 ? nb - 1 : jhi;
+        const int nblk = jhi - jlo + 1, NBLK = nblk <= 4 ? 4 : (nblk <= 10 ? 10 : RES_NB);
+        const int first = 16 * jlo - q0 - 15 + (D - 1);
+        const int last = which == 3 ? first + 16 * (NBLK + 1) + 15 : first + 32 * ((NBLK + 2) / 2) - 1;
+        over = last + 1 - NE > over ? last + 1 - NE : over;
+    }
+    const size_t bufs = (size_t)(which == 3 ? RES_W_FWD : RES_W_BQ) * 2 * F2_PTB, room = (size_t)over * ((size_t)dp * 2 + RES2_PAD);
+    return ((bufs > room ? bufs : room) + 15) / 16 * 16;
+}
 static size_t res_smem(int which, int T, int dp, int D) {
     const size_t PK = (size_t)dp * 2 + 16, nb = (size_t)(T + 15) / 16, Tr = nb * 16, NE = 2 * (size_t)D - 1, TQ = (nb + 1) / 2 * 32, tile = 16 * RT_LD * 2;
     if (which == 0) return 2 * Tr * PK + (NE + 2 * RES_PL) * PK + RES_W_FWD * tile + 16;
     if (which == 1) return 2 * Tr * PK + (NE + 96) * PK + RES_W_BQ * tile + 16;
-    if (which == 4) { const size_t PT = 2 * Tr * PK + NE * PK, e1 = PT + RES_W_BQ * 2 * (size_t)F2_PTB, e2 = PT + 160 * PK; return (e1 > e2 ? e1 : e2) + 16; }       // query-major backward on the P image
-    if (which == 5) return 2 * TQ * ((size_t)dp * 2 + KV2_PAD) + RES_W_BKV * 4 * (size_t)KV_TILE + (TQ + 7 * 32) * 4 + 16;                                                      // key-major backward on the P image
-    if (which == 3) { const size_t tail = RES_W_FWD * 2 * (size_t)F2_PTB + 16, over = 128 * PK + 16; return 2 * Tr * PK + NE * PK + (tail > over ? tail : over); }   // hand-scheduled forward: reads past the E table stay inside the allocation
+    if (which == 3 || which == 4) {     // hand-scheduled forward / query-major backward: [2 tables of Tr rows | E | tail]
+        const size_t P2 = (size_t)dp * 2 + RES2_PAD;
+        return 2 * Tr * P2 + NE * P2 + res2_tail(which, T, dp, D) + 16;
+    }
+    if (which == 5) return 2 * TQ * ((size_t)dp * 2 + RES2_PAD) + RES_W_BKV * 4 * (size_t)KV_TILE + (TQ + 7 * 32) * 4 + 16;                              // key-major backward on the P image
     return 2 * TQ * PK + NE * PK + RES_W_BKV * 2 * tile + 8 * TQ + 16;
 }
 static bool res_enabled(int dtype, int T) {
@@ -1867,6 +1884,7 @@ extern "C" int ss_relpos_attention_forward_p(int dtype, const void* qkv, const v
     p.pimg = pimg;
     if (!ss_relpos_attention_needs_transposed(dtype, T, dp, D)) {
         if (fwd2_enabled() && res_smem(3, T, dp, D) <= RES_LDS_MAX) {
+            p.tail = (int)res2_tail(3, T, dp, D);
             if (res_launch(res_pick(3, dp / 32, p.drop_thresh != 0), 24 + dp / 32 + (p.drop_thresh ? 4 : 0), B * H, RES_W_FWD, res_smem(3, T, dp, D), stream, p)) return 1;
         } else if (res_launch(res_pick(0, dp / 32, p.drop_thresh != 0), dp / 32 + (p.drop_thresh ? 12 : 0), B * H, RES_W_FWD, res_smem(0, T, dp, D), stream, p)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_forward");
@@ -1902,6 +1920,7 @@ extern "C" int ss_relpos_attention_backward_p(int dtype, const void* qkv, const 
     if (pimg) {
         SS_CHECK(ss_relpos_attention_saved_bytes(dtype, B, H, T, dp, D) > 0, "ss_relpos_attention_backward_p: this shape has no saved probabilities");
         p.pimg = (void*)pimg;
+        p.tail = (int)res2_tail(4, T, dp, D);
         if (res_launch(res_pick(4, dp / 32), 32 + dp / 32, B * H, RES_W_BQ, res_smem(4, T, dp, D), stream, p)) return 1;
         if (res_launch(res_pick(5, dp / 32), 36 + dp / 32, B * H, RES_W_BKV, res_smem(5, T, dp, D), stream, p)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_backward_p");
