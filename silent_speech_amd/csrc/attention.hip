@@ -46,6 +46,7 @@ struct AttnP {
     int B, H, T, Tp, dp, D, MPt, gx;
     float scale;
     unsigned drop_thresh; float drop_scale; unsigned long long seed; unsigned stream;
+    int h1;         // hand-scheduled kernels: half-workgroups dispatched FIRST (see res2_block)
     int tail;       // hand-scheduled kernels: bytes behind the last table (chunk buffers / room for reads that run past the E table)
     int debug;      // SS_ATTN_DEBUG (measurement only): bit 0 skips the operand staging, bit 1 the tile loop of the hand-scheduled forward
 };
@@ -888,6 +889,16 @@ __device__ __forceinline__ float row16_sum(float v) {
 // 16-lane service group stay conflict-free as well (even slots for its g = 0 lanes, odd for g = 1).  With the 208-byte pitch of the
 // compiler-scheduled kernels 42 % of the LDS cycles of the key-major kernel were bank conflicts (SQ_LDS_BANK_CONFLICT 7.0e6 -> 1.9e6).
 #define RES2_PAD 32
+// Workgroup -> (pair, half).  One workgroup occupies a CU and all of them stage their operands at the same moment: a bandwidth-bound
+// burst (115 KB x 256 CUs, 4.9 TB/s) during which nothing computes, followed by a compute phase during which HBM idles, round after round.
+// The pairs beyond the last full round are split into two half-workgroups anyway; dispatching p.h1 of those halves FIRST makes half of
+// the CUs finish their first item after ~0.6 of a round, and from then on the two populations stage in each other's compute phases.
+__device__ __forceinline__ void res2_block(const AttnP& p, int& pair, int& half) {
+    const int bid = blockIdx.x;
+    if (bid < p.h1) { pair = p.gx + (bid >> 1); half = bid & 1; }
+    else if (bid < p.h1 + p.gx) { pair = bid - p.h1; half = -1; }
+    else { const int hb = bid - p.gx; pair = p.gx + (hb >> 1); half = hb & 1; }
+}
 constexpr int F2_PTB = 32 * 20 * 2;       // bytes of one P~ chunk buffer: [32 keys][16 queries + 4] bf16
 constexpr float MASKED_NAT = -1e8f;       // transformer.py:256-261
 
@@ -1051,7 +1062,7 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res2_kernel(AttnP p)
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + RES2_PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
+    int pair, half; res2_block(p, pair, half);
     const int H = p.H, h = pair % H, b = pair / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1;
     unsigned char* lds = (unsigned char*)smem;
@@ -1245,7 +1256,7 @@ __global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q2_kernel(AttnP p)
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + RES2_PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
+    int pair, half; res2_block(p, pair, half);
     const int H = p.H, h = pair % H, b = pair / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1;
     unsigned char* lds = (unsigned char*)smem;
@@ -1422,7 +1433,7 @@ __global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv2_kernel(AttnP p)
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + RES2_PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int bid = blockIdx.x, pair = bid < p.gx ? bid : p.gx + ((bid - p.gx) >> 1), half = bid < p.gx ? -1 : ((bid - p.gx) & 1);
+    int pair, half; res2_block(p, pair, half);
     const int H = p.H, h = pair % H, b = pair / H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4;
     const int TQ = ((nb + 1) >> 1) * 32;                               // whole 32-query chunks
@@ -1808,7 +1819,7 @@ static bool fwd2_enabled() {
     return !(e && e[0] == '0');
 }
 typedef void (*ResKernel)(AttnP);
-static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, void* stream, AttnP p) {
+static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, void* stream, AttnP p, bool stagger = false) {
     // one workgroup per CU at a time: pairs beyond the last full round of #CU are split in two halves when that shortens it
     static int cus = 0;
     if (!cus) {
@@ -1822,6 +1833,8 @@ static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, 
     const bool split = pairs > cus && rem > 0 && 2 * rem <= cus;
     p.gx = split ? pairs - rem : pairs;
     const int blocks = split ? pairs + rem : pairs;
+    p.h1 = 0;
+    if (stagger && split) { const char* e = getenv("SS_ATTN_STAGGER"); if (!(e && e[0] == '0')) { p.h1 = 2 * rem < cus / 2 ? 2 * rem : (cus / 2) & ~1; } }
 #if !defined(SS_EMU)
     static size_t granted[48] = {0};
     if (granted[slot] < smem) {
@@ -1885,7 +1898,7 @@ extern "C" int ss_relpos_attention_forward_p(int dtype, const void* qkv, const v
     if (!ss_relpos_attention_needs_transposed(dtype, T, dp, D)) {
         if (fwd2_enabled() && res_smem(3, T, dp, D) <= RES_LDS_MAX) {
             p.tail = (int)res2_tail(3, T, dp, D);
-            if (res_launch(res_pick(3, dp / 32, p.drop_thresh != 0), 24 + dp / 32 + (p.drop_thresh ? 4 : 0), B * H, RES_W_FWD, res_smem(3, T, dp, D), stream, p)) return 1;
+            if (res_launch(res_pick(3, dp / 32, p.drop_thresh != 0), 24 + dp / 32 + (p.drop_thresh ? 4 : 0), B * H, RES_W_FWD, res_smem(3, T, dp, D), stream, p, true)) return 1;
         } else if (res_launch(res_pick(0, dp / 32, p.drop_thresh != 0), dp / 32 + (p.drop_thresh ? 12 : 0), B * H, RES_W_FWD, res_smem(0, T, dp, D), stream, p)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_forward");
         return 0;
@@ -1921,8 +1934,8 @@ extern "C" int ss_relpos_attention_backward_p(int dtype, const void* qkv, const 
         SS_CHECK(ss_relpos_attention_saved_bytes(dtype, B, H, T, dp, D) > 0, "ss_relpos_attention_backward_p: this shape has no saved probabilities");
         p.pimg = (void*)pimg;
         p.tail = (int)res2_tail(4, T, dp, D);
-        if (res_launch(res_pick(4, dp / 32), 32 + dp / 32, B * H, RES_W_BQ, res_smem(4, T, dp, D), stream, p)) return 1;
-        if (res_launch(res_pick(5, dp / 32), 36 + dp / 32, B * H, RES_W_BKV, res_smem(5, T, dp, D), stream, p)) return 1;
+        if (res_launch(res_pick(4, dp / 32), 32 + dp / 32, B * H, RES_W_BQ, res_smem(4, T, dp, D), stream, p, true)) return 1;
+        if (res_launch(res_pick(5, dp / 32), 36 + dp / 32, B * H, RES_W_BKV, res_smem(5, T, dp, D), stream, p, true)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_backward_p");
         return 0;
     }
