@@ -83,11 +83,22 @@ __device__ __forceinline__ float wave_shift_in(float v, float first, int lane) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 #endif
 }
-__device__ __forceinline__ float wave_pick(float v, int src_lane) {   // src_lane is wave-uniform
+// lane l <- lane l+1 (wave_shl:1): lane 0 of the boundary register walks through the 64 values of a super-step, one per step, so the
+// step reads "the row above the strip" from its OWN lane-0 slot -- no v_readlane (SGPR round trip + 4-5 hazard nops on the serial chain)
+__device__ __forceinline__ float wave_rotate_down(float v) {
 #if defined(SS_EMU)
-    return __shfl(v, src_lane);
+    return __shfl_down(v, 1);
 #else
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+#endif
+}
+// bits = 2 * bits + (x == y): compare into VCC, add-with-carry doubles and inserts the bit (2 instructions per flag; the
+// select / shift / or form the compiler builds from C costs 5-6 per cell)
+__device__ __forceinline__ void push_eq(unsigned& bits, float x, float y) {
+#if defined(SS_EMU)
+    bits = (bits << 1) | (x == y ? 1u : 0u);
+#else
+    asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(x), "v"(y) : "vcc");
 #endif
 }
 
@@ -106,11 +117,11 @@ __device__ __forceinline__ void dtw_step(int t, int lane, int w, bool multi_stri
     for (int r = 0; r < DR; ++r) {
         const float b = prev[r];
         // first minimum of (up, left, diag) [Python min() tie order]: the VALUE is min3 -- one instruction on the serial chain
-        // (min3 -> add -> next row's min3); which candidate it was is recovered off the chain: best == up wins ties, then left
+        // (min3 -> add -> next row's min3); which candidate it was is recovered off the chain as two equality flags per cell: the
+        // backtrace takes "up" if best == up, else "left" if best == left, else "diag" (up wins ties, then left)
         const float best = fminf(fminf(a, b), dg);
-        const unsigned dir = best == a ? 0u : (best == b ? 1u : 2u);
+        push_eq(bits, best, b); push_eq(bits, best, a);                    // cell code = 2 [best == left] + [best == up], row r at bits 2 (3 - r)
         const float nv = cv[r] + best;
-        bits |= dir << (2 * r);
         dg = b; a = nv; prev[r] = nv;
     }
     last_out = a;
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int t = t0 + g * 8 + e;
-                        if (t < ts) dtw_step(t, lane, w, nstrips > 1, M, cb[e], wave_pick(topv, g * 8 + e), prev, diag_sv, last_out, dp, lds_bnd[w + 1], &lds_bnd[DW][lane], bnd_cur);
+                        if (t < ts) { dtw_step(t, lane, w, nstrips > 1, M, cb[e], topv, prev, diag_sv, last_out, dp, lds_bnd[w + 1], &lds_bnd[DW][lane], bnd_cur); topv = wave_rotate_down(topv); }
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) cb[e] = nb[e];
@@ -214,8 +225,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
             __syncthreads();
         }
         const unsigned byte = chunk[(t - t_lo) * 64 + l];
-        const unsigned pm = (byte >> (2 * r)) & 3u;
-        if (pm == 0) { --p; } else if (pm == 1) { --s; } else { --p; --s; }
+        const unsigned pm = (byte >> (2 * (DR - 1 - r))) & 3u;            // 2 [best == left] + [best == up]
+        if (pm & 1u) { --p; } else if (pm & 2u) { --s; } else { --p; --s; }
     }
 }
 
