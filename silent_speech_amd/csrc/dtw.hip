@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                     const int tn = t0 + (g + 1) * 8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) nb[e] = (g + 1 < DG / 8 && tn + e < ts) ? *(const f32x4*)(skp + (long long)(tn + e) * (64 * DR)) : inf4;
+#if !defined(SS_EMU)
+                    // settle THIS group's costs (requested one group ago) now, leaving the 8 loads just issued in flight: every step is its own
+                    // basic block, and left to itself the compiler waits vmcnt(0) at the top of each -- i.e. for the previous step's direction
+                    // store (vmcnt counts stores too): one memory round trip on the serial chain of every step
+                    __builtin_amdgcn_s_waitcnt(0x0f78);          // vmcnt(8), expcnt / lgkmcnt untouched
+#endif
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int t = t0 + g * 8 + e;
