@@ -215,9 +215,10 @@ int ss_layernorm_backward(int dtype, const void* dy, const void* z, const float*
 int ss_layernorm_backward_bias(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                                void* dres, void* dbranch, float* dgamma, float* dbeta, float* dbranch_colsum, int rows, int C, float dropout_p,
                                uint64_t seed, uint32_t rng_stream, void* stream);
-/* The same with a scratch buffer of ss_layernorm_backward_scratch_floats(rows, C) floats: the per-workgroup column sums go there
- * instead of through atomics and a second small kernel adds them into dgamma / dbeta / dbranch_colsum (16 waves per CU, C = 256,
- * 512 or 768; scratch_floats returns 0 for other widths, and scratch == NULL runs the atomic form). */
+/* The 16-waves-per-CU form (C = 256, 512 or 768; dbranch required): selected by passing a scratch buffer of
+ * ss_layernorm_backward_scratch_floats(rows, C) floats (0 for other widths; scratch == NULL runs the round-1 form).  The column sums leave
+ * as one atomic per column and workgroup (#CU workgroups); with SS_LN_DIRECT=0 they go through the scratch buffer and a second small kernel
+ * instead (deterministic summation order). */
 int64_t ss_layernorm_backward_scratch_floats(int rows, int C); /* [host] */
 int ss_layernorm_backward_ws(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                              void* dres, void* dbranch, float* dgamma, float* dbeta, float* dbranch_colsum, float* scratch, int64_t scratch_floats,

@@ -643,10 +643,14 @@ template <> struct Piece4<float> {
 };
 constexpr int LNB2_WAVES = 16;
 
-template <class T, int P, bool BS>
+// DROP: dropout on the branch gradient (uniform).  The row loop is ONE basic block: the next row is always requested (its index
+// clamped to the last row: one redundant row per wave at the end), nothing is predicated -- with an `if (more)` prefetch block the
+// compiler drained vmcnt(0) at the top of every iteration, i.e. waited for the previous row's STORES before requesting the next row.
+template <class T, int P, bool BS, bool DROP>
 __global__ __launch_bounds__(LNB2_WAVES * 64) void ln_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   const float* __restrict__ gamma, T* __restrict__ dres, T* __restrict__ dbranch, float* __restrict__ partial,
-                                                                  int rows, unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id)
+                                                                  int rows, unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id,
+                                                                  float* dgamma, float* dbeta, float* dbsum, int direct)
 {
     constexpr int C = P * 256;
     __shared__ float red[LNB2_WAVES][C];
@@ -667,9 +671,10 @@ __global__ __launch_bounds__(LNB2_WAVES * 64) void ln_bwd2_kernel(const T* __res
     };
     if (r < rows) { load_row(r, dcur, zcur); mu = mean[r]; rs = rstd[r]; }
     for (; r < rows; r += stride) {
-        Raw dnx[P], znx[P]; float mun = 0.f, rsn = 0.f;
-        const bool more = r + stride < rows;
-        if (more) { load_row(r + stride, dnx, znx); mun = mean[r + stride]; rsn = rstd[r + stride]; }
+        Raw dnx[P], znx[P];
+        const int rn = r + stride < rows ? r + stride : rows - 1;
+        load_row(rn, dnx, znx);
+        const float mun = mean[rn], rsn = rstd[rn];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -687,22 +692,20 @@ __global__ __launch_bounds__(LNB2_WAVES * 64) void ln_bwd2_kernel(const T* __res
             float dc[4], zc[4], o[4], ob[4]; Piece4<T>::unpack(dcur[p], dc); Piece4<T>::unpack(zcur[p], zc);
             bool kp[4] = {true, true, true, true};
             const long long col = (p * 64 + lane) * 4;
-            if (thresh && dbranch) dropout_keep4(seed, stream_id, ((unsigned long long)r * C + col) >> 2, thresh, kp);
+            if (DROP) dropout_keep4(seed, stream_id, ((unsigned long long)r * C + col) >> 2, thresh, kp);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xh = (zc[e] - mu) * rs;
                 o[e] = rs * (dc[e] * gm[p][e] - s1 - xh * s2);
-                ob[e] = (thresh && !kp[e]) ? 0.f : (thresh ? o[e] * keep_scale : o[e]);
+                ob[e] = DROP ? (kp[e] ? o[e] * keep_scale : 0.f) : o[e];
                 if (BS) dbs[BS ? p : 0][e] += rnd<T>(ob[e]);
             }
             Piece4<T>::store(dres + (long long)r * C + col, o);
-            if (dbranch) Piece4<T>::store(dbranch + (long long)r * C + col, ob);
+            Piece4<T>::store(dbranch + (long long)r * C + col, ob);
         }
-        if (more) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) { dcur[p] = dnx[p]; zcur[p] = znx[p]; }
-            mu = mun; rs = rsn;
-        }
+        for (int p = 0; p < P; ++p) { dcur[p] = dnx[p]; zcur[p] = znx[p]; }
+        mu = mun; rs = rsn;
     }
 #pragma unroll
     for (int qn = 0; qn < 3; ++qn) {
@@ -716,7 +719,10 @@ __global__ __launch_bounds__(LNB2_WAVES * 64) void ln_bwd2_kernel(const T* __res
             float a = 0.f;
 #pragma unroll
             for (int ww = 0; ww < LNB2_WAVES; ++ww) a += red[ww][c];
-            partial[((long long)blockIdx.x * 3 + qn) * C + c] = a;
+            // direct: one atomic per column and workgroup (#CU workgroups: a quarter of the atomics of the 4-wave form, spread over the
+            // moments the workgroups finish) instead of a partial row + the second launch
+            if (direct) atomicAdd((qn == 0 ? dgamma : (qn == 1 ? dbeta : dbsum)) + c, a);
+            else partial[((long long)blockIdx.x * 3 + qn) * C + c] = a;
         }
         __syncthreads();
     }
@@ -804,14 +810,17 @@ extern "C" int ss_layernorm_backward_ws(int dtype, const void* dy, const void* z
     {
         const int64_t want = ss_layernorm_backward_scratch_floats(rows, C);
         const char* e = getenv("SS_LN_BWD2");                 // "0": the atomic form (A/B measurements, tests of both)
-        if (scratch && want > 0 && scratch_floats >= want && !(e && e[0] == '0')) {
+        if (scratch && dbranch && want > 0 && scratch_floats >= want && !(e && e[0] == '0')) {
             const int nb = lnb2_blocks(rows);
-#define SS_LNB2(TT, PP) do { if (dbranch_colsum) SS_LAUNCH(SS_KERNEL(ln_bwd2_kernel<TT, PP, true>), dim3(nb), dim3(LNB2_WAVES * 64), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, scratch, rows, th, ks, (unsigned long long)seed, rng_stream); \
-                             else SS_LAUNCH(SS_KERNEL(ln_bwd2_kernel<TT, PP, false>), dim3(nb), dim3(LNB2_WAVES * 64), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, scratch, rows, th, ks, (unsigned long long)seed, rng_stream); } while (0)
+            int direct = 1; { const char* e2 = getenv("SS_LN_DIRECT"); if (e2) direct = atoi(e2); }
+#define SS_LNB2K(TT, PP, BSV, DRV) SS_LAUNCH(SS_KERNEL(ln_bwd2_kernel<TT, PP, BSV, DRV>), dim3(nb), dim3(LNB2_WAVES * 64), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, scratch, rows, th, ks, (unsigned long long)seed, rng_stream, dgamma, dbeta, dbranch_colsum, direct)
+#define SS_LNB2(TT, PP) do { if (dbranch_colsum) { if (th) SS_LNB2K(TT, PP, true, true); else SS_LNB2K(TT, PP, true, false); } \
+                             else { if (th) SS_LNB2K(TT, PP, false, true); else SS_LNB2K(TT, PP, false, false); } } while (0)
             if (dtype == SS_BF16) { if (C == 256) SS_LNB2(bf16_t, 1); else if (C == 512) SS_LNB2(bf16_t, 2); else SS_LNB2(bf16_t, 3); }
             else { if (C == 256) SS_LNB2(float, 1); else if (C == 512) SS_LNB2(float, 2); else SS_LNB2(float, 3); }
+#undef SS_LNB2K
 #undef SS_LNB2
-            SS_LAUNCH(ln_bwd2_finalize_kernel, dim3(3 * C / 64), dim3(1024), 0, stream, (const float*)scratch, nb, C, dgamma, dbeta, dbranch_colsum);
+            if (!direct) SS_LAUNCH(ln_bwd2_finalize_kernel, dim3(3 * C / 64), dim3(1024), 0, stream, (const float*)scratch, nb, C, dgamma, dbeta, dbranch_colsum);
             SS_LAUNCH_CHECK("ss_layernorm_backward_ws");
             return 0;
         }
