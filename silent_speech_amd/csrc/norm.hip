@@ -187,9 +187,12 @@ __global__ void bn_apply_kernel(const T* __restrict__ xa, Seq sa, const float* _
 {
     const int CV = C >> 3, TT = sy.T;
     const long long rows_out = (long long)B * (TT + 2 * sy.pad), total = rows_out * CV;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int cx = (int)(i % CV); const long long ro = i / CV;
-        const int b = (int)(ro / (TT + 2 * sy.pad)), tp = (int)(ro - (long long)b * (TT + 2 * sy.pad)), t = tp - sy.pad;
+    // 32-bit index arithmetic (the host checks total < 2^31): the 64-bit divisions of the generic form were ~300 of the ~450 instructions
+    // a thread spent per 16-byte chunk
+    const unsigned TP = (unsigned)(TT + 2 * sy.pad), total32 = (unsigned)total, step32 = gridDim.x * blockDim.x;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total32; i += step32) {
+        const unsigned ro = i / (unsigned)CV; const int cx = (int)(i - ro * (unsigned)CV);
+        const unsigned bq = ro / TP; const int b = (int)bq, tp = (int)(ro - bq * TP), t = tp - sy.pad;
         float o[8];
         if (t < 0 || t >= TT) {
 #pragma unroll
@@ -209,7 +212,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ xa, Seq sa, const float* _
                 for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
             }
         }
-        Vec8<T>::store(y + ro * C + cx * 8, o);
+        Vec8<T>::store(y + (long long)ro * C + cx * 8, o);
     }
 }
 
@@ -224,6 +227,7 @@ extern "C" int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const
     SS_CHECK(C % 8 == 0 && C > 0 && B > 0 && T > 0, "ss_bn_apply: bad shape B=%d T=%d C=%d", B, T, C);
     Seq sa = {T, pad_xa}, sb = {T, pad_xb}, sy = {T, pad_y};
     const long long total = (long long)B * (T + 2 * pad_y) * (C / 8);
+    SS_CHECK(total < (1LL << 31) - (1LL << 22), "ss_bn_apply: tensor too large for 32-bit chunk indices");
     if (dtype == SS_BF16) SS_LAUNCH(bn_apply_kernel<bf16_t>, ew_grid(total, 256), dim3(256), 0, stream, (const bf16_t*)xa, sa, mean_a, invstd_a, gamma_a, beta_a, (const bf16_t*)xb, sb, mean_b, invstd_b, gamma_b, beta_b, (bf16_t*)y, sy, B, C, relu);
     else SS_LAUNCH(bn_apply_kernel<float>, ew_grid(total, 256), dim3(256), 0, stream, (const float*)xa, sa, mean_a, invstd_a, gamma_a, beta_a, (const float*)xb, sb, mean_b, invstd_b, gamma_b, beta_b, (float*)y, sy, B, C, relu);
     SS_LAUNCH_CHECK("ss_bn_apply");
@@ -311,9 +315,10 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* 
     const int CV = C >> 3, TT = sdy.T;
     const int padmax = sda.pad > sdb.pad ? sda.pad : sdb.pad;
     const long long total = (long long)B * (TT + 2 * padmax) * CV;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int cx = (int)(i % CV); const long long ro = i / CV;
-        const int b = (int)(ro / (TT + 2 * padmax)), t = (int)(ro - (long long)b * (TT + 2 * padmax)) - padmax;
+    const unsigned TP = (unsigned)(TT + 2 * padmax), total32 = (unsigned)total, step32 = gridDim.x * blockDim.x;      // 32-bit index arithmetic, see bn_apply_kernel
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total32; i += step32) {
+        const unsigned ro = i / (unsigned)CV; const int cx = (int)(i - ro * (unsigned)CV);
+        const unsigned bq = ro / TP; const int b = (int)bq, t = (int)(ro - bq * TP) - padmax;
         float oa[8], ob[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { oa[e] = 0.f; ob[e] = 0.f; }
@@ -374,6 +379,7 @@ extern "C" int ss_bn_backward_apply(int dtype, const void* dy, int pad_dy, const
     Seq sdy = {T, pad_dy}, sy = {T, pad_y}, sa = {T, pad_xa}, sb = {T, pad_xb}, sda = {T, pad_dxa}, sdb = {T, pad_dxb};
     const int padmax = pad_dxa > pad_dxb ? pad_dxa : pad_dxb;
     const long long total = (long long)B * (T + 2 * padmax) * (C / 8);
+    SS_CHECK(total < (1LL << 31) - (1LL << 22), "ss_bn_backward_apply: tensor too large for 32-bit chunk indices");
     const float inv_n = (float)(1.0 / n_total);
 #define SS_BNA(TT)                                                                                                                             \
     SS_LAUNCH(bn_bwd_apply_kernel<TT>, ew_grid(total, 256), dim3(256), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, gamma_a, \
