@@ -19,11 +19,13 @@
 //     hold +inf.  ss_dtw_align() builds it from an arbitrarily strided cost matrix (e.g. the non-contiguous
 //     costs.T view of transduction_model.py:126); the fused loss path writes it directly (loss.hip).
 //   * the 2-bit first-minimum direction of every cell (1 byte per lane per step) goes to HBM instead of the
-//     4-byte cumulative matrix (8 B/cell algorithmic traffic -> 4.25 B/cell); wave 0 then walks the path
-//     back through LDS-staged direction chunks and writes results[].
+//     4-byte cumulative matrix (8 B/cell algorithmic traffic -> 4.25 B/cell); the workgroup then stages the
+//     direction bytes of a wave strip in LDS and walks the path back with scalar arithmetic (results[]).
 #include "common.h"
 #include "silent_speech_hip.h"
 #include <math.h>
+#include <stdlib.h>
+#include <type_traits>
 
 #if defined(SS_EMU)
 inline void __threadfence() {}
@@ -34,7 +36,7 @@ constexpr int DW = 4;          // waves per matrix
 constexpr int DR = 4;          // rows per lane
 constexpr int DG = 64;         // steps per super-step (barrier interval)
 constexpr int DRING = 256;     // LDS boundary ring (columns)
-constexpr int DCH = 512;       // backtrace chunk (steps)
+constexpr int DCH = 2048;      // backtrace window (steps) staged in LDS: 128 KB of dynamic shared memory
 constexpr int DESC = 10;       // descriptor fields per matrix
 enum { D_N = 0, D_M, D_COST_OFF, D_SI, D_SJ, D_SK_OFF, D_DIRS_OFF, D_BND_OFF, D_RES_OFF };
 }
@@ -102,14 +104,18 @@ __device__ __forceinline__ void push_eq(unsigned& bits, float x, float y) {
 #endif
 }
 
+// ring slot of column s in the LDS hand-over between waves: (s + 62) & 255.  Lane 63 handles column t - 62 at step t, so inside a
+// super-step (64 steps from a multiple of 64) it writes the CONSECUTIVE slots (t0 & 255) + c: a constant ds_write offset, no address
+// arithmetic on the step
+__device__ __forceinline__ int ring_slot(int s) { return (s + 62) & (DRING - 1); }
+
 // One wavefront step.  No column predicate: cells outside the matrix carry cost +inf in the skewed layout, so a lane that
 // has not reached column 1 yet (or is past M-1) only turns +inf into +inf and its state stays what the recurrence needs
 // (dtw[i][0] = dtw[0][j] = +inf); the direction bytes it writes there are never read.  Branch-free: the per-step chain is
-// the 4 dependent (min3, add) pairs plus one DPP shift.
-__device__ __forceinline__ void dtw_step(int t, int lane, int w, bool multi_strip, int M, const f32x4& cv, float top, float (&prev)[DR], float& diag_sv, float& last_out,
-                                         unsigned char*& dp, float* ring_next, float* dump, float* bnd_cur)
+// the 4 dependent (min3, add) pairs plus one DPP shift.  dp / slot: this step's direction byte and ring word (lane 63: the ring
+// of the next wave; the other lanes hit a dump row).
+__device__ __forceinline__ void dtw_step(int lane, const f32x4& cv, float top, float (&prev)[DR], float& diag_sv, float& last_out, unsigned char* dp, float* slot)
 {
-    const int s = t + 1 - lane;
     const float up_in = wave_shift_in(last_out, top, lane);          // lane 0 takes the row above the strip / the previous wave's last row
     float a = up_in, dg = diag_sv;
     unsigned bits = 0;
@@ -127,17 +133,70 @@ __device__ __forceinline__ void dtw_step(int t, int lane, int w, bool multi_stri
     last_out = a;
     diag_sv = up_in;
     *dp = (unsigned char)bits;
-    dp += 256;
-    // hand the strip's last row to the next wave through the LDS ring: only lane 63 owns a ring slot, the others hit a dump word
-    float* slot = lane == 63 ? ring_next + (s & (DRING - 1)) : dump;
     *slot = a;
-    if (multi_strip && w == DW - 1 && lane == 63 && s >= 1 && s < M) bnd_cur[s] = a;
 }
 
-__global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ desc, unsigned char* __restrict__ ws, int* __restrict__ results)
+// ---- costs of a group of 8 steps -> registers WITHOUT the compiler knowing that these are loads.  Left to hipcc, every step is its
+// own basic block and the first use of a prefetched group is preceded by s_waitcnt vmcnt(0): that drains the 8 loads issued just before
+// (the NEXT group), i.e. one full memory round trip on the serial chain per 8 steps -- 40 % of the kernel.  Loads issued from asm are
+// invisible to the wait insertion; the counted waits below are written by hand (vector memory operations retire in issue order).
+template <int OFF>
+__device__ __forceinline__ void gload128(f32x4& v, const float* p) {
+#if defined(SS_EMU)
+    v = *(const f32x4*)((const char*)p + OFF);
+#else
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
+#endif
+}
+// p = this lane's cost pointer at step tg + 4 (8 steps x 1 KiB around it: offsets -4096 .. 3072 fit the 13-bit signed immediate)
+__device__ __forceinline__ void issue_group(f32x4 (&buf)[8], const float* p) {
+    gload128<-4096>(buf[0], p); gload128<-3072>(buf[1], p); gload128<-2048>(buf[2], p); gload128<-1024>(buf[3], p);
+    gload128<0>(buf[4], p); gload128<1024>(buf[5], p); gload128<2048>(buf[6], p); gload128<3072>(buf[7], p);
+}
+__device__ __forceinline__ void pin_group(f32x4 (&buf)[8]) {
+#if !defined(SS_EMU)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(buf[e]));
+#endif
+}
+template <int N> __device__ __forceinline__ void wait_vm() {       // s_waitcnt vmcnt(N), expcnt / lgkmcnt untouched
+#if !defined(SS_EMU)
+    __builtin_amdgcn_s_waitcnt((N & 15) | 0x0f70 | ((N >> 4) << 14));
+#endif
+}
+template <int I, int N, class F> __device__ __forceinline__ void dfor(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); dfor<I + 1, N>(f); }
+}
+__device__ __forceinline__ int dtw_uniform(int v) {
+#if defined(SS_EMU)
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+__device__ __forceinline__ unsigned dtw_writelane(unsigned old, int val, int l, int lane) {      // val, l wave-uniform
+#if defined(SS_EMU)
+    return lane == l ? (unsigned)val : old;
+#else
+    // one SGPR per VALU instruction on gfx9 (constant bus): the lane select travels in M0
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(l) : "m0");
+    return old;
+#endif
+}
+__device__ __forceinline__ unsigned dtw_readlane(unsigned v, int l) {      // l wave-uniform
+#if defined(SS_EMU)
+    return __shfl(v, l);
+#else
+    return __builtin_amdgcn_readlane(v, l);
+#endif
+}
+
+// dbg (SS_DTW_DEBUG, tuning only -- results are wrong): 1 no backtrace, 2 no sweep, 4 every super-step on the generic path
+__global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ desc, unsigned char* __restrict__ ws, int* __restrict__ results, int dbg)
 {
     __shared__ float lds_bnd[DW + 1][DRING];              // [w] = ring read by wave w (written by wave w-1); [DW] = dump / last wave's unused ring
-    __shared__ __attribute__((aligned(16))) unsigned char chunk[DCH * 64];
+    SS_DYN_SMEM(chunk_raw);                               // DCH x 64 direction bytes of the backtrace window
+    unsigned char* chunk = (unsigned char*)chunk_raw;
     const long long* d = desc + (long long)blockIdx.x * DESC;
     const int N = (int)d[D_N], M = (int)d[D_M];
     if (N <= 1 || M <= 1) return;                                   // no interior cell: results stay 0 (align.py:24)
@@ -145,15 +204,12 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
     unsigned char* dirs = ws + d[D_DIRS_OFF];
     float* bnd = (float*)(ws + d[D_BND_OFF]);
     int* res = results + d[D_RES_OFF];
-#if defined(SS_EMU)
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#else
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: step bounds become s_cbranch, not exec masks
-#endif
+    const int tid = threadIdx.x, lane = tid & 63, w = dtw_uniform(tid >> 6);      // scalar: step bounds become s_cbranch, not exec masks
     const int ts = (int)dtw_tsteps(M), nstrips = (int)dtw_strips(N);
     const int nss = (ts + DG - 1) / DG;
+    const bool multi = nstrips > 1;
 
-    for (int k = 0; k < nstrips; ++k) {
+    for (int k = 0; k < nstrips && !(dbg & 2); ++k) {
         const int rowbase = ((k * DW + w) * 64 + lane) * DR;
         float prev[DR];
 #pragma unroll
@@ -164,43 +220,74 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         unsigned char* dp0 = dirs + ((long long)k * ts) * 256 + w * 64 + lane;
         const float* bnd_prev = bnd + ((k + 1) & 1) * M;
         float* bnd_cur = bnd + (k & 1) * M;
+        float* const ring_next = lds_bnd[w + 1];
+        float* const dump = &lds_bnd[DW][lane];                       // lanes 0..62: words lane .. lane + 63 of the dump row
+        // Fast super-steps (all 64 steps inside the matrix' ts, one strip): 4 register buffers of 8 steps, group g in buffer g % 4,
+        // requested 3 groups ahead.  At every super-step boundary groups 0..2 of the NEXT super-step are loaded AND settled, so
+        // no request is in flight across control flow (a register copy the compiler places at a join would copy a value that has
+        // not arrived).  Group start beyond ts - 8: clamped (never consumed: that super-step takes the generic path).
+        const bool fast_ok = !multi && !(dbg & 4) && ts >= DG;
+        f32x4 cbuf[4][8];
+        auto group_ptr = [&](int tg) { const int tc = tg + 8 <= ts ? tg : ts - 8; return skp + (long long)(tc + 4) * (64 * DR); };
+        if (fast_ok) {
+            issue_group(cbuf[0], group_ptr(0)); issue_group(cbuf[1], group_ptr(8)); issue_group(cbuf[2], group_ptr(16));
+            wait_vm<0>();
+            pin_group(cbuf[0]); pin_group(cbuf[1]); pin_group(cbuf[2]);
+        }
         for (int ss = 0; ss < nss + 2 * (DW - 1); ++ss) {
             const int u = ss - 2 * w;
             if (u >= 0 && u < nss) {
                 const int t0 = u * DG;
-                unsigned char* dp = dp0 + (long long)t0 * 256;
                 // the 64 values lane 0 will need from above during this super-step (one per step), fetched up front
                 float topv;
                 { const int sb = t0 + 1 + lane;
                   if (w == 0) topv = (k == 0 || sb >= M) ? INFINITY : bnd_prev[sb];
-                  else topv = lds_bnd[w][sb & (DRING - 1)]; }
+                  else topv = lds_bnd[w][ring_slot(sb)]; }
 #if !defined(SS_EMU)
-                // settle the LDS read NOW: left pending, the compiler re-waits lgkmcnt(0) at the v_readlane of EVERY step, which also
+                // settle the LDS read NOW: left pending, the compiler re-waits lgkmcnt(0) at EVERY step, which also
                 // drains that step's ring write (an LDS round trip on the serial chain of each of the 64 steps)
                 __builtin_amdgcn_s_waitcnt(0xc07f);
 #endif
-                f32x4 cb[8];
-                const f32x4 inf4 = {INFINITY, INFINITY, INFINITY, INFINITY};
+                if (fast_ok && t0 + DG <= ts) {
+                    unsigned char* const dpb = dp0 + (long long)t0 * 256;
+                    float* const slot0 = lane == 63 ? ring_next + (t0 & (DRING - 1)) : dump;
+                    dfor<0, 8>([&](auto jc) {
+                        constexpr int j = jc;
+                        issue_group(cbuf[(j + 3) & 3], group_ptr(t0 + (j + 3) * 8));
+                        // after the loads of group j: stores of 3 groups + loads of 3 groups = 48 younger operations
+                        if constexpr (j >= 3) wait_vm<48>();
+                        pin_group(cbuf[j & 3]);
+                        dfor<0, 8>([&](auto ec) {
+                            constexpr int e = ec, c = j * 8 + e;
+                            dtw_step(lane, cbuf[j & 3][e], topv, prev, diag_sv, last_out, dpb + c * 256, slot0 + c);
+                            topv = wave_rotate_down(topv);
+                        });
+                    });
+                    wait_vm<0>();
+                    pin_group(cbuf[0]); pin_group(cbuf[1]); pin_group(cbuf[2]);
+                } else {
+                    f32x4 cb[8];
+                    const f32x4 inf4 = {INFINITY, INFINITY, INFINITY, INFINITY};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) cb[e] = t0 + e < ts ? *(const f32x4*)(skp + (long long)(t0 + e) * (64 * DR)) : inf4;
-                for (int g = 0; g < DG / 8; ++g) {
-                    f32x4 nb[8];
-                    const int tn = t0 + (g + 1) * 8;
+                    for (int e = 0; e < 8; ++e) cb[e] = t0 + e < ts ? *(const f32x4*)(skp + (long long)(t0 + e) * (64 * DR)) : inf4;
+                    for (int g = 0; g < DG / 8; ++g) {
+                        f32x4 nb[8];
+                        const int tn = t0 + (g + 1) * 8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) nb[e] = (g + 1 < DG / 8 && tn + e < ts) ? *(const f32x4*)(skp + (long long)(tn + e) * (64 * DR)) : inf4;
-#if !defined(SS_EMU)
-                    // settle THIS group's costs (requested one group ago) now, leaving the 8 loads just issued in flight: every step is its own
-                    // basic block, and left to itself the compiler waits vmcnt(0) at the top of each -- i.e. for the previous step's direction
-                    // store (vmcnt counts stores too): one memory round trip on the serial chain of every step
-                    __builtin_amdgcn_s_waitcnt(0x0f78);          // vmcnt(8), expcnt / lgkmcnt untouched
-#endif
+                        for (int e = 0; e < 8; ++e) nb[e] = (g + 1 < DG / 8 && tn + e < ts) ? *(const f32x4*)(skp + (long long)(tn + e) * (64 * DR)) : inf4;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int t = t0 + g * 8 + e;
-                        if (t < ts) { dtw_step(t, lane, w, nstrips > 1, M, cb[e], topv, prev, diag_sv, last_out, dp, lds_bnd[w + 1], &lds_bnd[DW][lane], bnd_cur); topv = wave_rotate_down(topv); }
+                        for (int e = 0; e < 8; ++e) {
+                            const int t = t0 + g * 8 + e;
+                            if (t < ts) {
+                                const int s = t + 1 - lane;
+                                dtw_step(lane, cb[e], topv, prev, diag_sv, last_out, dp0 + (long long)t * 256, lane == 63 ? ring_next + ring_slot(s) : dump);
+                                if (multi && w == DW - 1 && lane == 63 && s >= 1 && s < M) bnd_cur[s] = last_out;
+                                topv = wave_rotate_down(topv);
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) cb[e] = nb[e];
                     }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) cb[e] = nb[e];
                 }
             }
             __syncthreads();
@@ -208,31 +295,77 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         __threadfence();      // strip boundary row + direction bytes visible before they are re-read
         __syncthreads();
     }
+    if (dbg & 1) return;
 
-    if (w != 0) return;
-    // ---- backtrace (wave 0, wave-uniform walk; direction bytes staged through LDS in chunks)
+    // ---- backtrace: all four waves walk the path in lockstep (wave-uniform = scalar arithmetic; wave 0 writes results), so that the
+    // whole workgroup stages the direction bytes of a wave strip: window [t_lo, t_hi] x 64 lanes, up to DCH steps = the whole strip
+    // for M <= DCH - 62.  The walk is organised by LANE COLUMN (the 4 rows of one lane): inside a column the bytes come from a
+    // register cache (lane i = step c_top - i of column l) through v_readlane, and a cell costs ~12 scalar instructions (a wave on
+    // its own issues one instruction per ~5 cycles: the instruction count IS the latency).  The cache of the next column (l - 1) is
+    // requested on entry to a column -- its top step is known: t only decreases -- so that its LDS latency passes under the walk.
+    // results[i] = the column at which the path LEAVES row i (smallest j visited): collected in lanes 0..3 of a register and
+    // stored once per column.
     int p = N - 1, s = M - 1;
-    int cur_kw = -1, t_lo = 0, t_hi = -1;
+    int cur_kw = -1, t_lo = 0;
+    unsigned cache = 0, cache_nx = 0, rv = 0;
+    int c_top = 0, nx_top = 0;
+    bool nx_ok = false;
+    auto column = [&](int l, int top) -> unsigned {                       // lane i <- byte of step top - i (0 below the window)
+        const int tt = top - lane;
+        return tt >= t_lo ? (unsigned)chunk[(tt - t_lo) * 64 + l] : 0u;
+    };
     while (p > 0 && s > 0) {
-        if (lane == 0) res[p] = s;
         const int q = p - 1;
-        const int kw = q / (64 * DR), l = (q / DR) & 63, r = q % DR;
-        const int t = s - 1 + l;
-        if (kw != cur_kw || t < t_lo || t > t_hi) {
+        const int kw = q / (64 * DR), l = (q / DR) & 63;
+        int r = q % DR;
+        const int pbase = p - r;                                          // row of r = 0
+        int t = s - 1 + l;
+        if (kw != cur_kw || t < t_lo) {
             __syncthreads();
-            t_hi = t; t_lo = t - DCH + 1 < 0 ? 0 : t - DCH + 1; cur_kw = kw;
+            const int t_hi = t;
+            t_lo = t - DCH + 1 < 0 ? 0 : t - DCH + 1; cur_kw = kw; nx_ok = false;
             const int kk = kw / DW, ww = kw % DW;
             const unsigned char* src = dirs + ((long long)kk * ts + t_lo) * 256 + ww * 64;
-            const int nd = (t_hi - t_lo + 1) * 16;
-            for (int idx = lane; idx < nd; idx += 64) {
-                const int tt = idx >> 4, c = idx & 15;
-                *(unsigned*)(chunk + tt * 64 + c * 4) = *(const unsigned*)(src + (long long)tt * 256 + c * 4);
+            const int nd = (t_hi - t_lo + 1) * 4;                         // 16-byte pieces
+            for (int base = 0; base < nd; base += 256 * 8) {              // 8 loads in flight per thread, then the 8 LDS writes
+                u32x4 v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int idx = base + e * 256 + tid, tt = idx >> 2, c = idx & 3;
+                    if (idx < nd) v[e] = *(const u32x4*)(src + (long long)tt * 256 + c * 16);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int idx = base + e * 256 + tid, tt = idx >> 2, c = idx & 3;
+                    if (idx < nd) *(u32x4*)(chunk + tt * 64 + c * 16) = v[e];
+                }
             }
             __syncthreads();
         }
-        const unsigned byte = chunk[(t - t_lo) * 64 + l];
-        const unsigned pm = (byte >> (2 * (DR - 1 - r))) & 3u;            // 2 [best == left] + [best == up]
-        if (pm & 1u) { --p; } else if (pm & 2u) { --s; } else { --p; --s; }
+        if (nx_ok && nx_top >= t && nx_top - t < 64) { cache = cache_nx; c_top = nx_top; }
+        else { c_top = t; cache = column(l, t); }
+        nx_ok = l > 0;
+        if (nx_ok) { nx_top = t - 1; cache_nx = column(l - 1, nx_top); }
+        unsigned vis = 0;
+        int t_min = c_top - 63 > t_lo ? c_top - 63 : t_lo;                // the cache holds steps t_min .. c_top
+        for (;;) {
+            if (t < t_min) {                                              // a long horizontal run
+                if (t < t_lo) break;                                      // .. beyond the LDS window: back out, the column is re-entered behind a reload
+                c_top = t; cache = column(l, t); t_min = t - 63 > t_lo ? t - 63 : t_lo;
+            }
+            const unsigned code = (dtw_readlane(cache, c_top - t) >> (2 * (DR - 1 - r))) & 3u;     // 2 [best == left] + [best == up]
+            if (code == 2u) {                                             // left
+                --s; --t;
+                if (s == 0) { rv = dtw_writelane(rv, 1, r, lane); vis |= 1u << r; break; }
+            } else {                                                      // up (code & 1) or diagonal: the path leaves row r at column s
+                rv = dtw_writelane(rv, s, r, lane); vis |= 1u << r;
+                if (!(code & 1u)) { --s; --t; }
+                --r;
+                if (r < 0 || s == 0) break;
+            }
+        }
+        p = pbase + r;
+        if (w == 0 && lane < DR && ((vis >> lane) & 1u)) res[pbase + lane] = (int)rv;
     }
 }
 
@@ -247,7 +380,16 @@ static int dtw_launch(const long long* desc_dev, int n, int max_n, int max_m, vo
         SS_LAUNCH(dtw_skew_kernel, dim3((unsigned)blocks, n), dim3(256), 0, stream, costs, desc_dev, (unsigned char*)ws, results);
         SS_LAUNCH_CHECK("ss_dtw_align(skew)");
     }
-    SS_LAUNCH(dtw_kernel, dim3(n), dim3(256), 0, stream, desc_dev, (unsigned char*)ws, results);
+    static const int dbg = getenv("SS_DTW_DEBUG") ? atoi(getenv("SS_DTW_DEBUG")) : 0;
+    const size_t smem = (size_t)DCH * 64;
+#if !defined(SS_EMU)
+    static bool granted = false;
+    if (!granted) {
+        if (hipFuncSetAttribute((const void*)dtw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("ss_dtw_align: cannot reserve %zu bytes of LDS", smem); return 1; }
+        granted = true;
+    }
+#endif
+    SS_LAUNCH(dtw_kernel, dim3(n), dim3(256), smem, stream, desc_dev, (unsigned char*)ws, results, dbg);
     SS_LAUNCH_CHECK("ss_dtw_align");
     return 0;
 }

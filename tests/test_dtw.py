@@ -62,6 +62,25 @@ def test_dtw_batch_ragged(dev):
         assert res[ro:ro + s[0]].tolist() == dtw_ref.align_from_distances_c(m), s
 
 
+def test_dtw_sweep_paths_and_windows(dev):
+    """several fast super-steps + a generic tail, two row strips (N > 1025), a backtrace longer than the 2048-step LDS window, and
+    horizontal runs of hundreds / thousands of cells inside ONE lane column (register-cache refills, window exhausted mid-column)"""
+    rng = np.random.default_rng(12)
+    cases = [rng.random((150, 200), dtype=np.float32), rng.integers(0, 3, (1100, 70)).astype(np.float32),
+             (rng.standard_normal((40, 2300)) ** 2).astype(np.float32)]
+    for n, m in ((20, 300), (9, 2300), (270, 2200)):
+        c = rng.random((n, m), dtype=np.float32) + 5.0
+        c[n - 1, :] = 0.0                                   # the path runs along the last row, then climbs column 1
+        c[:, 1] = 0.0
+        cases.append(c)
+    c = rng.random((300, 90), dtype=np.float32) + 5.0
+    c[:, 88] = 0.0                                          # a vertical run through every lane column, then along row 1
+    c[1, :] = 0.0
+    cases.append(c)
+    for c in cases:
+        assert align.align_from_distances(c, device=dev) == dtw_ref.align_from_distances_c(c), c.shape
+
+
 @pytest.mark.gpu
 def test_dtw_big_golden_and_strips():
     """BASELINE cfg3 size (1000x1000, golden from the reference) and a >1024-row matrix (2 strips)."""
