@@ -10,6 +10,7 @@
 // `head` is the fused output of the two linear heads: row = packed frame, columns [0,n_mel) = mel
 // prediction (w_out, architecture.py:55), [n_mel, n_mel+n_phone) = phoneme logits (w_aux, :59), f32.
 #include "common.h"
+#include <stdlib.h>
 #include "silent_speech_hip.h"
 #include <math.h>
 
@@ -107,12 +108,12 @@ extern "C" int ss_voiced_loss(const float* head, int64_t ld, int n_mel, int n_ph
 
 // ---------------------------------------------------------------- silent utterances: cost matrix straight into the DTW strip layout
 // DTW runs on costs.T: row i = target frame k, column j = predicted frame q (transduction_model.py:126).
-// One thread owns one (lane, row) slot of a wave-strip -- i.e. ONE target frame i -- for a chunk of CT consecutive steps t:
+// One thread owns one (lane, row) slot of a wave-strip -- i.e. ONE target frame i -- for a chunk of CT (16) consecutive steps t:
 // the target row y_i stays in registers (n_mel <= 128), only the predicted rows stream in, and every step's 256 results
 // (64 lanes x 4 rows) leave as one contiguous 1 KiB store.  The 80-term sum runs in the reference order (bit-exact costs).
-constexpr int CT = 32, YMAX = 128;
+constexpr int YMAX = 128;
 __global__ __launch_bounds__(256) void silent_cost_skewed_kernel(const float* __restrict__ head, long long ld, int n_mel, const float* __restrict__ lse, const float* __restrict__ Y,
-                                                                 const long long* __restrict__ phones, const long long* __restrict__ desc, float lam, unsigned char* __restrict__ ws, int* __restrict__ results)
+                                                                 const long long* __restrict__ phones, const long long* __restrict__ desc, float lam, unsigned char* __restrict__ ws, int* __restrict__ results, int CT)
 {
     const long long* d = desc + (long long)blockIdx.y * DESC;
     const int N = (int)d[D_N], M = (int)d[D_M];
@@ -168,12 +169,15 @@ extern "C" int ss_silent_cost_skewed(const float* head, int64_t ld, int n_mel, c
     SS_CHECK(n_mel <= YMAX, "ss_silent_cost_skewed: at most %d mel bins", YMAX);
     long long strips = max_n <= 1 ? 0 : (max_n - 1 + DW * 64 * DR - 1) / (DW * 64 * DR);
     const long long ts_max = max_m <= 1 ? 0 : max_m - 1 + 63;
+    // steps per work item: every step is a dependent load -> 80-term sum round trip, so the kernel lives on the number of work items in
+    // flight (32 steps: 135 us for the bench batch, 16: 84, 8: 80; below that the re-loaded target row starts to show)
+    static const int CT = getenv("SS_COST_CT") ? atoi(getenv("SS_COST_CT")) : 16;
     long long blocks = strips * DW * ((ts_max + CT - 1) / CT);            // one workgroup per (wave-strip, chunk of CT steps)
     if (blocks < (max_n + 255) / 256) blocks = (max_n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     SS_LAUNCH(silent_cost_skewed_kernel, dim3((unsigned)blocks, n), dim3(256), 0, stream, head, (long long)ld, n_mel, lse, Y, (const long long*)phones,
-              (const long long*)desc_dev, lam, (unsigned char*)workspace, (int*)results);
+              (const long long*)desc_dev, lam, (unsigned char*)workspace, (int*)results, CT);
     SS_LAUNCH_CHECK("ss_silent_cost_skewed");
     return 0;
 }
