@@ -56,21 +56,60 @@ extern "C" int64_t ss_dtw_workspace_bytes(int n, int m, int64_t* sk_bytes, int64
 }
 
 // ------------------------------------------------------------------ cost matrix -> skewed strips
-__global__ void dtw_skew_kernel(const float* __restrict__ costs, const long long* __restrict__ desc, unsigned char* __restrict__ ws,
-                                int* __restrict__ results)
+// One workgroup = 64 rows (16 lanes of a wave strip) x SKT steps, through an LDS tile [64 rows][SKT]: the skewed layout needs, for
+// row 4 l + r, the SKT columns t0 + 1 - l .. -- a parallelogram of the matrix.  It is fetched along the matrix' unit-stride axis
+// (rows of 128 bytes for a row-major matrix; for a column-major one -- the costs.T view of transduction_model.py:126 -- column j is
+// needed by the lanes l = t0 + 1 - j .. of the tile: up to 64 consecutive rows) and leaves as 256-byte pieces of the strip's
+// 1 KiB rows.  Every thread has all of its 8 (12) loads in flight at once.  (A gather straight from the matrix, one element per
+// thread, ran at 1.4 TB/s of combined traffic for a batch: 64 distinct cache lines per 256 outputs.)
+constexpr int SKT = 32, SKR = 64;
+__global__ __launch_bounds__(256) void dtw_skew_kernel(const float* __restrict__ costs, const long long* __restrict__ desc, unsigned char* __restrict__ ws,
+                                                       int* __restrict__ results, int ntiles_max)
 {
+    __shared__ float tile[SKR][SKT + 1];
     const long long* d = desc + (long long)blockIdx.y * DESC;
     const int N = (int)d[D_N], M = (int)d[D_M];
     int* res = results + d[D_RES_OFF];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) res[i] = 0;
-    const long long ts = dtw_tsteps(M), total = dtw_strips(N) * DW * ts * 64 * DR;
+    const int tid = threadIdx.x;
+    for (int i = blockIdx.x * 256 + tid; i < N; i += gridDim.x * 256) res[i] = 0;
+    const int ts = (int)dtw_tsteps(M), nrt = (int)dtw_strips(N) * DW * (256 / SKR);      // row tiles: quarters of the wave strips
+    const int rt = blockIdx.x / ntiles_max, t0 = (blockIdx.x - rt * ntiles_max) * SKT;
+    if (rt >= nrt || t0 >= ts) return;
     float* sk = (float*)(ws + d[D_SK_OFF]);
     const float* c = costs + d[D_COST_OFF];
     const long long si = d[D_SI], sj = d[D_SJ];
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        int r = (int)(e % DR); long long x = e / DR; int l = (int)(x % 64); x /= 64; long long t = x % ts; long long kw = x / ts;
-        long long i = 1 + (kw * 64 + l) * DR + r, j = t + 1 - l;
-        sk[e] = (i < N && j >= 1 && j < M) ? c[i * si + j * sj] : INFINITY;
+    const int row0 = 1 + rt * SKR;                                        // matrix row of tile row 0
+    const int l0 = (rt * (SKR / DR)) & 63;                                // lane of tile row 0 inside its wave strip
+    if (sj == 1) {
+#pragma unroll
+        for (int pp = 0; pp < SKR / 8; ++pp) {                            // 8 rows x 32 columns per pass
+            const int rr = pp * 8 + (tid >> 5), cc = tid & 31;
+            const int i = row0 + rr, j = t0 + cc + 1 - (l0 + (rr >> 2));
+            tile[rr][cc] = (i < N && j >= 1 && j < M) ? c[(long long)i * si + j] : INFINITY;
+        }
+    } else if (si == 1) {
+        const int rr = tid & 63, l = l0 + (rr >> 2), i = row0 + rr;
+#pragma unroll
+        for (int pp = 0; pp < (SKT + SKR / DR - 1 + 3) / 4; ++pp) {       // 4 columns x 64 rows per pass; column j serves the lanes with 0 <= j - 1 + l - t0 < SKT
+            const int j = t0 + 1 - (l0 + SKR / DR - 1) + pp * 4 + (tid >> 6), cc = j - 1 + l - t0;
+            if (cc >= 0 && cc < SKT) tile[rr][cc] = (i < N && j >= 1 && j < M) ? c[(long long)j * sj + i] : INFINITY;
+        }
+    } else {
+        const int rr = tid & 63, l = l0 + (rr >> 2), i = row0 + rr;
+#pragma unroll
+        for (int pp = 0; pp < SKT / 4; ++pp) {
+            const int cc = pp * 4 + (tid >> 6), j = t0 + cc + 1 - l;
+            tile[rr][cc] = (i < N && j >= 1 && j < M) ? c[(long long)i * si + (long long)j * sj] : INFINITY;
+        }
+    }
+    __syncthreads();
+    // strip row t: [64 lanes][4 rows] floats; this tile owns the 64 consecutive floats from lane l0
+    const int kw = rt / (256 / SKR);
+    float* out = sk + ((long long)kw * ts + t0) * (64 * DR) + l0 * DR + (tid & 63);
+#pragma unroll
+    for (int pp = 0; pp < SKT / 4; ++pp) {
+        const int cc = pp * 4 + (tid >> 6);
+        if (t0 + cc < ts) out[(long long)cc * (64 * DR)] = tile[tid & 63][cc];
     }
 }
 
@@ -372,12 +411,11 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
 static int dtw_launch(const long long* desc_dev, int n, int max_n, int max_m, void* ws, int* results, void* stream, const float* costs)
 {
     if (costs) {
-        long long total = dtw_strips(max_n) * DW * dtw_tsteps(max_m) * 64 * DR;
-        long long blocks = (total + 255) / 256;
-        if (blocks < (max_n + 255) / 256) blocks = (max_n + 255) / 256;
-        if (blocks > 1024) blocks = 1024;
-        if (blocks < 1) blocks = 1;
-        SS_LAUNCH(dtw_skew_kernel, dim3((unsigned)blocks, n), dim3(256), 0, stream, costs, desc_dev, (unsigned char*)ws, results);
+        const long long nrt = dtw_strips(max_n) * DW * (256 / SKR), ntiles = (dtw_tsteps(max_m) + SKT - 1) / SKT;
+        long long blocks = nrt * ntiles;
+        if (blocks < 1) blocks = 1;                                       // results are zeroed by this launch
+        SS_CHECK(blocks < (1LL << 31), "ss_dtw_align: matrix too large (%d x %d)", max_n, max_m);
+        SS_LAUNCH(dtw_skew_kernel, dim3((unsigned)blocks, n), dim3(256), 0, stream, costs, desc_dev, (unsigned char*)ws, results, (int)(ntiles > 0 ? ntiles : 1));
         SS_LAUNCH_CHECK("ss_dtw_align(skew)");
     }
     static const int dbg = getenv("SS_DTW_DEBUG") ? atoi(getenv("SS_DTW_DEBUG")) : 0;

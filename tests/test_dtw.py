@@ -29,6 +29,13 @@ def test_dtw_strided_transposed_view(dev):
     want = dtw_ref.align_from_distances_c(c.T)
     assert align.align_from_distances(c.T, device=dev) == want
     assert align.align_from_distances(torch.from_numpy(c).t(), device=dev) == want
+    # neither axis unit-stride (a sliced view), and views a few hundred rows / columns large (several tiles of the skew pass)
+    big = rng.random((91, 130), dtype=np.float32)
+    v = big[::2, ::3]
+    assert align.align_from_distances(torch.from_numpy(big)[::2, ::3], device=dev) == dtw_ref.align_from_distances_c(np.ascontiguousarray(v))
+    wide = rng.random((300, 70), dtype=np.float32)
+    assert align.align_from_distances(torch.from_numpy(wide).t(), device=dev) == dtw_ref.align_from_distances_c(np.ascontiguousarray(wide.T))
+    assert align.align_from_distances(torch.from_numpy(wide), device=dev) == dtw_ref.align_from_distances_c(wide)
 
 
 def test_dtw_degenerate(dev):
