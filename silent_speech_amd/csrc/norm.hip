@@ -14,6 +14,7 @@ namespace {
 struct Seq {            // logical row r of a (B, T + 2*pad, C) buffer
     int T, pad;
     __device__ __forceinline__ long long row(int r) const { int b = r / T, t = r - b * T; return (long long)b * (T + 2 * pad) + pad + t; }
+    __device__ __forceinline__ long long at(int b, int t) const { return (long long)b * (T + 2 * pad) + pad + t; }     // the division of row() done once by the caller
 };
 
 // thread -> (vector column cx0 (+k*CVb), row lane ry) for column reductions over a [rows][C] matrix
@@ -180,16 +181,61 @@ extern "C" int ss_bn_finalize_shift(const float* sums, const float* shift, doubl
 }
 
 // =========================================================================== BatchNorm apply (+residual, +ReLU)
+// Elementwise kernels over (B, T + 2 pad, C) in 16-byte chunks.  The launch makes the grid stride a multiple of C / 8 whenever it can
+// (ew_grid), so that a thread stays on ONE column chunk: the per-channel constants then sit in registers for all of its rows, and
+// (b, t) advance without a division.  (Re-read per chunk they were 128 .. 192 bytes of L1 traffic per 16 bytes of data, and the 64-bit
+// row arithmetic -- a division per tensor and chunk -- outweighed the memory instructions.)
+struct RowWalk {
+    unsigned ro, b, tp, rstep, db, dtp, TP; int cx;
+    __device__ __forceinline__ RowWalk(unsigned gtid, unsigned step, unsigned CV, unsigned TP_) {
+        TP = TP_; ro = gtid / CV; cx = (int)(gtid - ro * CV); rstep = step / CV;
+        b = ro / TP; tp = ro - b * TP; db = rstep / TP; dtp = rstep - db * TP;
+    }
+    __device__ __forceinline__ void next() { ro += rstep; b += db; tp += dtp; if (tp >= TP) { tp -= TP; ++b; } }
+};
+
 template <class T>
 __global__ void bn_apply_kernel(const T* __restrict__ xa, Seq sa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a, const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
                                 const T* __restrict__ xb, Seq sb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b, const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
                                 T* __restrict__ y, Seq sy, int B, int C, int relu)
 {
     const int CV = C >> 3, TT = sy.T;
-    const long long rows_out = (long long)B * (TT + 2 * sy.pad), total = rows_out * CV;
-    // 32-bit index arithmetic (the host checks total < 2^31): the 64-bit divisions of the generic form were ~300 of the ~450 instructions
-    // a thread spent per 16-byte chunk
-    const unsigned TP = (unsigned)(TT + 2 * sy.pad), total32 = (unsigned)total, step32 = gridDim.x * blockDim.x;
+    const unsigned TP = (unsigned)(TT + 2 * sy.pad), rows_out = (unsigned)B * TP, step32 = gridDim.x * blockDim.x;     // the host checks rows_out * CV < 2^31
+    if (step32 % (unsigned)CV == 0) {
+        RowWalk w(blockIdx.x * blockDim.x + threadIdx.x, step32, (unsigned)CV, TP);
+        float ma[8], sca[8], ba[8], mb[8], scb[8], bb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = w.cx * 8 + e;
+            ma[e] = mean_a[c]; sca[e] = gamma_a[c] * invstd_a[c]; ba[e] = beta_a[c];
+            mb[e] = 0.f; scb[e] = 0.f; bb[e] = 0.f;
+            if (xb) { mb[e] = mean_b[c]; scb[e] = gamma_b[c] * invstd_b[c]; bb[e] = beta_b[c]; }
+        }
+        for (; w.ro < rows_out; w.next()) {
+            const int t = (int)w.tp - sy.pad;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;                 // zero halo rows
+            if (t >= 0 && t < TT) {
+                float v[8], u[8];
+                Vec8<T>::load(xa + sa.at((int)w.b, t) * C + w.cx * 8, v);
+                if (xb) Vec8<T>::load(xb + sb.at((int)w.b, t) * C + w.cx * 8, u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (v[e] - ma[e]) * sca[e] + ba[e];
+                if (xb) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += (u[e] - mb[e]) * scb[e] + bb[e];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = fmaxf(o[e], 0.f);
+                }
+            }
+            Vec8<T>::store(y + (long long)w.ro * C + w.cx * 8, o);
+        }
+        return;
+    }
+    const unsigned total32 = rows_out * (unsigned)CV;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total32; i += step32) {
         const unsigned ro = i / (unsigned)CV; const int cx = (int)(i - ro * (unsigned)CV);
         const unsigned bq = ro / TP; const int b = (int)bq, tp = (int)(ro - bq * TP), t = tp - sy.pad;
@@ -198,12 +244,11 @@ __global__ void bn_apply_kernel(const T* __restrict__ xa, Seq sa, const float* _
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = 0.f;             // zero halo rows
         } else {
-            const int r = b * TT + t;
-            float v[8]; Vec8<T>::load(xa + sa.row(r) * C + cx * 8, v);
+            float v[8]; Vec8<T>::load(xa + sa.at(b, t) * C + cx * 8, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float s = gamma_a[c] * invstd_a[c]; o[e] = (v[e] - mean_a[c]) * s + beta_a[c]; }
             if (xb) {
-                float u[8]; Vec8<T>::load(xb + sb.row(r) * C + cx * 8, u);
+                float u[8]; Vec8<T>::load(xb + sb.at(b, t) * C + cx * 8, u);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float s = gamma_b[c] * invstd_b[c]; o[e] += (u[e] - mean_b[c]) * s + beta_b[c]; }
             }
@@ -216,7 +261,24 @@ __global__ void bn_apply_kernel(const T* __restrict__ xa, Seq sa, const float* _
     }
 }
 
-static dim3 ew_grid(long long total, int block) { long long g = (total + block - 1) / block; if (g > 8192) g = 8192; if (g < 1) g = 1; return dim3((unsigned)g); }
+// grid of an elementwise kernel over `total` 16-byte chunks.  CV > 0: rows of CV chunks with per-column constants -- few, long-lived
+// workgroups (768 = 3 per CU; SS_BN_GRID) whose thread total is a multiple of CV, so that a thread keeps its column chunk and its
+// constants.  Measured on the bench shapes (bn_apply / bn_bwd_apply per step): 8190 workgroups 1.10 / 1.33 ms (the set-up -- four
+// divisions, 6..14 constant loads -- is paid per 1..4 chunks), 2046: 0.45 / 0.62, 768: 0.335 / 0.50, 510: 0.34 / 0.53; the per-chunk form
+// this replaces: 0.39 / 0.56.  Two rows in flight per thread: no gain (bn_apply), spills (bn_bwd_apply).
+static dim3 ew_grid(long long total, int block, int CV = 0) {
+    static const long long cap_cols = getenv("SS_BN_GRID") ? atoll(getenv("SS_BN_GRID")) : 768;
+    long long g = (total + block - 1) / block;
+    const long long cap = CV > 0 ? cap_cols : 8192;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    if (CV > 0) {
+        long long a = CV, bb = block; while (bb) { const long long t = a % bb; a = bb; bb = t; }      // gcd(CV, block)
+        const long long m = CV / a;
+        if (g >= 4 * m) g = g / m * m;
+    }
+    return dim3((unsigned)g);
+}
 
 extern "C" int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const float* invstd_a, const float* gamma_a, const float* beta_a, int pad_xa,
                            const void* xb, const float* mean_b, const float* invstd_b, const float* gamma_b, const float* beta_b, int pad_xb,
@@ -228,8 +290,8 @@ extern "C" int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const
     Seq sa = {T, pad_xa}, sb = {T, pad_xb}, sy = {T, pad_y};
     const long long total = (long long)B * (T + 2 * pad_y) * (C / 8);
     SS_CHECK(total < (1LL << 31) - (1LL << 22), "ss_bn_apply: tensor too large for 32-bit chunk indices");
-    if (dtype == SS_BF16) SS_LAUNCH(bn_apply_kernel<bf16_t>, ew_grid(total, 256), dim3(256), 0, stream, (const bf16_t*)xa, sa, mean_a, invstd_a, gamma_a, beta_a, (const bf16_t*)xb, sb, mean_b, invstd_b, gamma_b, beta_b, (bf16_t*)y, sy, B, C, relu);
-    else SS_LAUNCH(bn_apply_kernel<float>, ew_grid(total, 256), dim3(256), 0, stream, (const float*)xa, sa, mean_a, invstd_a, gamma_a, beta_a, (const float*)xb, sb, mean_b, invstd_b, gamma_b, beta_b, (float*)y, sy, B, C, relu);
+    if (dtype == SS_BF16) SS_LAUNCH(bn_apply_kernel<bf16_t>, ew_grid(total, 256, C / 8), dim3(256), 0, stream, (const bf16_t*)xa, sa, mean_a, invstd_a, gamma_a, beta_a, (const bf16_t*)xb, sb, mean_b, invstd_b, gamma_b, beta_b, (bf16_t*)y, sy, B, C, relu);
+    else SS_LAUNCH(bn_apply_kernel<float>, ew_grid(total, 256, C / 8), dim3(256), 0, stream, (const float*)xa, sa, mean_a, invstd_a, gamma_a, beta_a, (const float*)xb, sb, mean_b, invstd_b, gamma_b, beta_b, (float*)y, sy, B, C, relu);
     SS_LAUNCH_CHECK("ss_bn_apply");
     return 0;
 }
@@ -260,10 +322,11 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const T* __
                 const bool two = r + m.RY < r1;
                 const int rb = two ? r + m.RY : r;
                 float g[2][8], o[2][8], va[2][8], vb[2][8];
-                Vec8<T>::load(dy + sdy.row(r) * C + cx * 8, g[0]); Vec8<T>::load(dy + sdy.row(rb) * C + cx * 8, g[1]);
-                if (relu) { Vec8<T>::load(y + sy.row(r) * C + cx * 8, o[0]); Vec8<T>::load(y + sy.row(rb) * C + cx * 8, o[1]); }
-                Vec8<T>::load(xa + sa.row(r) * C + cx * 8, va[0]); Vec8<T>::load(xa + sa.row(rb) * C + cx * 8, va[1]);
-                if (xb) { Vec8<T>::load(xb + sb.row(r) * C + cx * 8, vb[0]); Vec8<T>::load(xb + sb.row(rb) * C + cx * 8, vb[1]); }
+                const int b0 = r / sdy.T, t0 = r - b0 * sdy.T, b1 = rb / sdy.T, t1 = rb - b1 * sdy.T;      // ONE division per row (Seq::row costs one per tensor)
+                Vec8<T>::load(dy + sdy.at(b0, t0) * C + cx * 8, g[0]); Vec8<T>::load(dy + sdy.at(b1, t1) * C + cx * 8, g[1]);
+                if (relu) { Vec8<T>::load(y + sy.at(b0, t0) * C + cx * 8, o[0]); Vec8<T>::load(y + sy.at(b1, t1) * C + cx * 8, o[1]); }
+                Vec8<T>::load(xa + sa.at(b0, t0) * C + cx * 8, va[0]); Vec8<T>::load(xa + sa.at(b1, t1) * C + cx * 8, va[1]);
+                if (xb) { Vec8<T>::load(xb + sb.at(b0, t0) * C + cx * 8, vb[0]); Vec8<T>::load(xb + sb.at(b1, t1) * C + cx * 8, vb[1]); }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if (u == 1 && !two) break;
@@ -316,6 +379,47 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* 
     const int padmax = sda.pad > sdb.pad ? sda.pad : sdb.pad;
     const long long total = (long long)B * (TT + 2 * padmax) * CV;
     const unsigned TP = (unsigned)(TT + 2 * padmax), total32 = (unsigned)total, step32 = gridDim.x * blockDim.x;      // 32-bit index arithmetic, see bn_apply_kernel
+    if (step32 % (unsigned)CV == 0) {
+        // thread <-> column chunk fixed (see bn_apply_kernel): dx = k (g - c0 - (x - mean) q) with k = gamma invstd, c0 = mean(g),
+        // q = invstd mean(g xhat) in registers
+        RowWalk w(blockIdx.x * blockDim.x + threadIdx.x, step32, (unsigned)CV, TP);
+        float ma[8], ka[8], qa[8], c0[8], mb[8], kb[8], qb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = w.cx * 8 + e;
+            ma[e] = mean_a[c]; ka[e] = gamma_a[c] * invstd_a[c]; qa[e] = invstd_a[c] * (coef[C + c] * inv_n); c0[e] = coef[c] * inv_n;
+            mb[e] = 0.f; kb[e] = 0.f; qb[e] = 0.f;
+            if (xb) { mb[e] = mean_b[c]; kb[e] = gamma_b[c] * invstd_b[c]; qb[e] = invstd_b[c] * (coef[2 * C + c] * inv_n); }
+        }
+        const unsigned rows_out = (unsigned)B * TP;
+        for (; w.ro < rows_out; w.next()) {
+            const int b = (int)w.b, t = (int)w.tp - padmax, cx = w.cx;
+            float oa[8], ob[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { oa[e] = 0.f; ob[e] = 0.f; }
+            if (t >= 0 && t < TT) {
+                float g[8], o[8], v[8], u[8];
+                Vec8<T>::load(dy + sdy.at(b, t) * C + cx * 8, g);
+                if (relu) Vec8<T>::load(y + sy.at(b, t) * C + cx * 8, o);
+                Vec8<T>::load(xa + sa.at(b, t) * C + cx * 8, v);
+                if (xb) Vec8<T>::load(xb + sb.at(b, t) * C + cx * 8, u);
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) oa[e] = ka[e] * (g[e] - c0[e] - (v[e] - ma[e]) * qa[e]);
+                if (xb) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ob[e] = kb[e] * (g[e] - c0[e] - (u[e] - mb[e]) * qb[e]);
+                }
+            }
+            const int ta = t + sda.pad, tb = t + sdb.pad;
+            if (dxa && ta >= 0 && ta < TT + 2 * sda.pad) Vec8<T>::store(dxa + ((long long)b * (TT + 2 * sda.pad) + ta) * C + cx * 8, oa);
+            if (dxb && tb >= 0 && tb < TT + 2 * sdb.pad) Vec8<T>::store(dxb + ((long long)b * (TT + 2 * sdb.pad) + tb) * C + cx * 8, ob);
+        }
+        return;
+    }
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total32; i += step32) {
         const unsigned ro = i / (unsigned)CV; const int cx = (int)(i - ro * (unsigned)CV);
         const unsigned bq = ro / TP; const int b = (int)bq, t = (int)(ro - bq * TP) - padmax;
@@ -324,16 +428,15 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* 
         for (int e = 0; e < 8; ++e) { oa[e] = 0.f; ob[e] = 0.f; }
         const bool halo = t < 0 || t >= TT;
         if (!halo) {
-            const int r = b * TT + t;
             float g[8], v[8];
-            Vec8<T>::load(dy + sdy.row(r) * C + cx * 8, g);
-            if (relu) { float o[8]; Vec8<T>::load(y + sy.row(r) * C + cx * 8, o);
+            Vec8<T>::load(dy + sdy.at(b, t) * C + cx * 8, g);
+            if (relu) { float o[8]; Vec8<T>::load(y + sy.at(b, t) * C + cx * 8, o);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
-            Vec8<T>::load(xa + sa.row(r) * C + cx * 8, v);
+            Vec8<T>::load(xa + sa.at(b, t) * C + cx * 8, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float xh = (v[e] - mean_a[c]) * invstd_a[c]; oa[e] = gamma_a[c] * invstd_a[c] * (g[e] - coef[c] * inv_n - xh * coef[C + c] * inv_n); }
-            if (xb) { Vec8<T>::load(xb + sb.row(r) * C + cx * 8, v);
+            if (xb) { Vec8<T>::load(xb + sb.at(b, t) * C + cx * 8, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float xh = (v[e] - mean_b[c]) * invstd_b[c]; ob[e] = gamma_b[c] * invstd_b[c] * (g[e] - coef[c] * inv_n - xh * coef[2 * C + c] * inv_n); } }
         }
@@ -382,7 +485,7 @@ extern "C" int ss_bn_backward_apply(int dtype, const void* dy, int pad_dy, const
     SS_CHECK(total < (1LL << 31) - (1LL << 22), "ss_bn_backward_apply: tensor too large for 32-bit chunk indices");
     const float inv_n = (float)(1.0 / n_total);
 #define SS_BNA(TT)                                                                                                                             \
-    SS_LAUNCH(bn_bwd_apply_kernel<TT>, ew_grid(total, 256), dim3(256), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, gamma_a, \
+    SS_LAUNCH(bn_bwd_apply_kernel<TT>, ew_grid(total, 256, C / 8), dim3(256), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, gamma_a, \
               (const TT*)xb, sb, mean_b, invstd_b, gamma_b, sums, inv_n, (TT*)dxa, sda, (TT*)dxb, sdb, B, C, relu)
     if (dtype == SS_BF16) { SS_BNA(bf16_t); } else { SS_BNA(float); }
 #undef SS_BNA
