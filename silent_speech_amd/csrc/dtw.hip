@@ -36,6 +36,7 @@ constexpr int DW = 4;          // waves per matrix
 constexpr int DR = 4;          // rows per lane
 constexpr int DG = 64;         // steps per super-step (barrier interval)
 constexpr int DRING = 256;     // LDS boundary ring (columns)
+constexpr int DTW_WAIT = 24;    // see the fast sweep path
 constexpr int DCH = 2048;      // backtrace window (steps) staged in LDS: 128 KB of dynamic shared memory
 constexpr int DESC = 10;       // descriptor fields per matrix
 enum { D_N = 0, D_M, D_COST_OFF, D_SI, D_SJ, D_SK_OFF, D_DIRS_OFF, D_BND_OFF, D_RES_OFF };
@@ -293,8 +294,10 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                     dfor<0, 8>([&](auto jc) {
                         constexpr int j = jc;
                         issue_group(cbuf[(j + 3) & 3], group_ptr(t0 + (j + 3) * 8));
-                        // after the loads of group j: stores of 3 groups + loads of 3 groups = 48 younger operations
-                        if constexpr (j >= 3) wait_vm<48>();
+                        // younger than the loads of group j: the 24 loads of groups j+1 .. j+3 and the 24 direction stores of the steps between.
+                        // Counting only the loads keeps the wait correct whatever the compiler does with the stores; it then also covers
+                        // group j+1, requested 16 steps ago (measured: no difference)
+                        if constexpr (j >= 3) wait_vm<DTW_WAIT>();
                         pin_group(cbuf[j & 3]);
                         dfor<0, 8>([&](auto ec) {
                             constexpr int e = ec, c = j * 8 + e;
