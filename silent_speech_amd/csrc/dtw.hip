@@ -18,7 +18,7 @@
 //     is one fully coalesced, 16-byte-aligned 1 KiB load (prefetched 8 steps ahead); out-of-matrix cells
 //     hold +inf.  ss_dtw_align() builds it from an arbitrarily strided cost matrix (e.g. the non-contiguous
 //     costs.T view of transduction_model.py:126); the fused loss path writes it directly (loss.hip).
-//   * the 2-bit first-minimum direction of every cell (1 byte per lane per step) goes to HBM instead of the
+//   * the 2-bit first-minimum direction of every cell (1 byte per lane per step, dirs[wave strip][t][lane]) goes to HBM instead of the
 //     4-byte cumulative matrix (8 B/cell algorithmic traffic -> 4.25 B/cell); the workgroup then stages the
 //     direction bytes of a wave strip in LDS and walks the path back with scalar arithmetic (results[]).
 #include "common.h"
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         float diag_sv = rowbase == 0 ? 0.f : INFINITY;               // dtw[i-1][0]; dtw[0][0] = 0
         float last_out = INFINITY;
         const float* skp = sk + ((long long)(k * DW + w) * ts) * (64 * DR) + lane * DR;
-        unsigned char* dp0 = dirs + ((long long)k * ts) * 256 + w * 64 + lane;
+        unsigned char* dp0 = dirs + ((long long)(k * DW + w) * ts) * 64 + lane;      // dirs[wave strip][t][lane]: a wave's steps are contiguous (full cache lines)
         const float* bnd_prev = bnd + ((k + 1) & 1) * M;
         float* bnd_cur = bnd + (k & 1) * M;
         float* const ring_next = lds_bnd[w + 1];
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                 __builtin_amdgcn_s_waitcnt(0xc07f);
 #endif
                 if (fast_ok && t0 + DG <= ts) {
-                    unsigned char* const dpb = dp0 + (long long)t0 * 256;
+                    unsigned char* const dpb = dp0 + (long long)t0 * 64;
                     float* const slot0 = lane == 63 ? ring_next + (t0 & (DRING - 1)) : dump;
                     dfor<0, 8>([&](auto jc) {
                         constexpr int j = jc;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                         pin_group(cbuf[j & 3]);
                         dfor<0, 8>([&](auto ec) {
                             constexpr int e = ec, c = j * 8 + e;
-                            dtw_step(lane, cbuf[j & 3][e], topv, prev, diag_sv, last_out, dpb + c * 256, slot0 + c);
+                            dtw_step(lane, cbuf[j & 3][e], topv, prev, diag_sv, last_out, dpb + c * 64, slot0 + c);
                             topv = wave_rotate_down(topv);
                         });
                     });
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                             const int t = t0 + g * 8 + e;
                             if (t < ts) {
                                 const int s = t + 1 - lane;
-                                dtw_step(lane, cb[e], topv, prev, diag_sv, last_out, dp0 + (long long)t * 256, lane == 63 ? ring_next + ring_slot(s) : dump);
+                                dtw_step(lane, cb[e], topv, prev, diag_sv, last_out, dp0 + (long long)t * 64, lane == 63 ? ring_next + ring_slot(s) : dump);
                                 if (multi && w == DW - 1 && lane == 63 && s >= 1 && s < M) bnd_cur[s] = last_out;
                                 topv = wave_rotate_down(topv);
                             }
@@ -366,20 +366,19 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
             __syncthreads();
             const int t_hi = t;
             t_lo = t - DCH + 1 < 0 ? 0 : t - DCH + 1; cur_kw = kw; nx_ok = false;
-            const int kk = kw / DW, ww = kw % DW;
-            const unsigned char* src = dirs + ((long long)kk * ts + t_lo) * 256 + ww * 64;
-            const int nd = (t_hi - t_lo + 1) * 4;                         // 16-byte pieces
+            const unsigned char* src = dirs + ((long long)kw * ts + t_lo) * 64;
+            const int nd = (t_hi - t_lo + 1) * 4;                         // 16-byte pieces, contiguous in the workspace
             for (int base = 0; base < nd; base += 256 * 8) {              // 8 loads in flight per thread, then the 8 LDS writes
                 u32x4 v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int idx = base + e * 256 + tid, tt = idx >> 2, c = idx & 3;
-                    if (idx < nd) v[e] = *(const u32x4*)(src + (long long)tt * 256 + c * 16);
+                    const int idx = base + e * 256 + tid;
+                    if (idx < nd) v[e] = *(const u32x4*)(src + (long long)idx * 16);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int idx = base + e * 256 + tid, tt = idx >> 2, c = idx & 3;
-                    if (idx < nd) *(u32x4*)(chunk + tt * 64 + c * 16) = v[e];
+                    const int idx = base + e * 256 + tid;
+                    if (idx < nd) *(u32x4*)(chunk + idx * 16) = v[e];
                 }
             }
             __syncthreads();
