@@ -36,7 +36,7 @@ constexpr int DW = 4;          // waves per matrix
 constexpr int DR = 4;          // rows per lane
 constexpr int DG = 64;         // steps per super-step (barrier interval)
 constexpr int DRING = 256;     // LDS boundary ring (columns)
-constexpr int DTW_WAIT = 24;    // see the fast sweep path
+constexpr int DNB = 4;           // register buffers of 8 steps in the fast sweep path (4 or 8: a super-step is 8 groups), requested DNB - 1 groups ahead
 constexpr int DCH = 2048;      // backtrace window (steps) staged in LDS: 128 KB of dynamic shared memory
 constexpr int DESC = 10;       // descriptor fields per matrix
 enum { D_N = 0, D_M, D_COST_OFF, D_SI, D_SJ, D_SK_OFF, D_DIRS_OFF, D_BND_OFF, D_RES_OFF };
@@ -215,13 +215,9 @@ __device__ __forceinline__ int dtw_uniform(int v) {
 #endif
 }
 __device__ __forceinline__ unsigned dtw_writelane(unsigned old, int val, int l, int lane) {      // val, l wave-uniform
-#if defined(SS_EMU)
+    // compare + select: v_writelane_b32 would need the value AND the lane select in scalar registers -- two constant-bus reads, which
+    // gfx9 encodings do not allow (the select could travel in M0, at the price of clobbering a register the compiler reserves)
     return lane == l ? (unsigned)val : old;
-#else
-    // one SGPR per VALU instruction on gfx9 (constant bus): the lane select travels in M0
-    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(l) : "m0");
-    return old;
-#endif
 }
 __device__ __forceinline__ unsigned dtw_readlane(unsigned v, int l) {      // l wave-uniform
 #if defined(SS_EMU)
@@ -262,17 +258,19 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         float* bnd_cur = bnd + (k & 1) * M;
         float* const ring_next = lds_bnd[w + 1];
         float* const dump = &lds_bnd[DW][lane];                       // lanes 0..62: words lane .. lane + 63 of the dump row
-        // Fast super-steps (all 64 steps inside the matrix' ts, one strip): 4 register buffers of 8 steps, group g in buffer g % 4,
-        // requested 3 groups ahead.  At every super-step boundary groups 0..2 of the NEXT super-step are loaded AND settled, so
-        // no request is in flight across control flow (a register copy the compiler places at a join would copy a value that has
-        // not arrived).  Group start beyond ts - 8: clamped (never consumed: that super-step takes the generic path).
+        // Fast super-steps (all 64 steps inside the matrix' ts, one strip): DNB register buffers of 8 steps, group g in buffer g % DNB,
+        // requested DNB - 1 groups ahead (8 buffers would keep 7 KiB per wave in flight for batches that stream their costs from HBM
+        // rather than L2, but the 64-step straight-line body then runs out of registers: 512 + spills).  At every super-step boundary the first
+        // DNB - 1 groups of the NEXT super-step are loaded AND settled, so no request is in flight across control flow (a register copy
+        // the compiler places at a join would copy a value that has not arrived).  Group start beyond ts - 8: clamped (never consumed:
+        // that super-step takes the generic path).
         const bool fast_ok = !multi && !(dbg & 4) && ts >= DG;
-        f32x4 cbuf[4][8];
+        f32x4 cbuf[DNB][8];
         auto group_ptr = [&](int tg) { const int tc = tg + 8 <= ts ? tg : ts - 8; return skp + (long long)(tc + 4) * (64 * DR); };
         if (fast_ok) {
-            issue_group(cbuf[0], group_ptr(0)); issue_group(cbuf[1], group_ptr(8)); issue_group(cbuf[2], group_ptr(16));
+            dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; issue_group(cbuf[g], group_ptr(g * 8)); });
             wait_vm<0>();
-            pin_group(cbuf[0]); pin_group(cbuf[1]); pin_group(cbuf[2]);
+            dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; pin_group(cbuf[g]); });
         }
         for (int ss = 0; ss < nss + 2 * (DW - 1); ++ss) {
             const int u = ss - 2 * w;
@@ -293,20 +291,20 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                     float* const slot0 = lane == 63 ? ring_next + (t0 & (DRING - 1)) : dump;
                     dfor<0, 8>([&](auto jc) {
                         constexpr int j = jc;
-                        issue_group(cbuf[(j + 3) & 3], group_ptr(t0 + (j + 3) * 8));
-                        // younger than the loads of group j: the 24 loads of groups j+1 .. j+3 and the 24 direction stores of the steps between.
-                        // Counting only the loads keeps the wait correct whatever the compiler does with the stores; it then also covers
-                        // group j+1, requested 16 steps ago (measured: no difference)
-                        if constexpr (j >= 3) wait_vm<DTW_WAIT>();
-                        pin_group(cbuf[j & 3]);
+                        issue_group(cbuf[(j + DNB - 1) % DNB], group_ptr(t0 + (j + DNB - 1) * 8));
+                        // younger than the loads of group j: the 8 (DNB - 1) loads of the groups requested since, and the direction stores of
+                        // the steps between.  Counting only the loads keeps the wait correct whatever the compiler does with the stores
+                        // (vector memory operations retire in issue order)
+                        if constexpr (j >= DNB - 1) wait_vm<8 * (DNB - 1)>();
+                        pin_group(cbuf[j % DNB]);
                         dfor<0, 8>([&](auto ec) {
                             constexpr int e = ec, c = j * 8 + e;
-                            dtw_step(lane, cbuf[j & 3][e], topv, prev, diag_sv, last_out, dpb + c * 64, slot0 + c);
+                            dtw_step(lane, cbuf[j % DNB][e], topv, prev, diag_sv, last_out, dpb + c * 64, slot0 + c);
                             topv = wave_rotate_down(topv);
                         });
                     });
                     wait_vm<0>();
-                    pin_group(cbuf[0]); pin_group(cbuf[1]); pin_group(cbuf[2]);
+                    dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; pin_group(cbuf[g]); });
                 } else {
                     f32x4 cb[8];
                     const f32x4 inf4 = {INFINITY, INFINITY, INFINITY, INFINITY};
