@@ -24,10 +24,13 @@ def _pad(x):           # (B,T,C) -> (B,T+2,C) with zero halo
 
 
 @pytest.mark.parametrize('dt', DTS)
-def test_batchnorm_resblock_tail_fwd_bwd(dev, dt):
-    """y = relu(bn2(xa) + res_norm(xb)) with padded input/outputs; forward, running stats, full backward."""
+@pytest.mark.parametrize('shape', ['fixed', 'generic', 'wide'])
+def test_batchnorm_resblock_tail_fwd_bwd(dev, dt, shape):
+    """y = relu(bn2(xa) + res_norm(xb)) with padded input/outputs; forward, running stats, full backward.  'fixed': the grid stride is a
+    multiple of C/8 (a thread keeps its column chunk, constants in registers); 'generic': C = 24, where it cannot be (per-chunk form);
+    'wide': the model's 768 channels."""
     big = not is_emu(dev)
-    B, T, C = (5, 130, 96) if big else (3, 20, 16)
+    B, T, C = {'fixed': ((5, 130, 96), (3, 20, 16)), 'generic': ((3, 50, 24), (2, 9, 24)), 'wide': ((2, 33, 768), (1, 6, 768))}[shape][0 if big else 1]
     g = torch.Generator().manual_seed(1)
     xa = (torch.randn(B, T, C, generator=g) * 2 + 0.5).to(dt); xb = torch.randn(B, T, C, generator=g).to(dt)
     ga, ba = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
