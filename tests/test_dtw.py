@@ -74,6 +74,7 @@ def test_dtw_sweep_paths_and_windows(dev):
     horizontal runs of hundreds / thousands of cells inside ONE lane column (register-cache refills, window exhausted mid-column)"""
     rng = np.random.default_rng(12)
     cases = [rng.random((150, 200), dtype=np.float32), rng.integers(0, 3, (1100, 70)).astype(np.float32),
+             rng.random((40, 2), dtype=np.float32), rng.random((2, 40), dtype=np.float32), rng.integers(0, 2, (70, 66)).astype(np.float32),   # 64 / 128 steps exactly: only fast super-steps
              (rng.standard_normal((40, 2300)) ** 2).astype(np.float32)]
     for n, m in ((20, 300), (9, 2300), (270, 2200)):
         c = rng.random((n, m), dtype=np.float32) + 5.0
