@@ -214,11 +214,6 @@ __device__ __forceinline__ int dtw_uniform(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 #endif
 }
-__device__ __forceinline__ unsigned dtw_writelane(unsigned old, int val, int l, int lane) {      // val, l wave-uniform
-    // compare + select: v_writelane_b32 would need the value AND the lane select in scalar registers -- two constant-bus reads, which
-    // gfx9 encodings do not allow (the select could travel in M0, at the price of clobbering a register the compiler reserves)
-    return lane == l ? (unsigned)val : old;
-}
 __device__ __forceinline__ unsigned dtw_readlane(unsigned v, int l) {      // l wave-uniform
 #if defined(SS_EMU)
     return __shfl(v, l);
@@ -343,7 +338,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
     // register cache (lane i = step c_top - i of column l) through v_readlane, and a cell costs ~12 scalar instructions (a wave on
     // its own issues one instruction per ~5 cycles: the instruction count IS the latency).  The cache of the next column (l - 1) is
     // requested on entry to a column -- its top step is known: t only decreases -- so that its LDS latency passes under the walk.
-    // results[i] = the column at which the path LEAVES row i (smallest j visited): collected in lanes 0..3 of a register and
+    // results[i] = the column at which the path LEAVES row i (smallest j visited): collected in lanes 0..3 of a register (compare +
+    // select: v_writelane would need value and lane select in scalar registers, two constant-bus reads gfx9 does not encode) and
     // stored once per column.
     int p = N - 1, s = M - 1;
     int cur_kw = -1, t_lo = 0;
@@ -385,26 +381,33 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         else { c_top = t; cache = column(l, t); }
         nx_ok = l > 0;
         if (nx_ok) { nx_top = t - 1; cache_nx = column(l - 1, nx_top); }
-        unsigned vis = 0;
-        int t_min = c_top - 63 > t_lo ? c_top - 63 : t_lo;                // the cache holds steps t_min .. c_top
+        // Walk state of the column, kept small (every instruction of this loop is ~5 cycles of latency): idx = c_top - t, the bit
+        // position sh = 2 (3 - r) of the current row's code (moving up a row = sh + 2, leaving the column = sh > 6) and s.  Lane k of
+        // rv holds the result of row 3 - k; the rows left in this visit are exactly those with sh_in <= 2 k < sh_out.
+        int idx = c_top - t, idx_max = c_top - t_lo < 63 ? c_top - t_lo : 63;            // the cache holds steps c_top - idx_max .. c_top
+        int sh = 2 * (DR - 1 - r);
+        const int sh_in = sh, lane2 = 2 * lane;
+        int sh_out;
         for (;;) {
-            if (t < t_min) {                                              // a long horizontal run
-                if (t < t_lo) break;                                      // .. beyond the LDS window: back out, the column is re-entered behind a reload
-                c_top = t; cache = column(l, t); t_min = t - 63 > t_lo ? t - 63 : t_lo;
+            if (idx > idx_max) {                                          // a long horizontal run
+                const int tt = c_top - idx;
+                if (tt < t_lo) { sh_out = sh; break; }                    // .. beyond the LDS window: back out, the column is re-entered behind a reload
+                c_top = tt; cache = column(l, tt); idx = 0; idx_max = c_top - t_lo < 63 ? c_top - t_lo : 63;
             }
-            const unsigned code = (dtw_readlane(cache, c_top - t) >> (2 * (DR - 1 - r))) & 3u;     // 2 [best == left] + [best == up]
+            const unsigned code = (dtw_readlane(cache, idx) >> sh) & 3u;  // 2 [best == left] + [best == up]
             if (code == 2u) {                                             // left
-                --s; --t;
-                if (s == 0) { rv = dtw_writelane(rv, 1, r, lane); vis |= 1u << r; break; }
-            } else {                                                      // up (code & 1) or diagonal: the path leaves row r at column s
-                rv = dtw_writelane(rv, s, r, lane); vis |= 1u << r;
-                if (!(code & 1u)) { --s; --t; }
-                --r;
-                if (r < 0 || s == 0) break;
+                --s; ++idx;
+                if (s == 0) { rv = lane2 == sh ? 1u : rv; sh_out = sh + 2; break; }      // the path ends in this row, at column 1
+            } else {                                                      // up (code & 1) or diagonal: the path leaves this row at column s
+                rv = lane2 == sh ? (unsigned)s : rv;
+                const int dgl = (int)((code & 1u) ^ 1u);
+                s -= dgl; idx += dgl;
+                sh += 2;
+                if (sh > 2 * (DR - 1) || s == 0) { sh_out = sh; break; }
             }
         }
-        p = pbase + r;
-        if (w == 0 && lane < DR && ((vis >> lane) & 1u)) res[pbase + lane] = (int)rv;
+        p = pbase + (DR - 1) - (sh >> 1);                                 // the row the walk stands in now (the row above the column for sh = 8)
+        if (w == 0 && lane < DR && lane2 >= sh_in && lane2 < sh_out) res[pbase + (DR - 1) - lane] = (int)rv;
     }
 }
 
