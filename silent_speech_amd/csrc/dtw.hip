@@ -389,22 +389,27 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         const int sh_in = sh, lane2 = 2 * lane;
         int sh_out;
         for (;;) {
-            if (idx > idx_max) {                                          // a long horizontal run
-                const int tt = c_top - idx;
-                if (tt < t_lo) { sh_out = sh; break; }                    // .. beyond the LDS window: back out, the column is re-entered behind a reload
-                c_top = tt; cache = column(l, tt); idx = 0; idx_max = c_top - t_lo < 63 ? c_top - t_lo : 63;
-            }
-            const unsigned code = (dtw_readlane(cache, idx) >> sh) & 3u;  // 2 [best == left] + [best == up]
-            if (code == 2u) {                                             // left
-                --s; ++idx;
-                if (s == 0) { rv = lane2 == sh ? 1u : rv; sh_out = sh + 2; break; }      // the path ends in this row, at column 1
-            } else {                                                      // up (code & 1) or diagonal: the path leaves this row at column s
-                rv = lane2 == sh ? (unsigned)s : rv;
-                const int dgl = (int)((code & 1u) ^ 1u);
+            // one cell per trip, branch-free (the compiler's if / else form of this loop was 35 instructions and three taken branches per
+            // cell): left (code 2) moves one column and leaves no row; up (code & 1) leaves the row at column s; diagonal does both
+            unsigned code;
+            for (;;) {
+                code = (dtw_readlane(cache, idx) >> sh) & 3u;                         // 2 [best == left] + [best == up]
+                const bool isl = code == 2u;
+                const int rec_sh = isl ? 64 : sh;
+                rv = lane2 == rec_sh ? (unsigned)s : rv;
+                const int dgl = (int)(~code & 1u);
                 s -= dgl; idx += dgl;
-                sh += 2;
-                if (sh > 2 * (DR - 1) || s == 0) { sh_out = sh; break; }
+                sh += isl ? 0 : 2;
+                if (((2 * (DR - 1) - sh) | (s - 1) | (idx_max - idx)) < 0) break;      // left the column upward | the path ended | cache exhausted
             }
+            if (s == 0) {                                                 // the path ends here; after a left move the current row ends at column 1
+                if (code == 2u) { rv = lane2 == sh ? 1u : rv; sh_out = sh + 2; } else sh_out = sh;
+                break;
+            }
+            if (sh > 2 * (DR - 1)) { sh_out = sh; break; }
+            const int tt = c_top - idx;                                   // a long horizontal run: the register cache is used up
+            if (tt < t_lo) { sh_out = sh; break; }                        // .. and so is the LDS window: back out, the column is re-entered behind a reload
+            c_top = tt; cache = column(l, tt); idx = 0; idx_max = c_top - t_lo < 63 ? c_top - t_lo : 63;
         }
         p = pbase + (DR - 1) - (sh >> 1);                                 // the row the walk stands in now (the row above the column for sh = 8)
         if (w == 0 && lane < DR && lane2 >= sh_in && lane2 < sh_out) res[pbase + (DR - 1) - lane] = (int)rv;
