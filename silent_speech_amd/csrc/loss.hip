@@ -112,6 +112,40 @@ extern "C" int ss_voiced_loss(const float* head, int64_t ld, int n_mel, int n_ph
 // the target row y_i stays in registers (n_mel <= 128), only the predicted rows stream in, and every step's 256 results
 // (64 lanes x 4 rows) leave as one contiguous 1 KiB store.  The 80-term sum runs in the reference order (bit-exact costs).
 constexpr int YMAX = 128;
+// value of lane (quad base + k) for every lane of the quad: quad_perm [k,k,k,k] as a DPP operand of the consuming instruction
+__device__ __forceinline__ float quad_bcast(float v, int k) {
+#if defined(SS_EMU)
+    return __shfl(v, (int)((threadIdx.x & 63) & ~3) + k);
+#else
+    switch (k) {
+    case 0: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00, 0xf, 0xf, true));
+    case 1: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x55, 0xf, 0xf, true));
+    case 2: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xAA, 0xf, 0xf, true));
+    default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xFF, 0xf, 0xf, true));
+    }
+#endif
+}
+// squared distance of the predicted row p (NQ 16-byte pieces per quad lane, shared through quad broadcasts) to this thread's target row yv,
+// the 16 NQ terms in the reference order
+template <int NQ>
+__device__ __forceinline__ float quad_shared_sqdist(const float* __restrict__ p, int r, const f32x4 (&yv)[YMAX / 4]) {
+    f32x4 own[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) own[q] = *(const f32x4*)(p + (r * NQ + q) * 4);
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 b = yv[k * NQ + q];
+            const float a0 = quad_bcast(own[q][0], k), a1 = quad_bcast(own[q][1], k), a2 = quad_bcast(own[q][2], k), a3 = quad_bcast(own[q][3], k);
+            const float d0 = a0 - b[0], d1 = a1 - b[1], d2 = a2 - b[2], d3 = a3 - b[3];
+            ss += d0 * d0; ss += d1 * d1; ss += d2 * d2; ss += d3 * d3;
+        }
+    }
+    return ss;
+}
+
 __global__ __launch_bounds__(256) void silent_cost_skewed_kernel(const float* __restrict__ head, long long ld, int n_mel, const float* __restrict__ lse, const float* __restrict__ Y,
                                                                  const long long* __restrict__ phones, const long long* __restrict__ desc, float lam, unsigned char* __restrict__ ws, int* __restrict__ results, int CT)
 {
@@ -138,6 +172,21 @@ __global__ __launch_bounds__(256) void silent_cost_skewed_kernel(const float* __
             ph = (int)phones[y0 + i];
         }
         const long long tend = t0 + CT < ts ? t0 + CT : ts;
+        // The four threads of a quad (the 4 rows of one lane) need the SAME predicted row: each loads a quarter of it (5 instead of 20
+        // 16-byte loads per cell; the kernel was bound by those) and the others read it through quad-broadcast DPP operands.  The 80-term
+        // sum keeps the reference order.  (80 mel bins; any other width: every thread loads the row itself.)
+        if (n_mel == 80) {                                               // the model's mel bins (NQ = 5)
+            for (long long t = t0; t < tend; ++t) {
+                const long long j = t + 1 - l;
+                const bool jv = j >= 1 && j < M;                          // quad-uniform
+                const float* p = head + (p0 + (jv ? j : 1)) * ld;           // columns outside the matrix: any valid row, result discarded --
+                const float ss = quad_shared_sqdist<5>(p, r, yv);         // every lane takes part in the broadcasts (no divergence around them)
+                float c = INFINITY;
+                if (jv && iv) c = sqrtf(ss) + lam * (lse[p0 + j] - p[n_mel + ph]);
+                sk[((kw * ts + t) * 64 + l) * DR + r] = c;
+            }
+            continue;
+        }
         for (long long t = t0; t < tend; ++t) {
             const long long j = t + 1 - l;
             float c = INFINITY;
