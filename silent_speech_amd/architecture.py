@@ -184,6 +184,7 @@ class Model(nn.Module):
         xr = x_raw if x_raw.is_contiguous() else x_raw.contiguous()
         self._step += 1
         seed = (self._seed_base * 0x9E3779B1 + self._step) & 0xFFFFFFFFFFFFFFFF
+        self.last_seed = seed                             # dropout draws are a pure function of (seed, stream, element): tests replay them
         if self._anchor is None or self._anchor.device != xr.device:
             self._anchor = torch.zeros(1, device=xr.device, requires_grad=True)
         if self.training and torch.is_grad_enabled():

@@ -28,14 +28,23 @@ def _pack(x, dp):          # (B,H,T,dh) -> (B,T,H,dp) zero padded
     return o
 
 
-def _run(dev, dt, B, H, T, dh, D, seed, tol_f, tol_b):
+def _run(dev, dt, B, H, T, dh, D, seed, tol_f, tol_b, p=0.0):
+    """p > 0: dropout on the probabilities with the kernels' own mask, restated by oracle/dropout_ref.py."""
     dp = (dh + 31) // 32 * 32
     Tp = (T + 7) // 8 * 8
     g = torch.Generator().manual_seed(seed)
     q, k, v = [(torch.randn(B, H, T, dh, generator=g) * 0.8).to(dt).float().requires_grad_(True) for _ in range(3)]
     E = (torch.randn(H, 2 * D - 1, dh, generator=g) * dh ** -0.5).to(dt).float()
     dO = torch.randn(B, H, T, dh, generator=g).to(dt).float()
-    O_ref, lse_ref = _reference(q, k, v, E, D, dh)
+    drop, kw = None, {}
+    if p > 0:
+        from oracle import dropout_ref
+        from silent_speech_amd import _lib
+        resident = _lib.lib().ss_relpos_attention_needs_transposed(_lib.dtype_code(dt), T, dp, D) == 0
+        mask = (dropout_ref.attention_mask_resident if resident else dropout_ref.attention_mask_tiled)(seed + 1000, 8, B, H, T, p)
+        drop = torch.from_numpy(mask).float() / (1.0 - p)
+        kw = dict(p=p, seed=seed + 1000, rng_stream=8)
+    O_ref, lse_ref = _reference(q, k, v, E, D, dh, drop=drop)
     O_ref.backward(dO)
     # device operands
     qkv = torch.cat([_pack(t.detach(), dp).reshape(B * T, H * dp) for t in (q, k, v)], 1).to(dt).contiguous()          # [B*T][3*H*dp]
@@ -50,7 +59,7 @@ def _run(dev, dt, B, H, T, dh, D, seed, tol_f, tol_b):
     scale = 1.0 / math.sqrt(dh)
     nsaved = ops.relpos_attention_saved_bytes(dt, B, H, T, dp, D)
     saved = torch.empty(nsaved, dtype=torch.uint8, device=dev) if nsaved else None             # the probability image of the resident kernels
-    ops.relpos_attention_forward(qkv_d, qkvT_d, E_d, out, lse, B, H, T, Tp, dp, D, scale, saved=saved)
+    ops.relpos_attention_forward(qkv_d, qkvT_d, E_d, out, lse, B, H, T, Tp, dp, D, scale, saved=saved, **kw)
     O = out.view(B, T, H, dp)[..., :dh].permute(0, 2, 1, 3)
     assert_close_robust(O, O_ref, tol_f, name='O', max_outlier_frac=0)
     assert_close_robust(lse, lse_ref, 1e-5 if dt == torch.float32 else 2e-2, name='lse', max_outlier_frac=0)
@@ -63,7 +72,7 @@ def _run(dev, dt, B, H, T, dh, D, seed, tol_f, tol_b):
     dsc = torch.empty(B, H, T, device=dev)
     for sv in ([saved, None] if saved is not None else [None]):              # backward from the saved probabilities, and recomputing them
         dqkv.fill_(7.0)
-        ops.relpos_attention_backward(qkv_d, qkvT_d, E_d, ET_d, out, lse, dOd.to(dev), dOT.to(dev), dsc, dqkv, B, H, T, Tp, dp, D, scale, saved=sv)
+        ops.relpos_attention_backward(qkv_d, qkvT_d, E_d, ET_d, out, lse, dOd.to(dev), dOT.to(dev), dsc, dqkv, B, H, T, Tp, dp, D, scale, saved=sv, **kw)
         dq, dk, dv = [dqkv.view(B, T, 3, H, dp)[:, :, i, :, :dh].permute(0, 2, 1, 3) for i in range(3)]
         tag = ' (saved P)' if sv is not None else ''
         assert_close_robust(dv, v.grad, tol_b, name='dV' + tag, max_outlier_frac=0)

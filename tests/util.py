@@ -24,3 +24,14 @@ def assert_close_robust(got, want, rtol, atol_frac=1e-5, name='', max_outlier_fr
     assert nbad <= allowed, '%s: %d/%d elements off (max err %.3e, scale %.3e, rtol %.1e)' % (
         name, nbad, got.size, float(err.max()), scale, rtol)
     return float(err.max()) / scale
+
+
+def rel_l2_cos(got, want):
+    """Per-tensor parity figures that no outlier allowance can hide behind: ||got - want||_2 / ||want||_2 and the cosine
+    between the two tensors (f64 accumulation)."""
+    g, w = to_np(got).astype(np.float64).ravel(), to_np(want).astype(np.float64).ravel()
+    assert g.shape == w.shape and np.isfinite(g).all()
+    nw, ng = np.linalg.norm(w), np.linalg.norm(g)
+    if nw == 0.0:
+        return (0.0, 1.0) if ng == 0.0 else (float('inf'), 0.0)
+    return float(np.linalg.norm(g - w) / nw), float(np.dot(g, w) / (ng * nw + 1e-300))
