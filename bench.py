@@ -95,9 +95,13 @@ def cpu_baseline(batch_cpu, rows_limit, warm, timed, model_sd, dev):
     return out, sub, ref_pred
 
 
-def parity_entry(sub, ref_pred, model_sd, dev):
+def parity_entry(sub, ref_pred, model_sd, dev, dropout_p=0.2):
     """mel-L1 (mean |pred - oracle pred| in normalised log-mel units) of the HIP model on the CPU baseline's sample, same weights,
-    training-mode statistics, dropout 0, shift 3: bf16 kernels (what the bench times) and exact-f32 kernels."""
+    training-mode statistics, shift 3: bf16 kernels (what the bench times) and exact-f32 kernels, with dropout off AND with the
+    dropout the bench runs (p = 0.2; the oracle replays the kernels' masks, restated in oracle/dropout_ref.py).  The full-batch
+    version with every gradient tensor is tests/test_fullsize.py."""
+    from oracle import dropout_ref, loss_ref, model_ref
+    from silent_speech_amd import _lib
     from silent_speech_amd.architecture import Model
     from silent_speech_amd.data_utils import combine_fixed_length
 
@@ -105,18 +109,29 @@ def parity_entry(sub, ref_pred, model_sd, dev):
         @staticmethod
         def randrange(n):
             return 3
-    out = {'rows': int(ref_pred.shape[0]), 'reference': 'oracle/model_ref.py (fp32 torch restatement pinned to the reference by tests/golden)'}
+    out = {'rows': int(ref_pred.shape[0]), 'dropout': dropout_p,
+           'reference': 'oracle/model_ref.py (fp32 torch restatement pinned to the reference by tests/golden), dropout masks replayed by oracle/dropout_ref.py'}
+    sd_cpu = {k: v.detach().cpu().clone() for k, v in model_sd.items()}
     for name, dt in (('bf16', torch.bfloat16), ('fp32', torch.float32)):
-        m = Model(112, 80, 48, model_size=768, num_layers=6, dropout=0.0, compute_dtype=dt)
-        m.load_state_dict(model_sd, strict=True)
-        m.to(dev)
-        m.shift_rng = _R
-        m.train()
-        X_raw = combine_fixed_length([t.to(dev) for t in sub['raw_emg']], 1600)
-        with torch.no_grad():
-            pred, _ = m(None, X_raw, None)
-        out['mel_l1_%s_vs_oracle' % name] = float((pred.float().cpu() - ref_pred).abs().mean())
-        del m
+        for p in (0.0, dropout_p):
+            m = Model(112, 80, 48, model_size=768, num_layers=6, dropout=p, compute_dtype=dt)
+            m.load_state_dict(model_sd, strict=True)
+            m.to(dev)
+            m.shift_rng = _R
+            m.train()
+            X_raw = combine_fixed_length([t.to(dev) for t in sub['raw_emg']], 1600)
+            with torch.no_grad():
+                pred, _ = m(None, X_raw, None)
+            want = ref_pred
+            if p > 0:
+                resident = _lib.lib().ss_relpos_attention_needs_transposed(_lib.dtype_code(dt), 200, m.dp, m.max_rel) == 0
+                B = int(X_raw.shape[0])
+                masks = dropout_ref.layer_masks(m.last_seed, 6, B, 200, 768, 8, 3072, p, resident)
+                with torch.no_grad():
+                    want, _ = model_ref.model_forward(sd_cpu, loss_ref.combine_fixed_length(sub['raw_emg'], 1600), training=True, shift_r=3,
+                                                      running_out={}, layer_masks=masks, dropout_p=p)
+            out['mel_l1_%s%s_vs_oracle' % (name, '_dropout' if p > 0 else '')] = float((pred.float().cpu() - want).abs().mean())
+            del m
     return out
 
 

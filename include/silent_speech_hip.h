@@ -27,6 +27,10 @@ extern "C" {
 
 const char* ss_last_error(void);
 /* Library/ABI version and the GPU architecture the kernels were compiled for ("gfx950"). */
+/* Bumped whenever a struct layout or an entry-point signature changes (3: ss_gemm_epilogue column-statistics fields, the plan /
+ * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
+ * library paired with newer headers would otherwise read garbage struct fields instead of failing. */
+#define SS_ABI_VERSION 3
 int ss_abi_version(void);
 const char* ss_target_arch(void);
 
@@ -157,6 +161,13 @@ int ss_dtw_align(const float* costs, const int64_t* desc_dev, int n, int max_n, 
 /* Same, for costs already in the skewed strip layout (written by ss_silent_cost_skewed); results must
  * have been zeroed by the producer. */
 int ss_dtw_align_skewed(const int64_t* desc_dev, int n, void* workspace, int32_t* results, void* stream);
+/* align.py:5-14 `time_warp` itself: the dense cumulative matrix dtw_out[N][M] (contiguous) of ONE cost matrix whose element (i, j)
+ * sits at costs + i*stride_i + j*stride_j (elements), in the dtype of the input (SS_F32 or SS_F64: `zeros_like(costs)`,
+ * align.py:6); dtw_out[N-1][M-1] is the alignment cost.  results (optional, N ints): the reference's backtrace on that matrix
+ * (align.py:16-34) -- this is how float64 input is aligned without rounding it to float32.  Not on the training path (one
+ * workgroup, one barrier per anti-diagonal); batches of f32 matrices go through ss_dtw_align. */
+int ss_dtw_cumulative(int dtype, const void* costs, int64_t stride_i, int64_t stride_j, int N, int M, void* dtw_out,
+                      int32_t* results, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * BatchNorm1d fused with ReLU / the ResBlock residual add (architecture.py:19,21,25 nn.BatchNorm1d,
@@ -271,6 +282,11 @@ int ss_soft_clip(const float* x, float* out, int64_t n, int C, const float* mean
  * windowed DFT matrix with overlapping hop-strided rows; magnitude (:57); mel matmul + log clamp (:59-60)
  * is ss_gemm with epilogue.log_clamp. */
 int ss_reflect_pad(const float* y, float* out, int B, int L, int pad, int64_t ld_out, void* stream);
+/* Ragged batch (data_utils.py:76 np.clip + :51 reflect pad for EVERY utterance of a batch in one launch): utterance b is
+ * y[offsets_dev[b] .. + lengths_dev[b]); row b of out[B][ld_out] gets its clipped (clip != 0), reflect-padded signal and zeros
+ * behind it.  min_len = the shortest length (host-known; reflect needs pad < length). */
+int ss_reflect_pad_ragged(const float* y, const int64_t* offsets_dev, const int32_t* lengths_dev, float* out, int B, int min_len,
+                          int pad, int64_t ld_out, int clip, void* stream);
 int ss_stft_magnitude(const float* spec, int64_t ld_spec, int n_bins, float* mag, int64_t ld_mag, int rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

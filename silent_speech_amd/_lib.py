@@ -13,7 +13,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, 'lib', 'libsilent_speech_hip.so')
 
-SS_F32, SS_BF16 = 0, 1
+SS_F32, SS_BF16, SS_F64 = 0, 1, 2
+ABI_VERSION = 3          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
 OP_KC, OP_OC = 0, 1
 
 
@@ -60,6 +61,8 @@ SIGNATURES = {
     'ss_permute3d_batch': [_P, _P, _I, _I, _P],
     'ss_dtw_align': [_P, _P, _I, _I, _I, _P, _P, _P],
     'ss_dtw_align_skewed': [_P, _I, _P, _P, _P],
+    'ss_reflect_pad_ragged': [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
+    'ss_dtw_cumulative': [_I, _P, _L, _L, _I, _I, _P, _P, _P],
     'ss_relpos_attention_forward': [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_relpos_attention_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_relpos_attention_forward_p': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
@@ -141,7 +144,13 @@ def load(path=None):
         raise RuntimeError('silent_speech_amd: %s not found -- build the gfx950 kernels first '
                            '(python -c "import __graft_entry__ as g; g.build()" or make -C silent_speech_amd/csrc). '
                            'There is no CPU fallback.' % path)
-    _lib = _declare(ctypes.CDLL(path))
+    cdll = ctypes.CDLL(path)
+    cdll.ss_abi_version.restype = ctypes.c_int
+    have = cdll.ss_abi_version()
+    if have != ABI_VERSION:
+        raise RuntimeError('silent_speech_amd: %s has ABI version %d, this binding needs %d -- rebuild it '
+                           '(make -C silent_speech_amd/csrc); struct layouts differ between versions' % (path, have, ABI_VERSION))
+    _lib = _declare(cdll)
     _is_emulator = _lib.ss_target_arch() != b'gfx950'
     return _lib
 
@@ -172,7 +181,9 @@ def dtype_code(dt):
         return SS_F32
     if dt == torch.bfloat16:
         return SS_BF16
-    raise TypeError('unsupported dtype %s (float32 or bfloat16)' % dt)
+    if dt == torch.float64:
+        return SS_F64
+    raise TypeError('unsupported dtype %s (float32, bfloat16; float64 for ss_dtw_cumulative only)' % dt)
 
 
 def ptr(t):

@@ -1,6 +1,7 @@
 """DTW alignment on the MI355X -- drop-in for the reference's align.py.
 
-  align_from_distances(distance_matrix: np.ndarray, debug=False) -> list[int]      (align.py:16)
+  time_warp(costs: np.ndarray) -> np.ndarray (cumulative cost matrix, dtype of the input)  (align.py:5)
+  align_from_distances(distance_matrix: np.ndarray, debug=False) -> list[int]               (align.py:16)
 
 plus the batched, device-resident form used by dtw_loss (no D2H of the cost matrix, no per-utterance
 sync): `dtw_align_batch`.  The HIP kernel (csrc/dtw.hip) is bit-exact against the reference's f32
@@ -65,23 +66,48 @@ def dtw_align_batch(costs, shapes, offsets, strides):
     return DtwBatch(shapes, offsets, strides, costs.device).run(costs)
 
 
-def align_from_distances(distance_matrix, debug=False, device=None):
-    """Reference-compatible entry point (align.py:16): numpy (N, M) matrix in, list[int] of length N out.
-    The matrix may be any strided view (the reference passes costs.T).  float32 follows the reference's
-    torch->numpy path; float64 input is rounded to float32 first (documented deviation: the HIP
-    recurrence is f32)."""
-    if isinstance(distance_matrix, torch.Tensor):
-        t = distance_matrix.detach()
-    else:
-        t = torch.from_numpy(np.asarray(distance_matrix))
+def _as_device_matrix(x, device):
+    t = x.detach() if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x))
     if t.dim() != 2:
-        raise ValueError('distance_matrix must be 2-D')
-    N, M = t.shape
-    if N < 1 or M < 1:
-        raise IndexError('align_from_distances: empty matrix')      # the reference raises at shape[0]-1 indexing too
+        raise ValueError('cost matrix must be 2-D')
+    if t.shape[0] < 1 or t.shape[1] < 1:
+        raise IndexError('empty cost matrix')                         # the reference raises at shape[0]-1 indexing too
     if device is None:
         device = t.device if (t.is_cuda or _lib.is_emulator()) else torch.device('cuda')
-    t = t.to(device=device, dtype=torch.float32)
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(torch.float32)
+    return t.to(device)
+
+
+def _cumulative(t, want_alignment):
+    N, M = t.shape
+    out = torch.empty(N, M, dtype=t.dtype, device=t.device)
+    res = torch.empty(N, dtype=torch.int32, device=t.device) if want_alignment else None
+    rc = _lib.lib().ss_dtw_cumulative(_lib.dtype_code(t.dtype), _lib.ptr(t), t.stride(0), t.stride(1), N, M, _lib.ptr(out),
+                                      _lib.ptr(res) if res is not None else None, _lib.stream_of(t))
+    _lib.check(rc, 'ss_dtw_cumulative')
+    return out, res
+
+
+def time_warp(costs, device=None):
+    """align.py:5-14: the cumulative cost matrix itself (`dtw[-1, -1]` is the alignment cost), in the dtype of the input like the
+    reference's `zeros_like(costs)` (float32 or float64; anything else is converted to float32).  numpy in -> numpy out, tensor
+    in -> tensor on the compute device.  Any strided view is read in place."""
+    t = _as_device_matrix(costs, device)
+    out, _ = _cumulative(t, False)
+    return out if isinstance(costs, torch.Tensor) else out.cpu().numpy()
+
+
+def align_from_distances(distance_matrix, debug=False, device=None):
+    """Reference-compatible entry point (align.py:16): numpy (N, M) matrix in, list[int] of length N out.
+    The matrix may be any strided view (the reference passes costs.T).  float32 (the reference's torch->numpy path) runs the
+    batched strip kernel; float64 input keeps float64 arithmetic like the reference (align.py:6 `zeros_like`): dense cumulative
+    matrix + backtrace in one launch of ss_dtw_cumulative."""
+    t = _as_device_matrix(distance_matrix, device)
+    N, M = t.shape
+    if t.dtype == torch.float64:
+        _, res = _cumulative(t, True)
+        return res.cpu().tolist()
     # keep the caller's strides: no transposed copy is materialised, the skew kernel reads strided
     results, _ = dtw_align_batch(t, [(N, M)], [0], [t.stride()])
     return results[:N].cpu().tolist()

@@ -33,7 +33,7 @@ int ss_check_launch(const char* what);
 
 // ------------------------------------------------------------------ element types
 typedef unsigned short bf16_t;   // raw bfloat16 bits
-enum { SS_F32 = 0, SS_BF16 = 1 };
+enum { SS_F32 = 0, SS_BF16 = 1, SS_F64 = 2 };
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -456,3 +456,56 @@ extern "C" int ss_dtw_align_skewed(const int64_t* desc_dev, int n, void* workspa
     SS_CHECK(desc_dev && workspace && results, "ss_dtw_align_skewed: null pointer");
     return dtw_launch((const long long*)desc_dev, n, 0, 0, workspace, results, stream, nullptr);
 }
+
+// ================================================================ dense cumulative matrix: align.py:5-14 `time_warp`
+// The batched path above never writes the cumulative matrix (2-bit directions are all a backtrace needs).  Callers of the
+// reference's public `time_warp` want the matrix itself (its last entry is the alignment cost), and `zeros_like(costs)` keeps the
+// input dtype (align.py:6: f32 from the torch path, f64 stays f64), so this entry point is templated on the element type.  Not on
+// the training path: one workgroup sweeps the anti-diagonals (cells of one diagonal are independent), a barrier per diagonal.
+//   dtw[0][0] = 0, dtw[0][1:] = dtw[1:][0] = +inf  (align.py:7-9: row 0 / column 0 of `costs` are never read)
+//   dtw[i][j] = costs[i][j] + min(dtw[i-1][j], dtw[i][j-1], dtw[i-1][j-1])                       (align.py:11-13)
+// With `results` != NULL the same launch walks the matrix back (align.py:21-26: first minimum of up, left, diag).
+template <class T>
+__global__ __launch_bounds__(1024) void dtw_cumulative_kernel(const T* __restrict__ costs, long long s0, long long s1, T* out, int N, int M, int* __restrict__ results)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const T inf = (T)INFINITY;
+    for (int j = tid; j < M; j += nt) out[j] = j ? inf : (T)0;
+    for (int i = 1 + tid; i < N; i += nt) out[(long long)i * M] = inf;
+    if (results) for (int i = tid; i < N; i += nt) results[i] = 0;
+    __syncthreads();
+    for (int d = 2; d <= N + M - 2; ++d) {
+        const int lo = d - (M - 1) > 1 ? d - (M - 1) : 1, hi = d - 1 < N - 1 ? d - 1 : N - 1;
+        for (int i = lo + tid; i <= hi; i += nt) {
+            const int j = d - i;
+            const T* up = out + (long long)(i - 1) * M + j;
+            const T a = up[0], b = out[(long long)i * M + j - 1], c = up[-1];
+            T best = a <= b ? a : b;
+            best = best <= c ? best : c;
+            out[(long long)i * M + j] = costs[i * s0 + j * s1] + best;
+        }
+        __syncthreads();
+    }
+    if (results && tid == 0) {
+        int i = N - 1, j = M - 1;
+        while (i > 0 && j > 0) {
+            results[i] = j;
+            const T up = out[(long long)(i - 1) * M + j], left = out[(long long)i * M + j - 1], diag = out[(long long)(i - 1) * M + j - 1];
+            if (up <= left && up <= diag) --i;
+            else if (left <= diag) --j;
+            else { --i; --j; }
+        }
+    }
+}
+
+extern "C" int ss_dtw_cumulative(int dtype, const void* costs, int64_t stride_i, int64_t stride_j, int N, int M, void* dtw_out, int32_t* results, void* stream)
+{
+    SS_CHECK(dtype == SS_F32 || dtype == SS_F64, "ss_dtw_cumulative: dtype must be f32 or f64 (align.py:6 keeps the input dtype)");
+    SS_CHECK(costs && dtw_out, "ss_dtw_cumulative: null pointer");
+    SS_CHECK(N >= 1 && M >= 1, "ss_dtw_cumulative: empty matrix (N=%d, M=%d)", N, M);
+    const int threads = N < 64 ? 64 : (N > 1024 ? 1024 : (N + 63) / 64 * 64);
+    if (dtype == SS_F32) SS_LAUNCH(SS_KERNEL(dtw_cumulative_kernel<float>), dim3(1), dim3(threads), 0, stream, (const float*)costs, (long long)stride_i, (long long)stride_j, (float*)dtw_out, N, M, (int*)results);
+    else SS_LAUNCH(SS_KERNEL(dtw_cumulative_kernel<double>), dim3(1), dim3(threads), 0, stream, (const double*)costs, (long long)stride_i, (long long)stride_j, (double*)dtw_out, N, M, (int*)results);
+    SS_LAUNCH_CHECK("ss_dtw_cumulative");
+    return 0;
+}

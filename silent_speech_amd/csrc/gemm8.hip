@@ -16,14 +16,9 @@
 //       (every dW = dY^T X), GROUPED: one persistent launch walks the (tile x K-slice) items of up to 8 problems, so
 //       the 4 weight gradients of an encoder layer (108 tiles) need a split of 2, not 7 per GEMM -> 3.5x fewer f32
 //       atomics.  Tiles are copied untransposed ([64 k][256 m], pitch 544 B) and transposed by ds_read_b64_tr_b16.
-#include "gemm_common.h"
-#include "silent_speech_hip.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "gemm8_common.h"
 
 namespace g8 {
-
-constexpr int TBN = 256, RB = 128, BK8 = 64;
 
 __device__ __forceinline__ int fsw(int row) { return (row & 7) ^ (((row >> 3) & 3) << 1); }
 
@@ -66,11 +61,6 @@ __device__ __forceinline__ void tile_coord(int it, int G, int nitems, int tiles_
     mt = idx / tiles_n; nt = idx - mt * tiles_n;
 }
 
-__device__ __forceinline__ void sched_fence() {
-#if !defined(SS_EMU)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
 // wait for this wave's LDS reads AND its outstanding global->LDS copies, then the workgroup barrier
 __device__ __forceinline__ void barrier_all() {
 #if defined(SS_EMU)
@@ -366,204 +356,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
     }
 }
 
-// ================================================================ grouped dW (OC x OC)
-struct DwJob {
-    const bf16_t* A; const bf16_t* B; float* C;
-    RowMap amap, bmap;                  // frame k -> element offset of its row (equal rows_per_batch)
-    long long ldc;
-    int M, N, K;                        // C is M x N, reduction over K frames
-    int tiles_n, ntiles, split, k_chunk, item0, nitem, atomic;
-};
-constexpr int DW_MAX_JOBS = 8;
-struct DwJobs { DwJob job[DW_MAX_JOBS]; int n; };
-
-namespace g8 {
-constexpr int TRP = 544;                // LDS row pitch of the untransposed [64 k][256 m] tiles: 512 B + 32 B (rows 8 banks apart)
-constexpr int TR_STAGE = 2 * 64 * TRP;  // A tile + B tile
-
-// Per thread: 16-byte chunk c of k rows r0 + 16 i (i < 4) of every 64-row K tile, for A and for B.  The frame -> row maps of
-// both operands cut the frames into batches of the same length, so ONE (frame-in-batch) counter per row serves both; the
-// element offsets advance incrementally (no division, no 64-bit multiply in the loop).  Outer columns beyond the matrix are
-// clamped to column 0 (their products land in C entries that are never stored); frames beyond k_end must read as zero in
-// both operands and only occur in the last K tile of an item (predicated variant).
-struct StageTR8 {
-    const unsigned char* pa; const unsigned char* pb;      // operand bases (+ this thread's outer column), bytes
-    unsigned offa[4], offb[4];                             // byte offsets of the 4 rows
-    int tt[4];                                             // frame index inside its batch
-    int c, r0, rpb, wraps;
-    unsigned stepa, stepb, wrapa, wrapb;                   // byte advance per 64 frames / extra advance per batch wrap
-    __device__ __forceinline__ void init(const DwJob& J, int m0, int n0, int k_begin, int tid) {
-        c = tid & 31; r0 = tid >> 5;
-        const int ca = m0 + c * 8 < J.M ? m0 + c * 8 : 0, cb = n0 + c * 8 < J.N ? n0 + c * 8 : 0;
-        pa = (const unsigned char*)(J.A + J.amap.base + ca); pb = (const unsigned char*)(J.B + J.bmap.base + cb);
-        rpb = J.amap.rows_per_batch;
-        wraps = rpb >= BK8 ? 1 : (BK8 + rpb - 1) / rpb;
-        stepa = (unsigned)(J.amap.row_stride * BK8 * 2); stepb = (unsigned)(J.bmap.row_stride * BK8 * 2);
-        wrapa = (unsigned)((J.amap.batch_stride - (long long)rpb * J.amap.row_stride) * 2);
-        wrapb = (unsigned)((J.bmap.batch_stride - (long long)rpb * J.bmap.row_stride) * 2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rr = k_begin + r0 + 16 * i;
-            int b_ = 0, t_ = rr;
-            if (rpb != 0x7fffffff) { b_ = rr / rpb; t_ = rr - b_ * rpb; }
-            tt[i] = t_;
-            offa[i] = (unsigned)(((long long)b_ * J.amap.batch_stride + (long long)t_ * J.amap.row_stride) * 2);
-            offb[i] = (unsigned)(((long long)b_ * J.bmap.batch_stride + (long long)t_ * J.bmap.row_stride) * 2);
-        }
-    }
-    __device__ __forceinline__ void advance() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            tt[i] += BK8; offa[i] += stepa; offb[i] += stepb;
-            for (int w = 0; w < wraps; ++w) { const bool over = tt[i] >= rpb; tt[i] -= over ? rpb : 0; offa[i] += over ? wrapa : 0u; offb[i] += over ? wrapb : 0u; }
-        }
-    }
-    template <bool PRED>
-    __device__ __forceinline__ void load(int k0, int kend, u32x4 (&ra)[4], u32x4 (&rb)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (PRED) {
-                u32x4 z = {0u, 0u, 0u, 0u};
-                const bool v = k0 + r0 + 16 * i < kend;
-                ra[i] = v ? *(const u32x4*)(pa + offa[i]) : z;
-                rb[i] = v ? *(const u32x4*)(pb + offb[i]) : z;
-            } else {
-                ra[i] = *(const u32x4*)(pa + offa[i]);
-                rb[i] = *(const u32x4*)(pb + offb[i]);
-            }
-        }
-    }
-    __device__ __forceinline__ void store(unsigned char* stage, const u32x4 (&ra)[4], const u32x4 (&rb)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { *(u32x4*)(stage + (r0 + 16 * i) * TRP + c * 16) = ra[i]; *(u32x4*)(stage + (64 + r0 + 16 * i) * TRP + c * 16) = rb[i]; }
-    }
-};
-__device__ __forceinline__ bf16x8 tr_frag8(const unsigned char* tile, int sub, int kk, int c, int q) {
-    const unsigned char* a0 = tile + (kk * 32 + q * 4 + (c >> 2)) * TRP + sub * 32 + (c & 3) * 8;
-    const s16x4 lo = lds_read_tr16(a0), hi = lds_read_tr16(a0 + 16 * TRP);
-    bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return f;
-}
-}  // namespace g8
-
-template <int PIN>
-__global__ __launch_bounds__(512) void gemm8_dw_kernel(DwJobs jobs, int nitems, int xorder)
-{
-    using namespace g8;
-    SS_DYN_SMEM(lds_raw);
-    unsigned char* lds = (unsigned char*)lds_raw;
-    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
-#if defined(SS_EMU)
-    const int wave = tid >> 6;
-#else
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
-    const int wm = wave >> 2, wn = wave & 3, G = gridDim.x;
-    StageTR8 st;
-    u32x4 ra[4], rb[4];
-    int it = blockIdx.x, ji = 0, m0, n0, k_begin, k_end, nsteps;
-
-#define G8_SETUP()                                                                                                          \
-    do {                                                                                                                     \
-        /* the 8 XCDs have private L2s and workgroup b runs on XCD b % 8: hand every XCD a CONTIGUOUS range of this round's items \
-           (same problem, same K slice, neighbouring tiles = shared 256-column operand blocks), so that the re-reads of a block  \
-           by the tiles of a tile row / column hit that XCD's L2 (was: every item fetched both of its operands from memory,      \
-           2.1 GB per launch for 0.54 GB of data) */                                                                           \
-        const int ch0_ = it / G * G, pos_ = it - ch0_;                                                                       \
-        int R_ = nitems - ch0_; R_ = R_ > G ? G : R_;                                                                        \
-        const int xq_ = R_ >> 3, xr_ = R_ & 7, xcd_ = pos_ & 7;                                                             \
-        const int lit = xorder ? ch0_ + (xcd_ < xr_ ? xcd_ * (xq_ + 1) : xr_ * (xq_ + 1) + (xcd_ - xr_) * xq_) + (pos_ >> 3) : it; \
-        ji = 0;                                                                                                              \
-        while (ji + 1 < jobs.n && lit >= jobs.job[ji].item0 + jobs.job[ji].nitem) ++ji;                                     \
-        const DwJob& J_ = jobs.job[ji];                                                                                      \
-        const int local = lit - J_.item0, z = local / J_.ntiles, tile = local - z * J_.ntiles;                               \
-        const int mt_ = tile / J_.tiles_n, nt_ = tile - mt_ * J_.tiles_n;                                                    \
-        m0 = mt_ * 256; n0 = nt_ * 256;                                                                                      \
-        k_begin = z * J_.k_chunk; k_end = min(J_.K, k_begin + J_.k_chunk);                                                   \
-        nsteps = (k_end - k_begin + BK8 - 1) / BK8;                                                                          \
-        st.init(J_, m0, n0, k_begin, tid);                                                                                   \
-        if (nsteps == 1) st.load<true>(k_begin, k_end, ra, rb); else if (nsteps > 1) st.load<false>(k_begin, k_end, ra, rb); \
-    } while (0)
-
-    G8_SETUP();
-    for (;;) {
-        f32x4 acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
-        if (nsteps > 0) st.store(lds, ra, rb);
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            const int cur = s & 1;
-            const bool more = s + 1 < nsteps;
-            if (more) {
-                st.advance();
-                const int k0 = k_begin + (s + 1) * BK8;
-                if (s + 2 == nsteps) st.load<true>(k0, k_end, ra, rb); else st.load<false>(k0, k_end, ra, rb);     // only the last K tile can be ragged
-            }
-            const unsigned char* As = lds + cur * TR_STAGE;
-            const unsigned char* Bs = As + 64 * TRP;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 a[8], b[4];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) a[i] = tr_frag8(As, wm * 8 + i, kk, c, q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = tr_frag8(Bs, wn * 4 + j, kk, c, q);
-                if (PIN) sched_fence();
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(a[i], b[j], acc[i][j]);
-                if (PIN) sched_fence();
-            }
-            if (more) st.store(lds + (cur ^ 1) * TR_STAGE, ra, rb);
-            __syncthreads();
-        }
-        // ---- next item: its first global loads fly during this item's epilogue
-        const DwJob& J = jobs.job[ji];
-        float* Cj = J.C; const long long ldc = J.ldc; const int Mj = J.M, Nj = J.N, atomic = J.atomic, cm0 = m0, cn0 = n0;
-        const bool has_next = it + G < nitems;
-        if (has_next) { it += G; G8_SETUP(); }
-        // ---- epilogue: lane holds rows q*4+reg, column c of each 16x16 tile
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = cn0 + wn * 64 + j * 16 + c, row0 = cm0 + (wm * 8 + i) * 16 + q * 4;
-                if (col < Nj) {
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        if (row0 + reg < Mj) {
-                            float* dst = Cj + (long long)(row0 + reg) * ldc + col;
-                            if (atomic) atomicAdd(dst, acc[i][j][reg]); else *dst += acc[i][j][reg];
-                        }
-                    }
-                }
-            }
-        if (!has_next) break;
-    }
-#undef G8_SETUP
-}
-
 // ---------------------------------------------------------------- host side
-static int g8_cus() {
-#if defined(SS_EMU)
-    return 3;
-#else
-    static int cus = 0;
-    if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
-    return cus;
-#endif
-}
-static int g8_grant(const void* fn, size_t smem) {
-#if !defined(SS_EMU)
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("gemm8: cannot reserve %zu bytes of LDS", smem); return 1; }
-#endif
-    return 0;
-}
-
 // which == NI (8 or 9).  Legality (bf16 in, K % 64 == 0, 32-bit operand offsets, no transposed second output) is the caller's job.
 template <class TO>
 int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, void* stream)
@@ -594,65 +387,3 @@ int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int 
 }
 template int gemm8_launch_kc<bf16_t>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*);
 template int gemm8_launch_kc<float>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*);
-
-static thread_local int g_dw_split_override = 0, g_dw_pin = 1, g_dw_xorder = -1;        // xorder: -1 = environment SS_GEMM_DW_XCD, default on
-extern "C" int ss_gemm_dw_set_option(int what, int value) {
-    int old = 0;
-    if (what == 0) { old = g_dw_split_override; g_dw_split_override = value; }
-    else if (what == 1) { old = g_dw_pin; g_dw_pin = value; }
-    else if (what == 2) { old = g_dw_xorder; g_dw_xorder = value; }
-    return old;
-}
-
-extern "C" int ss_gemm_dw_grouped(int n_jobs, const ss_dw_job* jobs, void* stream)
-{
-    SS_CHECK(jobs && n_jobs >= 1 && n_jobs <= DW_MAX_JOBS, "ss_gemm_dw_grouped: 1..%d jobs per launch", DW_MAX_JOBS);
-    DwJobs J; memset(&J, 0, sizeof(J));
-    J.n = n_jobs;
-    long long tiles_total = 0; int kmax = 0;
-    for (int i = 0; i < n_jobs; ++i) {
-        const ss_dw_job& s = jobs[i];
-        SS_CHECK(s.A && s.B && s.C, "ss_gemm_dw_grouped: null pointer in job %d", i);
-        SS_CHECK(s.M > 0 && s.N > 0 && s.K > 0 && s.M % 8 == 0 && s.N % 8 == 0, "ss_gemm_dw_grouped: job %d: M=%d, N=%d must be positive multiples of 8 (16-byte rows), K=%d > 0", i, s.M, s.N, s.K);
-        SS_CHECK(((uintptr_t)s.A) % 16 == 0 && ((uintptr_t)s.B) % 16 == 0, "ss_gemm_dw_grouped: job %d: operands must be 16-byte aligned", i);
-        const ss_rowmap* maps[2] = {&s.amap, &s.bmap};
-        for (int o = 0; o < 2; ++o)
-            SS_CHECK(maps[o]->base % 8 == 0 && maps[o]->batch_stride % 8 == 0 && maps[o]->row_stride % 8 == 0, "ss_gemm_dw_grouped: job %d operand %d: strides must be multiples of 8 elements", i, o);
-        DwJob& d = J.job[i];
-        d.A = (const bf16_t*)s.A; d.B = (const bf16_t*)s.B; d.C = s.C; d.ldc = s.ldc; d.M = s.M; d.N = s.N; d.K = s.K;
-        d.amap.base = s.amap.base; d.amap.batch_stride = s.amap.batch_stride; d.amap.row_stride = s.amap.row_stride; d.amap.rows_per_batch = s.amap.rows_per_batch > 0 ? s.amap.rows_per_batch : 0x7fffffff;
-        d.bmap.base = s.bmap.base; d.bmap.batch_stride = s.bmap.batch_stride; d.bmap.row_stride = s.bmap.row_stride; d.bmap.rows_per_batch = s.bmap.rows_per_batch > 0 ? s.bmap.rows_per_batch : 0x7fffffff;
-        SS_CHECK(d.amap.rows_per_batch == d.bmap.rows_per_batch, "ss_gemm_dw_grouped: job %d: both operands must split their rows into batches of the same length", i);
-        d.tiles_n = (s.N + 255) / 256; d.ntiles = ((s.M + 255) / 256) * d.tiles_n;
-        tiles_total += d.ntiles; kmax = s.K > kmax ? s.K : kmax;
-    }
-    // one K split for the whole group: the largest that keeps (tiles x split) inside ONE round of the CUs
-    const int cus = g8_cus();
-    int split = (int)(cus / (tiles_total > 0 ? tiles_total : 1)); split = split < 1 ? 1 : split;
-    if (g_dw_split_override > 0) split = g_dw_split_override;
-    int item0 = 0;
-    for (int i = 0; i < n_jobs; ++i) {
-        DwJob& d = J.job[i];
-        const int ksteps = (d.K + 63) / 64;
-        int sp = split; if (sp > ksteps / 4) sp = ksteps / 4 > 0 ? ksteps / 4 : 1;          // at least 4 K tiles per item
-        const int per = (ksteps + sp - 1) / sp;
-        d.k_chunk = per * 64; d.split = (ksteps + per - 1) / per;
-        d.atomic = d.split > 1 ? 1 : 0;                     // one item per tile: a plain read-modify-write of C suffices
-        d.item0 = item0; d.nitem = d.ntiles * d.split; item0 += d.nitem;
-    }
-    const int nitems = item0;
-    if (g_dw_xorder < 0) { const char* e = getenv("SS_GEMM_DW_XCD"); g_dw_xorder = e ? atoi(e) : 1; }
-    const size_t smem = 2 * g8::TR_STAGE;
-    dim3 grid(nitems < cus ? nitems : cus), block(512);
-    if (g_dw_pin) {
-        static bool granted = false;
-        if (!granted) { if (g8_grant((const void*)gemm8_dw_kernel<1>, smem)) return 1; granted = true; }
-        SS_LAUNCH(SS_KERNEL(gemm8_dw_kernel<1>), grid, block, smem, stream, J, nitems, g_dw_xorder);
-    } else {
-        static bool granted = false;
-        if (!granted) { if (g8_grant((const void*)gemm8_dw_kernel<0>, smem)) return 1; granted = true; }
-        SS_LAUNCH(SS_KERNEL(gemm8_dw_kernel<0>), grid, block, smem, stream, J, nitems, g_dw_xorder);
-    }
-    SS_LAUNCH_CHECK("ss_gemm_dw_grouped");
-    return 0;
-}

@@ -110,6 +110,34 @@ extern "C" int ss_reflect_pad(const float* y, float* out, int B, int L, int pad,
     return 0;
 }
 
+// The same for a RAGGED batch (one launch for every utterance of a batch): row b of `out` holds the clipped (data_utils.py:76
+// np.clip(audio, -1, 1)) and reflect-padded signal of utterance b, L_b + 2 pad samples, zeros behind it up to ld_out.
+__global__ void reflect_pad_ragged_kernel(const float* __restrict__ y, const long long* __restrict__ offs, const int* __restrict__ lens, float* __restrict__ out,
+                                          int B, int pad, long long ld_out, int clip)
+{
+    const long long total = (long long)B * ld_out;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / ld_out), j = (int)(i - (long long)b * ld_out);
+        const int L = lens[b], t = j - pad;
+        float v = 0.f;
+        if (j < L + 2 * pad) {
+            const int s = t < 0 ? -t : (t >= L ? 2 * (L - 1) - t : t);
+            v = y[offs[b] + s];
+            if (clip) v = fminf(fmaxf(v, -1.f), 1.f);
+        }
+        out[i] = v;
+    }
+}
+extern "C" int ss_reflect_pad_ragged(const float* y, const int64_t* offsets_dev, const int32_t* lengths_dev, float* out, int B, int min_len, int pad, int64_t ld_out, int clip, void* stream)
+{
+    SS_CHECK(y && out && offsets_dev && lengths_dev, "ss_reflect_pad_ragged: null pointer");
+    SS_CHECK(B > 0 && pad >= 0 && min_len > pad && ld_out >= min_len + 2 * pad, "ss_reflect_pad_ragged: bad sizes (reflect needs pad < the shortest signal)");
+    long long total = (long long)B * ld_out, blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    SS_LAUNCH(reflect_pad_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, (const long long*)offsets_dev, (const int*)lengths_dev, out, B, pad, (long long)ld_out, clip);
+    SS_LAUNCH_CHECK("ss_reflect_pad_ragged");
+    return 0;
+}
+
 // data_utils.py:56-57  sqrt(re^2 + im^2 + 1e-9); spec rows hold [re(0..nb-1) | im(0..nb-1)] with row stride ld_spec
 __global__ void stft_magnitude_kernel(const float* __restrict__ spec, long long ld_spec, int nb, float* __restrict__ mag, long long ld_mag, int rows)
 {

@@ -165,14 +165,16 @@ struct Plan {
         return timed(X, "grad_unlayout", 0, 0, stream, [&] { return ss_permute3d_batch(b.jobs, (const int32_t*)b.blocks, (int)b.total, (int)b.all_f32, stream); });
     }
     // fused != null: [2][C] sums already accumulated by the producing GEMM's epilogue (shift = the running mean before this update)
-    int bn_stats(Exec& X, const void* x, int B, int T, int C, float* scratch, BnP& bn, bool training, float** mean, float** invstd, float* fused = nullptr) {
+    // reduced_n > 0: the sums were already all-reduced by the caller (two BatchNorms of a block in ONE collective), reduced_n = global row count
+    int bn_stats(Exec& X, const void* x, int B, int T, int C, float* scratch, BnP& bn, bool training, float** mean, float** invstd, float* fused = nullptr, double reduced_n = 0.0) {
         *mean = (float*)X.alloc((size_t)C * 4); *invstd = (float*)X.alloc((size_t)C * 4);
         float* sums = (training && !fused) ? (float*)X.alloc((size_t)3 * C * 4) : fused;
         if (X.dry) return 0;
         double n_total = (double)B * T;
         if (training) {
             if (!fused && timed(X, "bn_stats", 0, (double)B * T * C * esz(), X.stream, [&] { return ss_bn_stats_sums(D.dtype, x, B, T, C, 0, scratch, hook ? bn.rmean : nullptr, sums, X.stream); })) return 1;
-            if (hook) n_total = hook(hook_user, sums, 2 * C, n_total, X.stream);
+            if (reduced_n > 0.0) n_total = reduced_n;
+            else if (hook) n_total = hook(hook_user, sums, 2 * C, n_total, X.stream);
         }
         if (fused) return timed(X, "bn_finalize", 0, 0, X.stream, [&] { return ss_bn_finalize_shift(sums, bn.rmean, n_total, C, *mean, *invstd, bn.rmean, bn.rvar, 0.1f, 1e-5f, 1, X.stream); });
         return timed(X, "bn_finalize", 0, 0, X.stream, [&] { return ss_bn_finalize(sums, n_total, C, *mean, *invstd, bn.rmean, bn.rvar, 0.1f, 1e-5f, training ? 1 : 0, X.stream); });
@@ -291,13 +293,17 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         float* f1 = conv_gemm(X, xin, w.w1f, c1, rows, O, 3 * Cin, RM(2 * Cin, Tout, in_bs), RM(3 * Cin), w.b1, w.bn1, slot, &rc); L_(rc);
         void* cr = X.alloc((size_t)rows * O * es);
         float* fr = conv_gemm(X, xin, w.wr, cr, rows, O, Cin, RM(2 * Cin, Tout, in_bs, Cin), RM(Cin), w.br, w.bnr, slot ? slot + 2 * d : nullptr, &rc); L_(rc);
-        L_(bn_stats(X, c1, B, Tout, O, s.scratch, w.bn1, training, &s.m1, &s.i1, f1));
+        // data parallel: bn1 and res_norm both normalise a function of the block input, their epilogue sums sit side by side in the
+        // slot -> ONE all-reduce of [4][O] floats instead of two of [2][O] (these collectives are latency-bound)
+        double nred = 0.0;
+        if (training && hook && f1 && fr == f1 + 2 * d && O == d && !X.dry) nred = hook(hook_user, f1, 4 * O, (double)B * Tout, stream);
+        L_(bn_stats(X, c1, B, Tout, O, s.scratch, w.bn1, training, &s.m1, &s.i1, f1, nred));
         void* h1 = X.alloc((size_t)B * (Tout + 2) * O * es);
         if (!X.dry) L_(timed(X, "bn_apply", 0, (double)B * Tout * O * es * 3, stream, [&] { return ss_bn_apply(dt, c1, s.m1, s.i1, w.bn1.gamma, w.bn1.beta, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h1, 1, B, Tout, O, 1, stream); }));
         void* c2 = X.alloc((size_t)rows * O * es);
         float* f2 = conv_gemm(X, h1, w.w2f, c2, rows, O, 3 * O, RM(O, Tout, (long long)(Tout + 2) * O), RM(3 * O), w.b2, w.bn2, slot ? slot + 4 * d : nullptr, &rc); L_(rc);
         L_(bn_stats(X, c2, B, Tout, O, s.scratch, w.bn2, training, &s.m2, &s.i2, f2));
-        L_(bn_stats(X, cr, B, Tout, O, s.scratch, w.bnr, training, &s.mr, &s.ir, fr));
+        L_(bn_stats(X, cr, B, Tout, O, s.scratch, w.bnr, training, &s.mr, &s.ir, fr, nred));
         const int pad_y = i == 2 ? 0 : 1;
         void* y = X.alloc((size_t)B * (Tout + 2 * pad_y) * O * es);
         if (!X.dry) L_(timed(X, "bn_apply", 0, (double)B * Tout * O * es * 3, stream, [&] { return ss_bn_apply(dt, c2, s.m2, s.i2, w.bn2.gamma, w.bn2.beta, 0, cr, s.mr, s.ir, w.bnr.gamma, w.bnr.beta, 0, y, pad_y, B, Tout, O, 1, stream); }));

@@ -11,7 +11,7 @@ void ss_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* ss_last_error(void) { return g_err; }
-extern "C" int ss_abi_version(void) { return 1; }
+extern "C" int ss_abi_version(void) { return SS_ABI_VERSION; }
 extern "C" const char* ss_target_arch(void) {
 #if defined(SS_EMU)
     return "host-emulator";

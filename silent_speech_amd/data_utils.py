@@ -109,6 +109,15 @@ def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin,
     if Lp < n_fft:
         raise ValueError('signal too short for one frame')
     F = 1 + (Lp - n_fft) // hop_size
+    out = torch.empty(B, num_mels, F, dtype=torch.float32, device=dev)
+    _stft_logmel(ypad, B, F, ldp, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major=False)
+    return out
+
+
+def _stft_logmel(ypad, B, F, ldp, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major):
+    """padded signals [B][ldp] -> log-mel of frames 0..F-1 of every row: two f32 GEMMs around the magnitude kernel.
+    frame_major: out is [B*F][num_mels] (frames of a signal are contiguous rows) instead of the reference's (B, num_mels, F)."""
+    dev = ypad.device
     nb = n_fft // 2 + 1
     W = _windowed_dft(n_fft, win_size, dev)
     ld_spec = (2 * nb + 7) // 8 * 8
@@ -116,12 +125,43 @@ def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin,
     ops.gemm(ypad, W, spec, B * F, 2 * nb, n_fft, ops.rowmap(hop_size, F, ldp), ops.rowmap(n_fft), ops.rowmap(ld_spec))
     ld_mag = (nb + 7) // 8 * 8
     mag = torch.empty(B * F, ld_mag, dtype=torch.float32, device=dev)
-    _lib.check(_lib.lib().ss_stft_magnitude(_lib.ptr(spec), ld_spec, nb, _lib.ptr(mag), ld_mag, B * F, _lib.stream_of(y)), 'ss_stft_magnitude')
+    _lib.check(_lib.lib().ss_stft_magnitude(_lib.ptr(spec), ld_spec, nb, _lib.ptr(mag), ld_mag, B * F, _lib.stream_of(ypad)), 'ss_stft_magnitude')
     basis = _mel_basis(sampling_rate, n_fft, num_mels, fmin, fmax, dev, ld_mag)
-    out = torch.empty(B, num_mels, F, dtype=torch.float32, device=dev)
-    ops.gemm_ex(mag, basis, out, B * F, num_mels, ld_mag, ops.rowmap(ld_mag), ops.rowmap(ld_mag), ops.rowmap(1, F, num_mels * F),
-                col_perm=(num_mels, F, 0), log_clamp=1e-5)
+    if frame_major:
+        ops.gemm_ex(mag, basis, out, B * F, num_mels, ld_mag, ops.rowmap(ld_mag), ops.rowmap(ld_mag), ops.rowmap(num_mels), log_clamp=1e-5)
+    else:
+        ops.gemm_ex(mag, basis, out, B * F, num_mels, ld_mag, ops.rowmap(ld_mag), ops.rowmap(ld_mag), ops.rowmap(1, F, num_mels * F),
+                    col_perm=(num_mels, F, 0), log_clamp=1e-5)
     return out
+
+
+def mel_spectrogram_batch(signals, n_fft=1024, num_mels=80, sampling_rate=22050, hop_size=256, win_size=1024, fmin=0, fmax=8000, clip=True):
+    """load_audio's `np.clip` + `mel_spectrogram(..., center=False)` (data_utils.py:76-78) for EVERY utterance of a batch in one
+    launch sequence: one ragged clip + reflect-pad kernel, ONE hop-strided DFT GEMM over all frames of all utterances (rows of the
+    padded buffer = utterances, RowMap batch stride), magnitude, one mel GEMM with the log-clamp epilogue.
+    signals: list of 1-D f32 device tensors at `sampling_rate`.  Returns (buf [B][F_max][num_mels] f32, frames per utterance):
+    utterance b's `pytorch_mspec.squeeze(0).T` is buf[b, :frames[b]] -- a contiguous view, no per-utterance copy."""
+    if hop_size % 4 or n_fft % 4:
+        raise ValueError('hop_size and n_fft must be multiples of 4 (16-byte f32 rows)')
+    B = len(signals)
+    lens = [int(t.shape[0]) for t in signals]
+    pad = int((n_fft - hop_size) / 2)
+    if min(lens) + 2 * pad < n_fft or min(lens) <= pad:
+        raise ValueError('signal too short for one frame')
+    dev = signals[0].device
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in signals]) if B > 1 else signals[0].reshape(-1).to(torch.float32).contiguous()
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    frames = [1 + (L + 2 * pad - n_fft) // hop_size for L in lens]
+    F = max(frames)
+    ldp = (max(lens) + 2 * pad + 3) // 4 * 4
+    offs_d = torch.from_numpy(offs).to(dev, non_blocking=True)
+    lens_d = torch.from_numpy(np.asarray(lens, dtype=np.int32)).to(dev, non_blocking=True)
+    ypad = torch.empty(B, ldp, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().ss_reflect_pad_ragged(_lib.ptr(flat), _lib.ptr(offs_d), _lib.ptr(lens_d), _lib.ptr(ypad), B, min(lens), pad, ldp, int(bool(clip)),
+                                                _lib.stream_of(flat)), 'ss_reflect_pad_ragged')
+    out = torch.empty(B, F, num_mels, dtype=torch.float32, device=dev)
+    _stft_logmel(ypad, B, F, ldp, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major=True)
+    return out, frames
 
 
 class FeatureNormalizer(object):

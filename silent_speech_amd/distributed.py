@@ -10,7 +10,9 @@ the contract here is "N-GPU step == 1-GPU step on the concatenated batch":
   * BatchNorm : the reference's batch statistics span the whole batch (architecture.py:19,21,25), so the
     per-channel sums of every BatchNorm (forward: sum, sum-of-squares; backward: sum g, sum g*xhat) are
     all-reduced between the two phases of the HIP kernels (ss_bn_stats_sums/ss_bn_finalize, ss_bn_backward_*).
-    18 tiny latency-bound collectives per step.
+    12 small latency-bound collectives per step (bn1 + res_norm of a block share one in the forward, bn2 + res_norm in the
+    backward), on a process group of their own: the gradient buckets use a second group (= a second RCCL communicator and stream),
+    so a 176 MB bucket in flight never sits in front of a 12 KB BatchNorm exchange the main stream is waiting for.
   * loss      : sum(losses)/sum(T2) uses the GLOBAL frame count (transduction_model.py:157); each rank
     scales by it, so the summed gradients equal the single-process ones.
   * relative-position embeddings never receive a gradient (transformer.py:214-218) and are not in the arena.
@@ -37,7 +39,16 @@ class DataParallel(object):
         # .item() per step, i.e. a full device sync that lets the GPU run dry while the host re-fills the launch queue.
         self.host_group = None
         if self.world > 1 and dist.get_backend(group) != 'gloo':
-            self.host_group = dist.new_group(backend='gloo')
+            try:
+                self.host_group = dist.new_group(backend='gloo')
+            except Exception as e:      # noqa: BLE001 -- no silent fallback to a per-step device sync
+                raise RuntimeError('DataParallel: could not create the gloo side group for the host-side counts (%s); '
+                                   'set MASTER_ADDR=127.0.0.1 / check that gloo can bind a local interface' % e)
+        # gradient buckets on their own communicator: with one group the async 176 MB bucket and the blocking BatchNorm exchanges
+        # share one collective stream, and the main stream's conv backward would stall behind the bucket
+        self.bucket_group = group
+        if self.world > 1 and bucketed:
+            self.bucket_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend=dist.get_backend(group))
 
     def attach(self, model, shift_seed=0x5EED):
         self._model = model
@@ -55,8 +66,8 @@ class DataParallel(object):
             # gradient buckets in the order backward completes them: what = 0 encoder + heads + w_raw_in, 1..3 ResBlocks 2, 1, 0
             ranges = model.arena_ranges()
 
-            def span(pred):
-                sel = [(a, b) for nme, a, b in ranges if pred(nme)]
+            def span(pred):       # up to the padded slot boundary (slots are 4-float aligned): the spans tile the arena without gaps
+                sel = [(a, (b + 3) // 4 * 4) for nme, a, b in ranges if pred(nme)]
                 return (min(a for a, _ in sel), max(b for _, b in sel)) if sel else None
             self._buckets = {0: span(lambda nme: not nme.startswith('conv_blocks.'))}
             for i in range(3):
@@ -108,21 +119,21 @@ class DataParallel(object):
         return float(self._host_sum(torch.tensor([local], dtype=torch.float64))[0])
 
     # ---- gradients
-    def _on_grads_ready(self, what):
-        """Called from inside ss_plan_backward when bucket `what` is final on the side stream: start its all-reduce there, so it
-        overlaps the rest of backward (xGMI is otherwise idle until the end of the step)."""
+    def _on_grads_ready(self, what, stream=0):
+        """Called from inside ss_plan_backward when bucket `what` is final on `stream` (the raw hipStream_t the plan produced the
+        gradients on: its side stream, or the main stream when the side stream is off): start the all-reduce behind exactly that
+        stream, so it overlaps the rest of backward (xGMI is otherwise idle until the end of the step)."""
         rng = self._buckets.get(what)
         if rng is None or self.world == 1:
             return
         model = self._model
         _, gflat, _ = model.flat_arenas()
         a, b = rng
-        side = getattr(model, '_side_stream', None)
-        if gflat.is_cuda and side is not None:
-            with torch.cuda.stream(side):
-                w = dist.all_reduce(gflat[a:b], group=self.group, async_op=True)
+        if gflat.is_cuda and stream and stream != torch.cuda.current_stream(gflat.device).cuda_stream:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=gflat.device)):
+                w = dist.all_reduce(gflat[a:b], group=self.bucket_group, async_op=True)
         else:
-            w = dist.all_reduce(gflat[a:b], group=self.group, async_op=True)
+            w = dist.all_reduce(gflat[a:b], group=self.bucket_group, async_op=True)
         self._works.append(w)
         self._covered.append((a, b))
 
@@ -143,3 +154,11 @@ class DataParallel(object):
         for a, b in todo:
             dist.all_reduce(gflat[a:b], group=self.group)           # losses are already divided by the GLOBAL frame count
         self._works, self._covered = [], []
+
+    def broadcast_scalars(self, *values):
+        """Rank 0's values on every rank (validation loss / accuracy before the LR scheduler: kernels with f32 atomics can differ
+        in the last bits between ranks, and a plateau decision taken on one rank only would let the weights diverge)."""
+        if self.world == 1:
+            return values
+        t = torch.tensor([float(v) if self.rank == 0 else 0.0 for v in values], dtype=torch.float64)
+        return tuple(float(v) for v in self._host_sum(t))

@@ -27,18 +27,6 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def _split_k(M, N, K):
-    """Split-K factor of a weight-gradient GEMM: the largest one that keeps tiles x split within ~400 work items, i.e. inside
-    ONE round of the 512 persistent workgroup slots (2 per CU) with room left for the main-stream kernels these GEMMs run
-    beside.  Measured alone (tools/dw_split_probe.py, K = 22 016): 144 tiles x 3 = 432 items 201 us, x 4 = 576 items 292 us
-    (a second, nearly empty round), x 7 = 1008 items 206 us (two full rounds, twice the f32 atomic epilogues); 36 tiles:
-    x 14 -> 72 us, x 28 -> 103 us.  Measured in the step: budgets of 340-420 items give 20.8-21.0 ms, 512 gives 21.4, 1024 gave 22.6."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    overlapped = SIDE_STREAM_ENABLED and os.environ.get('SS_AMD_SIDE_STREAM', '1') != '0'
-    s = max(1, min(64, (400 if overlapped else 512) // max(tiles, 1)))     # alone on the GPU a full round (<= 512 items) is best
-    return max(1, min(s, K // 512 if K >= 512 else 1))
-
-
 class Prepared(object):
     """GEMM-ready copies of the parameters in the compute dtype (bf16 or f32): layout changes for the conv / attention
     tensors, casts and transposed copies (so that dX = dY.W is K-contiguous as well) for the nn.Linear ones.
@@ -248,6 +236,7 @@ class PlanBinding(object):
         self.ws = None                               # workspace of the call in flight (the data-parallel hook maps pointers into it)
         self._hook = self._hook_fn = None
         self._event = self._event_fn = None
+        self.callback_error = None
 
     def __del__(self):
         try:
@@ -331,14 +320,19 @@ class PlanBinding(object):
             return
 
         def trampoline(user, sums_ptr, n_floats, n_local, stream):
-            off = int(sums_ptr) - self.ws.data_ptr()
-            sums = self.ws[off:off + 4 * n_floats].view(torch.float32)
-            return float(fn(sums, n_local))
+            try:                                  # an exception cannot cross the C frames of the plan: park it, re-raise after the call
+                off = int(sums_ptr) - self.ws.data_ptr()
+                sums = self.ws[off:off + 4 * n_floats].view(torch.float32)
+                return float(fn(sums, n_local))
+            except BaseException as e:            # noqa: BLE001
+                self.callback_error = self.callback_error or e
+                return float(n_local)
         self._hook = _REDUCE_HOOK(trampoline)
         self.lib.ss_plan_set_reduce_hook(self.handle, self._hook, None)
 
     def set_event_hook(self, fn):
-        """fn(what) is called when a group of parameter gradients is final on the side stream (bucketed all-reduce)."""
+        """fn(what, stream) is called when a group of parameter gradients is final on `stream` (the raw hipStream_t the plan
+        produced them on: the side stream, or the main stream when the side stream is off) -- bucketed all-reduce."""
         if fn is self._event_fn:
             return
         self._event_fn = fn
@@ -346,8 +340,19 @@ class PlanBinding(object):
             self._event = None
             self.lib.ss_plan_set_event_hook(self.handle, ctypes.cast(None, _EVENT_HOOK), None)
             return
-        self._event = _EVENT_HOOK(lambda user, what, stream: fn(int(what)))
+        def trampoline(user, what, stream):
+            try:
+                fn(int(what), int(stream or 0))
+            except BaseException as e:            # noqa: BLE001
+                self.callback_error = self.callback_error or e
+        self._event = _EVENT_HOOK(trampoline)
         self.lib.ss_plan_set_event_hook(self.handle, self._event, None)
+
+    def raise_callback_error(self):
+        """Re-raises the first exception a reduce / event hook threw inside the last native call (ctypes would only print it)."""
+        e, self.callback_error = self.callback_error, None
+        if e is not None:
+            raise e
 
 
 def plan_binding(model):
@@ -401,6 +406,7 @@ def forward(model, x_raw, training, shift_r, seed):
     p_drop = model.dropout_p if training else 0.0
     rc = L.ss_plan_forward(pb.handle, _lib.ptr(x_raw), _lib.ptr(shifted), _lib.ptr(ws), nbytes, B, T0, int(training), int(shift_r if training else 0),
                            float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(head), buf, _lib.stream_of(x_raw))
+    pb.raise_callback_error()
     _lib.check(rc, 'ss_plan_forward')
     return head, (Ctx(buf, ws, B * (T0 // 8)) if training else None)
 
@@ -422,4 +428,5 @@ def backward(model, ctx, dhead):
     L.ss_plan_set_option(pb.handle, 1, int(os.environ.get('SS_AMD_DW_GROUPED', '1') != '0'))
     L.ss_plan_set_option(pb.handle, 2, int(os.environ.get('SS_AMD_SIDE_BLOCKS', '2')))
     rc = L.ss_plan_backward(pb.handle, ctx.buf, _lib.ptr(dhead), _lib.stream_of(dhead), ctypes.c_void_p(side.cuda_stream) if side is not None else None)
+    pb.raise_callback_error()
     _lib.check(rc, 'ss_plan_backward')

@@ -231,7 +231,7 @@ def layernorm_backward(dy, z, mean, rstd, gamma, dres, dbranch, dgamma, dbeta, r
     n = int(_L().ss_layernorm_backward_scratch_floats(rows, C))
     scratch = None
     if n:
-        key = (str(dy.device), n)
+        key = (str(dy.device), n, int(_s(dy).value or 0))       # per stream: two streams must not share partial sums
         scratch = _ln_scratch.get(key)
         if scratch is None:
             scratch = _ln_scratch[key] = torch.empty(n, dtype=torch.float32, device=dy.device)

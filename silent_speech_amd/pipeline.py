@@ -58,6 +58,27 @@ def mel_targets(audio, normalizer=None, max_frames=None):
     return normalize_features(mspec, normalizer) if normalizer is not None else mspec
 
 
+def greedy_length_batches(order, length_of, max_len, yield_empty=False, on_oversize=None):
+    """read_emg.py:124-140, the ONE implementation of the reference's batching rule: walk `order`, keep adding utterances while the
+    running sum of their lengths (raw 1 kHz EMG samples) stays within `max_len`; an utterance that would overflow closes the batch
+    and opens the next one; the incomplete last batch is dropped.  length_of(idx) -> int, or None for utterances the reference
+    skips (:129-130).  yield_empty reproduces the reference's quirk of emitting an empty batch when the very first utterance of a
+    batch is already over budget (:135-137)."""
+    batch, batch_length = [], 0
+    for idx in order:
+        length = length_of(idx)
+        if length is None:
+            continue
+        if length > max_len and on_oversize is not None:
+            on_oversize(idx)
+        if length + batch_length > max_len and (batch or yield_empty):
+            yield batch
+            batch, batch_length = [], 0
+        batch.append(idx)
+        batch_length += length
+    # dropping last incomplete batch
+
+
 class SizeAwareSampler(torch.utils.data.Sampler):
     """Drop-in for read_emg.py:115-140 -- same constructor (emg_dataset, max_len), same greedy packing under a budget of raw 1 kHz
     EMG samples, reshuffled on every __iter__ with Python's `random`, text-less utterances skipped (:129-130), the incomplete
@@ -93,19 +114,8 @@ class SizeAwareSampler(torch.utils.data.Sampler):
             random.Random((self.seed or 0) * 1000003 + self.epoch).shuffle(indices)
         else:
             random.shuffle(indices)                         # read_emg.py:122
-        batch, batch_length = [], 0
-        for idx in indices:
-            length = self._length(idx)
-            if length is None:
-                continue
-            if length > self.max_len:
-                logging.warning(f'Warning: example {idx} cannot fit within desired batch length')
-            if length + batch_length > self.max_len:
-                yield batch
-                batch, batch_length = [], 0
-            batch.append(idx)
-            batch_length += length
-        # dropping last incomplete batch
+        return greedy_length_batches(indices, self._length, self.max_len, yield_empty=True,
+                                     on_oversize=lambda idx: logging.warning(f'Warning: example {idx} cannot fit within desired batch length'))
 
     def __iter__(self):
         if self.world == 1:
@@ -131,15 +141,7 @@ class ShardedSizeAwareSampler(torch.utils.data.Sampler):
         indices = list(range(len(self.lengths)))
         if self.shuffle:
             random.Random(self.seed * 1000003 + self.epoch).shuffle(indices)
-        batches, batch, batch_length = [], [], 0
-        for idx in indices:
-            length = self.lengths[idx]
-            if length + batch_length > self.max_len and batch:
-                batches.append(batch)
-                batch, batch_length = [], 0
-            batch.append(idx)
-            batch_length += length
-        return batches                                       # dropping last incomplete batch (:140)
+        return list(greedy_length_batches(indices, self.lengths.__getitem__, self.max_len))
 
     def __iter__(self):
         batches = self.all_batches()
@@ -148,3 +150,110 @@ class ShardedSizeAwareSampler(torch.utils.data.Sampler):
 
     def __len__(self):
         return len(self.all_batches()) // self.world
+
+
+# ------------------------------------------------------------------ the per-batch device loader (N3 composed with N4)
+def _feature_frames(n_1k):
+    """Frames of get_emg_features (data_utils.py:100: librosa.util.frame(frame_length=16, hop_length=6)) on the 516.79 Hz resample
+    (read_emg.py:71) of a recording of n_1k raw 1 kHz samples -- the count load_utterance truncates everything to (:82-88)."""
+    n516 = len(np.arange(0, (n_1k - 1) / 1000.0, 1 / 516.79))
+    return 0 if n516 < 16 else 1 + (n516 - 16) // 6
+
+
+class DeviceBatchBuilder(object):
+    """`[dataset[i] for i in batch]` + `collate_raw` (read_emg.py:223-296) on the MI355X, from in-memory recordings: what
+    load_utterance / load_audio / EMGDataset.__getitem__ compute per utterance on the host (and memoise with lru_cache) is computed
+    here per BATCH on the device, and the result is the batch dict the training step consumes (lists of per-utterance device
+    tensors), so `train_model` / `dtw_loss` / `bench.py` run from raw recordings.
+
+    A recording is a dict:
+        raw_emg (n, 8)              raw 1 kHz samples of `<idx>_emg.npy`          [+ raw_emg_before / raw_emg_after: the neighbours
+                                    load_utterance concatenates as filter context, read_emg.py:55-66]
+        audio (L,)                  waveform at 22 050 Hz, i.e. after load_audio's host-side decode / resample (data_utils.py:65-75)
+        phonemes (frames,) int64    read_phonemes output (optional: 'sil' everywhere like read_emg.py:98)
+        silent bool, text_int int64, session_index int
+        parallel                    for silent recordings: the voiced twin (same dict shape); its audio features and phonemes become
+                                    the targets (read_emg.py:242-256, collate_raw :268-271)
+    Stages (each ONE launch sequence for the whole batch unless noted):
+        EMG   : context concat -> 7 notch harmonics + 2 Hz high-pass, zero-phase, f64 (csrc/filters.hip; per recording: the
+                recurrences are serial in time and recordings differ in length) -> crop -> np.interp to 689.06 Hz -> rows 8..8+8n
+                (:90) -> /20, 50 tanh(./50) (:227-228) for all utterances in one kernel
+        audio : clip + reflect pad (ragged) -> one hop-strided DFT GEMM -> |.| -> one mel GEMM + log clamp -> FeatureNormalizer, all
+                utterances at once (data_utils.mel_spectrogram_batch); truncation to n frames is a view
+    The 112-d hand-crafted EMG features (`emg`, data_utils.py:92-136) are not inputs of the model (architecture.py:61 ignores
+    x_feat) and are emitted as zeros of the right shape unless the recording brings `emg_features`."""
+
+    def __init__(self, device, mfcc_norm=None, emg_norm=None, limit_length=False, sil_index=0):
+        self.device, self.mfcc_norm, self.emg_norm, self.limit_length, self.sil_index = torch.device(device), mfcc_norm, emg_norm, limit_length, sil_index
+
+    # ---- EMG
+    def _filtered_689(self, rec):
+        from .read_emg import butter_highpass_coeffs, filtfilt_cascade, iirnotch_coeffs, subsample
+        dev = self.device
+        parts = [rec.get('raw_emg_before'), rec['raw_emg'], rec.get('raw_emg_after')]
+        ts = [torch.as_tensor(np.asarray(p) if not torch.is_tensor(p) else p).to(device=dev, dtype=torch.float64) for p in parts if p is not None and len(p)]
+        nb = 0 if parts[0] is None else len(parts[0])
+        na = 0 if parts[2] is None else len(parts[2])
+        x = torch.cat(ts, 0) if len(ts) > 1 else ts[0]
+        filters = [iirnotch_coeffs(60 * h, 30, 1000) for h in range(1, 8)] + [butter_highpass_coeffs(3, 2, 1000)]
+        x = filtfilt_cascade(filters, x)
+        x = x[nb:x.shape[0] - na]
+        return subsample(x, 689.06, 1000)
+
+    def _frames(self, rec, mel_frames, limit):
+        n = min(_feature_frames(len(rec['raw_emg'])), mel_frames)
+        return min(n, 800) if limit else n
+
+    def build(self, recordings):
+        from .data_utils import mel_spectrogram_batch
+        dev = self.device
+        # audio of every recording whose mel frames are needed: own audio (lengths; targets when voiced) and the voiced twins
+        twins = [r['parallel'] if r['silent'] else None for r in recordings]
+        audio_src = list(recordings) + [t for t in twins if t is not None]
+        sig = [torch.as_tensor(np.asarray(r['audio']) if not torch.is_tensor(r['audio']) else r['audio']).to(device=dev, dtype=torch.float32) for r in audio_src]
+        mel, mframes = mel_spectrogram_batch(sig)
+        if self.mfcc_norm is not None:
+            mean, std = _normalizer_tensors(self.mfcc_norm, mel.shape[-1], dev)
+            _soft_clip(mel, mel, mel.shape[-1], mean, std, 1.0, 0.0)                       # FeatureNormalizer.normalize (read_emg.py:231), in place
+        n_own = [self._frames(r, mframes[i], self.limit_length) for i, r in enumerate(recordings)]
+        # raw EMG: filter every recording, gather rows 8 .. 8 + 8 n into ONE buffer, soft-clip it in one launch
+        total = sum(8 * n for n in n_own)
+        raw = torch.empty(total, 8, dtype=torch.float32, device=dev)
+        off, raw_views = 0, []
+        for r, n in zip(recordings, n_own):
+            e = self._filtered_689(r)
+            if e.shape[0] < 8 + 8 * n:
+                raise ValueError('recording too short: %d model-rate samples for %d frames' % (e.shape[0], n))
+            raw[off:off + 8 * n].copy_(e[8:8 + 8 * n])                                      # read_emg.py:90 (+ .astype(np.float32), :100)
+            raw_views.append(raw[off:off + 8 * n])
+            off += 8 * n
+        _soft_clip(raw, raw, 8, None, None, 20.0, 50.0)                                     # read_emg.py:227-228
+        out = {k: [] for k in ('audio_features', 'audio_feature_lengths', 'emg', 'raw_emg', 'parallel_voiced_emg', 'phonemes', 'session_ids',
+                               'lengths', 'silent', 'text_int', 'text_int_lengths')}
+        ti = len(recordings)
+        for i, (r, n) in enumerate(zip(recordings, n_own)):
+            if r['silent']:
+                t = r['parallel']
+                nt = self._frames(t, mframes[ti], False)                                    # load_utterance(voiced ..., limit_length=False), :245
+                feats, ph_src = mel[ti, :nt], t
+                ti += 1
+            else:
+                nt, feats, ph_src = n, mel[i, :n], r
+            ph = ph_src.get('phonemes')
+            ph = torch.full((nt,), self.sil_index, dtype=torch.int64) if ph is None else torch.as_tensor(ph, dtype=torch.int64)[:nt]
+            if ph.shape[0] != nt:
+                raise ValueError('phoneme labels shorter than the %d target frames' % nt)
+            ef = r.get('emg_features')
+            if ef is None:
+                emg = torch.zeros(n, 112, dtype=torch.float32, device=dev)
+            else:
+                emg = torch.as_tensor(ef, dtype=torch.float32)[:n].to(dev)
+                emg = normalize_features(emg, self.emg_norm, 8.0) if self.emg_norm is not None else emg
+            text = torch.as_tensor(r.get('text_int', np.zeros(0, dtype=np.int64)), dtype=torch.int64)
+            out['audio_features'].append(feats); out['audio_feature_lengths'].append(nt)
+            out['emg'].append(emg); out['raw_emg'].append(raw_views[i])
+            out['parallel_voiced_emg'].append(np.zeros(1))
+            out['phonemes'].append(ph.to(dev)); out['session_ids'].append(torch.full((n,), int(r.get('session_index', 0)), dtype=torch.int64, device=dev))
+            out['lengths'].append(n); out['silent'].append(bool(r['silent']))
+            out['text_int'].append(text); out['text_int_lengths'].append(int(text.shape[0]))
+        return out

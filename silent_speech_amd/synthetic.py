@@ -60,15 +60,8 @@ class SyntheticEMGDataset(torch.utils.data.Dataset):
         order = list(range(len(self.items)))
         if shuffle_seed is not None:
             np.random.default_rng(shuffle_seed).shuffle(order)
-        batches, cur, cur_len = [], [], 0
-        for i in order:
-            n = self.items[i]['length_1k']
-            if n + cur_len > max_len and cur:
-                batches.append(cur)
-                cur, cur_len = [], 0
-            cur.append(i)
-            cur_len += n
-        return batches
+        from .pipeline import greedy_length_batches
+        return list(greedy_length_batches(order, self.example_length, max_len))
 
     @staticmethod
     def collate_raw(batch):

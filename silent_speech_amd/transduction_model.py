@@ -295,7 +295,9 @@ def train_model(trainset, devset, device, save_sound_outputs=True, *, compute_dt
             if max_steps is not None and batch_idx >= max_steps:
                 break
         train_loss = float(torch.stack(losses).mean()) if losses else float('nan')      # one sync per epoch instead of per step (:207)
-        val, phoneme_acc, _ = test(model, devset, device)                                 # every rank evaluates (identical weights): the plateau scheduler stays in step
+        val, phoneme_acc, _ = test(model, devset, device)                                 # every rank evaluates (identical weights) ...
+        if data_parallel is not None:                                                      # ... and rank 0's figures decide: kernels with f32 atomics may differ in the
+            val, phoneme_acc = data_parallel.broadcast_scalars(val, phoneme_acc)           # last bits between ranks, a plateau decision must not
         lr_sched.step(val)
         if main_rank:
             logging.info(f'finished epoch {epoch_idx+1} - validation loss: {val:.4f} training loss: {train_loss:.4f} phoneme accuracy: {phoneme_acc*100:.2f}')

@@ -75,3 +75,17 @@ def test_package_never_imports_the_oracle():
             if f.endswith('.py') or f.endswith('.hip') or f.endswith('.h'):
                 txt = open(os.path.join(dp, f)).read()
                 assert 'import oracle' not in txt and 'from oracle' not in txt, os.path.join(dp, f)
+
+
+def test_abi_version_is_checked_at_load(hip_lib, monkeypatch):
+    """A library whose ABI version differs from the binding's is refused at load time (struct layouts change between versions)."""
+    from silent_speech_amd import _lib
+    src = open(os.path.join(ROOT, 'include', 'silent_speech_hip.h')).read()
+    declared = int(re.search(r'#define\s+SS_ABI_VERSION\s+(\d+)', src).group(1))
+    hip_lib.ss_abi_version.restype = ctypes.c_int
+    assert hip_lib.ss_abi_version() == declared == _lib.ABI_VERSION
+    monkeypatch.setattr(_lib, 'ABI_VERSION', declared + 1)
+    with pytest.raises(RuntimeError, match='ABI version'):
+        _lib.load()
+    monkeypatch.undo()
+    _lib.load()

@@ -103,3 +103,52 @@ def test_dtw_big_golden_and_strips():
     assert align.align_from_distances(tall, device=d) == dtw_ref.align_from_distances_c(tall)
     wide = (rng.standard_normal((300, 2500)) ** 2).astype(np.float32)
     assert align.align_from_distances(wide, device=d) == dtw_ref.align_from_distances_c(wide)
+
+
+def test_time_warp_matches_reference_matrices(dev):
+    """align.py:5-14: the cumulative matrix itself, bit for bit against the matrices the reference's time_warp produced."""
+    z = np.load(os.path.join(GOLD, 'dtw_small.npz'))
+    names = [k[6:] for k in z.files if k.startswith('costs/')]
+    if is_emu(dev):
+        names = [n for n in names if z['costs/' + n].size <= 2600]
+    for name in names:
+        got = align.time_warp(z['costs/' + name], device=dev)
+        want = z['dtw/' + name]
+        assert got.dtype == want.dtype == np.float32 and got.shape == want.shape
+        assert np.array_equal(got, want), name
+    # strided view in, tensor in -> tensor out
+    c = np.random.default_rng(5).random((23, 31), dtype=np.float32)
+    t = align.time_warp(torch.from_numpy(c).t(), device=dev)
+    assert isinstance(t, torch.Tensor) and np.array_equal(t.cpu().numpy(), dtw_ref.time_warp_numpy(np.ascontiguousarray(c.T)))
+    one = align.time_warp(np.ones((1, 4), dtype=np.float32), device=dev)
+    assert one[0, 0] == 0 and np.isinf(one[0, 1:]).all()
+
+
+def test_float64_input_keeps_float64_arithmetic(dev):
+    """align.py:6 `zeros_like(costs)`: a float64 matrix is accumulated in float64.  The matrix below ties in float32 (the small terms
+    are below half an ulp of 1) but not in float64: rounding the input to float32 changes the alignment ([0,1,2,3,4] vs [0,1,3,4,5])."""
+    k = np.array([[3, 2, 2, 1, 1, 0], [0, 0, 0, 3, 2, 3], [2, 2, 3, 2, 2, 2], [2, 3, 1, 3, 2, 0], [1, 3, 2, 0, 3, 2]], dtype=np.float64)
+    c = 1.0 + k * 1e-9                                         # all ones in float32
+    want64 = dtw_ref.backtrace_numpy(dtw_ref.time_warp_numpy(c))
+    want32 = dtw_ref.backtrace_numpy(dtw_ref.time_warp_numpy(c.astype(np.float32)))
+    assert want64 != want32, 'the test matrix must separate the two precisions'
+    assert align.align_from_distances(c, device=dev) == want64
+    assert align.align_from_distances(c.astype(np.float32), device=dev) == want32
+    d64 = align.time_warp(c, device=dev)
+    assert d64.dtype == np.float64 and np.array_equal(d64, dtw_ref.time_warp_numpy(c))
+    rng = np.random.default_rng(11)
+    r = rng.random((40, 57))
+    assert align.align_from_distances(r, device=dev) == dtw_ref.backtrace_numpy(dtw_ref.time_warp_numpy(r))
+
+
+@pytest.mark.gpu
+def test_time_warp_big_golden():
+    """The 1000 x 1000 reference matrix: last row and f64 checksum of the cumulative matrix the reference computed."""
+    from silent_speech_amd import _lib
+    _lib.load()
+    z = np.load(os.path.join(GOLD, 'dtw_big.npz'))
+    n, m = [int(v) for v in z['shape']]
+    big = np.random.default_rng(int(z['seed'])).random((n, m), dtype=np.float32)
+    d = align.time_warp(big, device=torch.device('cuda'))
+    assert np.array_equal(d[-1], z['dtw_last'])
+    assert float(d[1:, 1:].astype(np.float64).sum()) == float(z['dtw_sum64'])

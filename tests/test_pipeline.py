@@ -3,6 +3,7 @@ the oracle, the sharded size-aware sampler vs the reference's packing rule."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import mel_ref
@@ -120,3 +121,88 @@ def test_mel_spectrogram_center_true_matches_torch_stft(dev):
                       onesided=True, return_complex=True)
     want = torch.log(torch.clamp(torch.from_numpy(slaney_mel_filterbank(22050, 1024, 80, 0, 8000)) @ torch.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9), min=1e-5))
     assert got.shape == want.shape and float((got - want).abs().mean()) < 1e-4
+
+
+def _recording(rng, n_1k, audio_frames, silent=False, context=True):
+    t = np.arange(n_1k + 400) / 1000.0
+    walk = np.cumsum(rng.standard_normal((n_1k + 400, 8)), 0) * 2.0                    # drift
+    hum = 40.0 * np.sin(2 * np.pi * 60.0 * t)[:, None] * rng.uniform(0.5, 1.5, 8)[None]  # mains
+    x = (walk + hum + rng.standard_normal((n_1k + 400, 8)) * 30.0)
+    rec = {'raw_emg': x[200:200 + n_1k].copy(), 'silent': silent, 'session_index': 3,
+           'audio': np.clip(rng.standard_normal(256 * audio_frames).astype(np.float32) * 0.4, -1.2, 1.2),      # some samples out of range: np.clip matters
+           'text_int': rng.integers(0, 37, 5).astype(np.int64)}
+    if context:
+        rec['raw_emg_before'], rec['raw_emg_after'] = x[:200].copy(), x[200 + n_1k:].copy()
+    rec['phonemes'] = rng.integers(0, 48, audio_frames).astype(np.int64)
+    return rec
+
+
+def _oracle_item(rec, mean, std, limit=False):
+    """load_utterance + EMGDataset.__getitem__ (read_emg.py:52-100, 223-235) restated with the oracle's numpy pieces."""
+    from oracle import filter_ref, mel_ref
+    e689, e516 = filter_ref.condition(rec['raw_emg'], rec.get('raw_emg_before'), rec.get('raw_emg_after'))
+    n_feat = 1 + (e516.shape[0] - 16) // 6                                               # librosa.util.frame(16, 6), data_utils.py:100
+    mel = mel_ref.mel_spectrogram_ref(np.clip(rec['audio'], -1, 1)[None].astype(np.float32))[0].T
+    n = min(n_feat, mel.shape[0], 800 if limit else 10 ** 9)
+    raw = e689[8:8 + 8 * n].astype(np.float32)
+    raw = (50 * np.tanh((raw / 20) / 50.)).astype(np.float32)
+    return n, raw, ((mel[:n] - mean) / std).astype(np.float32), rec['phonemes'][:n]
+
+
+def test_device_batch_builder_matches_the_per_utterance_chain(dev):
+    """N3 composed: DeviceBatchBuilder.build(recordings) == [dataset[i] for i in batch] + collate_raw of the reference, restated per
+    utterance with the oracle's filtfilt / np.interp / mel pieces: frame counts, conditioned raw EMG, normalised mel targets, phoneme
+    targets (the voiced twin's for silent recordings)."""
+    from silent_speech_amd.data_utils import FeatureNormalizer
+    rng = np.random.default_rng(17)
+    if is_emu(dev):
+        recs = [_recording(rng, 260, 10), _recording(rng, 300, 14, silent=True, context=False)]
+        recs[1]['parallel'] = _recording(rng, 280, 12)
+    else:
+        recs = [_recording(rng, int(n), int(f), silent=s, context=c) for n, f, s, c in
+                [(3000, 300, False, True), (4200, 330, True, True), (5100, 500, False, False), (3600, 280, False, True),
+                 (6000, 520, True, False), (3300, 400, False, True), (4800, 390, False, True), (2500, 190, False, True)]]
+        recs[1]['parallel'] = _recording(rng, 4000, 350)
+        recs[4]['parallel'] = _recording(rng, 5600, 470)
+    norm = FeatureNormalizer([np.zeros((2, 80), dtype=np.float32)], share_scale=True)
+    norm.feature_means = np.linspace(-6, -3, 80, dtype=np.float32)[None]
+    norm.feature_stddevs = np.float32(2.5)
+    b = pipeline.DeviceBatchBuilder(dev, mfcc_norm=norm).build(recs)
+    assert set(b) == {'audio_features', 'audio_feature_lengths', 'emg', 'raw_emg', 'parallel_voiced_emg', 'phonemes', 'session_ids', 'lengths',
+                      'silent', 'text_int', 'text_int_lengths'}
+    mean, std = norm.feature_means.reshape(-1), float(norm.feature_stddevs)
+    for i, r in enumerate(recs):
+        n, raw, mel, ph = _oracle_item(r, mean, std)
+        assert b['lengths'][i] == n and b['silent'][i] == r['silent']
+        assert tuple(b['raw_emg'][i].shape) == (8 * n, 8) and tuple(b['emg'][i].shape) == (n, 112) and tuple(b['session_ids'][i].shape) == (n,)
+        got = b['raw_emg'][i].cpu().numpy()
+        assert float(np.abs(got - raw).max()) < 2e-4 * float(np.abs(raw).max()), (i, float(np.abs(got - raw).max()))
+        if r['silent']:
+            n, _, mel, ph = _oracle_item(r['parallel'], mean, std)
+        assert b['audio_feature_lengths'][i] == n and tuple(b['audio_features'][i].shape) == (n, 80)
+        d = b['audio_features'][i].cpu().numpy() - mel
+        assert float(np.abs(d).mean()) < 1e-4 and float(np.abs(d).max()) < 2e-2, (i, float(np.abs(d).mean()))
+        assert np.array_equal(b['phonemes'][i].cpu().numpy(), ph)
+        assert int(b['session_ids'][i][0]) == 3 and b['text_int_lengths'][i] == 5
+
+
+@pytest.mark.gpu
+def test_training_step_runs_from_a_built_batch():
+    """The dict the builder emits is what _pack_batch / Model / dtw_loss consume (silent + voiced utterances, device-resident)."""
+    from silent_speech_amd import _lib
+    from silent_speech_amd.architecture import Model
+    from silent_speech_amd.transduction_model import _pack_batch, dtw_loss
+    _lib.load()
+    dev = torch.device('cuda')
+    rng = np.random.default_rng(2)
+    recs = [_recording(rng, 3000, 300), _recording(rng, 3500, 320, silent=True), _recording(rng, 2800, 200)]
+    recs[1]['parallel'] = _recording(rng, 3300, 290)
+    batch = pipeline.DeviceBatchBuilder(dev).build(recs)
+    torch.manual_seed(0)
+    m = Model(112, 80, 48, model_size=64, num_layers=1, dropout=0.1).to(dev)
+    m.train()
+    X, X_raw, sess = _pack_batch(batch, dev)
+    pred, aux = m(X, X_raw, sess)
+    loss, _ = dtw_loss(pred, aux, batch, phoneme_loss_weight=0.5)
+    loss.backward()
+    assert torch.isfinite(loss).item() and float(m.w_out.weight.grad.abs().max()) > 0
