@@ -17,8 +17,13 @@ Prints ONE JSON line on rank 0:
                         HIP events around every launch on every 5th timed step (those steps run serially: no side stream)
   cpu_baseline          the oracle (CPU restatement of the reference step) on >= 16 packed rows of the same batch, this node's cores
   parity                mel-L1 of the HIP model (bf16 and exact-f32 kernels) against the oracle on those rows, same weights
-  dtw / mel             BASELINE configs[2] (64 x 1000^2 DTW, HIP vs the oracle's C twin on 1 core and on all cores) and the
+  dtw / mel             BASELINE configs[2] (64 and 256 x 1000^2 DTW, HIP vs the oracle's C twin on 1 core and on all cores) and the
                         mel-target extraction (frames/s vs the numpy oracle)
+  fp32_mode             the same step in exact-f32 kernels (the mode whose mel-L1 meets north_star's 1e-4), driver-timed
+  ctc                   BASELINE configs[4]: the recognition step (768-d / 6-layer encoder + CTC, 128 000-sample batches, x2 accumulation)
+  eval                  validation (`test()`, packed rows) and whole-utterance inference (`predict_utterance`, T up to ~1000: per-tile attention)
+  pipeline              the per-batch device loader (DeviceBatchBuilder: raw recordings + audio -> batch dict), frames/s vs the host chain
+--scaling strong deals ONE reference-size batch over the ranks by length (default: weak, a batch per rank).
 """
 import argparse
 import ctypes
@@ -42,7 +47,7 @@ def _median(xs):
     return xs[len(xs) // 2]
 
 
-def cpu_baseline(batch_cpu, rows_limit, warm, timed, model_sd, dev):
+def cpu_baseline(batch_cpu, rows_limit, warm, timed, model_sd, dev, want_pred=True):
     """The oracle (CPU restatement of the reference step, torch fp32 + compiled C DTW) timed on this node's host cores on a
     bounded sample of the same workload: the first utterances of the batch up to `rows_limit` packed rows.  Also returns the
     oracle's eval-free forward (dropout 0, shift 3) on that sample for the parity entry."""
@@ -64,8 +69,10 @@ def cpu_baseline(batch_cpu, rows_limit, warm, timed, model_sd, dev):
     opt = torch.optim.AdamW(params, lr=1e-5, weight_decay=1e-7)
     g = torch.Generator().manual_seed(0)
     x_raw = loss_ref.combine_fixed_length(sub['raw_emg'], 1600)
-    with torch.no_grad():
-        ref_pred, _ = model_ref.model_forward({k: v.detach().clone() for k, v in sd.items()}, x_raw.clone(), training=True, shift_r=3, running_out={})
+    ref_pred = None
+    if want_pred:
+        with torch.no_grad():
+            ref_pred, _ = model_ref.model_forward({k: v.detach().clone() for k, v in sd.items()}, x_raw.clone(), training=True, shift_r=3, running_out={})
 
     def step():
         opt.zero_grad()
@@ -211,6 +218,205 @@ def mel_leg(dev, n_utt=32, seconds=6.0):
                          'note': '1344 B per frame algorithmic; the dense-DFT formulation is f32-MFMA-bound (2.1 MFLOP/frame), not HBM-bound'}}
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources: stamped into profiles/*_pmc_traffic.json when the counters are collected (tools/pmc_summary.py)
+    and compared here, so that `traffic` figures measured on other kernels are reported as stale instead of silently reused."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'silent_speech_amd', 'csrc')
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith('.hip') or fn.endswith('.h'):
+            h.update(fn.encode()); h.update(open(os.path.join(d, fn), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def make_step(model, optim, batch, dp, it):
+    from silent_speech_amd.data_utils import combine_fixed_length
+    from silent_speech_amd.transduction_model import dtw_loss
+
+    def step():
+        optim.zero_grad()
+        i = it[0] + 1
+        if i <= 500:
+            for gp in optim.param_groups:
+                gp['lr'] = i * 1e-3 / 500                                       # transduction_model.py:186-189
+        X = combine_fixed_length(batch['emg'], 200)
+        X_raw = combine_fixed_length(batch['raw_emg'], 1600)
+        sess = combine_fixed_length(batch['session_ids'], 200)
+        if dp is not None:
+            dp.begin_step(X_raw.shape[0] * 200, dp.local_target_frames(batch))
+        pred, aux = model(X, X_raw, sess)
+        total = dp.global_total(batch) if dp is not None else None
+        loss, _ = dtw_loss(pred, aux, batch, phoneme_loss_weight=0.5, total_length=total)
+        loss.backward()
+        if dp is not None:
+            dp.sync_gradients(model)
+        optim.step()
+        it[0] += 1
+        return loss
+    return step
+
+
+def _time_steps(step, warm, timed):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        loss = step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / timed, loss
+
+
+def fp32_mode_leg(batch, init_sd, dev, frames, warm=2, timed=4):
+    """The SAME step in exact-f32 kernels (compute_dtype=float32: f32 MFMA 16x16x4, f32 activations): the mode whose `pred` sits within
+    north_star's 1e-4 mel-L1 of the reference (parity.mel_l1_fp32*), timed by the driver like the bf16 line."""
+    from silent_speech_amd.architecture import Model
+    from silent_speech_amd.optim import FusedAdamW
+    model = Model(112, 80, 48, model_size=768, num_layers=6, dropout=0.2, compute_dtype=torch.float32)
+    model.load_state_dict(init_sd, strict=True)
+    model.to(dev).train()
+    optim = FusedAdamW(model, weight_decay=1e-7)
+    dt, loss = _time_steps(make_step(model, optim, batch, None, [0]), warm, timed)
+    return {'dtype': 'fp32', 'ms_per_step': dt * 1e3, 'frames_per_s': frames / dt, 'steps': timed, 'warmup': warm, 'final_loss': float(loss.detach()),
+            'roofline_note': 'f32 MFMA peak is %.1f TFLOP/s: 398 MFLOP/frame => %.0f %% of it' % (PEAK_F32_TFLOPS, 100.0 * frames * 398e6 / dt / 1e12 / PEAK_F32_TFLOPS)}
+
+
+def ctc_leg(dev, warm=2, timed=6):
+    """BASELINE configs[4]: recognition_model.py:92-107 -- shared encoder (768-d, 6 layers, bf16) with a 38-way output, CTC loss on the
+    packed logits, an optimiser step every SECOND batch of a 128 000-sample budget.  One timed unit = two batches (forward, CTC,
+    backward each) + the AdamW step.  The loss lines (:96-101) alone are timed too, next to the reference's own CPU path for them
+    (torch CPU log_softmax + pad_sequence + F.ctc_loss on the same logits)."""
+    import torch.nn.functional as F
+    from silent_speech_amd.architecture import Model
+    from silent_speech_amd.optim import FusedAdamW
+    from silent_speech_amd.recognition_model import ctc_loss
+    from silent_speech_amd.synthetic import reference_size_batch
+    from silent_speech_amd.transduction_model import _pack_batch
+    torch.manual_seed(1)
+    model = Model(112, 38, model_size=768, num_layers=6, dropout=0.2, compute_dtype=torch.bfloat16).to(dev)
+    model.train()
+    optim = FusedAdamW(model, lr=3e-4, weight_decay=0.0)
+    batches = [reference_size_batch(seed=s, budget=128000, device=dev) for s in (11, 12)]
+    frames = sum(sum(b['lengths']) for b in batches)
+
+    def unit():
+        optim.zero_grad()
+        for b in batches:
+            X, X_raw, sess = _pack_batch(b, dev)
+            loss = ctc_loss(model(X, X_raw, sess), b, blank=37)
+            loss.backward()
+        optim.step()
+        return loss
+    dt, loss = _time_steps(unit, warm, timed)
+    # the loss lines alone, on the logits of the first batch
+    b = batches[0]
+    with torch.no_grad():
+        X, X_raw, sess = _pack_batch(b, dev)
+        pred = model(X, X_raw, sess).float()
+    logits = pred.detach().clone().requires_grad_(True)
+    ctc_loss(logits, b, blank=37).backward()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 10
+    e0.record()
+    for _ in range(iters):
+        logits.grad = None
+        gl = ctc_loss(logits, b, blank=37)
+        gl.backward()
+    e1.record()
+    torch.cuda.synchronize()
+    t_loss = e0.elapsed_time(e1) * 1e-3 / iters
+    # the reference's own lines on the host
+    from silent_speech_amd.data_utils import decollate_tensor
+    cpu_logits = pred.cpu().requires_grad_(True)
+    lens = b['lengths']
+    tgt = torch.nn.utils.rnn.pad_sequence([t.cpu() for t in b['text_int']], batch_first=True)
+    tl = [int(t.shape[0]) for t in b['text_int']]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    lp = F.log_softmax(cpu_logits, 2)
+    lp = torch.nn.utils.rnn.pad_sequence(decollate_tensor(lp, lens), batch_first=False)
+    ref = F.ctc_loss(lp, tgt, lens, tl, blank=37)
+    ref.backward()
+    t_cpu = time.perf_counter() - t0
+    M, V = int(pred.shape[0] * pred.shape[1]), 38
+    byts = M * V * 4.0 * 3 + M * 4.0 * 2                  # logits read twice (lse, gradient) + gradient written; lse / argmax
+    derr = float((logits.grad.cpu() - cpu_logits.grad).abs().max() / (cpu_logits.grad.abs().max() + 1e-30))
+    return {'workload': 'configs[4]: recognition step, 768-d / 6-layer encoder bf16 + CTC (38 classes), 2 batches of a 128 000-sample budget per optimiser step, dropout 0.2',
+            'frames_per_unit': frames, 'utterances': [len(x['lengths']) for x in batches], 'ms_per_unit': dt * 1e3, 'frames_per_s': frames / dt,
+            'final_loss': float(loss.detach()),
+            'ctc_loss': {'hip_ms': t_loss * 1e3, 'frames': int(sum(lens)), 'cpu_ms': t_cpu * 1e3, 'cpu_kind': 'torch CPU log_softmax + pad_sequence + F.ctc_loss + backward (the reference\'s own lines, recognition_model.py:96-101), %d threads' % torch.get_num_threads(),
+                         'loss_hip': float(gl.detach()), 'loss_cpu': float(ref.detach()), 'grad_max_err_over_max': derr,
+                         'roofline': {'bound': 'hbm', 'achieved': byts / t_loss / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': byts / t_loss / 1e9 / PEAK_HBM_GBPS,
+                                      'note': 'latency-bound: T dependent alpha/beta columns per utterance, one workgroup per (utterance, direction)'}}}
+
+
+def eval_leg(dev):
+    """Row N2: `test()` (transduction_model.py:33-55: eval-mode forward on packed rows + dtw_loss with the confusion matrix) over a synthetic
+    dev set, and whole-utterance inference (`predict_utterance`, :57-66) where T runs up to ~1000 frames and the per-tile banded attention
+    kernels run instead of the LDS-resident ones."""
+    from silent_speech_amd.architecture import Model
+    from silent_speech_amd.synthetic import SyntheticEMGDataset
+    from silent_speech_amd.transduction_model import predict_utterance, test
+    torch.manual_seed(2)
+    model = Model(112, 80, 48, model_size=768, num_layers=6, dropout=0.2, compute_dtype=torch.bfloat16).to(dev)
+    ds = SyntheticEMGDataset(64, seed=5, min_frames=200, max_frames=860)
+    frames = sum(int(ds[i]['emg'].shape[0]) for i in range(len(ds)))
+    test(model, ds, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss, acc, _ = test(model, ds, dev)
+    torch.cuda.synchronize()
+    t_test = time.perf_counter() - t0
+    long_ds = SyntheticEMGDataset(16, seed=6, min_frames=600, max_frames=1000, silent_fraction=0.0)
+    lframes = sum(int(long_ds[i]['emg'].shape[0]) for i in range(len(long_ds)))
+    for i in range(2):
+        predict_utterance(model, long_ds[i], dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(len(long_ds)):
+        out = predict_utterance(model, long_ds[i], dev)
+    torch.cuda.synchronize()
+    t_long = time.perf_counter() - t0
+    return {'test': {'utterances': len(ds), 'frames': frames, 'ms': t_test * 1e3, 'frames_per_s': frames / t_test, 'loss': float(loss), 'phoneme_acc': float(acc),
+                     'note': 'eval-mode forward on batches of 32 utterances packed into 200-frame rows + dtw_loss(eval) incl. one DTW per silent utterance and the host-side confusion matrix'},
+            'whole_utterance': {'utterances': len(long_ds), 'frames': lframes, 'ms': t_long * 1e3, 'frames_per_s': lframes / t_long, 'finite': bool(torch.isfinite(out).all()),
+                                'note': 'predict_utterance: B = 1, T = 600..1000 (un-chunked): per-tile banded attention kernels (cost linear in T)'}}
+
+
+def pipeline_leg(dev, n_utt=24):
+    """Row N3: DeviceBatchBuilder -- raw 1 kHz recordings (+ filter context) and 22.05 kHz audio -> the collate_raw batch dict on the device --
+    against the same chain on the host (the oracle's numpy restatement of scipy filtfilt / np.interp / the STFT-mel path), per frame."""
+    import numpy as np
+    from oracle import filter_ref, mel_ref
+    from silent_speech_amd.pipeline import DeviceBatchBuilder
+    rng = np.random.default_rng(4)
+    recs = []
+    for _ in range(n_utt):
+        T = int(rng.integers(200, 861))
+        n = int(T * 8 / 0.68906) + 40
+        x = np.cumsum(rng.standard_normal((n + 400, 8)), 0) + 40.0 * np.sin(2 * np.pi * 60.0 * np.arange(n + 400) / 1000.0)[:, None] + rng.standard_normal((n + 400, 8)) * 30.0
+        recs.append({'raw_emg': x[200:200 + n], 'raw_emg_before': x[:200], 'raw_emg_after': x[200 + n:], 'silent': False,
+                     'audio': np.clip(0.1 * rng.standard_normal(256 * (T + 2)), -1, 1).astype(np.float32), 'text_int': np.zeros(3, dtype=np.int64)})
+    b = DeviceBatchBuilder(dev).build(recs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b = DeviceBatchBuilder(dev).build(recs)
+    torch.cuda.synchronize()
+    t_dev = time.perf_counter() - t0
+    frames = int(sum(b['lengths']))
+    k = 3
+    t0 = time.perf_counter()
+    for r in recs[:k]:
+        e689, e516 = filter_ref.condition(r['raw_emg'], r['raw_emg_before'], r['raw_emg_after'])
+        mel_ref.mel_spectrogram_ref(r['audio'][None])
+    t_cpu = (time.perf_counter() - t0) * n_utt / k
+    return {'workload': '%d recordings (%d frames): 8-filter zero-phase IIR cascade + resample + soft clip, batched STFT / mel / normalise -> batch dict' % (n_utt, frames),
+            'hip_ms': t_dev * 1e3, 'frames_per_s': frames / t_dev, 'includes': 'H2D of the raw recordings and audio (host arrays in), per-recording filter launches',
+            'cpu_frames_per_s': frames / t_cpu, 'cpu_kind': 'oracle/filter_ref.py + oracle/mel_ref.py (numpy, 1 process; %d of %d recordings timed, scaled)' % (k, n_utt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -221,7 +427,9 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--cpu-warmup', type=int, default=3)
     ap.add_argument('--no-profile', action='store_true', help='no per-launch HIP events (roofline entry omitted)')
-    ap.add_argument('--no-legs', action='store_true', help='skip the DTW (configs[2]) and mel legs')
+    ap.add_argument('--no-legs', action='store_true', help='skip the DTW (configs[2]), mel, fp32-mode, CTC (configs[4]), eval and pipeline legs')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'], help='weak: one reference-size batch per rank; strong: ONE such batch dealt over the ranks by length')
+    ap.add_argument('--cpu-full', type=int, default=1, help='also time the CPU baseline on the FULL batch (1 warm-up + 2 timed steps, ~1 min); 0 = sample only')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -263,32 +471,18 @@ def main():
     if dp is not None:
         dp.attach(model)
     optim = FusedAdamW(model, weight_decay=1e-7)
-    batch_cpu = reference_size_batch(seed=rank)
+    if args.scaling == 'strong' and world > 1:
+        # ONE global batch, utterances dealt round-robin in order of decreasing length: frames (and DTW problems) per rank stay balanced
+        g = reference_size_batch(seed=0)
+        order = sorted(range(len(g['lengths'])), key=lambda i: -g['lengths'][i])[rank::world]
+        batch_cpu = {k: [v[i] for i in order] for k, v in g.items()}
+    else:
+        batch_cpu = reference_size_batch(seed=rank)
     batch = {k: ([t.to(dev) for t in v] if isinstance(v, list) and len(v) and torch.is_tensor(v[0]) else v) for k, v in batch_cpu.items()}
     frames = sum(batch['lengths'])
     rows = (frames + 199) // 200
     it = [0]
-
-    def step():
-        optim.zero_grad()
-        i = it[0] + 1
-        if i <= 500:
-            for gp in optim.param_groups:
-                gp['lr'] = i * 1e-3 / 500                                       # transduction_model.py:186-189
-        X = combine_fixed_length(batch['emg'], 200)
-        X_raw = combine_fixed_length(batch['raw_emg'], 1600)
-        sess = combine_fixed_length(batch['session_ids'], 200)
-        if dp is not None:
-            dp.begin_step(X_raw.shape[0] * 200, dp.local_target_frames(batch))
-        pred, aux = model(X, X_raw, sess)
-        total = dp.global_total(batch) if dp is not None else None
-        loss, _ = dtw_loss(pred, aux, batch, phoneme_loss_weight=0.5, total_length=total)
-        loss.backward()
-        if dp is not None:
-            dp.sync_gradients(model)
-        optim.step()
-        it[0] += 1
-        return loss
+    step = make_step(model, optim, batch, dp, it)
 
     for _ in range(args.warmup):
         loss = step()
@@ -340,7 +534,7 @@ def main():
         out = {
             'metric': 'EMG frames/s training (transduction_model.py)', 'value': total_frames * args.steps / elapsed, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': args.scaling if world > 1 else 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'configs[1]: full transduction model (768-d, 6-layer rel-pos encoder, 3 ResBlocks) training step '
                                    '(pack+fwd+dtw_loss incl. on-device DTW+bwd+AdamW), dropout 0.2, synthetic 8-ch EMG',
                        'frames_per_gpu_step': frames, 'rows_per_gpu_step': rows, 'utterances_per_gpu_step': len(batch['lengths']),
@@ -357,14 +551,21 @@ def main():
                 table[r.name.decode()] = dict(calls=int(r.calls), flops=float(r.flops), bytes=float(r.bytes), seconds=float(r.seconds))
             for k, v in prof.summary().items():
                 table[k] = v
-            pmc = {}
-            for fn in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            pmc, pmc_src, pmc_stale = {}, None, None
+            for fn in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
                 try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py)
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
                     pmc_src = 'profiles/' + fn
                     break
                 except Exception:
                     continue
+            # the counters belong to the kernels they were collected on: the file carries a fingerprint of csrc/ (tools/pmc_summary.py);
+            # when the sources have changed since, the figures are reported as stale and `traffic` stays null
+            here = csrc_fingerprint()
+            stamp = (pmc.get('_meta') or {}).get('csrc_fingerprint')
+            pmc_stale = stamp != here
+            if pmc_stale:
+                pmc = {}
             hints = {'gemm8_kc_kernel (288x256)': 'gemm8_kc_kernel<unsigned short, 9', 'gemm8_kc_kernel (256x256)': 'gemm8_kc_kernel<unsigned short, 8',
                      'gemm_dw_grouped': 'gemm8_dw_kernel', 'gemm_smallk_kernel (K <= 32, first conv)': 'gemm_smallk_kernel', 'gemm_w2_kernel (128|144 x 128)': 'gemm_w2_kernel', 'gemm_glds_kernel (128x128)': 'gemm_glds_kernel',
                      'attn_fwd': 'attn_fwd_res2_kernel', 'attn_bwd': ('attn_bwd_kv2_kernel', 'attn_bwd_q2_kernel', 'attn_dsum_kernel'), 'bn_stats': 'bn_partial_kernel', 'bn_apply': 'bn_apply_kernel',
@@ -380,7 +581,7 @@ def main():
                 tot, hit = 0.0, False
                 for h in hs:
                     for k, v in pmc.items():
-                        if h in k:
+                        if k != '_meta' and h in k:
                             tot += v.get('hbm_bytes_per_launch') or 0.0
                             hit = True
                             break
@@ -400,21 +601,30 @@ def main():
                                 'algorithmic_per_launch': (v['flops'] if mfma else v['bytes']) / v['calls'], 'traffic': traffic_of(name)})
             top = kernels[0]
             out['roofline'] = {'bound': top['bound'], 'achieved': top['achieved'], 'peak': top['peak'], 'unit': top['unit'], 'frac': top['frac'],
-                               'traffic': top['traffic'], 'traffic_source': pmc_src if pmc and top['traffic'] is not None else None, 'kernel': top['kernel'],
+                               'traffic': top['traffic'], 'traffic_source': pmc_src if pmc and top['traffic'] is not None else None,
+                               'traffic_stale': bool(pmc_stale), 'csrc_fingerprint': here, 'traffic_fingerprint': stamp, 'kernel': top['kernel'],
                                'launches_per_step': top['launches_per_step'], 'avg_launch_us': top['avg_launch_us'],
                                'algorithmic_per_launch': top['algorithmic_per_launch'], 'event_timed_steps': psteps,
                                'serial_kernel_ms_per_step': total_s / psteps * 1e3,
                                'timing': 'HIP events around every kernel launch (inside the native plan: ss_plan_profile; Python-launched kernels: '
                                          'torch events on the launch stream) on every 5th timed step; those steps run without the side stream '
-                                         '(exclusive durations); rocprofv3 counterpart: profiles/r02_serial_kernel_stats.txt',
+                                         '(exclusive durations); rocprofv3 counterpart: profiles/r03_serial_kernel_stats.txt',
                                'kernels': kernels[:16]}
         if world == 1 and args.cpu_rows > 0:
             base, sub, ref_pred = cpu_baseline(batch_cpu, args.cpu_rows, args.cpu_warmup, args.cpu_steps, init_sd, dev)
             out['cpu_baseline'] = base
             out['parity'] = parity_entry(sub, ref_pred, init_sd, dev)
+            if args.cpu_full:        # SURVEY 8d asks for the identical batch: the whole 110-row step once next to the bounded sample
+                full, _, _ = cpu_baseline(batch_cpu, 10 ** 9, 1, 2, init_sd, dev, want_pred=False)
+                out['cpu_baseline']['full_batch'] = {k: full[k] for k in ('value', 'unit', 'cores', 'sample')}
         if world == 1 and not args.no_legs:
             out['dtw'] = dtw_leg(dev)
+            out['dtw']['saturating'] = {k: v for k, v in dtw_leg(dev, nb=256).items() if k in ('workload', 'hip_ms', 'matrices_per_s', 'roofline', 'bit_exact_vs_oracle')}
             out['mel'] = mel_leg(dev)
+            out['fp32_mode'] = fp32_mode_leg(batch, init_sd, dev, frames)
+            out['ctc'] = ctc_leg(dev)
+            out['eval'] = eval_leg(dev)
+            out['pipeline'] = pipeline_leg(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -278,6 +278,11 @@ int ss_cast_f32(const float* in, void* out, int out_dtype, int64_t n, void* stre
  * mel targets: FeatureNormalizer only (read_emg.py:231).  In place is allowed. */
 int ss_soft_clip(const float* x, float* out, int64_t n, int C, const float* mean, const float* stdv, float pre_div, float limit, void* stream);
 
+/* combine_fixed_length (data_utils.py:158-167; call sites transduction_model.py:200-202) as ONE gather: concatenates n device
+ * blobs and zero-fills the tail of `out` (total_bytes).  table_dev = n source pointers followed by n + 1 cumulative byte offsets
+ * (int64 each, device memory); granule (16, 8, 4 or 1) must divide every offset, pointer and total_bytes. */
+int ss_concat_pad(const void* table_dev, int n, void* out, int64_t total_bytes, int granule, void* stream);
+
 /* mel target extraction (data_utils.py:39-62): reflect pad (:51); the STFT itself is ss_gemm against a
  * windowed DFT matrix with overlapping hop-strided rows; magnitude (:57); mel matmul + log clamp (:59-60)
  * is ss_gemm with epilogue.log_clamp. */

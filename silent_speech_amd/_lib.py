@@ -62,6 +62,7 @@ SIGNATURES = {
     'ss_dtw_align': [_P, _P, _I, _I, _I, _P, _P, _P],
     'ss_dtw_align_skewed': [_P, _I, _P, _P, _P],
     'ss_reflect_pad_ragged': [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
+    'ss_concat_pad': [_P, _I, _P, _L, _I, _P],
     'ss_dtw_cumulative': [_I, _P, _L, _L, _I, _I, _P, _P, _P],
     'ss_relpos_attention_forward': [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_relpos_attention_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],

@@ -160,6 +160,44 @@ extern "C" int ss_stft_magnitude(const float* spec, int64_t ld_spec, int n_bins,
     return 0;
 }
 
+// ---------------------------------------------------------------- packing utterances into fixed-length rows (data_utils.py:158-167)
+// combine_fixed_length = concatenate the utterances along time and zero-pad to a whole number of rows.  In bytes that is one gather:
+// output granule g belongs to the utterance u with off[u] <= g * G < off[u + 1] (binary search over the cumulative byte offsets) or to
+// the zero tail.  One launch instead of torch.cat over ~40 inputs + a padding tensor; G = 16, 8, 4 or 1 bytes, whatever every
+// utterance size and pointer is a multiple of.
+template <class V>
+__global__ void concat_pad_kernel(const unsigned long long* __restrict__ ptrs, const long long* __restrict__ offs, int n, V* __restrict__ out, long long total_granules)
+{
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total_granules; g += (long long)gridDim.x * blockDim.x) {
+        const long long byte = g * (long long)sizeof(V);
+        V v;
+        memset(&v, 0, sizeof(V));
+        if (byte < offs[n]) {
+            int lo = 0, hi = n - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (offs[mid] <= byte) lo = mid; else hi = mid - 1; }
+            v = *(const V*)((const unsigned char*)(uintptr_t)ptrs[lo] + (byte - offs[lo]));
+        }
+        out[g] = v;
+    }
+}
+// table_dev: [n] source pointers followed by [n + 1] cumulative byte offsets (int64 each); granule: 16 / 8 / 4 / 1
+extern "C" int ss_concat_pad(const void* table_dev, int n, void* out, int64_t total_bytes, int granule, void* stream)
+{
+    SS_CHECK(table_dev && out && n >= 1 && total_bytes >= 0, "ss_concat_pad: bad arguments");
+    SS_CHECK((granule == 16 || granule == 8 || granule == 4 || granule == 1) && total_bytes % granule == 0, "ss_concat_pad: granule must be 16, 8, 4 or 1 and divide the output size");
+    if (total_bytes == 0) return 0;
+    const unsigned long long* ptrs = (const unsigned long long*)table_dev;
+    const long long* offs = (const long long*)table_dev + n;
+    const long long tg = total_bytes / granule;
+    long long blocks = (tg + 255) / 256; if (blocks > 4096) blocks = 4096;
+    if (granule == 16) SS_LAUNCH(SS_KERNEL(concat_pad_kernel<u32x4>), dim3((unsigned)blocks), dim3(256), 0, stream, ptrs, offs, n, (u32x4*)out, tg);
+    else if (granule == 8) SS_LAUNCH(SS_KERNEL(concat_pad_kernel<u32x2>), dim3((unsigned)blocks), dim3(256), 0, stream, ptrs, offs, n, (u32x2*)out, tg);
+    else if (granule == 4) SS_LAUNCH(SS_KERNEL(concat_pad_kernel<unsigned>), dim3((unsigned)blocks), dim3(256), 0, stream, ptrs, offs, n, (unsigned*)out, tg);
+    else SS_LAUNCH(SS_KERNEL(concat_pad_kernel<unsigned char>), dim3((unsigned)blocks), dim3(256), 0, stream, ptrs, offs, n, (unsigned char*)out, tg);
+    SS_LAUNCH_CHECK("ss_concat_pad");
+    return 0;
+}
+
 // ---------------------------------------------------------------- ss_counters_add
 struct CounterPtrs { long long* p[16]; };
 __global__ void counters_add_kernel(CounterPtrs c, int n, long long delta) { const int i = threadIdx.x; if (i < n && c.p[i]) c.p[i][0] += delta; }

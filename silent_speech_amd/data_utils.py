@@ -181,16 +181,51 @@ class FeatureNormalizer(object):
         return sample * self.feature_stddevs + self.feature_means
 
 
+_pack_tables = {}          # signature of a list of device tensors -> device table of (pointers, cumulative byte offsets); a handful of entries
+
+
 def combine_fixed_length(tensor_list, length):
-    """data_utils.py:158-167: concatenate along time, zero-pad to a multiple of `length`, view as rows."""
-    total_length = sum(t.size(0) for t in tensor_list)
-    if total_length % length != 0:
-        pad_length = length - (total_length % length)
-        tensor_list = list(tensor_list)
-        tensor_list.append(torch.zeros(pad_length, *tensor_list[0].size()[1:], dtype=tensor_list[0].dtype, device=tensor_list[0].device))
-        total_length += pad_length
-    tensor = torch.cat(tensor_list, 0)
-    return tensor.view(total_length // length, length, *tensor.size()[1:])
+    """data_utils.py:158-167: the utterances back to back along time, zero-padded to a whole number of rows of `length` frames,
+    viewed as (rows, length, ...).  Device tensors are packed by ONE gather launch over an offset table (csrc/optim.hip
+    `ss_concat_pad`); the table is cached per list of (pointer, size), so a batch that is packed again costs no host-to-device
+    copy.  Host tensors (staging code, tests) are packed with plain slice copies."""
+    first = tensor_list[0]
+    trailing = tuple(first.shape[1:])
+    frames = sum(int(t.shape[0]) for t in tensor_list)
+    rows = (frames + length - 1) // length
+    out_shape = (rows, length) + trailing
+    on_device = first.is_cuda or _lib.is_emulator()          # emulator (tests): CPU tensors run the same kernel source
+    if not on_device:
+        out = torch.zeros((rows * length,) + trailing, dtype=first.dtype, device=first.device)
+        at = 0
+        for t in tensor_list:
+            out[at:at + t.shape[0]] = t
+            at += t.shape[0]
+        return out.view(out_shape)
+    ts = [t if t.is_contiguous() else t.contiguous() for t in tensor_list]
+    assert all(t.dtype == first.dtype and tuple(t.shape[1:]) == trailing for t in ts), 'utterances of one batch share dtype and feature shape'
+    row_bytes = first.element_size()
+    for d in trailing:
+        row_bytes *= int(d)
+    sizes = [int(t.shape[0]) * row_bytes for t in ts]
+    ptrs = [t.data_ptr() for t in ts]
+    total = rows * length * row_bytes
+    sig = (first.device, tuple(ptrs), tuple(sizes), total)
+    hit = _pack_tables.get(sig)
+    if hit is None:
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        gran = 16
+        while gran > 1 and (any(v % gran for v in sizes) or any(p % gran for p in ptrs) or total % gran):
+            gran //= 2
+        gran = 1 if gran == 2 else gran
+        table = torch.from_numpy(np.concatenate([np.asarray(ptrs, dtype=np.uint64).view(np.int64), offs])).to(first.device, non_blocking=True)
+        if len(_pack_tables) >= 16:
+            _pack_tables.clear()
+        hit = _pack_tables[sig] = (table, gran)              # the table holds exactly the pointers of the signature: valid whenever the signature matches
+    table, gran = hit
+    out = torch.empty(out_shape, dtype=first.dtype, device=first.device)
+    _lib.check(_lib.lib().ss_concat_pad(_lib.ptr(table), len(ts), _lib.ptr(out), total, gran, _lib.stream_of(out)), 'ss_concat_pad')
+    return out
 
 
 def decollate_tensor(tensor, lengths):

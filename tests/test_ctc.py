@@ -160,3 +160,74 @@ def test_recognition_bf16_tracks_reference():
     z, out = _recog_steps(torch.device('cuda'), torch.bfloat16)
     for b in range(2):
         assert abs(out['loss'][b] - float(z['loss/%d' % b])) < 2e-2 * abs(float(z['loss/%d' % b]))
+
+
+@pytest.mark.gpu
+def test_recognition_step_at_full_size_vs_oracle():
+    """BASELINE configs[4] at its real size: 768-d / 6-layer encoder with a 38-way output on one 128 000-sample batch (~55 rows of 200
+    frames, ~20 utterances of up to 860 frames with ~T/6 labels each).  Oracle: oracle/model_ref.model_forward + the reference's own
+    loss lines on torch CPU (recognition_model.py:96-101), two of the utterances re-checked with the f64 recursion of oracle/ctc_ref.py.
+    f32 kernels: logits 2e-4, loss 1e-4, every gradient tensor 3e-3 relative L2 / cosine 0.99999; bf16: loss within 2 %, recorded."""
+    import json
+    import torch.nn.functional as F
+    from oracle import ctc_ref, loss_ref, model_ref
+    from silent_speech_amd import _lib
+    from silent_speech_amd.architecture import Model
+    from silent_speech_amd.synthetic import reference_size_batch
+    from silent_speech_amd.transduction_model import _pack_batch
+    from tests.util import assert_close_robust, rel_l2_cos
+    _lib.load()
+    dev = torch.device('cuda')
+    torch.manual_seed(4)
+    m0 = Model(112, 38, model_size=768, num_layers=6, dropout=0.0, compute_dtype=torch.float32)
+    sd = {k: v.detach().clone() for k, v in m0.state_dict().items()}
+    batch = reference_size_batch(seed=3, budget=128000)
+    lens, text = batch['lengths'], batch['text_int']
+    # ---- oracle
+    ref = {k: v.clone() for k, v in sd.items()}
+    for v in ref.values():
+        if v.dtype == torch.float32:
+            v.requires_grad_(True)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    xr = loss_ref.combine_fixed_length(batch['raw_emg'], 1600)
+    logits_ref = model_ref.model_forward(ref, xr, training=True, shift_r=3, running_out={})
+    lp = F.log_softmax(logits_ref, 2)
+    lp = torch.nn.utils.rnn.pad_sequence(loss_ref.decollate_tensor(lp, lens), batch_first=False)
+    y = torch.nn.utils.rnn.pad_sequence(text, batch_first=True)
+    loss_ref_v = F.ctc_loss(lp, y, lens, [int(t.shape[0]) for t in text], blank=37)
+    loss_ref_v.backward()
+    flat = F.log_softmax(logits_ref.detach().double(), 2).reshape(-1, 38).numpy()
+    off = 0
+    for i, (T, t) in enumerate(zip(lens, text)):                  # torch's CTC == the f64 Graves recursion on the two shortest utterances
+        if T <= sorted(lens)[1]:
+            nll, _ = ctc_ref.ctc_utterance(flat[off:off + T], t.numpy(), 37)
+            want = float(F.ctc_loss(torch.from_numpy(flat[off:off + T]).unsqueeze(1), t.unsqueeze(0), [T], [int(t.shape[0])], blank=37, reduction='sum'))
+            assert abs(nll - want) < 1e-6 * abs(want)
+        off += T
+    rec = {}
+    for name, dt in (('fp32', torch.float32), ('bf16', torch.bfloat16)):
+        m = Model(112, 38, model_size=768, num_layers=6, dropout=0.0, compute_dtype=dt)
+        m.load_state_dict(sd, strict=True)
+        m.to(dev).train()
+        m.shift_rng = _FixedShift(3)
+        X, X_raw, sess = _pack_batch(batch, dev)
+        pred = m(X, X_raw, sess)
+        loss = rm.ctc_loss(pred, batch, blank=37)
+        loss.backward()
+        torch.cuda.synchronize()
+        figs = {n: rel_l2_cos(p.grad, ref[n].grad) for n, p in m.named_parameters() if not ('relative_positional' in n or _is_bn_bias(n))}
+        worst = max(figs, key=lambda n: figs[n][0])
+        rec[name] = {'loss': float(loss), 'loss_oracle': float(loss_ref_v), 'rows': int(pred.shape[0]), 'utterances': len(lens),
+                     'logit_max_err_over_max': float((pred.detach().float().cpu() - logits_ref.detach()).abs().max() / logits_ref.detach().abs().max()),
+                     'worst_grad': worst, 'worst_rel_l2': figs[worst][0], 'min_cos': min(c for _, c in figs.values())}
+        if dt == torch.float32:
+            assert_close_robust(pred, logits_ref.detach(), 2e-4, name='logits', max_outlier_frac=0)
+            assert abs(float(loss) - float(loss_ref_v)) < 1e-4 * abs(float(loss_ref_v))
+            for n, (rl2, cos) in figs.items():     # 3e-3: half as many frames as the transduction batch average the ReLU-kink flips of the conv stack less (measured 2.1e-3 on conv_blocks.0.conv1)
+                assert rl2 <= 3e-3 and cos >= 0.99999, (n, rl2, cos)
+        else:
+            assert abs(float(loss) - float(loss_ref_v)) < 2e-2 * abs(float(loss_ref_v))
+    out = os.path.join(os.path.dirname(__file__), '..', 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    json.dump(rec, open(os.path.join(out, 'ctc_fullsize_parity.json'), 'w'), indent=1)
+    print('ctc fullsize parity:', json.dumps(rec))

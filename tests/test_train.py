@@ -92,3 +92,25 @@ def test_fused_adamw_state_dict_round_trip():
     with pytest.raises(ValueError, match='one param group'):
         opt.add_param_group({'params': [torch.nn.Parameter(torch.zeros(1))]})
         opt.step()
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` end to end (rendezvous, DataParallel.attach, begin_step, bucketed all-reduce from the plan's events, barriers,
+    MAX / SUM reductions of the timing line, JSON) with two gloo ranks sharing the one GPU of the test box -- the driver's RCCL run is the
+    first time the nccl backend itself executes, everything around it has run here.  Weak and strong scaling."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    for scaling in ('weak', 'strong'):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, SS_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+        out = subprocess.check_output([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                                       '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                                       '--scaling', scaling, '--no-profile', '--no-legs'], env=env, timeout=600, stderr=subprocess.STDOUT).decode()
+        line = [l for l in out.splitlines() if l.startswith('{')][-1]
+        d = json.loads(line)
+        assert d['n_gpus'] == 2 and d['scaling'] == scaling and d['steps'] == 3 and d['value'] > 0
+        assert d['config']['parallelism'] == 'dp2' and d['config']['final_loss'] == d['config']['final_loss']

@@ -14,7 +14,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o pf -- python bench.py --st
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o pw -- python bench.py --steps 2 --warmup 1 --cpu-rows 0 --no-legs --no-profile > $O/pw.log 2>&1
 python tools/pmc_summary.py $(find $O/pf -name "*.db" | head -1) $(find $O/pw -name "*.db" | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt
 rm -rf $O/kt $O/ks $O/pf $O/pw
-cp $O/pmc_traffic.json profiles/r02_pmc_traffic.json            # the bench line's `traffic` fields come from THIS run's counters
+cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json            # the bench line's `traffic` fields come from THIS run's counters
 python bench.py > $O/bench.json.log 2>$O/bench.err
 bash tools/attn_trace.sh > /dev/null 2>&1; cp gpurun_out/attn_trace/kernel_stats.txt $O/attention_kernel_stats.txt
 bash tools/attn_pmc.sh > /dev/null 2>&1; cp gpurun_out/attn_pmc/table.txt $O/attention_sq_counters.txt

@@ -4,8 +4,11 @@
 exactly half of the bytes of a wide coalesced read stream, so it is doubled (WRITE_SIZE checked against AdamW: 12 B/param).
 usage: tools/pmc_summary.py <fetch.db> <write.db> [out.json]"""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 
 
 def per_kernel(db, counter):
@@ -24,4 +27,6 @@ for k in sorted(f, key=lambda k: -(f[k][1] * 2 + w.get(k, (0, 0))[1]) * f[k][0])
     out[k] = {'launches': f[k][0], 'read_bytes_per_launch': rd, 'write_bytes_per_launch': wr, 'hbm_bytes_per_launch': rd + wr}
     print('%-90s %7d %14.2f %14.2f %14.2f' % (k[:90], f[k][0], rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
 if len(sys.argv) > 3:
+    from bench import csrc_fingerprint          # the kernels these counters belong to: bench.py refuses the figures once csrc/ has changed
+    out['_meta'] = {'csrc_fingerprint': csrc_fingerprint(), 'counters': 'FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes, separate --pmc passes with --kernel-trace only'}
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
