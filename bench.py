@@ -413,7 +413,7 @@ def pipeline_leg(dev, n_utt=24):
         mel_ref.mel_spectrogram_ref(r['audio'][None])
     t_cpu = (time.perf_counter() - t0) * n_utt / k
     return {'workload': '%d recordings (%d frames): 8-filter zero-phase IIR cascade + resample + soft clip, batched STFT / mel / normalise -> batch dict' % (n_utt, frames),
-            'hip_ms': t_dev * 1e3, 'frames_per_s': frames / t_dev, 'includes': 'H2D of the raw recordings and audio (host arrays in), per-recording filter launches',
+            'hip_ms': t_dev * 1e3, 'frames_per_s': frames / t_dev, 'includes': 'H2D of the raw recordings and audio (host arrays in); ONE ragged filter / resample launch sequence and one DFT GEMM for the whole batch',
             'cpu_frames_per_s': frames / t_cpu, 'cpu_kind': 'oracle/filter_ref.py + oracle/mel_ref.py (numpy, 1 process; %d of %d recordings timed, scaled)' % (k, n_utt)}
 
 

@@ -339,6 +339,14 @@ int64_t ss_iir_filtfilt_workspace_bytes(int T, int C, int max_padlen); /* [host]
 int ss_iir_filtfilt(const double* x, double* y, int T, int C, int n_filt, const double* coef, void* workspace, int64_t workspace_bytes, void* stream);
 /* y[i] = np.interp(i / new_freq, arange(T) / old_freq, x[:, c]) for i < T_out (the caller sizes T_out = len(arange(0, (T-1)/old_freq, 1/new_freq))) */
 int ss_linear_resample(const double* x, double* y, int T, int C, double old_freq, double new_freq, int T_out, void* stream);
+/* The same for a RAGGED BATCH of recordings (one launch sequence for all of them): x / y are the recordings back to back, packed
+ * (sum T_u, C) f64; lengths_host = the R lengths (host memory, like coef).  Work items are (chunk, channel) pairs over all recordings. */
+int64_t ss_iir_filtfilt_batch_workspace_bytes(const int32_t* lengths_host, int R, int C, int max_padlen, int n_filt); /* [host] */
+int ss_iir_filtfilt_batch(const double* x, double* y, const int32_t* lengths_host, int R, int C, int n_filt, const double* coef,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+/* np.interp of every recording onto its own grid; table_dev: int64 [R][4] = {first input row, T, first output row, T_out}. */
+int ss_linear_resample_batch(const double* x, double* y, const int64_t* table_dev, int R, int C, double old_freq, double new_freq,
+                             int64_t total_out_rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The execution plan of the transduction model as native code: ONE call enqueues the whole forward pass of Model.forward

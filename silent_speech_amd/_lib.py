@@ -91,12 +91,15 @@ SIGNATURES = {
     'ss_reflect_pad': [_P, _P, _I, _I, _I, _L, _P],
     'ss_iir_filtfilt': [_P, _P, _I, _I, _I, _P, _P, _L, _P],
     'ss_linear_resample': [_P, _P, _I, _I, ctypes.c_double, ctypes.c_double, _I, _P],
+    'ss_iir_filtfilt_batch': [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P],
+    'ss_linear_resample_batch': [_P, _P, _P, _I, _I, ctypes.c_double, ctypes.c_double, _L, _P],
     'ss_stft_magnitude': [_P, _L, _I, _P, _L, _I, _P],
 }
 _LP = ctypes.POINTER(ctypes.c_int64)
 _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int64),
                'ss_bn_scratch_floats': ([_I, _I, _I], ctypes.c_int64),
                'ss_iir_filtfilt_workspace_bytes': ([_I, _I, _I], ctypes.c_int64),
+               'ss_iir_filtfilt_batch_workspace_bytes': ([_P, _I, _I, _I, _I], ctypes.c_int64),
                'ss_colsum_scratch_floats': ([_I, _I], ctypes.c_int64),
                'ss_gemm_set_blocks_per_cu': ([_I], ctypes.c_int),
                'ss_gemm_last_kernel': ([], ctypes.c_int),

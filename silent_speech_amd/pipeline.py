@@ -175,9 +175,9 @@ class DeviceBatchBuilder(object):
         parallel                    for silent recordings: the voiced twin (same dict shape); its audio features and phonemes become
                                     the targets (read_emg.py:242-256, collate_raw :268-271)
     Stages (each ONE launch sequence for the whole batch unless noted):
-        EMG   : context concat -> 7 notch harmonics + 2 Hz high-pass, zero-phase, f64 (csrc/filters.hip; per recording: the
-                recurrences are serial in time and recordings differ in length) -> crop -> np.interp to 689.06 Hz -> rows 8..8+8n
-                (:90) -> /20, 50 tanh(./50) (:227-228) for all utterances in one kernel
+        EMG   : context concat -> 7 notch harmonics + 2 Hz high-pass, zero-phase, f64 (csrc/filters.hip, ragged batch: work items are
+                (chunk, channel) pairs over all recordings) -> crop -> np.interp to 689.06 Hz -> rows 8..8+8n (:90) gathered by one
+                launch -> /20, 50 tanh(./50) (:227-228) in one kernel
         audio : clip + reflect pad (ragged) -> one hop-strided DFT GEMM -> |.| -> one mel GEMM + log clamp -> FeatureNormalizer, all
                 utterances at once (data_utils.mel_spectrogram_batch); truncation to n frames is a view
     The 112-d hand-crafted EMG features (`emg`, data_utils.py:92-136) are not inputs of the model (architecture.py:61 ignores
@@ -186,19 +186,20 @@ class DeviceBatchBuilder(object):
     def __init__(self, device, mfcc_norm=None, emg_norm=None, limit_length=False, sil_index=0):
         self.device, self.mfcc_norm, self.emg_norm, self.limit_length, self.sil_index = torch.device(device), mfcc_norm, emg_norm, limit_length, sil_index
 
-    # ---- EMG
-    def _filtered_689(self, rec):
-        from .read_emg import butter_highpass_coeffs, filtfilt_cascade, iirnotch_coeffs, subsample
+    # ---- EMG: every recording of the batch through ONE filter / resample launch sequence
+    def _filtered_689(self, recordings):
+        from .read_emg import butter_highpass_coeffs, filtfilt_cascade_batch, iirnotch_coeffs, subsample_batch
         dev = self.device
-        parts = [rec.get('raw_emg_before'), rec['raw_emg'], rec.get('raw_emg_after')]
-        ts = [torch.as_tensor(np.asarray(p) if not torch.is_tensor(p) else p).to(device=dev, dtype=torch.float64) for p in parts if p is not None and len(p)]
-        nb = 0 if parts[0] is None else len(parts[0])
-        na = 0 if parts[2] is None else len(parts[2])
-        x = torch.cat(ts, 0) if len(ts) > 1 else ts[0]
+        sigs, cuts = [], []
+        for rec in recordings:
+            parts = [rec.get('raw_emg_before'), rec['raw_emg'], rec.get('raw_emg_after')]
+            ts = [torch.as_tensor(np.asarray(p) if not torch.is_tensor(p) else p).to(device=dev, dtype=torch.float64) for p in parts if p is not None and len(p)]
+            cuts.append((0 if parts[0] is None else len(parts[0]), 0 if parts[2] is None else len(parts[2])))
+            sigs.append(torch.cat(ts, 0) if len(ts) > 1 else ts[0])                        # read_emg.py:66
         filters = [iirnotch_coeffs(60 * h, 30, 1000) for h in range(1, 8)] + [butter_highpass_coeffs(3, 2, 1000)]
-        x = filtfilt_cascade(filters, x)
-        x = x[nb:x.shape[0] - na]
-        return subsample(x, 689.06, 1000)
+        ys = filtfilt_cascade_batch(filters, sigs)                                         # :67-68
+        ys = [y[nb:y.shape[0] - na] for y, (nb, na) in zip(ys, cuts)]                      # :69
+        return subsample_batch(ys, 689.06, 1000)                                           # :70
 
     def _frames(self, rec, mel_frames, limit):
         n = min(_feature_frames(len(rec['raw_emg'])), mel_frames)
@@ -217,14 +218,17 @@ class DeviceBatchBuilder(object):
             _soft_clip(mel, mel, mel.shape[-1], mean, std, 1.0, 0.0)                       # FeatureNormalizer.normalize (read_emg.py:231), in place
         n_own = [self._frames(r, mframes[i], self.limit_length) for i, r in enumerate(recordings)]
         # raw EMG: filter every recording, gather rows 8 .. 8 + 8 n into ONE buffer, soft-clip it in one launch
-        total = sum(8 * n for n in n_own)
-        raw = torch.empty(total, 8, dtype=torch.float32, device=dev)
-        off, raw_views = 0, []
-        for r, n in zip(recordings, n_own):
-            e = self._filtered_689(r)
+        e689 = self._filtered_689(recordings)
+        for e, n in zip(e689, n_own):
             if e.shape[0] < 8 + 8 * n:
                 raise ValueError('recording too short: %d model-rate samples for %d frames' % (e.shape[0], n))
-            raw[off:off + 8 * n].copy_(e[8:8 + 8 * n])                                      # read_emg.py:90 (+ .astype(np.float32), :100)
+        # rows 8 .. 8 + 8 n of every recording (read_emg.py:90), as f32 (:100), gathered into ONE buffer by one launch
+        e32 = e689[0]._base.to(torch.float32) if e689[0]._base is not None else torch.cat(e689, 0).to(torch.float32)
+        offs = np.concatenate([[0], np.cumsum([int(e.shape[0]) for e in e689])])
+        from .data_utils import combine_fixed_length
+        raw = combine_fixed_length([e32[offs[u] + 8:offs[u] + 8 + 8 * n] for u, n in enumerate(n_own)], 1).view(-1, 8)
+        off, raw_views = 0, []
+        for n in n_own:
             raw_views.append(raw[off:off + 8 * n])
             off += 8 * n
         _soft_clip(raw, raw, 8, None, None, 20.0, 50.0)                                     # read_emg.py:227-228

@@ -128,6 +128,49 @@ def filtfilt_cascade(filters, signal):
     return restore(y)
 
 
+def filtfilt_cascade_batch(filters, signals):
+    """filtfilt_cascade for a RAGGED BATCH: `signals` = list of (T_u, C) f64 device tensors of different lengths -> list of filtered
+    tensors (views of one packed buffer).  One launch sequence for all recordings (8 launches per filter + 1), instead of one per
+    recording: the recurrences are serial in time, so the parallelism is (chunks x channels) and a batch supplies many more of them."""
+    dev = signals[0].device
+    C = int(signals[0].shape[1])
+    lens = np.asarray([int(t.shape[0]) for t in signals], dtype=np.int32)
+    x = torch.cat([t.to(torch.float64) for t in signals], 0).contiguous() if len(signals) > 1 else signals[0].to(torch.float64).contiguous()
+    coef = _pack_filters(filters)
+    maxpad = int(coef[:, 12].max())
+    if int(lens.min()) <= maxpad:
+        raise ValueError('The length of the input vector x must be greater than padlen, which is %d.' % maxpad)
+    L = _lib.lib()
+    lp = lens.ctypes.data_as(ctypes.c_void_p)
+    nbytes = int(L.ss_iir_filtfilt_batch_workspace_bytes(lp, len(signals), C, maxpad, coef.shape[0]))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    y = torch.empty_like(x)
+    rc = L.ss_iir_filtfilt_batch(_lib.ptr(x), _lib.ptr(y), lp, len(signals), C, coef.shape[0], coef.ctypes.data_as(ctypes.c_void_p), _lib.ptr(ws), nbytes, _lib.stream_of(x))
+    _lib.check(rc, 'ss_iir_filtfilt_batch')
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    return [y[offs[u]:offs[u + 1]] for u in range(len(signals))]
+
+
+def resampled_length(T, new_freq, old_freq):
+    """len(np.arange(0, (T - 1) / old_freq, 1 / new_freq)): the number of samples read_emg.py:40-44 produces."""
+    return len(np.arange(0, (T - 1) / old_freq, 1 / new_freq))
+
+
+def subsample_batch(signals, new_freq, old_freq):
+    """subsample() for a list of (T_u, C) f64 device tensors in ONE launch -> list of (T_out_u, C) views of one packed buffer."""
+    dev = signals[0].device
+    C = int(signals[0].shape[1])
+    lens = [int(t.shape[0]) for t in signals]
+    outs = [resampled_length(T, new_freq, old_freq) for T in lens]
+    x = torch.cat(signals, 0).contiguous() if len(signals) > 1 else signals[0].contiguous()
+    io, oo = np.concatenate([[0], np.cumsum(lens)]), np.concatenate([[0], np.cumsum(outs)])
+    table = torch.from_numpy(np.stack([io[:-1], lens, oo[:-1], outs], 1).astype(np.int64)).to(dev, non_blocking=True)
+    y = torch.empty(int(oo[-1]), C, dtype=torch.float64, device=dev)
+    rc = _lib.lib().ss_linear_resample_batch(_lib.ptr(x), _lib.ptr(y), _lib.ptr(table), len(signals), C, float(old_freq), float(new_freq), int(oo[-1]), _lib.stream_of(x))
+    _lib.check(rc, 'ss_linear_resample_batch')
+    return [y[oo[u]:oo[u + 1]] for u in range(len(signals))]
+
+
 def remove_drift(signal, fs):
     return filtfilt_cascade([butter_highpass_coeffs(3, 2, fs)], signal)
 

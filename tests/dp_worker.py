@@ -25,11 +25,11 @@ def make_batch(seed_list):
     return SyntheticEMGDataset.collate_raw(items)
 
 
-UTTS = [(1, 40, False), (2, 80, True), (3, 80, False), (4, 40, True), (5, 80, False), (6, 40, True), (7, 40, False), (8, 80, True)]
-# whole rows of 40 frames -> per-rank rows == global rows; 8 utterances deal evenly to 1, 2 and 4 ranks
+UTTS = [(1, 24, False), (2, 48, True), (3, 48, False), (4, 24, True), (5, 48, False), (6, 24, True), (7, 24, False), (8, 48, True)]
+# whole rows of 24 frames -> per-rank rows == global rows; 8 utterances deal evenly to 1, 2 and 4 ranks
 
 
-def run_step(model, batch, dp, seq_len=40):
+def run_step(model, batch, dp, seq_len=24):
     from silent_speech_amd.data_utils import combine_fixed_length
     from silent_speech_amd.transduction_model import dtw_loss
     X_raw = combine_fixed_length(batch['raw_emg'], seq_len * 8)

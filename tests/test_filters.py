@@ -119,3 +119,26 @@ def test_long_recording_on_gpu():
     assert np.abs(y[:, :2] - want).max() < TOL_DRIFT
     y2 = R.condition_raw_emg_recording(2.0 * x + 1000.0)[0]                    # linear, and a constant is removed entirely
     assert np.abs(y2 - 2.0 * y).max() < 1e-6
+
+
+def test_ragged_batch_equals_per_recording(dev):
+    """ss_iir_filtfilt_batch / ss_linear_resample_batch: all recordings of a batch through one launch sequence.  Chunk boundaries are
+    relative to each recording's own extended signal, so the results are bit-identical to the one-recording entry points -- and
+    therefore within the same bounds of the reference's golden chain."""
+    from silent_speech_amd import read_emg as rd
+    xs = [torch.from_numpy(GOLD[t + '/x'].astype(np.float64)).to(dev) for t in ['short', 'mid', 'short']]
+    xs[-1] = xs[-1][: xs[-1].shape[0] - 7].contiguous()                 # a length none of the others has
+    if dev.type != 'cpu':                                               # many chunks per recording, chunk counts that differ between recordings
+        rng = np.random.default_rng(8)
+        xs += [torch.from_numpy(np.cumsum(rng.standard_normal((n, 8)), 0) * 3.0).to(dev) for n in (20000, 5121, 1024)]
+    filters = [rd.iirnotch_coeffs(60 * h, 30, 1000) for h in range(1, 8)] + [rd.butter_highpass_coeffs(3, 2, 1000)]
+    ys = rd.filtfilt_cascade_batch(filters, xs)
+    for x, y in zip(xs, ys):
+        assert torch.equal(y, rd.filtfilt_cascade(filters, x))
+    assert np.abs(ys[1].cpu().numpy() - GOLD['mid/chain']).max() < TOL_DRIFT
+    rs = rd.subsample_batch(ys, 689.06, 1000)
+    for y, r in zip(ys, rs):
+        assert torch.equal(r, rd.subsample(y, 689.06, 1000))
+    assert np.array_equal(rd.subsample_batch([torch.from_numpy(GOLD['mid/chain']).to(dev)], 689.06, 1000)[0].cpu().numpy(), GOLD['mid/emg_orig'])
+    with pytest.raises(ValueError, match='padlen'):
+        rd.filtfilt_cascade_batch(filters, [xs[0], xs[0][:9]])
