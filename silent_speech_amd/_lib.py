@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'lib', 'libsilent_speech_hip.so')
+_LIB_PATH = os.environ.get('SS_AMD_LIBRARY') or os.path.join(_HERE, 'lib', 'libsilent_speech_hip.so')      # override: A/B runs of two builds on one box
 
 SS_F32, SS_BF16, SS_F64 = 0, 1, 2
 ABI_VERSION = 3          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)

@@ -641,7 +641,8 @@ extern "C" int ss_gemm_set_blocks_per_cu(int n) { int old = g_blocks_per_cu; if 
 //   1 SS_GEMM_W2_BM  force its tile height (128 / 144), 0 = cost model
 //   2 SS_GEMM8       8-wave 256/288 x 256 kernel: 0 never, 1 cost model, 2 whenever legal
 //   3 SS_GEMM8_NI    force its tile height in 16-row units per M-wave (8 / 9), 0 = cost model
-//   4 SS_GEMM8_PIN   bit 0: its fragment reads, bit 1: its DMA pieces spread between the MFMA groups (else a burst per phase); 4 = per tile height
+//   4 SS_GEMM8_PIN   bit 0: its fragment reads, bit 1: its DMA pieces spread between the MFMA groups (else a burst per phase); bits 2..3: 16-row
+//                    tiles per phase (0: three / four, 1: one, 2: two); 16 = chosen per shape
 //   5 SS_GEMM_DEBUG  ablation mask for tuning (results are then wrong): 1 no flush stores, 2 no epilogue staging, 4 no MFMA (128-wide
 //                    kernels); 16 no MFMA, 32 no in-loop global->LDS copies, 64 no in-loop fragment reads, 128 no C flush (8-wave kernel)
 //   6 SS_GEMM_SMALLK the LDS-free K <= 32 kernel (gemm_smallk.hip): 0 never, 1 whenever legal
@@ -649,7 +650,7 @@ enum { OPT_W2 = 0, OPT_W2_BM, OPT_G8, OPT_G8_NI, OPT_G8_PIN, OPT_DEBUG, OPT_SMAL
 static int g_opt[OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1};
 static int gemm_opt(int what) {
     static const char* names[OPT_COUNT] = {"SS_GEMM_W2", "SS_GEMM_W2_BM", "SS_GEMM8", "SS_GEMM8_NI", "SS_GEMM8_PIN", "SS_GEMM_DEBUG", "SS_GEMM_SMALLK"};
-    static const int defaults[OPT_COUNT] = {1, 0, 1, 0, 4, 0, 1};
+    static const int defaults[OPT_COUNT] = {1, 0, 1, 0, 16, 0, 1};
     if (g_opt[what] < 0) { const char* e = getenv(names[what]); g_opt[what] = e ? atoi(e) : defaults[what]; }
     return g_opt[what];
 }
@@ -704,10 +705,11 @@ static bool pick_gemm8(bool bf16_in, int a_mode, int b_mode, int M, int N, int K
     }
     const double cost_old = 6.0 + 2.0 * M * N * K / ((K <= 1024 ? 560.0 : 680.0) * 1e6);
     if (!ni || !(gemm_opt(OPT_G8) == 2 || best8 < cost_old)) return false;
-    // spreading the fragment reads / DMA pieces between the MFMA groups pays on the 256-row tiles (+12 %); the 288-row variant of it
-    // spills (144 accumulator registers) and loses on multi-tile shapes
+    // Spreading the fragment reads / DMA pieces between the MFMA groups (PIN = 3) is the default for both tile heights: since the
+    // steady K steps are one straight-line block with scalar-base copies (gemm8.hip) the 288-row variant no longer spills in the loop and
+    // beats the burst schedule by 0..16 % depending on the shape and the box (tools/gemm_bench.cpp: 22 000 x 768 x 3072 96 vs 113 us).
     *ni_out = ni;
-    *pin_out = gemm_opt(OPT_G8_PIN) >= 0 && gemm_opt(OPT_G8_PIN) <= 3 ? gemm_opt(OPT_G8_PIN) : (ni == 8 ? 3 : 0);
+    *pin_out = gemm_opt(OPT_G8_PIN) >= 0 && gemm_opt(OPT_G8_PIN) <= 15 ? gemm_opt(OPT_G8_PIN) : 3;
     return true;
 }
 

@@ -51,6 +51,25 @@ struct Stage {
         int p = I * 8 + wave; p = p < PIECES ? p : p - 8;
         glds16(base_k + off[I], tile + p * 1024);
     }
+    // The same copy with the address split the way the hardware takes it: a wave-uniform 64-bit base in SGPRs (operand base + K
+    // offset), this lane's 32-bit byte offset in ONE VGPR, and M0 = LDS address of the wave's slot + an immediate.  Left to the
+    // compiler the copy carried a 64-bit VGPR address (a v_lshl_add_u64 per piece and 2 registers per offset) and one hoisted SGPR per
+    // piece for M0 -- 9 live scalars that were spilled to VGPR lanes and came back through v_readlane inside the K loop.
+    // slot = LDS byte address of (tile + wave * 1024); slot_last = the same for the last piece group (waves beyond it repeat their previous piece).
+    template <int I>
+    __device__ __forceinline__ void issue_one_s(const unsigned char* base_k, unsigned char* tile, int wave, unsigned slot, unsigned slot_last) {
+#if defined(SS_EMU)
+        (void)slot; (void)slot_last;
+        issue_one<I>(base_k, tile, wave);
+#else
+        (void)tile; (void)wave;
+        constexpr bool LASTG = (I + 1 == NP) && (PIECES % 8 != 0);
+        if constexpr (LASTG) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(slot_last), "v"(off[I]), "s"(base_k) : "memory", "m0");
+        else asm volatile("s_add_i32 m0, %0, %1\n\tglobal_load_lds_dwordx4 %2, %3" : : "s"(slot), "n"(I * 8192), "v"(off[I]), "s"(base_k) : "memory", "m0");
+#endif
+    }
+    // slot_last relative to the tile: piece (NP - 1) * 8 + wave when it exists, else the wave's previous piece
+    __device__ __forceinline__ static unsigned last_piece_off(int wave) { int p = (NP - 1) * 8 + wave; p = p < PIECES ? p : p - 8; return (unsigned)p * 1024u; }
 };
 
 __device__ __forceinline__ void tile_coord(int it, int G, int nitems, int tiles_n, int& mt, int& nt) {
@@ -66,7 +85,11 @@ __device__ __forceinline__ void barrier_all() {
 #if defined(SS_EMU)
     __syncthreads();
 #else
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // the wait as a BUILTIN: the compiler's own wait insertion then knows that nothing it issued (register reloads, ...) is pending
+    // behind this point, and places no s_waitcnt vmcnt(0) of its own inside the K loop -- where it would also drain the copies of the next
+    // K tile (issued from asm, invisible to it) a few instructions after their issue
+    __builtin_amdgcn_s_waitcnt(0);
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #endif
 }
@@ -94,8 +117,9 @@ __device__ __forceinline__ void lds_read128_async(bf16x8& d, const unsigned char
 template <int N>
 __device__ __forceinline__ void lds_wait_pin(bf16x8 (&f)[N]) {
 #if !defined(SS_EMU)
-    static_assert(N >= 2 && N <= 4, "fragment set size");
-    if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
+    static_assert(N >= 1 && N <= 4, "fragment set size");
+    if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]));
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
     else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]));
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
 #endif
@@ -176,7 +200,8 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
 {
     using namespace g8;
     constexpr int BMT = 2 * NI * 16, STAGE = (BMT + TBN) * RB;
-    constexpr int HR = NI % 3 == 0 ? 3 : 4;                 // 16-row MFMA tiles per phase
+    constexpr int HRSEL = PIN >> 2;                         // PIN bits 2..3: rows of 16 per phase -- 0: 3 or 4, 1: one, 2: two (even NI)
+    constexpr int HR = HRSEL == 1 ? 1 : (HRSEL == 2 && NI % 2 == 0 ? 2 : (NI % 3 == 0 ? 3 : 4));                 // 16-row MFMA tiles per phase
     constexpr int NPK = NI / HR, NPH = 2 * NPK;             // phases per K half / per K step (even: the ping-pong parity carries over)
     static_assert(NI % HR == 0 && NPH % 2 == 0, "phase split");
     SS_DYN_SMEM(lds_raw);
@@ -204,6 +229,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
 #else
     const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);      // LDS byte address of the dynamic segment
 #endif
+    const unsigned wslot = (unsigned)wave * 1024u;                                 // this wave's 1 KiB slot inside an 8-piece group of a stage
     int it = blockIdx.x, mt, nt, cur = 0;
     tile_coord(it, G, nitems, tiles_n, mt, nt);
     int m0 = mt * BMT, n0 = nt * TBN;
@@ -237,8 +263,9 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
         };
         auto dma = [&](auto kc, long long kbyte, unsigned st) {      // piece k of the K tile at byte offset kbyte -> stage at st
             constexpr int k = kc;
-            if constexpr (k < SA_NP) sa.template issue_one<k>((const unsigned char*)A + kbyte, lds + st, wave);
-            else if constexpr (k < NPW) sb.template issue_one<k - SA_NP>((const unsigned char*)B + kbyte, lds + st + BMT * RB, wave);
+            if constexpr (k < SA_NP) sa.template issue_one_s<k>((const unsigned char*)A + kbyte, lds + st, wave, lbase + st + wslot, lbase + st + Stage<BMT>::last_piece_off(wave));
+            else if constexpr (k < NPW) sb.template issue_one_s<k - SA_NP>((const unsigned char*)B + kbyte, lds + st + BMT * RB, wave, lbase + st + BMT * RB + wslot,
+                                                                            lbase + st + BMT * RB + Stage<TBN>::last_piece_off(wave));
         };
         auto mfma_row = [&](auto phc, auto xc) {
             constexpr int ph = phc, x = xc, kk = ph / NPK, i = (ph % NPK) * HR + x;
@@ -248,19 +275,23 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
         // One phase = HR groups of {a share of the NEXT phase's fragment reads, a share of a DMA chunk, 4 MFMAs}, then ONE wait for
         // the fragments requested in it.  PIN = 0: reads and DMA in a burst at the phase start (every wave queues behind the LDS /
         // TA pipes before its first MFMA: measured +0.35 us per K tile each); PIN = 1: spread between the MFMA groups.
-        //   DMA chunks of K tile t: chunk 0 right after the mid-step barrier of step t-2 (last phase), chunks 1.. in phases 0..
-        //   of step t-1, all of them >= 3 phases ahead of the barrier (step t-1, last phase) that waits for them.
-        auto phase = [&](auto phc, const unsigned S, const unsigned O, const int s) {
+        //   DMA chunks of K tile t: chunk 0 right after the mid-step barrier of step t-2 (last phase; for tile 1: right after the barrier
+        //   in front of step 0), chunks 1.. in phases 0.. of step t-1, all of them >= 3 phases ahead of the barrier (step t-1, last phase)
+        //   that waits for them.
+        // STEADY (compile time): K step s with s + 2 < nsteps -- every condition below is true, the step is ONE basic block
+        // up to its barrier (with the conditions evaluated at run time each MFMA group of a spread phase became its own block, and the
+        // compiler re-materialised addresses and spilled around the branches)
+        auto phase = [&](auto phc, auto steady_c, const unsigned S, const unsigned O, const int s) {
             constexpr int ph = phc, nx = ph + 1 < NPH ? ph + 1 : 0;
-            constexpr bool last = ph + 1 == NPH;
+            constexpr bool last = ph + 1 == NPH, STEADY = steady_c;
             constexpr int chunk = last ? 0 : ph + 1;
             bool rd = true, dm = false; unsigned rst = S, dst = 0; long long kb = 0;
             if constexpr (last) {
-                if (s + 1 < nsteps) {
+                if (STEADY || s + 1 < nsteps) {
                     barrier_all();               // every wave holds its last fragments of stage S; K tile s+1 has landed in O
-                    rst = O; dm = s + 2 < nsteps && !(ABL & 2); kb = (long long)(s + 2) * BK8 * 2; dst = S;
+                    rst = O; dm = (STEADY || s + 2 < nsteps) && !(ABL & 2); kb = (long long)(s + 2) * BK8 * 2; dst = S;
                 } else rd = false;
-            } else if constexpr (chunk < NCH) { dm = s >= 1 && s + 1 < nsteps && !(ABL & 2); kb = (long long)(s + 1) * BK8 * 2; dst = O; }
+            } else if constexpr (chunk < NCH) { dm = (STEADY || s + 1 < nsteps) && !(ABL & 2); kb = (long long)(s + 1) * BK8 * 2; dst = O; }
             if (ABL & 4) rd = false;
             static_for<0, HR>([&](auto xc) {
                 constexpr int x = xc;
@@ -281,15 +312,16 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             sched_fence();
         };
         barrier_all();                                       // K tile 0 of this item has landed in stage `cur`; stage cur^1 is free
-        if (nsteps > 1) { sa.issue((const unsigned char*)A + BK8 * 2, lds + (cur ^ 1) * STAGE, wave); sb.issue((const unsigned char*)B + BK8 * 2, lds + (cur ^ 1) * STAGE + BMT * RB, wave); }
+        // chunk 0 of K tile 1 (its other chunks follow from the phases of step 0, like those of every later tile)
+        if (nsteps > 1 && !(ABL & 2)) static_for<0, (NCH > 1 ? CS : NPW)>([&](auto k) { dma(k, (long long)BK8 * 2, (unsigned)((cur ^ 1) * STAGE)); });
         static_for<0, HR>([&](auto x) { read_a(std::integral_constant<int, 0>{}, x, (unsigned)(cur * STAGE)); });
         static_for<0, 4>([&](auto j) { read_b(std::integral_constant<int, 0>{}, j, (unsigned)(cur * STAGE)); });
         wait_frags(std::integral_constant<int, 0>{});
         sched_fence();
-        for (int s = 0; s < nsteps; ++s) {
-            const unsigned S = cur * STAGE, O = (cur ^ 1) * STAGE;
-            static_for<0, NPH>([&](auto ph) { phase(ph, S, O, s); });
-            cur ^= 1;
+        {   // steady steps 0 .. nsteps - 3 (straight-line body, every condition of a phase true at compile time) | the last two steps
+            int s = 0;
+            for (; s + 2 < nsteps; ++s) { const unsigned S = cur * STAGE, O = (cur ^ 1) * STAGE; static_for<0, NPH>([&](auto ph) { phase(ph, std::true_type{}, S, O, s); }); cur ^= 1; }
+            for (; s < nsteps; ++s) { const unsigned S = cur * STAGE, O = (cur ^ 1) * STAGE; static_for<0, NPH>([&](auto ph) { phase(ph, std::false_type{}, S, O, s); }); cur ^= 1; }
         }
         // `cur` names the stage the last K tile did NOT use (free since the previous mid-step barrier): the next item's first
         // K tile goes there while this item's C tile leaves through the other stage
@@ -372,8 +404,17 @@ int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int 
         SS_LAUNCH(SS_KERNEL(gemm8_kc_kernel<TO, NI_, PIN_, ABL_, ST_>), grid, block, smem, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, tiles_n, nitems); \
     } while (0)
     const int abl = (epi.debug >> 4) & 7;
-    if (epi.col_sum) {                      // column statistics: the burst schedule (fewest live registers) of either tile height
-        if (ni == 9) G8_CASE(9, 0, 0, true); else G8_CASE(8, 0, 0, true);
+#if defined(G8_FAST_BUILD)        // tuning builds: three bf16-out main-loop variants only (a full build of this file takes minutes)
+    if constexpr (sizeof(TO) == 2) {
+        if (ni == 9) { switch (pin) { case 3: G8_CASE(9, 3, 0, false); break; case 4: G8_CASE(9, 4, 0, false); break; case 7: G8_CASE(9, 7, 0, false); break; default: G8_CASE(9, 0, 0, false); } }
+        else { switch (pin) { case 7: G8_CASE(8, 7, 0, false); break; case 11: G8_CASE(8, 11, 0, false); break; default: G8_CASE(8, 3, 0, false); } }
+        SS_LAUNCH_CHECK("ss_gemm(gemm8)");
+        return 0;
+    } else { ss_set_error("gemm8: tuning build"); return 1; }
+#else
+    if (epi.col_sum) {                      // column statistics: burst or spread schedule of either tile height
+        if (ni == 9) { if (pin & 3) G8_CASE(9, 3, 0, true); else G8_CASE(9, 0, 0, true); }
+        else { if (pin & 3) G8_CASE(8, 3, 0, true); else G8_CASE(8, 0, 0, true); }
     }
     else if (abl && sizeof(TO) == 2) {      // tuning builds only (bf16 out): which of MFMA / DMA / fragment reads bounds the loop
         if (ni == 9) { switch (abl) { case 1: G8_CASE(9, 0, 1, false); break; case 2: G8_CASE(9, 0, 2, false); break; case 4: G8_CASE(9, 0, 4, false); break; case 5: G8_CASE(9, 0, 5, false); break; case 6: G8_CASE(9, 0, 6, false); break; default: G8_CASE(9, 0, 7, false); } }
@@ -381,9 +422,10 @@ int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int 
     }
     else if (ni == 9) { switch (pin) { case 1: G8_CASE(9, 1, 0, false); break; case 2: G8_CASE(9, 2, 0, false); break; case 3: G8_CASE(9, 3, 0, false); break; default: G8_CASE(9, 0, 0, false); } }
     else { switch (pin) { case 1: G8_CASE(8, 1, 0, false); break; case 2: G8_CASE(8, 2, 0, false); break; case 3: G8_CASE(8, 3, 0, false); break; default: G8_CASE(8, 0, 0, false); } }
-#undef G8_CASE
     SS_LAUNCH_CHECK("ss_gemm(gemm8)");
     return 0;
+#endif
+#undef G8_CASE
 }
 template int gemm8_launch_kc<bf16_t>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*);
 template int gemm8_launch_kc<float>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*);

@@ -68,7 +68,7 @@ static void bench_kc(const char* tag, int M, int N, int K, int iters, bool relu_
     float t = time_us(iters, run_kc, &a);
     printf("%-10s M=%6d N=%5d K=%5d  %-14s kernel %d  %8.1f us  %7.1f TF\n", tag, M, N, K, "128-wide", ss_gemm_last_kernel(), t, flops / t / 1e6);
     for (int ni = 8; ni <= 9; ++ni)
-        for (int pin = 0; pin <= 3; ++pin) {
+        for (int pin = 0; pin <= 3; pin += 3) {              // burst / spread schedule
             ss_gemm_set_option(2, 2); ss_gemm_set_option(3, ni); ss_gemm_set_option(4, pin);
             a.C = Cnew; CK(hipMemset(Cnew, 0xff, (size_t)M * N * 2));
             t = time_us(iters, run_kc, &a);
