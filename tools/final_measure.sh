@@ -19,4 +19,6 @@ python bench.py > $O/bench.json.log 2>$O/bench.err
 bash tools/attn_trace.sh > /dev/null 2>&1; cp gpurun_out/attn_trace/kernel_stats.txt $O/attention_kernel_stats.txt
 bash tools/attn_pmc.sh > /dev/null 2>&1; cp gpurun_out/attn_pmc/table.txt $O/attention_sq_counters.txt
 ./tools/bin/attn_bench > $O/attention_bench.txt 2>&1
-cat $O/pytest_gpu.log; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/attention_bench.txt
+./tools/bin/mfma_peak 4000 > $O/mfma_peak.txt 2>&1
+./tools/bin/gemm_bench 20 > $O/gemm_bench.txt 2>&1
+cat $O/pytest_gpu.log; cat $O/mfma_peak.txt; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/attention_bench.txt

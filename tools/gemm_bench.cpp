@@ -117,13 +117,13 @@ static void bench_dw(const char* tag, int rows, int n, const int (*mn)[2], int i
     float t_old = time_us(iters, run_dw_old, &b);
     printf("%-10s rows=%6d jobs=%d  %-22s %8.1f us  %7.1f TF\n", tag, rows, n, "128-wide TR, per GEMM", t_old, flops / t_old / 1e6);
     const int splits[3] = {0, 1, 2};
-    for (int si = 0; si < 3; ++si) {
-        ss_gemm_dw_set_option(0, splits[si]);
+    for (int pin = 0; pin < 2; ++pin) {                 // compiler order / reads fenced in front of the MFMAs of a K half
+        ss_gemm_dw_set_option(1, pin);
         float t = time_us(iters, run_dw_grouped, &a);
-        char name[40]; snprintf(name, sizeof name, "grouped split%d", splits[si]);
+        char name[40]; snprintf(name, sizeof name, "grouped pin%d", pin);
         printf("%-10s rows=%6d jobs=%d  %-22s %8.1f us  %7.1f TF\n", tag, rows, n, name, t, flops / t / 1e6);
     }
-    ss_gemm_dw_set_option(0, 0);
+    ss_gemm_dw_set_option(1, 1);
     // cross-check one accumulation of each (buffers re-zeroed)
     for (int i = 0; i < n; ++i) { CK(hipMemset(a.jobs[i].C, 0, (size_t)a.jobs[i].M * a.jobs[i].N * 4)); CK(hipMemset(b.jobs[i].C, 0, (size_t)a.jobs[i].M * a.jobs[i].N * 4)); }
     run_dw_grouped(&a); run_dw_old(&b); CK(hipDeviceSynchronize());
