@@ -154,7 +154,12 @@ int ss_permute3d_batch(const void* jobs_dev, const int32_t* job_of_block_dev, in
  *    `results`), 0}.
  * results[res_off + i], i < N: the reference's `results` list (smallest j visited in row i; 0 for
  * row 0 and for degenerate 1xM / Nx1 inputs).  Bit-exact: f32, one add per cell, first-minimum tie
- * order (up, left, diag).  The cumulative matrix itself is never written (2-bit directions are). */
+ * order (up, left, diag).  The cumulative matrix itself is never written (2-bit directions are).
+ * Where the recurrence takes its costs from is decided per matrix (ss_dtw_source): a matrix with one unit-stride axis of at most 1025
+ * cells is read IN PLACE (2: row-major -- the lanes own columns, the kernel sweeps the transposed problem; 1: column-major, e.g. the
+ * costs.T view of transduction_model.py:126 -- the lanes own rows); anything else (0: both strides > 1, a unit-stride axis longer than
+ * one strip, fewer than 5 cells on it) is first copied into skewed strips inside `workspace`. */
+int ss_dtw_source(int n, int m, int64_t stride_i, int64_t stride_j); /* [host] */
 int64_t ss_dtw_workspace_bytes(int n, int m, int64_t* sk_bytes, int64_t* dirs_bytes, int64_t* bnd_bytes); /* [host] */
 int ss_dtw_align(const float* costs, const int64_t* desc_dev, int n, int max_n, int max_m, void* workspace,
                  int32_t* results, void* stream);

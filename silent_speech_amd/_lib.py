@@ -97,6 +97,7 @@ SIGNATURES = {
 }
 _LP = ctypes.POINTER(ctypes.c_int64)
 _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int64),
+               'ss_dtw_source': ([_I, _I, _L, _L], ctypes.c_int),
                'ss_bn_scratch_floats': ([_I, _I, _I], ctypes.c_int64),
                'ss_iir_filtfilt_workspace_bytes': ([_I, _I, _I], ctypes.c_int64),
                'ss_iir_filtfilt_batch_workspace_bytes': ([_P, _I, _I, _I, _I], ctypes.c_int64),

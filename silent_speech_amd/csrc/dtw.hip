@@ -44,11 +44,27 @@ enum { D_N = 0, D_M, D_COST_OFF, D_SI, D_SJ, D_SK_OFF, D_DIRS_OFF, D_BND_OFF, D_
 
 __host__ __device__ static inline long long dtw_strips(long long n) { long long rows = n - 1; long long cap = DW * 64 * DR; return rows <= 0 ? 0 : (rows + cap - 1) / cap; }
 __host__ __device__ static inline long long dtw_tsteps(long long m) { return m <= 1 ? 0 : (m - 1) + 63; }
+__host__ __device__ static inline long long dtw_tpitch(long long m) { return (dtw_tsteps(m) + DG - 1) / DG * DG; }     // steps per wave strip in `dirs`: whole super-steps
+// Where the sweep takes its costs from (per matrix).  0: the skewed strips (written by dtw_skew_kernel or by the fused loss kernels).
+// 1 / 2: IN PLACE from the caller's matrix -- possible when one axis is unit-stride, that axis fits one strip (<= 1024 interior cells) and
+// is dealt to the lanes: 1 = lanes own ROWS (a column-major matrix: the costs.T view of transduction_model.py:126), 2 = lanes own COLUMNS
+// (row-major; the sweep then solves the transposed problem and the backtrace reads its codes accordingly).
+__host__ __device__ static inline int dtw_source(bool have_costs, long long n, long long m, long long si, long long sj)
+{
+    if (!have_costs || n <= 1 || m <= 1) return 0;
+    if (sj == 1 && m >= 5 && m - 1 <= DW * 64 * DR && si >= 4 && si < (1 << 22)) return 2;
+    if (si == 1 && n >= 5 && n - 1 <= DW * 64 * DR && sj >= 4 && sj < (1 << 22)) return 1;
+    return 0;
+}
+
+extern "C" int ss_dtw_source(int n, int m, int64_t stride_i, int64_t stride_j) { return dtw_source(true, n, m, stride_i, stride_j); }
 
 extern "C" int64_t ss_dtw_workspace_bytes(int n, int m, int64_t* sk_bytes, int64_t* dirs_bytes, int64_t* bnd_bytes)
 {
     long long strips = dtw_strips(n), ts = dtw_tsteps(m);
-    long long sk = strips * DW * ts * 64 * DR * 4, dirs = strips * ts * 256, bnd = 2LL * (m > 0 ? m : 0) * 4;
+    long long sk = strips * DW * ts * 64 * DR * 4, dirs = strips * dtw_tpitch(m) * 256, bnd = 2LL * (m > 0 ? m : 0) * 4;
+    const long long dirs_t = dtw_strips(m) * dtw_tpitch(n) * 256;          // the transposed sweep of a row-major matrix (dtw_source() == 2)
+    if (dirs_t > dirs) dirs = dirs_t;
     sk = (sk + 255) / 256 * 256; dirs = (dirs + 255) / 256 * 256; bnd = (bnd + 255) / 256 * 256;
     if (sk_bytes) *sk_bytes = sk;
     if (dirs_bytes) *dirs_bytes = dirs;
@@ -65,7 +81,7 @@ extern "C" int64_t ss_dtw_workspace_bytes(int n, int m, int64_t* sk_bytes, int64
 // thread, ran at 1.4 TB/s of combined traffic for a batch: 64 distinct cache lines per 256 outputs.)
 constexpr int SKT = 32, SKR = 64;
 __global__ __launch_bounds__(256) void dtw_skew_kernel(const float* __restrict__ costs, const long long* __restrict__ desc, unsigned char* __restrict__ ws,
-                                                       int* __restrict__ results, int ntiles_max)
+                                                       int* __restrict__ results, int ntiles_max, int dbg)
 {
     __shared__ float tile[SKR][SKT + 1];
     const long long* d = desc + (long long)blockIdx.y * DESC;
@@ -73,6 +89,7 @@ __global__ __launch_bounds__(256) void dtw_skew_kernel(const float* __restrict__
     int* res = results + d[D_RES_OFF];
     const int tid = threadIdx.x;
     for (int i = blockIdx.x * 256 + tid; i < N; i += gridDim.x * 256) res[i] = 0;
+    if (dtw_source(!(dbg & 8), N, M, d[D_SI], d[D_SJ])) return;                  // the sweep reads this matrix in place
     const int ts = (int)dtw_tsteps(M), nrt = (int)dtw_strips(N) * DW * (256 / SKR);      // row tiles: quarters of the wave strips
     const int rt = blockIdx.x / ntiles_max, t0 = (blockIdx.x - rt * ntiles_max) * SKT;
     if (rt >= nrt || t0 >= ts) return;
@@ -183,9 +200,17 @@ __device__ __forceinline__ void dtw_step(int lane, const f32x4& cv, float top, f
 template <int OFF>
 __device__ __forceinline__ void gload128(f32x4& v, const float* p) {
 #if defined(SS_EMU)
-    v = *(const f32x4*)((const char*)p + OFF);
+    __builtin_memcpy(&v, (const char*)p + OFF, 16);                  // in-place sources are dword-aligned only
 #else
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
+#endif
+}
+// in-place source: scalar base (the step's line of the matrix, 62 lines back so that the lane offset is never negative) + 32-bit lane offset
+__device__ __forceinline__ void gload128_s(f32x4& v, unsigned voff, const float* sbase) {
+#if defined(SS_EMU)
+    __builtin_memcpy(&v, (const char*)sbase + voff, 16);
+#else
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
 #endif
 }
 // p = this lane's cost pointer at step tg + 4 (8 steps x 1 KiB around it: offsets -4096 .. 3072 fit the 13-bit signed immediate)
@@ -222,8 +247,13 @@ __device__ __forceinline__ unsigned dtw_readlane(unsigned v, int l) {      // l 
 #endif
 }
 
-// dbg (SS_DTW_DEBUG, tuning only -- results are wrong): 1 no backtrace, 2 no sweep, 4 every super-step on the generic path
-__global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ desc, unsigned char* __restrict__ ws, int* __restrict__ results, int dbg)
+// dbg (SS_DTW_DEBUG, tuning only -- results are wrong): 1 no backtrace, 2 no sweep, 4 every super-step on the generic path, 8 never in place
+enum { SRC_STRIP = 0, SRC_DIRECT = 1, SRC_CLAMP = 2 };
+// HAVE_COSTS = false: the instantiation behind ss_dtw_align_skewed (the training step's loss): strips only, none of the in-place paths'
+// registers (the three straight-line 64-step bodies side by side push the kernel past 256 VGPRs, which costs the strip path moves)
+template <bool HAVE_COSTS>
+__global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ desc, unsigned char* __restrict__ ws, int* __restrict__ results, int dbg,
+                                                  const float* __restrict__ costs)
 {
     __shared__ float lds_bnd[DW + 1][DRING];              // [w] = ring read by wave w (written by wave w-1); [DW] = dump / last wave's unused ring
     SS_DYN_SMEM(chunk_raw);                               // DCH x 64 direction bytes of the backtrace window
@@ -231,14 +261,37 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
     const long long* d = desc + (long long)blockIdx.x * DESC;
     const int N = (int)d[D_N], M = (int)d[D_M];
     if (N <= 1 || M <= 1) return;                                   // no interior cell: results stay 0 (align.py:24)
+    // in-place sources: the sweep runs on (Np, Mp) = (cells dealt to lanes, cells along the steps); for source 2 that is the transposed problem
+    const int source = HAVE_COSTS ? dtw_source(!(dbg & 8), N, M, d[D_SI], d[D_SJ]) : 0;
+    const int Np = source == 2 ? M : N, Mp = source == 2 ? N : M;
+    const long long ld = source == 2 ? d[D_SI] : d[D_SJ];           // element stride along the steps (the lanes' axis is unit-stride)
     const float* sk = (const float*)(ws + d[D_SK_OFF]);
     unsigned char* dirs = ws + d[D_DIRS_OFF];
     float* bnd = (float*)(ws + d[D_BND_OFF]);
     int* res = results + d[D_RES_OFF];
     const int tid = threadIdx.x, lane = tid & 63, w = dtw_uniform(tid >> 6);      // scalar: step bounds become s_cbranch, not exec masks
-    const int ts = (int)dtw_tsteps(M), nstrips = (int)dtw_strips(N);
+    const int ts = (int)dtw_tsteps(Mp), nstrips = (int)dtw_strips(Np), tsp = (int)dtw_tpitch(Mp);
     const int nss = (ts + DG - 1) / DG;
     const bool multi = nstrips > 1;
+    if (source) for (int i = tid; i < N; i += 256) res[i] = 0;       // (the skew launch zeroes them too; kept here so that this kernel does not depend on it)
+
+    // ---- in-place source, per lane: owned cells o0 .. o0 + 3 of the lanes' axis (16 contiguous bytes of every step's line)
+    const float* cmat = source ? costs + d[D_COST_OFF] : nullptr;
+    const int o0 = 1 + (w * 64 + lane) * DR;
+    const bool straddle = source && o0 <= Np - 1 && o0 + DR - 1 > Np - 1;       // the 16 bytes run past the end of the line: fine on every line but the last
+    const int o0c = (!source || o0 <= Np - 1) ? o0 : Np - DR;                   // lanes past the matrix read valid memory; their cells are never looked at
+    const int hi_l = Mp - 1 - (straddle ? 1 : 0);                               // last line this lane may load 16 bytes from
+    const float* lane_base = cmat + o0c;
+    const unsigned voff = source ? (unsigned)(((63 - lane) * ld + o0c) * 4) : 0u;
+    f32x4 last4 = {0.f, 0.f, 0.f, 0.f};
+    if (straddle) {
+#pragma unroll
+        for (int r = 0; r < DR; ++r) if (o0 + r <= Np - 1) last4[r] = cmat[(long long)(Mp - 1) * ld + o0 + r];
+    }
+#if !defined(SS_EMU)
+    __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0) HERE: left to the compiler the wait lands in front of the first patched step of every
+    asm volatile("" : "+v"(last4));                      // clamped super-step, where it also drains the cost loads just issued
+#endif
 
     for (int k = 0; k < nstrips && !(dbg & 2); ++k) {
         const int rowbase = ((k * DW + w) * 64 + lane) * DR;
@@ -248,9 +301,9 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         float diag_sv = rowbase == 0 ? 0.f : INFINITY;               // dtw[i-1][0]; dtw[0][0] = 0
         float last_out = INFINITY;
         const float* skp = sk + ((long long)(k * DW + w) * ts) * (64 * DR) + lane * DR;
-        unsigned char* dp0 = dirs + ((long long)(k * DW + w) * ts) * 64 + lane;      // dirs[wave strip][t][lane]: a wave's steps are contiguous (full cache lines)
-        const float* bnd_prev = bnd + ((k + 1) & 1) * M;
-        float* bnd_cur = bnd + (k & 1) * M;
+        unsigned char* dp0 = dirs + ((long long)(k * DW + w) * tsp) * 64 + lane;     // dirs[wave strip][t][lane]: a wave's steps are contiguous (full cache lines)
+        const float* bnd_prev = bnd + ((k + 1) & 1) * Mp;
+        float* bnd_cur = bnd + (k & 1) * Mp;
         float* const ring_next = lds_bnd[w + 1];
         float* const dump = &lds_bnd[DW][lane];                       // lanes 0..62: words lane .. lane + 63 of the dump row
         // Fast super-steps (all 64 steps inside the matrix' ts, one strip): DNB register buffers of 8 steps, group g in buffer g % DNB,
@@ -259,48 +312,90 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         // DNB - 1 groups of the NEXT super-step are loaded AND settled, so no request is in flight across control flow (a register copy
         // the compiler places at a join would copy a value that has not arrived).  Group start beyond ts - 8: clamped (never consumed:
         // that super-step takes the generic path).
-        const bool fast_ok = !multi && !(dbg & 4) && ts >= DG;
+        // In-place sources run EVERY super-step here.  Cells outside the matrix need no +inf: a cell left of column 1 only ever combines
+        // +inf states (inf + any finite cost = inf), and cells past the last line / past the lanes' axis feed only cells that are outside
+        // too -- so out-of-range loads are merely clamped to valid addresses (SRC_CLAMP: per-lane line index clamped to [0, hi_l]; the
+        // straddling lane takes its last line from `last4`), and super-steps whose every load is in range skip the clamp (SRC_DIRECT).
+        const bool fast_ok = source || (!multi && !(dbg & 4) && ts >= DG);
         f32x4 cbuf[DNB][8];
         auto group_ptr = [&](int tg) { const int tc = tg + 8 <= ts ? tg : ts - 8; return skp + (long long)(tc + 4) * (64 * DR); };
+        auto issue = [&](auto srcc, f32x4 (&buf)[8], int tg) {
+            constexpr int SRC = decltype(srcc)::value;
+            if constexpr (SRC == SRC_STRIP) issue_group(buf, group_ptr(tg));
+            else if constexpr (SRC == SRC_DIRECT) {
+                const float* sb = cmat + (long long)(tg - 62) * ld;          // lane l reads line tg + e + 1 - l = (tg + e - 62) + (63 - l)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gload128_s(buf[e], voff, sb + (long long)e * ld);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    int li = tg + e + 1 - lane;
+                    li = li < 0 ? 0 : (li > hi_l ? hi_l : li);
+                    gload128<0>(buf[e], lane_base + (long long)li * ld);
+                }
+            }
+        };
+        auto issue_any = [&](f32x4 (&buf)[8], int tg) {
+            if (source) issue(std::integral_constant<int, SRC_CLAMP>{}, buf, tg); else issue(std::integral_constant<int, SRC_STRIP>{}, buf, tg);
+        };
         if (fast_ok) {
-            dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; issue_group(cbuf[g], group_ptr(g * 8)); });
+            dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; issue_any(cbuf[g], g * 8); });
             wait_vm<0>();
             dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; pin_group(cbuf[g]); });
         }
+        auto super_fast = [&](auto srcc, int t0, float topv) {
+            constexpr int SRC = decltype(srcc)::value;
+            unsigned char* const dpb = dp0 + (long long)t0 * 64;
+            float* const slot0 = lane == 63 ? ring_next + (t0 & (DRING - 1)) : dump;
+            dfor<0, 8>([&](auto jc) {
+                constexpr int j = jc;
+                issue(srcc, cbuf[(j + DNB - 1) % DNB], t0 + (j + DNB - 1) * 8);
+                // younger than the loads of group j: the 8 (DNB - 1) loads of the groups requested since, and the direction stores of
+                // the steps between.  Counting only the loads keeps the wait correct whatever the compiler does with the stores
+                // (vector memory operations retire in issue order)
+                if constexpr (j >= DNB - 1) wait_vm<8 * (DNB - 1)>();
+                pin_group(cbuf[j % DNB]);
+                dfor<0, 8>([&](auto ec) {
+                    constexpr int e = ec, c = j * 8 + e;
+                    if constexpr (SRC == SRC_CLAMP) {
+                        f32x4 cv = cbuf[j % DNB][e];
+                        const bool patch = straddle && t0 + c + 1 - lane >= Mp - 1;
+#pragma unroll
+                        for (int r = 0; r < DR; ++r) cv[r] = patch ? last4[r] : cv[r];
+                        dtw_step(lane, cv, topv, prev, diag_sv, last_out, dpb + c * 64, slot0 + c);
+                    } else dtw_step(lane, cbuf[j % DNB][e], topv, prev, diag_sv, last_out, dpb + c * 64, slot0 + c);
+                    topv = wave_rotate_down(topv);
+                });
+            });
+            wait_vm<0>();
+            dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; pin_group(cbuf[g]); });
+        };
         for (int ss = 0; ss < nss + 2 * (DW - 1); ++ss) {
             const int u = ss - 2 * w;
             if (u >= 0 && u < nss) {
                 const int t0 = u * DG;
                 // the 64 values lane 0 will need from above during this super-step (one per step), fetched up front
-                float topv;
-                { const int sb = t0 + 1 + lane;
-                  if (w == 0) topv = (k == 0 || sb >= M) ? INFINITY : bnd_prev[sb];
-                  else topv = lds_bnd[w][ring_slot(sb)]; }
+                // (single-strip matrices -- every fast super-step -- have nothing above wave 0.  The global load of the strip boundary must not
+                // even sit on a path that reaches a fast super-step: the compiler would wait vmcnt(0) for it in front of the first step, and that
+                // also drains the cost loads issued just before -- one memory round trip per super-step)
+                auto top_lds = [&]() {
+                    const float v = w == 0 ? INFINITY : lds_bnd[w][ring_slot(t0 + 1 + lane)];
 #if !defined(SS_EMU)
-                // settle the LDS read NOW: left pending, the compiler re-waits lgkmcnt(0) at EVERY step, which also
-                // drains that step's ring write (an LDS round trip on the serial chain of each of the 64 steps)
-                __builtin_amdgcn_s_waitcnt(0xc07f);
+                    // settle the LDS read NOW: left pending, the compiler re-waits lgkmcnt(0) at EVERY step, which also
+                    // drains that step's ring write (an LDS round trip on the serial chain of each of the 64 steps)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
 #endif
-                if (fast_ok && t0 + DG <= ts) {
-                    unsigned char* const dpb = dp0 + (long long)t0 * 64;
-                    float* const slot0 = lane == 63 ? ring_next + (t0 & (DRING - 1)) : dump;
-                    dfor<0, 8>([&](auto jc) {
-                        constexpr int j = jc;
-                        issue_group(cbuf[(j + DNB - 1) % DNB], group_ptr(t0 + (j + DNB - 1) * 8));
-                        // younger than the loads of group j: the 8 (DNB - 1) loads of the groups requested since, and the direction stores of
-                        // the steps between.  Counting only the loads keeps the wait correct whatever the compiler does with the stores
-                        // (vector memory operations retire in issue order)
-                        if constexpr (j >= DNB - 1) wait_vm<8 * (DNB - 1)>();
-                        pin_group(cbuf[j % DNB]);
-                        dfor<0, 8>([&](auto ec) {
-                            constexpr int e = ec, c = j * 8 + e;
-                            dtw_step(lane, cbuf[j % DNB][e], topv, prev, diag_sv, last_out, dpb + c * 64, slot0 + c);
-                            topv = wave_rotate_down(topv);
-                        });
-                    });
-                    wait_vm<0>();
-                    dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; pin_group(cbuf[g]); });
+                    return v;
+                };
+                if (source) {
+                    // every load this super-step issues (its own groups DNB - 1 .. 7 and the first DNB - 1 groups of the next one) in range for every lane?
+                    if (t0 >= 64 && t0 + 2 * DG + 8 <= Mp - 2) super_fast(std::integral_constant<int, SRC_DIRECT>{}, t0, top_lds());
+                    else super_fast(std::integral_constant<int, SRC_CLAMP>{}, t0, top_lds());
+                } else if (fast_ok && t0 + DG <= ts) {
+                    super_fast(std::integral_constant<int, SRC_STRIP>{}, t0, top_lds());
                 } else {
+                    float topv = top_lds();
+                    { const int sb = t0 + 1 + lane; if (w == 0 && k > 0 && sb < Mp) topv = bnd_prev[sb]; }
                     f32x4 cb[8];
                     const f32x4 inf4 = {INFINITY, INFINITY, INFINITY, INFINITY};
 #pragma unroll
@@ -316,7 +411,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                             if (t < ts) {
                                 const int s = t + 1 - lane;
                                 dtw_step(lane, cb[e], topv, prev, diag_sv, last_out, dp0 + (long long)t * 64, lane == 63 ? ring_next + ring_slot(s) : dump);
-                                if (multi && w == DW - 1 && lane == 63 && s >= 1 && s < M) bnd_cur[s] = last_out;
+                                if (multi && w == DW - 1 && lane == 63 && s >= 1 && s < Mp) bnd_cur[s] = last_out;
                                 topv = wave_rotate_down(topv);
                             }
                         }
@@ -346,37 +441,70 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
     unsigned cache = 0, cache_nx = 0, rv = 0;
     int c_top = 0, nx_top = 0;
     bool nx_ok = false;
+    auto stage = [&](int kw, int t) {                                     // window [t - DCH + 1, t] of wave strip kw -> LDS (whole workgroup)
+        __syncthreads();
+        const int t_hi = t;
+        t_lo = t - DCH + 1 < 0 ? 0 : t - DCH + 1; cur_kw = kw; nx_ok = false;
+        const unsigned char* src = dirs + ((long long)kw * tsp + t_lo) * 64;
+        const int nd = (t_hi - t_lo + 1) * 4;                             // 16-byte pieces, contiguous in the workspace
+        for (int base = 0; base < nd; base += 256 * 8) {                  // 8 loads in flight per thread, then the 8 LDS writes
+            u32x4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = base + e * 256 + tid;
+                if (idx < nd) v[e] = *(const u32x4*)(src + (long long)idx * 16);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = base + e * 256 + tid;
+                if (idx < nd) *(u32x4*)(chunk + idx * 16) = v[e];
+            }
+        }
+        __syncthreads();
+    };
     auto column = [&](int l, int top) -> unsigned {                       // lane i <- byte of step top - i (0 below the window)
         const int tt = top - lane;
         return tt >= t_lo ? (unsigned)chunk[(tt - t_lo) * 64 + l] : 0u;
     };
+    if (source == 2) {
+        // ---- transposed sweep (lanes own COLUMNS of the matrix, steps run along its rows): a byte holds the codes of columns 4 l + 1 .. 4 l + 4 of
+        // row t + 1 - l, code = 2 [best == up] + [best == left] in the MATRIX' terms (the sweep's "left" is the matrix' "up"), up wins ties.
+        // Same organisation as below with the roles swapped: inside a lane column a move up steps through the register cache (idx), a move
+        // left shifts to the next code of the byte (sh).  results[i] = the column at the LAST cell visited in row i: lane idx of `rv` follows
+        // the row at cache position idx; rows are stored when the path has left them (the row the walk stands in is carried on).
+        int nx_l = -1;
+        while (p > 0 && s > 0) {
+            const int q = s - 1;
+            const int kw = q / (64 * DR), l = (q / DR) & 63, r = q % DR;
+            const int t = p - 1 + l;
+            if (kw != cur_kw || t < t_lo) stage(kw, t);
+            if (nx_ok && nx_l == l && nx_top >= t && nx_top - t < 64) { cache = cache_nx; c_top = nx_top; }
+            else { c_top = t; cache = column(l, t); }
+            nx_ok = l > 0;
+            if (nx_ok) { nx_top = t - 1; nx_l = l - 1; cache_nx = column(l - 1, nx_top); }
+            const int p0c = c_top + 1 - l;                                // row at cache position 0
+            const int idx_in = c_top - t, idx_max = c_top - t_lo < 63 ? c_top - t_lo : 63;
+            int idx = idx_in, sh = 2 * (DR - 1 - r), up;
+            do {
+                rv = lane == idx ? (unsigned)s : rv;
+                const unsigned code = (dtw_readlane(cache, idx) >> sh) & 3u;
+                up = code != 1u;                                          // up or diagonal: the row is left
+                const int lf = (int)((code >> 1) ^ 1u);                   // left or diagonal: the column moves
+                idx += up; s -= lf; sh += 2 * lf;
+            } while (((2 * (DR - 1) - sh) | (s - 1) | (idx_max - idx) | (p0c - idx - 1)) >= 0);      // column left | path ended (s == 0 | p == 0) | cache exhausted
+            const int idx_hi = s == 0 ? idx - up : idx - 1;               // rows left in this visit (+ the current one where the path ends in it)
+            if (w == 0 && lane >= idx_in && lane <= idx_hi) res[p0c - lane] = (int)rv;
+            p = p0c - idx;
+        }
+        return;
+    }
     while (p > 0 && s > 0) {
         const int q = p - 1;
         const int kw = q / (64 * DR), l = (q / DR) & 63;
         int r = q % DR;
         const int pbase = p - r;                                          // row of r = 0
         int t = s - 1 + l;
-        if (kw != cur_kw || t < t_lo) {
-            __syncthreads();
-            const int t_hi = t;
-            t_lo = t - DCH + 1 < 0 ? 0 : t - DCH + 1; cur_kw = kw; nx_ok = false;
-            const unsigned char* src = dirs + ((long long)kw * ts + t_lo) * 64;
-            const int nd = (t_hi - t_lo + 1) * 4;                         // 16-byte pieces, contiguous in the workspace
-            for (int base = 0; base < nd; base += 256 * 8) {              // 8 loads in flight per thread, then the 8 LDS writes
-                u32x4 v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int idx = base + e * 256 + tid;
-                    if (idx < nd) v[e] = *(const u32x4*)(src + (long long)idx * 16);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int idx = base + e * 256 + tid;
-                    if (idx < nd) *(u32x4*)(chunk + idx * 16) = v[e];
-                }
-            }
-            __syncthreads();
-        }
+        if (kw != cur_kw || t < t_lo) stage(kw, t);
         if (nx_ok && nx_top >= t && nx_top - t < 64) { cache = cache_nx; c_top = nx_top; }
         else { c_top = t; cache = column(l, t); }
         nx_ok = l > 0;
@@ -418,24 +546,26 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
 
 static int dtw_launch(const long long* desc_dev, int n, int max_n, int max_m, void* ws, int* results, void* stream, const float* costs)
 {
+    static const int dbg = getenv("SS_DTW_DEBUG") ? atoi(getenv("SS_DTW_DEBUG")) : 0;
     if (costs) {
         const long long nrt = dtw_strips(max_n) * DW * (256 / SKR), ntiles = (dtw_tsteps(max_m) + SKT - 1) / SKT;
         long long blocks = nrt * ntiles;
         if (blocks < 1) blocks = 1;                                       // results are zeroed by this launch
         SS_CHECK(blocks < (1LL << 31), "ss_dtw_align: matrix too large (%d x %d)", max_n, max_m);
-        SS_LAUNCH(dtw_skew_kernel, dim3((unsigned)blocks, n), dim3(256), 0, stream, costs, desc_dev, (unsigned char*)ws, results, (int)(ntiles > 0 ? ntiles : 1));
+        SS_LAUNCH(dtw_skew_kernel, dim3((unsigned)blocks, n), dim3(256), 0, stream, costs, desc_dev, (unsigned char*)ws, results, (int)(ntiles > 0 ? ntiles : 1), dbg);
         SS_LAUNCH_CHECK("ss_dtw_align(skew)");
     }
-    static const int dbg = getenv("SS_DTW_DEBUG") ? atoi(getenv("SS_DTW_DEBUG")) : 0;
     const size_t smem = (size_t)DCH * 64;
 #if !defined(SS_EMU)
     static bool granted = false;
     if (!granted) {
-        if (hipFuncSetAttribute((const void*)dtw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("ss_dtw_align: cannot reserve %zu bytes of LDS", smem); return 1; }
+        if (hipFuncSetAttribute((const void*)dtw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+            hipFuncSetAttribute((const void*)dtw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("ss_dtw_align: cannot reserve %zu bytes of LDS", smem); return 1; }
         granted = true;
     }
 #endif
-    SS_LAUNCH(dtw_kernel, dim3(n), dim3(256), smem, stream, desc_dev, (unsigned char*)ws, results, dbg);
+    if (costs) SS_LAUNCH(SS_KERNEL(dtw_kernel<true>), dim3(n), dim3(256), smem, stream, desc_dev, (unsigned char*)ws, results, dbg, costs);
+    else SS_LAUNCH(SS_KERNEL(dtw_kernel<false>), dim3(n), dim3(256), smem, stream, desc_dev, (unsigned char*)ws, results, dbg, costs);
     SS_LAUNCH_CHECK("ss_dtw_align");
     return 0;
 }

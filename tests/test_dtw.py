@@ -89,6 +89,50 @@ def test_dtw_sweep_paths_and_windows(dev):
         assert align.align_from_distances(c, device=dev) == dtw_ref.align_from_distances_c(c), c.shape
 
 
+def _inplace_cases(rng, emu):
+    """Matrices the sweep reads IN PLACE (one unit-stride axis of <= 1025 cells dealt to the lanes): lane counts that end inside a lane's
+    4 cells (a straddling lane), exactly full lanes, the single-strip maximum, enough steps for clamp-free super-steps, exact ties."""
+    shapes = [(5, 5), (6, 9), (9, 6), (70, 200), (200, 70), (131, 300), (258, 77), (66, 129)]
+    shapes += [(1025, 90), (90, 1025)] if emu else [(1025, 700), (700, 1025), (1024, 1000), (999, 1023), (1000, 1000), (517, 1021)]
+    for n, m in shapes:
+        yield rng.random((n, m), dtype=np.float32)
+        yield rng.integers(0, 3, (n, m)).astype(np.float32)               # ties: first-minimum order (up, left, diag)
+    n, m = (300, 150) if emu else (900, 800)
+    for kind in range(4):                                                 # long runs: along the last row / the last column / row 1 / column 1
+        c = rng.random((n, m), dtype=np.float32) + 5.0
+        if kind == 0: c[n - 1, :] = 0.0; c[:, 1] = 0.0
+        if kind == 1: c[:, m - 1] = 0.0; c[1, :] = 0.0
+        if kind == 2: c[:, m // 2] = 0.0; c[n // 2, :] = 0.0
+        if kind == 3: c[:] = 1.0                                          # all ties: the pure "up" staircase of the reference's min()
+        yield c
+
+
+def test_dtw_in_place_sources(dev):
+    """ss_dtw_align reads row-major matrices (lanes own columns: the transposed sweep + its own backtrace) and column-major views
+    (lanes own rows) straight from the caller's memory; SS_DTW_DEBUG=8 would force the skewed-strip copy instead.  Bit-exact either way."""
+    from silent_speech_amd import _lib
+    rng = np.random.default_rng(21)
+    src = _lib.lib().ss_dtw_source
+    assert (src(1000, 1000, 1000, 1), src(1000, 1000, 1, 1000), src(300, 2000, 2000, 1), src(300, 2000, 1, 300), src(50, 60, 120, 2), src(4, 4, 4, 1)) == (2, 1, 0, 1, 0, 0)
+    for c in _inplace_cases(rng, is_emu(dev)):
+        assert src(c.shape[0], c.shape[1], c.shape[1], 1) == 2 and src(c.shape[0], c.shape[1], 1, c.shape[0]) == 1
+        want = dtw_ref.align_from_distances_c(c)
+        assert align.align_from_distances(c, device=dev) == want, ('row-major', c.shape)
+        ct = torch.from_numpy(np.ascontiguousarray(c.T)).to(dev).t()      # same matrix, column-major
+        assert align.align_from_distances(ct, device=dev) == want, ('column-major', c.shape)
+    # padded rows (stride > width) and a batch mixing both orientations with a strip-path matrix
+    big = rng.random((120, 260), dtype=np.float32)
+    v = big[:, 3:203]
+    assert align.align_from_distances(torch.from_numpy(big)[:, 3:203], device=dev) == dtw_ref.align_from_distances_c(np.ascontiguousarray(v))
+    mats = [rng.random((60, 45), dtype=np.float32), rng.random((33, 80), dtype=np.float32), rng.random((20, 70), dtype=np.float32)]
+    flat = torch.from_numpy(np.concatenate([mats[0].ravel(), np.ascontiguousarray(mats[1].T).ravel(), np.repeat(mats[2].ravel(), 2)])).to(dev)
+    offs = [0, mats[0].size, mats[0].size + mats[1].size]
+    res, roffs = align.dtw_align_batch(flat, [m.shape for m in mats], offs, [(45, 1), (1, 33), (140, 2)])
+    res = res.cpu().numpy()
+    for m, ro in zip(mats, roffs):
+        assert res[ro:ro + m.shape[0]].tolist() == dtw_ref.align_from_distances_c(m), m.shape
+
+
 @pytest.mark.gpu
 def test_dtw_big_golden_and_strips():
     """BASELINE cfg3 size (1000x1000, golden from the reference) and a >1024-row matrix (2 strips)."""
