@@ -169,9 +169,9 @@ __device__ __forceinline__ int ring_slot(int s) { return (s + 62) & (DRING - 1);
 // One wavefront step.  No column predicate: cells outside the matrix carry cost +inf in the skewed layout, so a lane that
 // has not reached column 1 yet (or is past M-1) only turns +inf into +inf and its state stays what the recurrence needs
 // (dtw[i][0] = dtw[0][j] = +inf); the direction bytes it writes there are never read.  Branch-free: the per-step chain is
-// the 4 dependent (min3, add) pairs plus one DPP shift.  dp / slot: this step's direction byte and ring word (lane 63: the ring
+// the 4 dependent (min3, add) pairs plus one DPP shift.  Returns this step's direction byte; slot: ring word (lane 63: the ring
 // of the next wave; the other lanes hit a dump row).
-__device__ __forceinline__ void dtw_step(int lane, const f32x4& cv, float top, float (&prev)[DR], float& diag_sv, float& last_out, unsigned char* dp, float* slot)
+__device__ __forceinline__ unsigned dtw_step(int lane, const f32x4& cv, float top, float (&prev)[DR], float& diag_sv, float& last_out, float* slot)
 {
     const float up_in = wave_shift_in(last_out, top, lane);          // lane 0 takes the row above the strip / the previous wave's last row
     float a = up_in, dg = diag_sv;
@@ -189,9 +189,12 @@ __device__ __forceinline__ void dtw_step(int lane, const f32x4& cv, float top, f
     }
     last_out = a;
     diag_sv = up_in;
-    *dp = (unsigned char)bits;
     *slot = a;
+    return bits;
 }
+// Direction bytes: dirs[wave strip][t / 4][lane][t % 4] -- the four steps of a lane share a dword, so the fast paths store once per 4 steps
+// (a quarter of the store instructions, and fewer stores between the counted waits of the cost prefetch)
+__device__ __forceinline__ long long dir_byte(int t, int lane) { return ((long long)(t >> 2) * 64 + lane) * 4 + (t & 3); }
 
 // ---- costs of a group of 8 steps -> registers WITHOUT the compiler knowing that these are loads.  Left to hipcc, every step is its
 // own basic block and the first use of a prefetched group is preceded by s_waitcnt vmcnt(0): that drains the 8 loads issued just before
@@ -205,12 +208,43 @@ __device__ __forceinline__ void gload128(f32x4& v, const float* p) {
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
 #endif
 }
-// in-place source: scalar base (the step's line of the matrix, 62 lines back so that the lane offset is never negative) + 32-bit lane offset
-__device__ __forceinline__ void gload128_s(f32x4& v, unsigned voff, const float* sbase) {
+// ---- in-place source: the cost FIFO in LDS.  Read straight into registers, lane l needs 16 bytes of line t + 1 - l at step t: 64 distinct
+// cache lines per load instruction, and the texture addresser takes them at one line per clock -- 256 clocks per step for the four waves of a
+// matrix, more than the step's arithmetic (measured: tools/ta_probe, 262 clocks).  But the 8 lanes of a group g = l / 8 own the 8 pieces of the
+// SAME 128-byte line, only at different times.  So fetch-step T loads line T - 8 g for all 8 lanes of group g at once (8 lines per instruction,
+// straight into LDS: global_load_lds, 1 KiB slot T % 32 of the wave's ring), and lane l = 8 g + i picks its piece up i steps later: at step t it
+// reads slot (t + 1 - i) % 32.  Every lane reads only what it fetched itself (a per-lane FIFO), so no barrier is involved; completion of the
+// fetches is counted by hand (vmcnt), the reads travel one group of 8 steps ahead of their use (lgkmcnt).
+constexpr int CR_SLOTS = 32, CR_WAVE = CR_SLOTS * 1024, CR_PAD = 8192;     // pad: the lanes' read base addresses reach 7 KiB below their ring
+static_assert(DW * CR_WAVE == DCH * 64, "the four cost rings alias the backtrace window");
+__device__ __forceinline__ void cost_fetch_s(unsigned m0, unsigned voff, const float* sbase, unsigned char* ring_emu) {   // scalar line base + lane offset
 #if defined(SS_EMU)
-    __builtin_memcpy(&v, (const char*)sbase + voff, 16);
+    __builtin_memcpy(ring_emu + m0 + (threadIdx.x & 63) * 16, (const char*)sbase + voff, 16);
 #else
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+    (void)ring_emu;
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m0), "v"(voff), "s"(sbase) : "memory", "m0");
+#endif
+}
+__device__ __forceinline__ void cost_fetch_v(unsigned m0, const float* p, unsigned char* ring_emu) {                      // per-lane address (clamped lines)
+#if defined(SS_EMU)
+    __builtin_memcpy(ring_emu + m0 + (threadIdx.x & 63) * 16, p, 16);
+#else
+    (void)ring_emu;
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0), "v"(p) : "memory", "m0");
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ void cost_read(f32x4& v, unsigned addr, const unsigned char* ring_emu) {
+#if defined(SS_EMU)
+    __builtin_memcpy(&v, ring_emu + addr + OFF, 16);
+#else
+    (void)ring_emu;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+#endif
+}
+__device__ __forceinline__ void wait_lds() {
+#if !defined(SS_EMU)
+    __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
 #endif
 }
 // p = this lane's cost pointer at step tg + 4 (8 steps x 1 KiB around it: offsets -4096 .. 3072 fit the 13-bit signed immediate)
@@ -277,21 +311,30 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
 
     // ---- in-place source, per lane: owned cells o0 .. o0 + 3 of the lanes' axis (16 contiguous bytes of every step's line)
     const float* cmat = source ? costs + d[D_COST_OFF] : nullptr;
-    const int o0 = 1 + (w * 64 + lane) * DR;
+    const int o0 = 1 + (w * 64 + lane) * DR, grp = lane >> 3, sub = lane & 7;
     const bool straddle = source && o0 <= Np - 1 && o0 + DR - 1 > Np - 1;       // the 16 bytes run past the end of the line: fine on every line but the last
     const int o0c = (!source || o0 <= Np - 1) ? o0 : Np - DR;                   // lanes past the matrix read valid memory; their cells are never looked at
     const int hi_l = Mp - 1 - (straddle ? 1 : 0);                               // last line this lane may load 16 bytes from
     const float* lane_base = cmat + o0c;
-    const unsigned voff = source ? (unsigned)(((63 - lane) * ld + o0c) * 4) : 0u;
+    const unsigned voff = source ? (unsigned)(((56 - 8 * grp) * ld + o0c) * 4) : 0u;      // fetch-step T: line T - 8 grp = (T - 56) + (56 - 8 grp)
     f32x4 last4 = {0.f, 0.f, 0.f, 0.f};
     if (straddle) {
 #pragma unroll
         for (int r = 0; r < DR; ++r) if (o0 + r <= Np - 1) last4[r] = cmat[(long long)(Mp - 1) * ld + o0 + r];
     }
-#if !defined(SS_EMU)
+#if defined(SS_EMU)
+    const unsigned lbase = 0;
+#else
     __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0) HERE: left to the compiler the wait lands in front of the first patched step of every
-    asm volatile("" : "+v"(last4));                      // clamped super-step, where it also drains the cost loads just issued
+    asm volatile("" : "+v"(last4));                      // clamped super-step, where it also drains the cost fetches just issued
+    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)chunk);      // LDS byte address of the dynamic segment
 #endif
+    unsigned char* const ring_emu = chunk;               // (emulator: ring addresses are offsets into the dynamic segment)
+    const unsigned ring_w = lbase + CR_PAD + (unsigned)w * CR_WAVE;           // this wave's cost ring (aliases the backtrace window: the phases do not overlap)
+    const unsigned rd1 = ring_w + lane * 16 - sub * 1024;                     // read base: slot (tau - sub) for tau >= sub ..
+    unsigned rsel[7];                                                          // .. and for tau = 0 .. 6 the lanes with sub > tau wrap to the top of the ring
+#pragma unroll
+    for (int q = 0; q < 7; ++q) rsel[q] = sub > q ? rd1 + CR_WAVE : rd1;
 
     for (int k = 0; k < nstrips && !(dbg & 2); ++k) {
         const int rowbase = ((k * DW + w) * 64 + lane) * DR;
@@ -301,55 +344,32 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         float diag_sv = rowbase == 0 ? 0.f : INFINITY;               // dtw[i-1][0]; dtw[0][0] = 0
         float last_out = INFINITY;
         const float* skp = sk + ((long long)(k * DW + w) * ts) * (64 * DR) + lane * DR;
-        unsigned char* dp0 = dirs + ((long long)(k * DW + w) * tsp) * 64 + lane;     // dirs[wave strip][t][lane]: a wave's steps are contiguous (full cache lines)
+        unsigned char* const dstrip = dirs + ((long long)(k * DW + w) * tsp) * 64;   // dirs[wave strip][t / 4][lane][t % 4]: a wave's steps are contiguous (full cache lines)
         const float* bnd_prev = bnd + ((k + 1) & 1) * Mp;
         float* bnd_cur = bnd + (k & 1) * Mp;
         float* const ring_next = lds_bnd[w + 1];
         float* const dump = &lds_bnd[DW][lane];                       // lanes 0..62: words lane .. lane + 63 of the dump row
-        // Fast super-steps (all 64 steps inside the matrix' ts, one strip): DNB register buffers of 8 steps, group g in buffer g % DNB,
-        // requested DNB - 1 groups ahead (8 buffers would keep 7 KiB per wave in flight for batches that stream their costs from HBM
-        // rather than L2, but the 64-step straight-line body then runs out of registers: 512 + spills).  At every super-step boundary the first
-        // DNB - 1 groups of the NEXT super-step are loaded AND settled, so no request is in flight across control flow (a register copy
-        // the compiler places at a join would copy a value that has not arrived).  Group start beyond ts - 8: clamped (never consumed:
+        // Fast super-steps of the STRIP source (all 64 steps inside the matrix' ts, one strip): DNB register buffers of 8 steps, group g in
+        // buffer g % DNB, requested DNB - 1 groups ahead (8 buffers would keep 7 KiB per wave in flight for batches that stream their costs
+        // from HBM rather than L2, but the 64-step straight-line body then runs out of registers: 512 + spills).  At every super-step boundary
+        // the first DNB - 1 groups of the NEXT super-step are loaded AND settled, so no request is in flight across control flow (a register
+        // copy the compiler places at a join would copy a value that has not arrived).  Group start beyond ts - 8: clamped (never consumed:
         // that super-step takes the generic path).
-        // In-place sources run EVERY super-step here.  Cells outside the matrix need no +inf: a cell left of column 1 only ever combines
-        // +inf states (inf + any finite cost = inf), and cells past the last line / past the lanes' axis feed only cells that are outside
-        // too -- so out-of-range loads are merely clamped to valid addresses (SRC_CLAMP: per-lane line index clamped to [0, hi_l]; the
-        // straddling lane takes its last line from `last4`), and super-steps whose every load is in range skip the clamp (SRC_DIRECT).
-        const bool fast_ok = source || (!multi && !(dbg & 4) && ts >= DG);
+        const bool fast_ok = !source && !multi && !(dbg & 4) && ts >= DG;
         f32x4 cbuf[DNB][8];
         auto group_ptr = [&](int tg) { const int tc = tg + 8 <= ts ? tg : ts - 8; return skp + (long long)(tc + 4) * (64 * DR); };
-        auto issue = [&](auto srcc, f32x4 (&buf)[8], int tg) {
-            constexpr int SRC = decltype(srcc)::value;
-            if constexpr (SRC == SRC_STRIP) issue_group(buf, group_ptr(tg));
-            else if constexpr (SRC == SRC_DIRECT) {
-                const float* sb = cmat + (long long)(tg - 62) * ld;          // lane l reads line tg + e + 1 - l = (tg + e - 62) + (63 - l)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gload128_s(buf[e], voff, sb + (long long)e * ld);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    int li = tg + e + 1 - lane;
-                    li = li < 0 ? 0 : (li > hi_l ? hi_l : li);
-                    gload128<0>(buf[e], lane_base + (long long)li * ld);
-                }
-            }
-        };
-        auto issue_any = [&](f32x4 (&buf)[8], int tg) {
-            if (source) issue(std::integral_constant<int, SRC_CLAMP>{}, buf, tg); else issue(std::integral_constant<int, SRC_STRIP>{}, buf, tg);
-        };
         if (fast_ok) {
-            dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; issue_any(cbuf[g], g * 8); });
+            dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; issue_group(cbuf[g], group_ptr(g * 8)); });
             wait_vm<0>();
             dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; pin_group(cbuf[g]); });
         }
-        auto super_fast = [&](auto srcc, int t0, float topv) {
-            constexpr int SRC = decltype(srcc)::value;
-            unsigned char* const dpb = dp0 + (long long)t0 * 64;
+        auto super_fast = [&](int t0, float topv) {
+            unsigned* const dpb = (unsigned*)(dstrip + dir_byte(t0, lane));
             float* const slot0 = lane == 63 ? ring_next + (t0 & (DRING - 1)) : dump;
+            unsigned dacc = 0;
             dfor<0, 8>([&](auto jc) {
                 constexpr int j = jc;
-                issue(srcc, cbuf[(j + DNB - 1) % DNB], t0 + (j + DNB - 1) * 8);
+                issue_group(cbuf[(j + DNB - 1) % DNB], group_ptr(t0 + (j + DNB - 1) * 8));
                 // younger than the loads of group j: the 8 (DNB - 1) loads of the groups requested since, and the direction stores of
                 // the steps between.  Counting only the loads keeps the wait correct whatever the compiler does with the stores
                 // (vector memory operations retire in issue order)
@@ -357,18 +377,84 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                 pin_group(cbuf[j % DNB]);
                 dfor<0, 8>([&](auto ec) {
                     constexpr int e = ec, c = j * 8 + e;
-                    if constexpr (SRC == SRC_CLAMP) {
-                        f32x4 cv = cbuf[j % DNB][e];
-                        const bool patch = straddle && t0 + c + 1 - lane >= Mp - 1;
-#pragma unroll
-                        for (int r = 0; r < DR; ++r) cv[r] = patch ? last4[r] : cv[r];
-                        dtw_step(lane, cv, topv, prev, diag_sv, last_out, dpb + c * 64, slot0 + c);
-                    } else dtw_step(lane, cbuf[j % DNB][e], topv, prev, diag_sv, last_out, dpb + c * 64, slot0 + c);
+                    const unsigned bits = dtw_step(lane, cbuf[j % DNB][e], topv, prev, diag_sv, last_out, slot0 + c);
+                    dacc = (c & 3) ? dacc | (bits << (8 * (c & 3))) : bits;
+                    if constexpr ((c & 3) == 3) dpb[(c >> 2) * 64] = dacc;
                     topv = wave_rotate_down(topv);
                 });
             });
             wait_vm<0>();
             dfor<0, DNB - 1>([&](auto gc) { constexpr int g = gc; pin_group(cbuf[g]); });
+        };
+        // ---- in-place sources run EVERY super-step on the cost ring.  Cells outside the matrix need no +inf: a cell left of column 1 only ever
+        // combines +inf states (inf + any finite cost = inf), and cells past the last line / past the lanes' axis feed only cells that are
+        // outside too -- so out-of-range fetches are merely clamped to valid addresses (CLAMP: per-lane line index clamped to [0, hi_l]; the
+        // straddling lane takes its last line from `last4`), and super-steps whose every fetch is in range use the scalar-base form.
+        // Fetch group D = fetch-steps 8 D + 1 .. 8 D + 8; the reads of sweep group J (steps 8 J .. 8 J + 7) need groups J - 1 and J.  At the start
+        // of sweep group J: groups <= J + 1 have landed (vmcnt(8): group J + 2, requested one sweep group ago, may still be in flight) -> the reads
+        // of group J + 1 are issued -> group J + 3 is requested (its slots are 9 .. 30 behind the oldest slot those reads touch) -> the 8 steps of
+        // group J -> one lgkmcnt(0) settles the reads.  Nothing but LDS-bound fetches crosses control flow (no register destination).
+        f32x4 rb[2][8];
+        const float* fbase = nullptr;                                         // scalar-base form: line base of the next fetch-step (fetches are requested in order)
+        auto fetch = [&](auto clampc, int t0, auto crelc) {                   // fetch-step T = t0 + crel (t0 a multiple of 64 -> slot = crel & 31)
+            constexpr bool CLAMP = decltype(clampc)::value;
+            constexpr int crel = decltype(crelc)::value;
+            const unsigned m0 = ring_w + (unsigned)((crel & (CR_SLOTS - 1)) * 1024);
+            if constexpr (!CLAMP) { cost_fetch_s(m0, voff, fbase, ring_emu); fbase += ld; }
+            else {
+                int li = t0 + crel - 8 * grp;
+                li = li < 0 ? 0 : (li > hi_l ? hi_l : li);
+                cost_fetch_v(m0, lane_base + (long long)li * ld, ring_emu);
+            }
+        };
+        auto reads = [&](auto jc) {                                           // the 8 reads of sweep group j (relative to the super-step; j = 8: the next one's first)
+            constexpr int j = jc;
+            dfor<0, 8>([&](auto ec) {
+                constexpr int e = ec, tau = (j * 8 + e + 1) & (CR_SLOTS - 1);
+                if constexpr (tau < 7) cost_read<tau * 1024>(rb[j & 1][e], rsel[tau], ring_emu);
+                else cost_read<tau * 1024>(rb[j & 1][e], rd1, ring_emu);
+            });
+        };
+        auto settle = [&](int par) {
+            wait_lds();
+#if !defined(SS_EMU)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { if (par) asm volatile("" : "+v"(rb[1][e])); else asm volatile("" : "+v"(rb[0][e])); }
+#endif
+        };
+        if (source) {
+            dfor<0, 32>([&](auto cc) { constexpr int c = cc; fetch(std::true_type{}, 0, std::integral_constant<int, c - 7>{}); });     // groups -1 .. 2
+            wait_vm<16>();
+            reads(std::integral_constant<int, 0>{});
+            settle(0);
+        }
+        auto super_ring = [&](auto clampc, int t0, float topv) {
+            constexpr bool CLAMP = decltype(clampc)::value;
+            unsigned* const dpb = (unsigned*)(dstrip + dir_byte(t0, lane));
+            float* const slot0 = lane == 63 ? ring_next + (t0 & (DRING - 1)) : dump;
+            unsigned dacc = 0;
+            if constexpr (!CLAMP) fbase = cmat + (long long)(t0 + 25 - 56) * ld;        // first fetch-step of this super-step: t0 + 25
+            dfor<0, 8>([&](auto jc) {
+                constexpr int j = jc;
+                wait_vm<8>();
+                reads(std::integral_constant<int, j + 1>{});
+                dfor<0, 8>([&](auto ec) { constexpr int e = ec; fetch(clampc, t0, std::integral_constant<int, (j + 3) * 8 + 1 + e>{}); });
+                dfor<0, 8>([&](auto ec) {
+                    constexpr int e = ec, c = j * 8 + e;
+                    unsigned bits;
+                    if constexpr (CLAMP) {
+                        f32x4 cv = rb[j & 1][e];
+                        const bool patch = straddle && t0 + c + 1 - lane >= Mp - 1;
+#pragma unroll
+                        for (int r = 0; r < DR; ++r) cv[r] = patch ? last4[r] : cv[r];
+                        bits = dtw_step(lane, cv, topv, prev, diag_sv, last_out, slot0 + c);
+                    } else bits = dtw_step(lane, rb[j & 1][e], topv, prev, diag_sv, last_out, slot0 + c);
+                    dacc = (c & 3) ? dacc | (bits << (8 * (c & 3))) : bits;
+                    if constexpr ((c & 3) == 3) dpb[(c >> 2) * 64] = dacc;
+                    topv = wave_rotate_down(topv);
+                });
+                settle((j + 1) & 1);
+            });
         };
         for (int ss = 0; ss < nss + 2 * (DW - 1); ++ss) {
             const int u = ss - 2 * w;
@@ -388,11 +474,11 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                     return v;
                 };
                 if (source) {
-                    // every load this super-step issues (its own groups DNB - 1 .. 7 and the first DNB - 1 groups of the next one) in range for every lane?
-                    if (t0 >= 64 && t0 + 2 * DG + 8 <= Mp - 2) super_fast(std::integral_constant<int, SRC_DIRECT>{}, t0, top_lds());
-                    else super_fast(std::integral_constant<int, SRC_CLAMP>{}, t0, top_lds());
+                    // every fetch this super-step requests (fetch-steps t0 + 25 .. t0 + 88, lines T - 56 .. T) in range for every lane, the last line excluded?
+                    if (t0 >= 64 && t0 + 90 <= Mp) super_ring(std::false_type{}, t0, top_lds());
+                    else super_ring(std::true_type{}, t0, top_lds());
                 } else if (fast_ok && t0 + DG <= ts) {
-                    super_fast(std::integral_constant<int, SRC_STRIP>{}, t0, top_lds());
+                    super_fast(t0, top_lds());
                 } else {
                     float topv = top_lds();
                     { const int sb = t0 + 1 + lane; if (w == 0 && k > 0 && sb < Mp) topv = bnd_prev[sb]; }
@@ -410,7 +496,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                             const int t = t0 + g * 8 + e;
                             if (t < ts) {
                                 const int s = t + 1 - lane;
-                                dtw_step(lane, cb[e], topv, prev, diag_sv, last_out, dp0 + (long long)t * 64, lane == 63 ? ring_next + ring_slot(s) : dump);
+                                dstrip[dir_byte(t, lane)] = (unsigned char)dtw_step(lane, cb[e], topv, prev, diag_sv, last_out, lane == 63 ? ring_next + ring_slot(s) : dump);
                                 if (multi && w == DW - 1 && lane == 63 && s >= 1 && s < Mp) bnd_cur[s] = last_out;
                                 topv = wave_rotate_down(topv);
                             }
@@ -422,6 +508,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
             }
             __syncthreads();
         }
+        wait_vm<0>();         // cost fetches still on their way into the ring (it becomes the backtrace window)
         __threadfence();      // strip boundary row + direction bytes visible before they are re-read
         __syncthreads();
     }
@@ -441,10 +528,10 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
     unsigned cache = 0, cache_nx = 0, rv = 0;
     int c_top = 0, nx_top = 0;
     bool nx_ok = false;
-    auto stage = [&](int kw, int t) {                                     // window [t - DCH + 1, t] of wave strip kw -> LDS (whole workgroup)
+    auto stage = [&](int kw, int t) {                                     // window [.., t] of wave strip kw -> LDS (whole workgroup); whole dwords: 4-step units
         __syncthreads();
-        const int t_hi = t;
-        t_lo = t - DCH + 1 < 0 ? 0 : t - DCH + 1; cur_kw = kw; nx_ok = false;
+        const int t_hi = t | 3;
+        t_lo = t_hi - DCH + 1 < 0 ? 0 : t_hi - DCH + 1; cur_kw = kw; nx_ok = false;
         const unsigned char* src = dirs + ((long long)kw * tsp + t_lo) * 64;
         const int nd = (t_hi - t_lo + 1) * 4;                             // 16-byte pieces, contiguous in the workspace
         for (int base = 0; base < nd; base += 256 * 8) {                  // 8 loads in flight per thread, then the 8 LDS writes
@@ -464,7 +551,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
     };
     auto column = [&](int l, int top) -> unsigned {                       // lane i <- byte of step top - i (0 below the window)
         const int tt = top - lane;
-        return tt >= t_lo ? (unsigned)chunk[(tt - t_lo) * 64 + l] : 0u;
+        return tt >= t_lo ? (unsigned)chunk[dir_byte(tt - t_lo, l)] : 0u;
     };
     if (source == 2) {
         // ---- transposed sweep (lanes own COLUMNS of the matrix, steps run along its rows): a byte holds the codes of columns 4 l + 1 .. 4 l + 4 of
@@ -555,7 +642,7 @@ static int dtw_launch(const long long* desc_dev, int n, int max_n, int max_m, vo
         SS_LAUNCH(dtw_skew_kernel, dim3((unsigned)blocks, n), dim3(256), 0, stream, costs, desc_dev, (unsigned char*)ws, results, (int)(ntiles > 0 ? ntiles : 1), dbg);
         SS_LAUNCH_CHECK("ss_dtw_align(skew)");
     }
-    const size_t smem = (size_t)DCH * 64;
+    const size_t smem = (size_t)DCH * 64 + CR_PAD;        // backtrace window; during the sweep of in-place sources: pad + 4 cost rings
 #if !defined(SS_EMU)
     static bool granted = false;
     if (!granted) {
