@@ -125,76 +125,143 @@ __device__ __forceinline__ void lds_wait_pin(bf16x8 (&f)[N]) {
 #endif
 }
 
-// flush of an epilogue pass: the LDS piece holds IPP*16 rows of each of the two M halves of the tile
-// A thread always handles the same 16-byte column chunk (512 % CPR == 0), so the optional column statistics accumulate in registers
-// (cs / cq) over all rows the thread stores, across the passes of a tile.
-template <class TO, int NI, int IPP, bool STATS>
-__device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* __restrict__ C, const GemmEpi& epi, int m0, int n0, int pass, int M, int N, int tid,
-                                       float (&cs)[OutVec<TO>::N], float (&cq)[OutVec<TO>::N], const float (&sh)[OutVec<TO>::N])
+// ---- epilogue.  Everything the epilogue reads from memory is requested EARLY and all at once: the bias of the wave's four column groups
+// before the tile's first pass, and the per-element side input of a flush pass (the gate = saved activation of the ReLU / dropout backward, or
+// the old C of "C += v") one pass ahead, into registers the main loop no longer needs.  Left inside the per-chunk loop of the flush, each of
+// the 18 chunks of a tile paid its own memory round trip while no MFMA ran (22 000 x 3072 x 768 alone: gate +42 us, bias +14 us, C += v +14 us
+// over the plain 131 us; tools/gemm_bench epi).
+template <class TO, int GEN>        // GEN: 0 alpha / bias / ReLU, 1 + dropout, 2 + log-clamp
+__device__ __forceinline__ void stage8(const f32x4& a, TO* __restrict__ ct, int ldc, int lrow0, int lcol, const GemmEpi& epi, int row0, int col, int N, float bias)
 {
-    constexpr int EV = OutVec<TO>::N, CPR = TBN / EV, R = IPP * 16, TOTAL = 2 * R * CPR;
-    for (int idx = tid; idx < TOTAL; idx += 512) {
-        const int lr = idx / CPR, ch = idx - lr * CPR;
-        const int half = lr >= R ? 1 : 0, rr = lr - half * R;
-        const int trow = pass * R + rr;                                   // row inside the half
-        const int row = m0 + half * NI * 16 + trow, col = n0 + ch * EV;
-        if (trow < NI * 16 && row < M && col < N) {
+    const float lo = epi.relu ? 0.f : -INFINITY;
+    bool kp[4] = {true, true, true, true};
+    if (GEN == 1) dropout_keep4(epi.seed, epi.stream, (unsigned long long)(row0 >> 2) * (unsigned)N + col, epi.drop_thresh, kp);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        float x = fmaxf(a[reg] * epi.alpha + bias, lo);
+        if (GEN == 1) x = kp[reg] ? x * epi.drop_scale : 0.f;
+        if (GEN == 2) x = logf(fmaxf(x, epi.log_clamp));
+        stf(ct + (lrow0 + reg) * ldc + lcol, x);
+    }
+}
+
+// chunk `it` of thread `tid` in flush pass `pass`: LDS row / column chunk, output row / column, validity
+template <class TO, int NI, int IPP>
+struct Flush8 {
+    static constexpr int EV = OutVec<TO>::N, CPR = TBN / EV, R = IPP * 16, TOTAL = 2 * R * CPR, NIT = TOTAL / 512;
+    static_assert(TOTAL % 1024 == 0 && 512 % CPR == 0, "flush chunks per thread (an even number)");
+    __device__ __forceinline__ static bool map(int it, int tid, int pass, int m0, int n0, int M, int N, int& lr, int& ch, int& row, int& col) {
+        const int idx = it * 512 + tid;
+        lr = idx / CPR; ch = idx - lr * CPR;
+        const int half = lr >= R ? 1 : 0, rr = lr - half * R, trow = pass * R + rr;         // row inside the half
+        row = m0 + half * NI * 16 + trow; col = n0 + ch * EV;
+        return trow < NI * 16 && row < M && col < N;
+    }
+};
+__device__ __forceinline__ void raw_to_float(const u32x4& w, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+__device__ __forceinline__ void raw_to_float(const u32x4& w, float (&v)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(w[e]);
+}
+// side input (src addressed like C: the gate, or C itself) of HALF a flush pass -> registers: chunks H * NIT/2 .. of pass `pass`, all in flight at once
+template <class TO, int NI, int IPP, int H>
+__device__ __forceinline__ void flush8_prefetch(const TO* __restrict__ src, const GemmEpi& epi, int m0, int n0, int pass, int M, int N, int tid, u32x4 (&pre)[Flush8<TO, NI, IPP>::NIT / 2])
+{
+    using F = Flush8<TO, NI, IPP>;
+#pragma unroll
+    for (int i = 0; i < F::NIT / 2; ++i) {
+        int lr, ch, row, col;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        pre[i] = F::map(H * (F::NIT / 2) + i, tid, pass, m0, n0, M, N, lr, ch, row, col) ? *(const u32x4*)(src + rowmap_off(epi.cmap, row) + col) : z;
+    }
+}
+// flush of HALF an epilogue pass (the LDS piece holds IPP*16 rows of each of the two M halves of the tile).
+// A thread always handles the same 16-byte column chunk (512 % CPR == 0), so the optional column statistics accumulate in registers
+// (cs / cq) over all rows the thread stores, across the passes of a tile.  pf: 1 = `pre` holds the gate chunks, 2 = the old C chunks.
+template <class TO, int NI, int IPP, int STATS, int H>
+__device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* __restrict__ C, const GemmEpi& epi, int m0, int n0, int pass, int M, int N, int tid,
+                                       float (&cs)[OutVec<TO>::N], float (&cq)[OutVec<TO>::N], const float (&sh)[OutVec<TO>::N],
+                                       const u32x4 (&pre)[Flush8<TO, NI, IPP>::NIT / 2], int pf)
+{
+    using F = Flush8<TO, NI, IPP>;
+    constexpr int EV = F::EV;
+#pragma unroll
+    for (int i = 0; i < F::NIT / 2; ++i) {
+        int lr, ch, row, col;
+        if (F::map(H * (F::NIT / 2) + i, tid, pass, m0, n0, M, N, lr, ch, row, col)) {
             float v[EV];
             outvec_load(ct + lr * ldc + ch * EV, v);
             const long long off = rowmap_off(epi.cmap, row) + col;
             if (epi.gate) {
-                float g[EV]; outvec_load((const TO*)epi.gate + off, g);
+                float g[EV];
+                if (pf == 1) raw_to_float(pre[i], g); else outvec_load((const TO*)epi.gate + off, g);
 #pragma unroll
                 for (int e = 0; e < EV; ++e) v[e] = g[e] > 0.f ? v[e] * epi.gate_scale : 0.f;
             }
             if (epi.mode == 1) {
-                float o[EV]; outvec_load(C + off, o);
+                float o[EV];
+                if (pf == 2) raw_to_float(pre[i], o); else outvec_load(C + off, o);
 #pragma unroll
                 for (int e = 0; e < EV; ++e) v[e] += o[e];
             }
             outvec_store(C + off, v);
-            if (STATS) {
+            if (STATS == 1) {
 #pragma unroll
                 for (int e = 0; e < EV; ++e) { const float x = rnd<TO>(v[e]) - sh[e]; cs[e] += x; cq[e] += x * x; }
+            } else if (STATS == 2) {
+#pragma unroll
+                for (int e = 0; e < EV; ++e) cs[e] += rnd<TO>(v[e]);
             }
         }
+        sched_fence();          // one chunk at a time: interleaved, the chunks' temporaries push the epilogue past the register file (accumulators + side inputs are live)
     }
 }
 
-template <class TO, int GEN, int NI, int IPP, int P, int NPASS, bool STATS>
+// The side input travels half a pass ahead of its use, and is always requested BEFORE the stores of the half in front of it (a wait for a
+// load that was issued behind a store also waits for that store: vmcnt counts in order): pa = first halves, pb = second halves.
+template <class TO, int GEN, int NI, int IPP, int P, int NPASS, int STATS>
 struct Passes8 {
     static __device__ __forceinline__ void run(const f32x4 (&acc)[NI][4], TO* ct, int ldc, TO* C, const GemmEpi& epi, int m0, int n0, int M, int N, int tid, int wm, int wn, int r, int q,
-                                               float (&cs)[OutVec<TO>::N], float (&cq)[OutVec<TO>::N], const float (&sh)[OutVec<TO>::N]) {
+                                               float (&cs)[OutVec<TO>::N], float (&cq)[OutVec<TO>::N], const float (&sh)[OutVec<TO>::N],
+                                               const float (&bias4)[4], u32x4 (&pa)[Flush8<TO, NI, IPP>::NIT / 2], u32x4 (&pb)[Flush8<TO, NI, IPP>::NIT / 2], int pf, const TO* pf_src) {
 #pragma unroll
         for (int ii = 0; ii < IPP; ++ii) {
             constexpr int I0 = P * IPP;
             if (I0 + ii < NI) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    epilogue_stage<TO, GEN>(acc[I0 + ii < NI ? I0 + ii : 0][j], ct, ldc, (wm * IPP + ii) * 16 + q * 4, wn * 64 + j * 16 + r, epi,
-                                            m0 + (wm * NI + I0 + ii) * 16 + q * 4, n0 + wn * 64 + j * 16 + r, M, N);
+                    stage8<TO, GEN>(acc[I0 + ii < NI ? I0 + ii : 0][j], ct, ldc, (wm * IPP + ii) * 16 + q * 4, wn * 64 + j * 16 + r, epi,
+                                    m0 + (wm * NI + I0 + ii) * 16 + q * 4, n0 + wn * 64 + j * 16 + r, N, bias4[j]);
             }
         }
         barrier_keep_vm();
-        flush8<TO, NI, IPP, STATS>(ct, ldc, C, epi, m0, n0, P, M, N, tid, cs, cq, sh);
+        if (pf) flush8_prefetch<TO, NI, IPP, 1>(pf_src, epi, m0, n0, P, M, N, tid, pb);
+        flush8<TO, NI, IPP, STATS, 0>(ct, ldc, C, epi, m0, n0, P, M, N, tid, cs, cq, sh, pa, pf);
+        if (P + 1 < NPASS && pf) flush8_prefetch<TO, NI, IPP, 0>(pf_src, epi, m0, n0, P + 1, M, N, tid, pa);
+        flush8<TO, NI, IPP, STATS, 1>(ct, ldc, C, epi, m0, n0, P, M, N, tid, cs, cq, sh, pb, pf);
         if (P + 1 < NPASS) barrier_keep_vm();
-        Passes8<TO, GEN, NI, IPP, P + 1, NPASS, STATS>::run(acc, ct, ldc, C, epi, m0, n0, M, N, tid, wm, wn, r, q, cs, cq, sh);
+        Passes8<TO, GEN, NI, IPP, P + 1, NPASS, STATS>::run(acc, ct, ldc, C, epi, m0, n0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
     }
 };
-template <class TO, int GEN, int NI, int IPP, int NPASS, bool STATS>
+template <class TO, int GEN, int NI, int IPP, int NPASS, int STATS>
 struct Passes8<TO, GEN, NI, IPP, NPASS, NPASS, STATS> {
     static __device__ __forceinline__ void run(const f32x4 (&)[NI][4], TO*, int, TO*, const GemmEpi&, int, int, int, int, int, int, int, int, int,
-                                               float (&)[OutVec<TO>::N], float (&)[OutVec<TO>::N], const float (&)[OutVec<TO>::N]) {}
+                                               float (&)[OutVec<TO>::N], float (&)[OutVec<TO>::N], const float (&)[OutVec<TO>::N],
+                                               const float (&)[4], u32x4 (&)[Flush8<TO, NI, IPP>::NIT / 2], u32x4 (&)[Flush8<TO, NI, IPP>::NIT / 2], int, const TO*) {}
 };
 
 }  // namespace g8
 
 // ================================================================ KC x KC
 // PIN: bit 0 = fragment reads, bit 1 = DMA pieces spread between the MFMA groups of a phase (else issued in a burst at the phase start).
-// STATS: the epilogue also accumulates per-column sums / sums of squares of the stored tile (a separate instantiation: the extra live
+// STATS: 1 = the epilogue also accumulates per-column sums / sums of squares (about a shift) of the stored tile, 2 = plain column sums only
+// (a bias gradient: a third of the registers, which leaves room for the side-input buffers of a gated epilogue) (separate instantiations: the extra live
 // registers of that path would otherwise spill in the main loop of every launch).
 // ABL: compile-time ablation mask for tuning (results are wrong): 1 no MFMA, 2 no in-loop global->LDS copies, 4 no in-loop fragment reads.
-template <class TO, int NI, int PIN, int ABL, bool STATS>
+template <class TO, int NI, int PIN, int ABL, int STATS>
 __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
                                                        int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi, int tiles_n, int nitems)
 {
@@ -334,11 +401,21 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             sa.init(amap, m0, M, wave, lane); sb.init(bmap, n0, N, wave, lane);
             sa.issue((const unsigned char*)A, lds + cur * STAGE, wave); sb.issue((const unsigned char*)B, lds + cur * STAGE + BMT * RB, wave);
         }
+        // side inputs of the epilogue (after the next item's copies: a wait for these must not have to drain younger copies first)
+        constexpr int IPP = sizeof(TO) == 2 ? (NI % 3 == 0 ? 3 : 2) : 1;
+        constexpr int NPASS = (NI + IPP - 1) / IPP;
+        float bias4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int col = cn0 + wn * 64 + j * 16 + r; bias4[j] = (epi.bias && col < N) ? epi.bias[col] : 0.f; }
+        // (not in the full column-statistics instantiation: its three per-column register arrays leave no room for the side-input buffers --
+        // with them the gate + column-sum epilogue of the FFN input gradient spilled and ran 219 instead of 185 us; the sums-only form has room)
+        const int pf = STATS == 1 ? 0 : (epi.gate ? 1 : (epi.mode == 1 ? 2 : 0));
+        const TO* pf_src = pf == 1 ? (const TO*)epi.gate : C;
+        u32x4 pa[Flush8<TO, NI, IPP>::NIT / 2], pb[Flush8<TO, NI, IPP>::NIT / 2];
+        if (pf) flush8_prefetch<TO, NI, IPP, 0>(pf_src, epi, cm0, cn0, 0, M, N, tid, pa);
         barrier_keep_vm();                                   // every wave is done reading stage cur^1 -> it becomes the C piece
         TO* ct = (TO*)(lds + (cur ^ 1) * STAGE);
         constexpr int LDC = TBN + 16 / (int)sizeof(TO);
-        constexpr int IPP = sizeof(TO) == 2 ? (NI % 3 == 0 ? 3 : 2) : 1;
-        constexpr int NPASS = (NI + IPP - 1) / IPP;
         static_assert((size_t)2 * IPP * 16 * LDC * sizeof(TO) <= (size_t)STAGE, "C piece does not fit the free stage");
         constexpr int EV = OutVec<TO>::N, CPR = TBN / EV;
         float cs[EV], cq[EV], sh[EV];
@@ -352,37 +429,39 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             float* bins = (float*)(lds + (cur ^ 1) * STAGE + BINS_OFF);
             static_assert((size_t)2 * IPP * 16 * LDC * sizeof(TO) <= BINS_OFF && BINS_OFF + 8 * 2 * TBN * 4 <= STAGE, "column-statistics bins overlap the C piece");
             const int ch = tid % CPR;
-            if (epi.col_shift) {
+            if (STATS == 1 && epi.col_shift) {
 #pragma unroll
                 for (int e = 0; e < EV; ++e) { const int col = cn0 + ch * EV + e; sh[e] = col < N ? epi.col_shift[col] : 0.f; }
             }
-            if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS, true>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
-            else if (epi.general == 2) Passes8<TO, 2, NI, IPP, 0, NPASS, true>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
-            else Passes8<TO, 0, NI, IPP, 0, NPASS, true>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
+            if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
+            else if (epi.general == 2) Passes8<TO, 2, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
+            else Passes8<TO, 0, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
             if (CPR == 32) {                  // bf16 out: lanes l and l + 32 of a wave hold the same column chunk
 #pragma unroll
-                for (int e = 0; e < EV; ++e) { cs[e] += __shfl_xor(cs[e], 32); cq[e] += __shfl_xor(cq[e], 32); }
+                for (int e = 0; e < EV; ++e) { cs[e] += __shfl_xor(cs[e], 32); if (STATS == 1) cq[e] += __shfl_xor(cq[e], 32); }
             }
             if (CPR == 64 || lane < 32) {
                 float* wb = bins + wave * 2 * TBN;
 #pragma unroll
-                for (int e = 0; e < EV; ++e) { wb[ch * EV + e] = cs[e]; wb[TBN + ch * EV + e] = cq[e]; }
+                for (int e = 0; e < EV; ++e) { wb[ch * EV + e] = cs[e]; if (STATS == 1) wb[TBN + ch * EV + e] = cq[e]; }
             }
             barrier_keep_vm();
             {
                 float t = 0.f;
+                if (STATS == 1 || tid < TBN) {
 #pragma unroll
-                for (int w8 = 0; w8 < 8; ++w8) t += bins[w8 * 2 * TBN + tid];
+                    for (int w8 = 0; w8 < 8; ++w8) t += bins[w8 * 2 * TBN + tid];
+                }
                 const int col = cn0 + (tid & (TBN - 1));
                 if (col < N) {
                     if (tid < TBN) atomicAdd(epi.col_sum + col, t);
-                    else if (epi.col_sumsq) atomicAdd(epi.col_sumsq + col, t);
+                    else if (STATS == 1 && epi.col_sumsq) atomicAdd(epi.col_sumsq + col, t);
                 }
             }
         } else {
-            if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS, false>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
-            else if (epi.general == 2) Passes8<TO, 2, NI, IPP, 0, NPASS, false>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
-            else Passes8<TO, 0, NI, IPP, 0, NPASS, false>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh);
+            if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
+            else if (epi.general == 2) Passes8<TO, 2, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
+            else Passes8<TO, 0, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
         }
         if (!has_next) break;
     }
@@ -406,15 +485,20 @@ int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int 
     const int abl = (epi.debug >> 4) & 7;
 #if defined(G8_FAST_BUILD)        // tuning builds: three bf16-out main-loop variants only (a full build of this file takes minutes)
     if constexpr (sizeof(TO) == 2) {
-        if (ni == 9) { switch (pin) { case 3: G8_CASE(9, 3, 0, false); break; case 4: G8_CASE(9, 4, 0, false); break; case 7: G8_CASE(9, 7, 0, false); break; default: G8_CASE(9, 0, 0, false); } }
+        if (epi.col_sum && ni == 9) G8_CASE(9, 3, 0, 2);
+        else if (ni == 9) { switch (pin) { case 3: G8_CASE(9, 3, 0, false); break; case 4: G8_CASE(9, 4, 0, false); break; case 7: G8_CASE(9, 7, 0, false); break; default: G8_CASE(9, 0, 0, false); } }
         else { switch (pin) { case 7: G8_CASE(8, 7, 0, false); break; case 11: G8_CASE(8, 11, 0, false); break; default: G8_CASE(8, 3, 0, false); } }
         SS_LAUNCH_CHECK("ss_gemm(gemm8)");
         return 0;
     } else { ss_set_error("gemm8: tuning build"); return 1; }
 #else
-    if (epi.col_sum) {                      // column statistics: burst or spread schedule of either tile height
-        if (ni == 9) { if (pin & 3) G8_CASE(9, 3, 0, true); else G8_CASE(9, 0, 0, true); }
-        else { if (pin & 3) G8_CASE(8, 3, 0, true); else G8_CASE(8, 0, 0, true); }
+    if (epi.col_sum && !epi.col_sumsq && !epi.col_shift) {      // plain column sums (a bias gradient)
+        if (ni == 9) { if (pin & 3) G8_CASE(9, 3, 0, 2); else G8_CASE(9, 0, 0, 2); }
+        else { if (pin & 3) G8_CASE(8, 3, 0, 2); else G8_CASE(8, 0, 0, 2); }
+    }
+    else if (epi.col_sum) {                 // column statistics: burst or spread schedule of either tile height
+        if (ni == 9) { if (pin & 3) G8_CASE(9, 3, 0, 1); else G8_CASE(9, 0, 0, 1); }
+        else { if (pin & 3) G8_CASE(8, 3, 0, 1); else G8_CASE(8, 0, 0, 1); }
     }
     else if (abl && sizeof(TO) == 2) {      // tuning builds only (bf16 out): which of MFMA / DMA / fragment reads bounds the loop
         if (ni == 9) { switch (abl) { case 1: G8_CASE(9, 0, 1, false); break; case 2: G8_CASE(9, 0, 2, false); break; case 4: G8_CASE(9, 0, 4, false); break; case 5: G8_CASE(9, 0, 5, false); break; case 6: G8_CASE(9, 0, 6, false); break; default: G8_CASE(9, 0, 7, false); } }

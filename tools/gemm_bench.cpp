@@ -138,6 +138,39 @@ static void bench_dw(const char* tag, int rows, int n, const int (*mn)[2], int i
     fflush(stdout);
 }
 
+// what the heavier epilogues of the step cost on top of the plain GEMM of the same shape (22 000 x 3072 x 768: FFN1 forward with bias + ReLU +
+// dropout; its input gradient with the ReLU / dropout gate read from the saved activation and the column sums of linear1.bias.grad; C += v)
+static void bench_epi(int iters) {
+    const int M = 22000, N = 3072, K = 768;
+    KcArgs a; memset(&a, 0, sizeof(a));
+    a.M = M; a.N = N; a.K = K;
+    a.A = dev_bf16((size_t)M * K, 1.0f); a.B = dev_bf16((size_t)N * K, 0.05f);
+    CK(hipMalloc(&a.C, (size_t)M * N * 2)); CK(hipMemset(a.C, 0, (size_t)M * N * 2));
+    void* gate = dev_bf16((size_t)M * N, 1.0f);
+    float *bias, *cs; std::vector<float> hb(N); for (int i = 0; i < N; ++i) hb[i] = rnd();
+    CK(hipMalloc((void**)&bias, N * 4)); CK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMalloc((void**)&cs, N * 4)); CK(hipMemset(cs, 0, N * 4));
+    a.am = plain(K); a.bm = plain(K); a.cm = plain(N);
+    const double flops = 2.0 * M * N * K;
+    const char* names[6] = {"plain", "bias+relu", "bias+relu+dropout", "gate", "gate+colsum", "C += v"};
+    for (int v = 0; v < 6; ++v) {
+        memset(&a.epi, 0, sizeof(a.epi)); a.epi.alpha = 1.f; a.epi.gate_scale = 1.f;
+        if (v == 1 || v == 2) { a.epi.bias = bias; a.epi.relu = 1; }
+        if (v == 2) { a.epi.dropout_p = 0.2f; a.epi.seed = 77; a.epi.rng_stream = 3; }
+        if (v == 3 || v == 4) { a.epi.gate = gate; a.epi.gate_scale = 1.25f; }
+        if (v == 4) a.epi.col_sum = cs;
+        if (v == 5) a.epi.mode = 1;
+        const float t = time_us(iters, run_kc, &a);
+        if (v == 5) CK(hipMemset(a.C, 0, (size_t)M * N * 2));
+        run_kc(&a); if (v == 5) run_kc(&a);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned short> hc((size_t)M * N); CK(hipMemcpy(hc.data(), a.C, hc.size() * 2, hipMemcpyDeviceToHost));
+        double cks = 0; for (size_t i = 0; i < hc.size(); i += 7) cks += fabs((double)bf2f(hc[i]));
+        printf("epilogue   M=%6d N=%5d K=%5d  %-18s kernel %d  %8.1f us  %7.1f TF   checksum %.9e\n", M, N, K, names[v], ss_gemm_last_kernel(), t, flops / t / 1e6, cks);
+    }
+    CK(hipFree(a.A)); CK(hipFree(a.B)); CK(hipFree(a.C)); CK(hipFree(gate)); CK(hipFree(bias)); CK(hipFree(cs));
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 20;
     const char* only = argc > 2 ? argv[2] : "";
@@ -155,6 +188,7 @@ int main(int argc, char** argv) {
         bench_kc("heads", M, 128, 768, iters, true);
         bench_kc("dheads", M, 768, 128, iters, false);
     }
+    if (strstr(only, "epi")) bench_epi(iters);
     if (strstr(only, "abl")) {        // where does the time of the 8-wave kernel go?  (results are wrong under a non-zero mask)
         const int masks[7] = {0, 16, 32, 64, 16 | 64, 32 | 64, 16 | 32 | 64};
         const char* names[7] = {"full", "no mfma", "no glds", "no frag reads", "glds only", "mfma only", "skeleton"};
