@@ -599,6 +599,13 @@ def main():
                                 'frac': ach / peak, 'ms_per_step': v['seconds'] / psteps * 1e3, 'launches_per_step': v['calls'] / psteps,
                                 'avg_launch_us': v['seconds'] / v['calls'] * 1e6,
                                 'algorithmic_per_launch': (v['flops'] if mfma else v['bytes']) / v['calls'], 'traffic': traffic_of(name)})
+                k = kernels[-1]
+                if k['traffic']:        # the measured HBM bytes of a launch over its duration: what share of the 8 TB/s the kernel actually drew
+                    k['traffic_frac_of_hbm_peak'] = k['traffic'] / (k['avg_launch_us'] * 1e-6) / 1e9 / PEAK_HBM_GBPS
+                if name in ('attn_fwd', 'attn_bwd'):
+                    k['note'] = ('counted as MFMA work (band-limited flops), but at T = 200 / d_head = 96 with the saved probability image the kernel moves '
+                                 '63 (forward) / 41 (backward) flops per HBM byte against a machine balance of 312: it is bound by HBM and LDS traffic; '
+                                 'traffic_frac_of_hbm_peak is the figure to read (DESIGN.md section 4)')
             top = kernels[0]
             out['roofline'] = {'bound': top['bound'], 'achieved': top['achieved'], 'peak': top['peak'], 'unit': top['unit'], 'frac': top['frac'],
                                'traffic': top['traffic'], 'traffic_source': pmc_src if pmc and top['traffic'] is not None else None,

@@ -192,9 +192,16 @@ __device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* _
     for (int i = 0; i < F::NIT / 2; ++i) {
         int lr, ch, row, col;
         if (F::map(H * (F::NIT / 2) + i, tid, pass, m0, n0, M, N, lr, ch, row, col)) {
+            const long long off = rowmap_off(epi.cmap, row) + col;
+            if (STATS == 0 && !epi.gate && epi.mode != 1) {
+                // nothing is applied per element here (bias / ReLU / dropout went in before the LDS piece): the 16 bytes leave as they are --
+                // unpacking 8 bf16 to f32 and rounding them back was ~60 of this chunk's instructions, on every plain tile of the step
+                *(u32x4*)(C + off) = *(const u32x4*)(ct + lr * ldc + ch * EV);
+                sched_fence();
+                continue;
+            }
             float v[EV];
             outvec_load(ct + lr * ldc + ch * EV, v);
-            const long long off = rowmap_off(epi.cmap, row) + col;
             if (epi.gate) {
                 float g[EV];
                 if (pf == 1) raw_to_float(pre[i], g); else outvec_load((const TO*)epi.gate + off, g);
