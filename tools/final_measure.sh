@@ -21,4 +21,6 @@ bash tools/attn_pmc.sh > /dev/null 2>&1; cp gpurun_out/attn_pmc/table.txt $O/att
 ./tools/bin/attn_bench > $O/attention_bench.txt 2>&1
 ./tools/bin/mfma_peak 4000 > $O/mfma_peak.txt 2>&1
 ./tools/bin/gemm_bench 20 > $O/gemm_bench.txt 2>&1
-cat $O/pytest_gpu.log; cat $O/mfma_peak.txt; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/attention_bench.txt
+./tools/bin/gemm_bench 20 epi >> $O/gemm_bench.txt 2>&1
+(./tools/bin/dtw_bench 64 1000 10; ./tools/bin/dtw_bench 256 1000 10; SS_DTW_DEBUG=8 ./tools/bin/dtw_bench 64 1000 10; SS_DTW_DEBUG=8 ./tools/bin/dtw_bench 256 1000 10; ./tools/bin/ta_probe) > $O/dtw_bench.txt 2>&1
+cat $O/pytest_gpu.log; cat $O/mfma_peak.txt; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/attention_bench.txt; cat $O/dtw_bench.txt
