@@ -3,6 +3,8 @@
 //   mode 0: MFMAs only (register operands, 36 independent accumulator tiles per wave = the 288 x 256 tile of gemm8.hip)
 //   mode 1: + the fragment reads of that tile (26 ds_read_b128 per 72 MFMAs per wave), results discarded
 //   mode 2: + 8.5 LDS writes of 1 KiB per wave and 72 MFMAs (the copy traffic of one K tile; ds_write_b128 stands in for the DMA)
+//   mode 3: the grouped weight-gradient kernel's traffic: 24 TRANSPOSING 8-byte reads (ds_read_b64_tr_b16) + 4 ds_write_b128 per 32 MFMAs and wave
+//   mode 4: the same with 16 transposing reads (what 128 x 128 per wave would need)
 // Prints TFLOP/s and the shader clock that rate implies (1024 flop / clk / SIMD), plus s_memtime / s_memrealtime deltas of one wave.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -39,8 +41,17 @@ __global__ __launch_bounds__(512) void probe(float* out, unsigned long long* clk
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { f32x4 v = acc[0][0]; asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(base + 8192), "v"(v), "n"(0) : "memory"); }
             }
+            if (MODE == 3 || MODE == 4) {     // the weight-gradient kernel's K half: 24 (8 waves) / 32 per 64 MFMAs (4-wave form) transposing 8-byte reads, 4 LDS writes
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                s16x4 sink = {0, 0, 0, 0};
 #pragma unroll
-            for (int i = 0; i < 9; ++i)
+                for (int r = 0; r < (MODE == 3 ? 24 : 16); ++r) { s16x4 v; asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(0)); sink += v; }
+                asm volatile("" :: "v"(sink));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { f32x4 v = acc[0][0]; asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(base + 8192), "v"(v), "n"(0) : "memory"); }
+            }
+#pragma unroll
+            for (int i = 0; i < (MODE >= 3 ? 8 : 9); ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
@@ -66,7 +77,7 @@ static void run(const char* name, int iters)
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
-    const double flops = (double)cus * 8 * iters * 72.0 * 16 * 16 * 32 * 2;
+    const double flops = (double)cus * 8 * iters * (MODE >= 3 ? 64.0 : 72.0) * 16 * 16 * 32 * 2;
     const double tf = flops / (ms * 1e-3) / 1e12;
     printf("%-34s %8.3f ms  %8.1f TFLOP/s  => %.2f GHz at 1024 flop/clk/SIMD;  s_memtime %llu, s_memrealtime %llu (ratio %.2f)\n", name, ms, tf,
            tf * 1e12 / (cus * 4 * 1024.0) / 1e9, h[0], h[1], h[1] ? (double)h[0] / h[1] : 0.0);
@@ -79,6 +90,8 @@ int main(int argc, char** argv)
     run<0>("MFMA only", iters);
     run<1>("MFMA + fragment reads", iters);
     run<2>("MFMA + fragment reads + LDS writes", iters);
+    run<3>("dW K half: 24 tr reads + 4 writes / 32 MFMA", iters);
+    run<4>("dW 4-wave form: 16 tr reads / 32 MFMA", iters);
     run<0>("MFMA only (again)", iters);
     return 0;
 }
