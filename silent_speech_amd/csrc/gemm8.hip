@@ -441,7 +441,6 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
                 for (int e = 0; e < EV; ++e) { const int col = cn0 + ch * EV + e; sh[e] = col < N ? epi.col_shift[col] : 0.f; }
             }
             if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
-            else if (epi.general == 2) Passes8<TO, 2, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
             else Passes8<TO, 0, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
             if (CPR == 32) {                  // bf16 out: lanes l and l + 32 of a wave hold the same column chunk
 #pragma unroll
@@ -467,7 +466,6 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             }
         } else {
             if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
-            else if (epi.general == 2) Passes8<TO, 2, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
             else Passes8<TO, 0, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
         }
         if (!has_next) break;
