@@ -683,6 +683,7 @@ static int gemm_slots() {
 static bool pick_gemm8(bool bf16_in, int a_mode, int b_mode, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, int split_k, int* ni_out, int* pin_out)
 {
     if (!(bf16_in && gemm_opt(OPT_G8) && a_mode == OP_KC && b_mode == OP_KC && epi.fast && !epi.c2 && split_k == 1 && K % 64 == 0 && K > 0)) return false;
+    if (epi.general == 1 && epi.col_sum) return false;       // column statistics of a dropout epilogue: not instantiated (nothing asks for it)
     if (epi.general == 2) return false;                      // log-clamp epilogue (the f32 mel GEMM): not instantiated in the 8-wave kernel (its logf path only cost registers there)
     const int cus = gemm_slots() / g_blocks_per_cu;
     auto max_off = [](const RowMap& m, int rows, int K_) {     // largest element offset the kernel forms for this operand

@@ -268,7 +268,7 @@ struct Passes8<TO, GEN, NI, IPP, NPASS, NPASS, STATS> {
 // (a bias gradient: a third of the registers, which leaves room for the side-input buffers of a gated epilogue) (separate instantiations: the extra live
 // registers of that path would otherwise spill in the main loop of every launch).
 // ABL: compile-time ablation mask for tuning (results are wrong): 1 no MFMA, 2 no in-loop global->LDS copies, 4 no in-loop fragment reads.
-template <class TO, int NI, int PIN, int ABL, int STATS>
+template <class TO, int NI, int PIN, int ABL, int STATS, int GENSEL>
 __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
                                                        int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi, int tiles_n, int nitems)
 {
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int e = 0; e < EV; ++e) { const int col = cn0 + ch * EV + e; sh[e] = col < N ? epi.col_shift[col] : 0.f; }
             }
-            if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
+            if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
             else Passes8<TO, 0, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
             if (CPR == 32) {                  // bf16 out: lanes l and l + 32 of a wave hold the same column chunk
 #pragma unroll
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
                 }
             }
         } else {
-            if (epi.general == 1) Passes8<TO, 1, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
+            if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
             else Passes8<TO, 0, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
         }
         if (!has_next) break;
@@ -481,40 +481,44 @@ int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int 
     const size_t smem = (size_t)2 * (bmt + 256) * 128;
     const int cus = g8_cus();
     dim3 grid(nitems < cus ? nitems : cus), block(512);
-#define G8_CASE(NI_, PIN_, ABL_, ST_)                                                                                        \
+#define G8_CASE(NI_, PIN_, ABL_, ST_) G8_CASE6(NI_, PIN_, ABL_, ST_, -1)
+#define G8_CASE6(NI_, PIN_, ABL_, ST_, GS_)                                                                                        \
     do {                                                                                                                      \
         static bool granted = false;                                                                                          \
-        if (!granted) { if (g8_grant((const void*)gemm8_kc_kernel<TO, NI_, PIN_, ABL_, ST_>, smem)) return 1; granted = true; } \
-        SS_LAUNCH(SS_KERNEL(gemm8_kc_kernel<TO, NI_, PIN_, ABL_, ST_>), grid, block, smem, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, tiles_n, nitems); \
+        if (!granted) { if (g8_grant((const void*)gemm8_kc_kernel<TO, NI_, PIN_, ABL_, ST_, GS_>, smem)) return 1; granted = true; } \
+        SS_LAUNCH(SS_KERNEL(gemm8_kc_kernel<TO, NI_, PIN_, ABL_, ST_, GS_>), grid, block, smem, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, tiles_n, nitems); \
     } while (0)
     const int abl = (epi.debug >> 4) & 7;
 #if defined(G8_FAST_BUILD)        // tuning builds: three bf16-out main-loop variants only (a full build of this file takes minutes)
     if constexpr (sizeof(TO) == 2) {
-        if (epi.col_sum && ni == 9) G8_CASE(9, 3, 0, 2);
-        else if (ni == 9) { switch (pin) { case 3: G8_CASE(9, 3, 0, false); break; case 4: G8_CASE(9, 4, 0, false); break; case 7: G8_CASE(9, 7, 0, false); break; default: G8_CASE(9, 0, 0, false); } }
+        if (epi.col_sum && ni == 9) G8_CASE6(9, 3, 0, 2, 0);
+        else if (ni == 9) { switch (pin) { case 3: if (epi.general == 1) G8_CASE6(9, 3, 0, 0, 1); else G8_CASE6(9, 3, 0, 0, 0); break; case 4: G8_CASE(9, 4, 0, false); break; case 7: G8_CASE(9, 7, 0, false); break; default: G8_CASE(9, 0, 0, false); } }
         else { switch (pin) { case 7: G8_CASE(8, 7, 0, false); break; case 11: G8_CASE(8, 11, 0, false); break; default: G8_CASE(8, 3, 0, false); } }
         SS_LAUNCH_CHECK("ss_gemm(gemm8)");
         return 0;
     } else { ss_set_error("gemm8: tuning build"); return 1; }
 #else
+    // (column statistics never come with the dropout epilogue -- pick_gemm8 refuses the combination -- so these kernels carry one epilogue path)
     if (epi.col_sum && !epi.col_sumsq && !epi.col_shift) {      // plain column sums (a bias gradient)
-        if (ni == 9) { if (pin & 3) G8_CASE(9, 3, 0, 2); else G8_CASE(9, 0, 0, 2); }
-        else { if (pin & 3) G8_CASE(8, 3, 0, 2); else G8_CASE(8, 0, 0, 2); }
+        if (ni == 9) { if (pin & 3) G8_CASE6(9, 3, 0, 2, 0); else G8_CASE6(9, 0, 0, 2, 0); }
+        else { if (pin & 3) G8_CASE6(8, 3, 0, 2, 0); else G8_CASE6(8, 0, 0, 2, 0); }
     }
     else if (epi.col_sum) {                 // column statistics: burst or spread schedule of either tile height
-        if (ni == 9) { if (pin & 3) G8_CASE(9, 3, 0, 1); else G8_CASE(9, 0, 0, 1); }
-        else { if (pin & 3) G8_CASE(8, 3, 0, 1); else G8_CASE(8, 0, 0, 1); }
+        if (ni == 9) { if (pin & 3) G8_CASE6(9, 3, 0, 1, 0); else G8_CASE6(9, 0, 0, 1, 0); }
+        else { if (pin & 3) G8_CASE6(8, 3, 0, 1, 0); else G8_CASE6(8, 0, 0, 1, 0); }
     }
     else if (abl && sizeof(TO) == 2) {      // tuning builds only (bf16 out): which of MFMA / DMA / fragment reads bounds the loop
         if (ni == 9) { switch (abl) { case 1: G8_CASE(9, 0, 1, false); break; case 2: G8_CASE(9, 0, 2, false); break; case 4: G8_CASE(9, 0, 4, false); break; case 5: G8_CASE(9, 0, 5, false); break; case 6: G8_CASE(9, 0, 6, false); break; default: G8_CASE(9, 0, 7, false); } }
         else { switch (abl) { case 1: G8_CASE(8, 0, 1, false); break; case 2: G8_CASE(8, 0, 2, false); break; case 4: G8_CASE(8, 0, 4, false); break; case 5: G8_CASE(8, 0, 5, false); break; case 6: G8_CASE(8, 0, 6, false); break; default: G8_CASE(8, 0, 7, false); } }
     }
-    else if (ni == 9) { switch (pin) { case 1: G8_CASE(9, 1, 0, false); break; case 2: G8_CASE(9, 2, 0, false); break; case 3: G8_CASE(9, 3, 0, false); break; default: G8_CASE(9, 0, 0, false); } }
-    else { switch (pin) { case 1: G8_CASE(8, 1, 0, false); break; case 2: G8_CASE(8, 2, 0, false); break; case 3: G8_CASE(8, 3, 0, false); break; default: G8_CASE(8, 0, 0, false); } }
+    // the default schedule comes in two instantiations: without / with the dropout epilogue (one epilogue path per kernel: fewer registers)
+    else if (ni == 9) { switch (pin) { case 1: G8_CASE(9, 1, 0, false); break; case 2: G8_CASE(9, 2, 0, false); break; case 3: if (epi.general == 1) G8_CASE6(9, 3, 0, 0, 1); else G8_CASE6(9, 3, 0, 0, 0); break; default: G8_CASE(9, 0, 0, false); } }
+    else { switch (pin) { case 1: G8_CASE(8, 1, 0, false); break; case 2: G8_CASE(8, 2, 0, false); break; case 3: if (epi.general == 1) G8_CASE6(8, 3, 0, 0, 1); else G8_CASE6(8, 3, 0, 0, 0); break; default: G8_CASE(8, 0, 0, false); } }
     SS_LAUNCH_CHECK("ss_gemm(gemm8)");
     return 0;
 #endif
 #undef G8_CASE
+#undef G8_CASE6
 }
 template int gemm8_launch_kc<bf16_t>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*);
 template int gemm8_launch_kc<float>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*);
