@@ -301,7 +301,7 @@ extern "C" int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const
 // g = dy * 1[y>0]  (ReLU of the fused output);  per branch: dgamma = sum g*xhat, dbeta = sum g,
 // dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).
 template <class T>
-__global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const T* __restrict__ dy, Seq sdy, const T* __restrict__ y, Seq sy,
+__global__ __launch_bounds__(RED_THREADS, sizeof(T) == 2 ? 4 : 2) void bn_bwd_partial_kernel(const T* __restrict__ dy, Seq sdy, const T* __restrict__ y, Seq sy,
                                                                      const T* __restrict__ xa, Seq sa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a,
                                                                      const T* __restrict__ xb, Seq sb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b,
                                                                      int rows, int C, int rows_per_chunk, int relu, float* __restrict__ partial)
