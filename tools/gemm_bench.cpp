@@ -168,6 +168,22 @@ static void bench_epi(int iters) {
         printf("epilogue   M=%6d N=%5d K=%5d  %-18s kernel %d  %8.1f us  %7.1f TF   checksum %.9e\n", M, N, K, names[v], ss_gemm_last_kernel(), t, flops / t / 1e6, cks);
     }
     CK(hipFree(a.A)); CK(hipFree(a.B)); CK(hipFree(a.C)); CK(hipFree(gate)); CK(hipFree(bias)); CK(hipFree(cs));
+    // the output map of a convolution: (B, T + 2, C) with a zero halo row at each end of every sequence -> a division per output row
+    {
+        const int Bq = 110, T = 400, Cc = 768, Mc = Bq * T, Kc = 2304;
+        KcArgs c; memset(&c, 0, sizeof(c));
+        c.M = Mc; c.N = Cc; c.K = Kc;
+        c.A = dev_bf16((size_t)Mc * Kc, 1.0f); c.B = dev_bf16((size_t)Cc * Kc, 0.05f);
+        CK(hipMalloc(&c.C, (size_t)Bq * (T + 2) * Cc * 2)); CK(hipMemset(c.C, 0, (size_t)Bq * (T + 2) * Cc * 2));
+        c.am = plain(Kc); c.bm = plain(Kc); c.epi.alpha = 1.f; c.epi.gate_scale = 1.f;
+        for (int v = 0; v < 2; ++v) {
+            if (v == 0) c.cm = plain(Cc);
+            else { c.cm.base = Cc; c.cm.batch_stride = (long long)(T + 2) * Cc; c.cm.row_stride = Cc; c.cm.rows_per_batch = T; }
+            const float t = time_us(iters, run_kc, &c);
+            printf("conv out   M=%6d N=%5d K=%5d  %-18s kernel %d  %8.1f us  %7.1f TF\n", Mc, Cc, Kc, v ? "halo rows (B,T+2,C)" : "plain rows", ss_gemm_last_kernel(), t, 2.0 * Mc * Cc * Kc / t / 1e6);
+        }
+        CK(hipFree(c.A)); CK(hipFree(c.B)); CK(hipFree(c.C));
+    }
     fflush(stdout);
 }
 
