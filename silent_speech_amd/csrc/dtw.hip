@@ -571,6 +571,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
             if (nx_ok) { nx_top = t - 1; nx_l = l - 1; cache_nx = column(l - 1, nx_top); }
             const int p0c = c_top + 1 - l;                                // row at cache position 0
             const int idx_in = c_top - t, idx_max = c_top - t_lo < 63 ? c_top - t_lo : 63;
+            const int ilim = idx_max < p0c - 1 ? idx_max : p0c - 1;       // cache exhausted | row 0 reached: one limit on idx
             int idx = idx_in, sh = 2 * (DR - 1 - r), up;
             do {
                 rv = lane == idx ? (unsigned)s : rv;
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                 up = code != 1u;                                          // up or diagonal: the row is left
                 const int lf = (int)((code >> 1) ^ 1u);                   // left or diagonal: the column moves
                 idx += up; s -= lf; sh += 2 * lf;
-            } while (((2 * (DR - 1) - sh) | (s - 1) | (idx_max - idx) | (p0c - idx - 1)) >= 0);      // column left | path ended (s == 0 | p == 0) | cache exhausted
+            } while (((2 * (DR - 1) - sh) | (s - 1) | (ilim - idx)) >= 0);      // column left | path ended (s == 0 | p == 0) | cache exhausted
             const int idx_hi = s == 0 ? idx - up : idx - 1;               // rows left in this visit (+ the current one where the path ends in it)
             if (w == 0 && lane >= idx_in && lane <= idx_hi) res[p0c - lane] = (int)rv;
             p = p0c - idx;
@@ -607,6 +608,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
             // one cell per trip, branch-free (the compiler's if / else form of this loop was 35 instructions and three taken branches per
             // cell): left (code 2) moves one column and leaves no row; up (code & 1) leaves the row at column s; diagonal does both
             unsigned code;
+            // s and idx move together (s + idx is constant in this loop): "the path ended" (s < 1) and "cache exhausted" (idx > idx_max) are ONE limit on s
+            const int s_lim = s + idx - idx_max > 1 ? s + idx - idx_max : 1;
             for (;;) {
                 code = (dtw_readlane(cache, idx) >> sh) & 3u;                         // 2 [best == left] + [best == up]
                 const bool isl = code == 2u;
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                 const int dgl = (int)(~code & 1u);
                 s -= dgl; idx += dgl;
                 sh += isl ? 0 : 2;
-                if (((2 * (DR - 1) - sh) | (s - 1) | (idx_max - idx)) < 0) break;      // left the column upward | the path ended | cache exhausted
+                if (((2 * (DR - 1) - sh) | (s - s_lim)) < 0) break;      // left the column upward | the path ended or the cache is exhausted
             }
             if (s == 0) {                                                 // the path ends here; after a left move the current row ends at column 1
                 if (code == 2u) { rv = lane2 == sh ? 1u : rv; sh_out = sh + 2; } else sh_out = sh;
