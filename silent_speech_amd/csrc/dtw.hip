@@ -14,13 +14,16 @@
 //     same column one step earlier and hands its last row down with ONE cross-lane shift per step (no LDS,
 //     no barrier inside a wave).  Across waves the hand-off goes through an LDS ring and a barrier every
 //     G = 64 steps: wave w runs two super-steps behind wave w-1 (blocked wavefront).
-//   * costs are consumed in a SKEWED layout  sk[(strip*4+wave)][t][lane][r]  so that every step of a wave
-//     is one fully coalesced, 16-byte-aligned 1 KiB load (prefetched 8 steps ahead); out-of-matrix cells
-//     hold +inf.  ss_dtw_align() builds it from an arbitrarily strided cost matrix (e.g. the non-contiguous
-//     costs.T view of transduction_model.py:126); the fused loss path writes it directly (loss.hip).
-//   * the 2-bit first-minimum direction of every cell (1 byte per lane per step, dirs[wave strip][t][lane]) goes to HBM instead of the
-//     4-byte cumulative matrix (8 B/cell algorithmic traffic -> 4.25 B/cell); the workgroup then stages the
-//     direction bytes of a wave strip in LDS and walks the path back with scalar arithmetic (results[]).
+//   * costs come from one of two sources, decided per matrix (dtw_source): a matrix with one unit-stride axis of at most 1025 cells is read
+//     IN PLACE -- that axis is dealt to the lanes (for a row-major matrix the lanes therefore own COLUMNS and the sweep solves the transposed
+//     problem), 8-lane groups fetch their shared 128-byte lines together into a per-wave LDS ring and every lane picks its 16 bytes up
+//     when its step comes (see "the cost FIFO in LDS" below).  Everything else is consumed in a SKEWED layout
+//     sk[(strip*4+wave)][t][lane][r], one fully coalesced, 16-byte-aligned 1 KiB load per wave and step (prefetched 24 steps ahead);
+//     out-of-matrix cells hold +inf.  ss_dtw_align() builds it from an arbitrarily strided cost matrix, the fused loss path writes it
+//     directly (loss.hip).
+//   * the 2-bit first-minimum direction of every cell (1 byte per lane per step, dirs[wave strip][t / 4][lane][t % 4]) goes to HBM instead
+//     of the 4-byte cumulative matrix (8 B/cell algorithmic traffic -> 4.25 B/cell); the workgroup then stages the direction bytes of a
+//     wave strip in LDS and walks the path back with scalar arithmetic (results[]).
 #include "common.h"
 #include "silent_speech_hip.h"
 #include <math.h>
@@ -203,7 +206,7 @@ __device__ __forceinline__ long long dir_byte(int t, int lane) { return ((long l
 template <int OFF>
 __device__ __forceinline__ void gload128(f32x4& v, const float* p) {
 #if defined(SS_EMU)
-    __builtin_memcpy(&v, (const char*)p + OFF, 16);                  // in-place sources are dword-aligned only
+    __builtin_memcpy(&v, (const char*)p + OFF, 16);
 #else
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF) : "memory");
 #endif
@@ -282,7 +285,6 @@ __device__ __forceinline__ unsigned dtw_readlane(unsigned v, int l) {      // l 
 }
 
 // dbg (SS_DTW_DEBUG, tuning only -- results are wrong): 1 no backtrace, 2 no sweep, 4 every super-step on the generic path, 8 never in place
-enum { SRC_STRIP = 0, SRC_DIRECT = 1, SRC_CLAMP = 2 };
 // HAVE_COSTS = false: the instantiation behind ss_dtw_align_skewed (the training step's loss): strips only, none of the in-place paths'
 // registers (the three straight-line 64-step bodies side by side push the kernel past 256 VGPRs, which costs the strip path moves)
 template <bool HAVE_COSTS>
