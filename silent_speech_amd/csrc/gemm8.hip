@@ -145,6 +145,20 @@ __device__ __forceinline__ void stage8(const f32x4& a, TO* __restrict__ ct, int 
     }
 }
 
+// The same for the TRANSPOSED accumulator layout of the kernels without dropout (MFMA operands swapped): lane (r, q) holds row r and columns
+// 4 q .. 4 q + 3 of the 16 x 16 tile, so the four values leave as ONE 8-byte (bf16) / 16-byte (f32) LDS store instead of four 2-byte ones
+// (a store's cost is its address + data transfer: 4 cycles for a 2-byte ds_write, 6 for 8 bytes)
+template <class TO>
+__device__ __forceinline__ void stage8_sw(const f32x4& a, TO* __restrict__ ct, int ldc, int lrow, int lcol0, const GemmEpi& epi, const f32x4& bias)
+{
+    const float lo = epi.relu ? 0.f : -INFINITY;
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = fmaxf(a[e] * epi.alpha + bias[e], lo);
+    if constexpr (sizeof(TO) == 2) { u32x2 w; w[0] = pack_bf16(x[0], x[1]); w[1] = pack_bf16(x[2], x[3]); *(u32x2*)(ct + lrow * ldc + lcol0) = w; }
+    else { f32x4 w = {x[0], x[1], x[2], x[3]}; *(f32x4*)(ct + lrow * ldc + lcol0) = w; }
+}
+
 // chunk `it` of thread `tid` in flush pass `pass`: LDS row / column chunk, output row / column, validity
 template <class TO, int NI, int IPP>
 struct Flush8 {
@@ -229,19 +243,22 @@ __device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* _
 
 // The side input travels half a pass ahead of its use, and is always requested BEFORE the stores of the half in front of it (a wait for a
 // load that was issued behind a store also waits for that store: vmcnt counts in order): pa = first halves, pb = second halves.
-template <class TO, int GEN, int NI, int IPP, int P, int NPASS, int STATS>
+template <class TO, int GEN, int NI, int IPP, int P, int NPASS, int STATS, bool SW = false>
 struct Passes8 {
     static __device__ __forceinline__ void run(const f32x4 (&acc)[NI][4], TO* ct, int ldc, TO* C, const GemmEpi& epi, int m0, int n0, int M, int N, int tid, int wm, int wn, int r, int q,
                                                float (&cs)[OutVec<TO>::N], float (&cq)[OutVec<TO>::N], const float (&sh)[OutVec<TO>::N],
-                                               const float (&bias4)[4], u32x4 (&pa)[Flush8<TO, NI, IPP>::NIT / 2], u32x4 (&pb)[Flush8<TO, NI, IPP>::NIT / 2], int pf, const TO* pf_src) {
+                                               const float (&bias4)[4], u32x4 (&pa)[Flush8<TO, NI, IPP>::NIT / 2], u32x4 (&pb)[Flush8<TO, NI, IPP>::NIT / 2], int pf, const TO* pf_src,
+                                               const f32x4 (&b16)[4]) {
 #pragma unroll
         for (int ii = 0; ii < IPP; ++ii) {
             constexpr int I0 = P * IPP;
             if (I0 + ii < NI) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    stage8<TO, GEN>(acc[I0 + ii < NI ? I0 + ii : 0][j], ct, ldc, (wm * IPP + ii) * 16 + q * 4, wn * 64 + j * 16 + r, epi,
-                                    m0 + (wm * NI + I0 + ii) * 16 + q * 4, n0 + wn * 64 + j * 16 + r, N, bias4[j]);
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (SW) stage8_sw<TO>(acc[I0 + ii < NI ? I0 + ii : 0][j], ct, ldc, (wm * IPP + ii) * 16 + r, wn * 64 + j * 16 + q * 4, epi, b16[j]);
+                    else stage8<TO, GEN>(acc[I0 + ii < NI ? I0 + ii : 0][j], ct, ldc, (wm * IPP + ii) * 16 + q * 4, wn * 64 + j * 16 + r, epi,
+                                         m0 + (wm * NI + I0 + ii) * 16 + q * 4, n0 + wn * 64 + j * 16 + r, N, bias4[j]);
+                }
             }
         }
         barrier_keep_vm();
@@ -250,14 +267,15 @@ struct Passes8 {
         if (P + 1 < NPASS && pf) flush8_prefetch<TO, NI, IPP, 0>(pf_src, epi, m0, n0, P + 1, M, N, tid, pa);
         flush8<TO, NI, IPP, STATS, 1>(ct, ldc, C, epi, m0, n0, P, M, N, tid, cs, cq, sh, pb, pf);
         if (P + 1 < NPASS) barrier_keep_vm();
-        Passes8<TO, GEN, NI, IPP, P + 1, NPASS, STATS>::run(acc, ct, ldc, C, epi, m0, n0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
+        Passes8<TO, GEN, NI, IPP, P + 1, NPASS, STATS, SW>::run(acc, ct, ldc, C, epi, m0, n0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
     }
 };
-template <class TO, int GEN, int NI, int IPP, int NPASS, int STATS>
-struct Passes8<TO, GEN, NI, IPP, NPASS, NPASS, STATS> {
+template <class TO, int GEN, int NI, int IPP, int NPASS, int STATS, bool SW>
+struct Passes8<TO, GEN, NI, IPP, NPASS, NPASS, STATS, SW> {
     static __device__ __forceinline__ void run(const f32x4 (&)[NI][4], TO*, int, TO*, const GemmEpi&, int, int, int, int, int, int, int, int, int,
                                                float (&)[OutVec<TO>::N], float (&)[OutVec<TO>::N], const float (&)[OutVec<TO>::N],
-                                               const float (&)[4], u32x4 (&)[Flush8<TO, NI, IPP>::NIT / 2], u32x4 (&)[Flush8<TO, NI, IPP>::NIT / 2], int, const TO*) {}
+                                               const float (&)[4], u32x4 (&)[Flush8<TO, NI, IPP>::NIT / 2], u32x4 (&)[Flush8<TO, NI, IPP>::NIT / 2], int, const TO*,
+                                               const f32x4 (&)[4]) {}
 };
 
 }  // namespace g8
@@ -273,6 +291,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
                                                        int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi, int tiles_n, int nitems)
 {
     using namespace g8;
+    constexpr bool SWAP = GENSEL == 0;                       // kernels that can never run the dropout epilogue: transposed accumulator tiles (see stage8_sw)
     constexpr int BMT = 2 * NI * 16, STAGE = (BMT + TBN) * RB;
     constexpr int HRSEL = PIN >> 2;                         // PIN bits 2..3: rows of 16 per phase -- 0: 3 or 4, 1: one, 2: two (even NI)
     constexpr int HR = HRSEL == 1 ? 1 : (HRSEL == 2 && NI % 2 == 0 ? 2 : (NI % 3 == 0 ? 3 : 4));                 // 16-row MFMA tiles per phase
@@ -344,7 +363,10 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
         auto mfma_row = [&](auto phc, auto xc) {
             constexpr int ph = phc, x = xc, kk = ph / NPK, i = (ph % NPK) * HR + x;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[ph & 1][x], fb[kk][j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (SWAP) acc[i][j] = mfma_bf16_16x16x32(fb[kk][j], fa[ph & 1][x], acc[i][j]);      // D^T: lane (r, q) <- row r, columns 4 q .. 4 q + 3
+                else acc[i][j] = mfma_bf16_16x16x32(fa[ph & 1][x], fb[kk][j], acc[i][j]);
+            }
         };
         // One phase = HR groups of {a share of the NEXT phase's fragment reads, a share of a DMA chunk, 4 MFMAs}, then ONE wait for
         // the fragments requested in it.  PIN = 0: reads and DMA in a burst at the phase start (every wave queues behind the LDS /
@@ -412,8 +434,13 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
         constexpr int IPP = sizeof(TO) == 2 ? (NI % 3 == 0 ? 3 : 2) : 1;
         constexpr int NPASS = (NI + IPP - 1) / IPP;
         float bias4[4];
+        f32x4 b16[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int col = cn0 + wn * 64 + j * 16 + r; bias4[j] = (epi.bias && col < N) ? epi.bias[col] : 0.f; }
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (SWAP) { const int col = cn0 + wn * 64 + j * 16 + q * 4; bias4[j] = 0.f; b16[j] = (epi.bias && col < N) ? *(const f32x4*)(epi.bias + col) : z; }      // N % 8 == 0 (epi.fast)
+            else { const int col = cn0 + wn * 64 + j * 16 + r; bias4[j] = (epi.bias && col < N) ? epi.bias[col] : 0.f; b16[j] = z; }
+        }
         // (not in the full column-statistics instantiation: its three per-column register arrays leave no room for the side-input buffers --
         // with them the gate + column-sum epilogue of the FFN input gradient spilled and ran 219 instead of 185 us; the sums-only form has room)
         const int pf = STATS == 1 ? 0 : (epi.gate ? 1 : (epi.mode == 1 ? 2 : 0));
@@ -440,8 +467,8 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
 #pragma unroll
                 for (int e = 0; e < EV; ++e) { const int col = cn0 + ch * EV + e; sh[e] = col < N ? epi.col_shift[col] : 0.f; }
             }
-            if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
-            else Passes8<TO, 0, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
+            if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+            else Passes8<TO, 0, NI, IPP, 0, NPASS, STATS, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
             if (CPR == 32) {                  // bf16 out: lanes l and l + 32 of a wave hold the same column chunk
 #pragma unroll
                 for (int e = 0; e < EV; ++e) { cs[e] += __shfl_xor(cs[e], 32); if (STATS == 1) cq[e] += __shfl_xor(cq[e], 32); }
@@ -465,8 +492,8 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
                 }
             }
         } else {
-            if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
-            else Passes8<TO, 0, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src);
+            if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+            else Passes8<TO, 0, NI, IPP, 0, NPASS, 0, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
         }
         if (!has_next) break;
     }
