@@ -230,19 +230,23 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
-def make_step(model, optim, batch, dp, it):
-    from silent_speech_amd.data_utils import combine_fixed_length
-    from silent_speech_amd.transduction_model import dtw_loss
+def make_step(model, optim, batches, dp, it):
+    """One training step per call, on batches[it % len(batches)]: the timed loop ROTATES distinct reference-size batches, so every step
+    hands the path tensors it has not seen the step before -- the per-batch host work (pack tables, loss plan, their upload) is paid
+    every step exactly as reference transduction_model.py:196-212 pays it for every DataLoader batch.  (Nothing in the package caches
+    per-batch state across steps any more; a single-element list reproduces the old same-batch loop for the `same_batch` figure.)"""
+    from silent_speech_amd.transduction_model import dtw_loss, prepare_batch
+    if isinstance(batches, dict):
+        batches = [batches]
 
     def step():
+        batch = batches[it[0] % len(batches)]
         optim.zero_grad()
         i = it[0] + 1
         if i <= 500:
             for gp in optim.param_groups:
                 gp['lr'] = i * 1e-3 / 500                                       # transduction_model.py:186-189
-        X = combine_fixed_length(batch['emg'], 200)
-        X_raw = combine_fixed_length(batch['raw_emg'], 1600)
-        sess = combine_fixed_length(batch['session_ids'], 200)
+        X, X_raw, sess = prepare_batch(batch, X_dev(batch))                     # the three combine_fixed_length calls + the loss plan, one upload
         if dp is not None:
             dp.begin_step(X_raw.shape[0] * 200, dp.local_target_frames(batch))
         pred, aux = model(X, X_raw, sess)
@@ -255,6 +259,10 @@ def make_step(model, optim, batch, dp, it):
         it[0] += 1
         return loss
     return step
+
+
+def X_dev(batch):
+    return batch['raw_emg'][0].device
 
 
 def _time_steps(step, warm, timed):
@@ -292,7 +300,7 @@ def ctc_leg(dev, warm=2, timed=6):
     from silent_speech_amd.optim import FusedAdamW
     from silent_speech_amd.recognition_model import ctc_loss
     from silent_speech_amd.synthetic import reference_size_batch
-    from silent_speech_amd.transduction_model import _pack_batch
+    from silent_speech_amd.transduction_model import prepare_batch
     torch.manual_seed(1)
     model = Model(112, 38, model_size=768, num_layers=6, dropout=0.2, compute_dtype=torch.bfloat16).to(dev)
     model.train()
@@ -303,7 +311,7 @@ def ctc_leg(dev, warm=2, timed=6):
     def unit():
         optim.zero_grad()
         for b in batches:
-            X, X_raw, sess = _pack_batch(b, dev)
+            X, X_raw, sess = prepare_batch(b, dev, loss_plan=False)
             loss = ctc_loss(model(X, X_raw, sess), b, blank=37)
             loss.backward()
         optim.step()
@@ -312,7 +320,7 @@ def ctc_leg(dev, warm=2, timed=6):
     # the loss lines alone, on the logits of the first batch
     b = batches[0]
     with torch.no_grad():
-        X, X_raw, sess = _pack_batch(b, dev)
+        X, X_raw, sess = prepare_batch(b, dev, loss_plan=False)
         pred = model(X, X_raw, sess).float()
     logits = pred.detach().clone().requires_grad_(True)
     ctc_loss(logits, b, blank=37).backward()
@@ -426,6 +434,8 @@ def main():
     ap.add_argument('--cpu-rows', type=int, default=16, help='packed rows of the batch given to the CPU baseline (0 = skip baseline and parity)')
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--cpu-warmup', type=int, default=3)
+    ap.add_argument('--batches', type=int, default=4, help='distinct reference-size batches rotated through warm-up and the timed loop (1 = the same batch every step)')
+    ap.add_argument('--no-same', action='store_true', help='skip the same-batch comparison loop after the timed loop (profiling runs)')
     ap.add_argument('--no-profile', action='store_true', help='no per-launch HIP events (roofline entry omitted)')
     ap.add_argument('--no-legs', action='store_true', help='skip the DTW (configs[2]), mel, fp32-mode, CTC (configs[4]), eval and pipeline legs')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'], help='weak: one reference-size batch per rank; strong: ONE such batch dealt over the ranks by length')
@@ -471,18 +481,26 @@ def main():
     if dp is not None:
         dp.attach(model)
     optim = FusedAdamW(model, weight_decay=1e-7)
+    def to_dev(b):
+        return {k: ([t.to(dev) for t in v] if isinstance(v, list) and len(v) and torch.is_tensor(v[0]) else v) for k, v in b.items()}
+    nb = max(1, args.batches)
     if args.scaling == 'strong' and world > 1:
-        # ONE global batch, utterances dealt round-robin in order of decreasing length: frames (and DTW problems) per rank stay balanced
-        g = reference_size_batch(seed=0)
-        order = sorted(range(len(g['lengths'])), key=lambda i: -g['lengths'][i])[rank::world]
-        batch_cpu = {k: [v[i] for i in order] for k, v in g.items()}
+        # ONE global batch per rotation slot, utterances dealt round-robin in order of decreasing length: frames (and DTW problems) per rank stay balanced
+        batches_cpu = []
+        for j in range(nb):
+            g = reference_size_batch(seed=100 * j)
+            order = sorted(range(len(g['lengths'])), key=lambda i: -g['lengths'][i])[rank::world]
+            batches_cpu.append({k: [v[i] for i in order] for k, v in g.items()})
     else:
-        batch_cpu = reference_size_batch(seed=rank)
-    batch = {k: ([t.to(dev) for t in v] if isinstance(v, list) and len(v) and torch.is_tensor(v[0]) else v) for k, v in batch_cpu.items()}
-    frames = sum(batch['lengths'])
+        batches_cpu = [reference_size_batch(seed=rank + 100 * j) for j in range(nb)]      # slot 0 = the batch of the earlier rounds (seed = rank)
+    batch_cpu = batches_cpu[0]
+    batches = [to_dev(b) for b in batches_cpu]
+    batch = batches[0]
+    frames_of = [sum(b['lengths']) for b in batches]
+    frames = frames_of[0]
     rows = (frames + 199) // 200
     it = [0]
-    step = make_step(model, optim, batch, dp, it)
+    step = make_step(model, optim, batches, dp, it)
 
     for _ in range(args.warmup):
         loss = step()
@@ -500,7 +518,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host_enqueue = 0.0
+    timed_frames = 0
     for i in range(args.steps):
+        timed_frames += frames_of[it[0] % len(batches)]
         profiled = prof is not None and i % 5 == 0
         if prof is not None:
             # every 5th timed step carries the per-launch HIP events (roofline numerator); those steps run serially (no side stream):
@@ -522,23 +542,58 @@ def main():
     ops.PROFILER = None
     final_loss = float(loss.detach())
 
-    stats = torch.tensor([elapsed, float(frames)], dtype=torch.float64, device=dev)
+    # the same loop on ONE batch (what rounds 1-3 timed), un-profiled: how much of a step is per-batch host work / uploads
+    # Un-profiled comparison loops after the timed one (the timed loop carries per-launch events on every 5th step, which run
+    # without the side stream): the SAME loop rotating the batches, and the loop rounds 1-3 reported (batch 0 every step).
+    same_ms = rot_ms = float('nan')
+    n_same, rot_frames = 0, 0
+    if not args.no_same:
+        n_same = min(max(args.steps, len(batches)), 12)
+
+        def loop(fn, n):
+            for _ in range(2):
+                fn()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            return (time.perf_counter() - ts) / n * 1e3
+        L.ss_plan_profile(plan.handle, 0)
+        rot_it = [it[0]]
+        rot_ms = loop(make_step(model, optim, batches, dp, rot_it), n_same)
+        rot_frames = sum(frames_of[(rot_it[0] - n_same + j) % len(batches)] for j in range(n_same)) / n_same
+        same_ms = loop(make_step(model, optim, [batch], dp, [rot_it[0]]), n_same)
+
+    stats = torch.tensor([elapsed, float(timed_frames), same_ms, rot_ms], dtype=torch.float64, device=dev)
     if world > 1:
         mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, total_frames = float(mx[0]), float(sm[1])
+        elapsed, total_frames, same_ms, rot_ms = float(mx[0]), float(sm[1]), float(mx[2]), float(mx[3])
     else:
-        total_frames = float(frames)
+        total_frames = float(timed_frames)
 
     if rank == 0:
         out = {
-            'metric': 'EMG frames/s training (transduction_model.py)', 'value': total_frames * args.steps / elapsed, 'unit': 'frames/s',
+            'metric': 'EMG frames/s training (transduction_model.py)', 'value': total_frames / elapsed, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': args.scaling if world > 1 else 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'configs[1]: full transduction model (768-d, 6-layer rel-pos encoder, 3 ResBlocks) training step '
                                    '(pack+fwd+dtw_loss incl. on-device DTW+bwd+AdamW), dropout 0.2, synthetic 8-ch EMG',
-                       'frames_per_gpu_step': frames, 'rows_per_gpu_step': rows, 'utterances_per_gpu_step': len(batch['lengths']),
-                       'silent_utterances': int(sum(batch['silent'])), 'parallelism': 'dp%d' % world, 'final_loss': final_loss,
+                       'batch_rotation': '%d distinct reference-size batches (seeds rank + 100 j) resident in HBM, rotated through warm-up and the timed '
+                                         'loop: every step packs and plans a batch it did not see the step before (no per-batch cache exists in the package)' % len(batches),
+                       'frames_per_gpu_step': [int(f) for f in frames_of], 'rows_per_gpu_step': [(f + 199) // 200 for f in frames_of],
+                       'utterances_per_gpu_step': [len(b['lengths']) for b in batches],
+                       'silent_utterances': [int(sum(b['silent'])) for b in batches], 'parallelism': 'dp%d' % world, 'final_loss': final_loss,
+                       'unprofiled': None if n_same == 0 else {
+                           'steps': n_same, 'ms_per_step_rotated': rot_ms, 'frames_per_s_rotated': rot_frames / rot_ms * 1e3,
+                           'ms_per_step_same_batch': same_ms, 'frames_per_s_same_batch': frames / same_ms * 1e3,
+                           'note': 'after the timed loop, no per-launch events (the timed loop runs every 5th step serially for the roofline table): '
+                                   'the rotating loop again, and batch 0 on every step (what rounds 1-3 timed)'},
                        'host_enqueue_ms_per_step': host_enqueue / max(n_plain, 1) * 1e3,
                        'host_enqueue_note': 'host time to enqueue one un-profiled step (forward and backward are one native call each)'},
         }
@@ -621,9 +676,10 @@ def main():
             base, sub, ref_pred = cpu_baseline(batch_cpu, args.cpu_rows, args.cpu_warmup, args.cpu_steps, init_sd, dev)
             out['cpu_baseline'] = base
             out['parity'] = parity_entry(sub, ref_pred, init_sd, dev)
-            if args.cpu_full:        # SURVEY 8d asks for the identical batch: the whole 110-row step once next to the bounded sample
-                full, _, _ = cpu_baseline(batch_cpu, 10 ** 9, 1, 2, init_sd, dev, want_pred=False)
-                out['cpu_baseline']['full_batch'] = {k: full[k] for k in ('value', 'unit', 'cores', 'sample')}
+            if args.cpu_full:        # SURVEY 8d asks for the identical batch: the whole 110-row step is the headline CPU figure, the bounded
+                full, _, _ = cpu_baseline(batch_cpu, 10 ** 9, 1, 2, init_sd, dev, want_pred=False)        # sample (faster per frame: it fits the caches) rides along
+                full['bounded_sample'] = {k: base[k] for k in ('value', 'unit', 'cores', 'sample')}
+                out['cpu_baseline'] = full
         if world == 1 and not args.no_legs:
             out['dtw'] = dtw_leg(dev)
             out['dtw']['saturating'] = {k: v for k, v in dtw_leg(dev, nb=256).items() if k in ('workload', 'hip_ms', 'matrices_per_s', 'roofline', 'bit_exact_vs_oracle')}

@@ -28,9 +28,9 @@ extern "C" {
 const char* ss_last_error(void);
 /* Library/ABI version and the GPU architecture the kernels were compiled for ("gfx950"). */
 /* Bumped whenever a struct layout or an entry-point signature changes (3: ss_gemm_epilogue column-statistics fields, the plan /
- * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
+ * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative; 4: ss_loss_index_tables).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
  * library paired with newer headers would otherwise read garbage struct fields instead of failing. */
-#define SS_ABI_VERSION 3
+#define SS_ABI_VERSION 4
 int ss_abi_version(void);
 const char* ss_target_arch(void);
 
@@ -250,6 +250,13 @@ int ss_emg_prepare(int dtype, const float* x_raw, void* out_padded, float* shift
  * dtw_loss (transduction_model.py:98-157).  `head` = [pred (n_mel) | phoneme logits (n_phone)] per
  * packed frame, f32, row stride ld.  All kernels produce value AND gradient (dhead, same layout,
  * must be zero-initialised; scaled by inv_total = 1/sum(T2)); loss_accum/correct_accum are += . */
+/* Per-frame index tables of one batch (the decollate_tensor + zip bookkeeping of transduction_model.py:101-111) expanded on the
+ * device from one row of 8 int64 per utterance: [n_pred, n_tgt, silent, first packed pred row, first target row, offset into
+ * `results`, offset into the voiced tables, offset into the silent tables].  Voiced utterance: vo_pred / vo_tgt [vo_off + i] =
+ * pred_row0 + i / tgt_row0 + i; silent: si_tgt = tgt_row0 + i, si_base = pred_row0, si_res = res_off + i (i < n_tgt).  The tables
+ * are what ss_voiced_loss / ss_silent_loss take; they may be sized exactly (sum of voiced n_pred / silent n_tgt, at least 1). */
+int ss_loss_index_tables(const int64_t* utt_dev, int n_utt, int32_t* vo_pred, int32_t* vo_tgt, int32_t* si_tgt, int32_t* si_base,
+                         int32_t* si_res, void* stream);
 int ss_frame_lse(const float* head, int64_t ld, int col0, int ncls, int rows, float* lse, int32_t* argmax, void* stream);
 int ss_voiced_loss(const float* head, int64_t ld, int n_mel, int n_phone, const float* lse, const int32_t* argmax, const float* Y,
                    const int64_t* phones, const int32_t* pred_row, const int32_t* tgt_row, int nframes, float lam, float inv_total,

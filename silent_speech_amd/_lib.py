@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('SS_AMD_LIBRARY') or os.path.join(_HERE, 'lib', 'libsilent_speech_hip.so')      # override: A/B runs of two builds on one box
 
 SS_F32, SS_BF16, SS_F64 = 0, 1, 2
-ABI_VERSION = 3          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
+ABI_VERSION = 4          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
 OP_KC, OP_OC = 0, 1
 
 
@@ -81,6 +81,7 @@ SIGNATURES = {
     'ss_layernorm_backward_ws': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _U64, _U32, _P],
     'ss_emg_prepare': [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     'ss_frame_lse': [_P, _L, _I, _I, _I, _P, _P, _P],
+    'ss_loss_index_tables': [_P, _I, _P, _P, _P, _P, _P, _P],
     'ss_voiced_loss': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],
     'ss_silent_cost_skewed': [_P, _L, _I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
     'ss_silent_loss': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],

@@ -92,12 +92,35 @@ class Model(nn.Module):
         self.shift_rng = random                           # architecture.py:65 draws r = random.randrange(8)
         self._anchor = None
         self._flat = None
+        self._cache = {}
 
     # ------------------------------------------------------------------ flat parameter / gradient arenas
     def optimized_parameters(self):
         """Every parameter except the relative-position embeddings, which never receive a gradient in the
         reference (padded under no_grad, transformer.py:214-218) and are therefore never updated by AdamW."""
-        return [p for n, p in self.named_parameters() if 'relative_positional' not in n]
+        c = self._cache.get('opt')
+        if c is None:
+            c = self._cache['opt'] = [p for n, p in self.named_parameters() if 'relative_positional' not in n]
+        return c
+
+    def all_parameters(self):
+        """list(self.parameters()), cached: the per-step signature checks (engine.py) walk the parameters several times, and
+        nn.Module.parameters() re-traverses the module tree on every call (1.5 ms of host time per step before the cache).
+        The module tree is fixed after construction; Module._apply (.to / .cuda / .float) drops the cache."""
+        c = self._cache.get('all')
+        if c is None:
+            c = self._cache['all'] = list(self.parameters())
+        return c
+
+    def all_buffers(self):
+        c = self._cache.get('buf')
+        if c is None:
+            c = self._cache['buf'] = list(self.buffers())
+        return c
+
+    def _apply(self, fn, *a, **k):
+        self._cache.clear()
+        return super()._apply(fn, *a, **k)
 
     def flatten_parameters(self):
         """Re-home all optimised parameters (and their .grad) in two contiguous f32 arenas: one fused AdamW

@@ -20,6 +20,7 @@ void ss_set_error(const char* fmt, ...);
         if (!(cond)) { ss_set_error(__VA_ARGS__); return 1; } \
     } while (0)
 int ss_check_launch(const char* what);
+int ss_upload_table(void* dst_dev, const void* src_host, size_t bytes, void* stream);   // runtime.hip: via a pinned staging ring
 #define SS_LAUNCH_CHECK(what) do { int rc_ = ss_check_launch(what); if (rc_) return rc_; } while (0)
 
 #if defined(SS_EMU)

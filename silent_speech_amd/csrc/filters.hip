@@ -372,12 +372,7 @@ extern "C" int ss_iir_filtfilt_batch(const double* x, double* y, const int32_t* 
         total_rows = rows;
     }
     { long long rows = 0; for (int u = 0; u < R; ++u) { RagRow& r = tabs[(size_t)n_filt * R + u]; memset(&r, 0, sizeof(r)); r.src_off = rows * C; r.T = lengths_host[u]; rows += r.T; } }
-#if defined(SS_EMU)
-    memcpy(tabs_dev, tabs.data(), tabs.size() * sizeof(RagRow));
-#else
-    if (hipMemcpyAsync(tabs_dev, tabs.data(), tabs.size() * sizeof(RagRow), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) { ss_set_error("ss_iir_filtfilt_batch: table upload failed"); return 1; }
-    // (pageable source: the runtime has copied `tabs` into its staging buffer when the call returns, so the local may go out of scope)
-#endif
+    if (ss_upload_table(tabs_dev, tabs.data(), tabs.size() * sizeof(RagRow), stream)) return 1;      // through pinned staging: `tabs` is a local
     const int tpb = 256 / C * C, cpb = tpb / C;
     const double* src = x;
     for (int q = 0; q < n_filt; ++q) {

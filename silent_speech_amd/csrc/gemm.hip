@@ -641,8 +641,9 @@ extern "C" int ss_gemm_set_blocks_per_cu(int n) { int old = g_blocks_per_cu; if 
 //   1 SS_GEMM_W2_BM  force its tile height (128 / 144), 0 = cost model
 //   2 SS_GEMM8       8-wave 256/288 x 256 kernel: 0 never, 1 cost model, 2 whenever legal
 //   3 SS_GEMM8_NI    force its tile height in 16-row units per M-wave (8 / 9), 0 = cost model
-//   4 SS_GEMM8_PIN   bit 0: its fragment reads, bit 1: its DMA pieces spread between the MFMA groups (else a burst per phase); bits 2..3: 16-row
-//                    tiles per phase (0: three / four, 1: one, 2: two); 16 = chosen per shape
+//   4 SS_GEMM8_PIN   bit 0: its fragment reads, bit 1: its DMA pieces spread between the MFMA groups (else a burst per phase); values 0..3.
+//                    (Tuning builds, -DG8_FAST_BUILD, additionally read bits 2..3 as 16-row tiles per phase; the release build ignores
+//                    values above 3 and keeps the default schedule, 3.)
 //   5 SS_GEMM_DEBUG  ablation mask for tuning (results are then wrong): 1 no flush stores, 2 no epilogue staging, 4 no MFMA (128-wide
 //                    kernels); 16 no MFMA, 32 no in-loop global->LDS copies, 64 no in-loop fragment reads, 128 no C flush (8-wave kernel)
 //   6 SS_GEMM_SMALLK the LDS-free K <= 32 kernel (gemm_smallk.hip): 0 never, 1 whenever legal
@@ -711,7 +712,11 @@ static bool pick_gemm8(bool bf16_in, int a_mode, int b_mode, int M, int N, int K
     // steady K steps are one straight-line block with scalar-base copies (gemm8.hip) the 288-row variant no longer spills in the loop and
     // beats the burst schedule by 0..16 % depending on the shape and the box (tools/gemm_bench.cpp: 22 000 x 768 x 3072 96 vs 113 us).
     *ni_out = ni;
-    *pin_out = gemm_opt(OPT_G8_PIN) >= 0 && gemm_opt(OPT_G8_PIN) <= 15 ? gemm_opt(OPT_G8_PIN) : 3;
+#if defined(G8_FAST_BUILD)
+    *pin_out = gemm_opt(OPT_G8_PIN) >= 0 && gemm_opt(OPT_G8_PIN) <= 15 ? gemm_opt(OPT_G8_PIN) : 3;      // tuning builds: bits 2..3 select tiles per phase
+#else
+    *pin_out = gemm_opt(OPT_G8_PIN) >= 0 && gemm_opt(OPT_G8_PIN) <= 3 ? gemm_opt(OPT_G8_PIN) : 3;       // release: schedules 0..3 exist; anything else = the default
+#endif
     return true;
 }
 

@@ -51,6 +51,38 @@ extern "C" int ss_frame_lse(const float* head, int64_t ld, int col0, int ncls, i
     return 0;
 }
 
+// ---------------------------------------------------------------- per-frame index tables of a batch, expanded on the device
+// The packed-row <-> utterance bookkeeping of decollate_tensor + zip (transduction_model.py:101-111) as data: one row of 8 int64 per
+// utterance [n_pred, n_tgt, silent, pred_row0, tgt_row0, res_off, vo_off, si_off] (44 rows for a reference-size batch: ONE small upload)
+// instead of five per-frame int32 arrays built on the host (22 000 entries each) and copied over per step.
+constexpr int UTT = 8;
+__global__ void loss_index_tables_kernel(const long long* __restrict__ utt, int* __restrict__ vo_pred, int* __restrict__ vo_tgt,
+                                         int* __restrict__ si_tgt, int* __restrict__ si_base, int* __restrict__ si_res)
+{
+    const long long* u = utt + (long long)blockIdx.x * UTT;
+    const int n1 = (int)u[0], n2 = (int)u[1];
+    const int p0 = (int)u[3], t0 = (int)u[4], r0 = (int)u[5];
+    if (u[2]) {
+        const long long o = u[7];
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) { si_tgt[o + i] = t0 + i; si_base[o + i] = p0; si_res[o + i] = r0 + i; }
+    } else {
+        const long long o = u[6];
+        for (int i = threadIdx.x; i < n1; i += blockDim.x) { vo_pred[o + i] = p0 + i; vo_tgt[o + i] = t0 + i; }
+    }
+}
+
+extern "C" int ss_loss_index_tables(const int64_t* utt_dev, int n_utt, int32_t* vo_pred, int32_t* vo_tgt, int32_t* si_tgt, int32_t* si_base,
+                                    int32_t* si_res, void* stream)
+{
+    SS_CHECK(n_utt >= 0, "ss_loss_index_tables: negative utterance count");
+    if (n_utt == 0) return 0;
+    SS_CHECK(utt_dev && vo_pred && vo_tgt && si_tgt && si_base && si_res, "ss_loss_index_tables: null pointer");
+    SS_LAUNCH(loss_index_tables_kernel, dim3((unsigned)n_utt), dim3(256), 0, stream, (const long long*)utt_dev, (int*)vo_pred, (int*)vo_tgt, (int*)si_tgt,
+              (int*)si_base, (int*)si_res);
+    SS_LAUNCH_CHECK("ss_loss_index_tables");
+    return 0;
+}
+
 // per-wave partial sums (held by lane 0) -> ONE atomic per workgroup: thousands of waves hitting the same two addresses
 // serialise in the L2 atomic unit (that, not the arithmetic, was most of these kernels' time)
 __device__ __forceinline__ void loss_block_commit(float lsum, int csum, float inv_total, float* loss_acc, int* correct_acc)

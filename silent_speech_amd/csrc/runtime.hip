@@ -25,6 +25,46 @@ int ss_check_launch(const char* what) {
     return 0;
 }
 
+// ---------------------------------------------------------------- host tables -> device, from memory that outlives the call
+// A host-built table that a kernel sequence reads must not be copied from a local with hipMemcpyAsync: a pageable source is only safe
+// as long as the runtime stages it before returning, which it does not promise (and does not do under stream capture).  The table is
+// copied into a slot of a small process-wide ring of pinned buffers first; a slot is reused only after the event recorded behind its
+// last copy has completed.
+#if !defined(SS_EMU)
+#include <mutex>
+namespace {
+struct PinnedRing {
+    static constexpr int N = 8;
+    void* buf[N] = {}; size_t cap[N] = {}; hipEvent_t ev[N] = {}; bool used[N] = {}; int at = 0; std::mutex mu;
+};
+PinnedRing g_ring;
+}
+#endif
+int ss_upload_table(void* dst_dev, const void* src_host, size_t bytes, void* stream)
+{
+    if (bytes == 0) return 0;
+#if defined(SS_EMU)
+    memcpy(dst_dev, src_host, bytes);
+    return 0;
+#else
+    std::lock_guard<std::mutex> lock(g_ring.mu);
+    const int i = g_ring.at; g_ring.at = (i + 1) % PinnedRing::N;
+    if (g_ring.used[i] && hipEventSynchronize(g_ring.ev[i]) != hipSuccess) { ss_set_error("table upload: event wait failed"); return 1; }
+    if (g_ring.cap[i] < bytes) {
+        if (g_ring.buf[i]) (void)hipHostFree(g_ring.buf[i]);
+        size_t cap = 1 << 16; while (cap < bytes) cap <<= 1;
+        if (hipHostMalloc(&g_ring.buf[i], cap, hipHostMallocDefault) != hipSuccess) { g_ring.buf[i] = nullptr; g_ring.cap[i] = 0; ss_set_error("table upload: pinned allocation of %zu bytes failed", cap); return 1; }
+        g_ring.cap[i] = cap;
+    }
+    if (!g_ring.ev[i] && hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming) != hipSuccess) { ss_set_error("table upload: event creation failed"); return 1; }
+    memcpy(g_ring.buf[i], src_host, bytes);
+    if (hipMemcpyAsync(dst_dev, g_ring.buf[i], bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) { ss_set_error("table upload failed"); return 1; }
+    if (hipEventRecord(g_ring.ev[i], (hipStream_t)stream) != hipSuccess) { ss_set_error("table upload: event record failed"); return 1; }
+    g_ring.used[i] = true;
+    return 0;
+#endif
+}
+
 // ---------------------------------------------------------------- ss_permute3d
 template <class TI, class TO>
 __global__ void permute3d_kernel(const TI* __restrict__ in, TO* __restrict__ out, int d0, int d1, int d2,

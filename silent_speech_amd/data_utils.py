@@ -181,51 +181,73 @@ class FeatureNormalizer(object):
         return sample * self.feature_stddevs + self.feature_means
 
 
-_pack_tables = {}          # signature of a list of device tensors -> device table of (pointers, cumulative byte offsets); a handful of entries
+class PackJob(object):
+    """One combine_fixed_length (or plain concatenation, length=None) of device tensors as data: the [pointers | cumulative byte
+    offsets] table the gather kernel (csrc/optim.hip `ss_concat_pad`) reads, and the launch over it.  Building the table is host
+    arithmetic on ~40 (pointer, size) pairs; it travels to the device through staging.upload -- alone (combine_fixed_length) or
+    together with every other table of the batch (transduction_model.prepare_batch: ONE copy per batch)."""
+
+    def __init__(self, tensor_list, length=None):
+        first = tensor_list[0]
+        trailing = tuple(first.shape[1:])
+        ts = [t if t.is_contiguous() else t.contiguous() for t in tensor_list]
+        assert all(t.dtype == first.dtype and tuple(t.shape[1:]) == trailing for t in ts), 'utterances of one batch share dtype and feature shape'
+        frames = sum(int(t.shape[0]) for t in ts)
+        row_bytes = first.element_size()
+        for d in trailing:
+            row_bytes *= int(d)
+        if length is None:
+            self.out_shape = (frames,) + trailing
+            total = frames * row_bytes
+        else:
+            rows = (frames + length - 1) // length
+            self.out_shape = (rows, length) + trailing
+            total = rows * length * row_bytes
+        n = len(ts)
+        table = np.empty(2 * n + 1, dtype=np.int64)
+        table[:n] = np.fromiter((t.data_ptr() for t in ts), dtype=np.uint64, count=n).view(np.int64)
+        sizes = np.fromiter((int(t.shape[0]) for t in ts), dtype=np.int64, count=n) * row_bytes
+        table[n] = 0
+        np.cumsum(sizes, out=table[n + 1:])
+        gran = 16
+        probe = int(np.bitwise_or.reduce(table[:n])) | int(np.bitwise_or.reduce(sizes)) | total
+        while gran > 1 and probe % gran:
+            gran //= 2
+        self.gran = 1 if gran == 2 else gran
+        self.table, self.n, self.total, self.keep = table, n, total, ts
+        self.dtype, self.device = first.dtype, first.device
+
+    def launch(self, table_dev):
+        out = torch.empty(self.out_shape, dtype=self.dtype, device=self.device)
+        _lib.check(_lib.lib().ss_concat_pad(_lib.ptr(table_dev), self.n, _lib.ptr(out), self.total, self.gran, _lib.stream_of(out)), 'ss_concat_pad')
+        return out
+
+
+def _host_pack(tensor_list, length, pin=False):
+    first = tensor_list[0]
+    trailing = tuple(first.shape[1:])
+    frames = sum(int(t.shape[0]) for t in tensor_list)
+    rows = frames if length is None else (frames + length - 1) // length * length
+    out = torch.empty((rows,) + trailing, dtype=first.dtype, pin_memory=pin)
+    if frames:
+        torch.cat(list(tensor_list), 0, out=out[:frames])
+    out[frames:].zero_()
+    return out if length is None else out.view((rows // length, length) + trailing)
 
 
 def combine_fixed_length(tensor_list, length):
     """data_utils.py:158-167: the utterances back to back along time, zero-padded to a whole number of rows of `length` frames,
     viewed as (rows, length, ...).  Device tensors are packed by ONE gather launch over an offset table (csrc/optim.hip
-    `ss_concat_pad`); the table is cached per list of (pointer, size), so a batch that is packed again costs no host-to-device
-    copy.  Host tensors (staging code, tests) are packed with plain slice copies."""
+    `ss_concat_pad`; the table is rebuilt for every call -- a training loop hands over new tensors every step -- and uploaded
+    from pinned memory).  Host tensors (staging code, tests) are packed with a host concatenation."""
     first = tensor_list[0]
-    trailing = tuple(first.shape[1:])
-    frames = sum(int(t.shape[0]) for t in tensor_list)
-    rows = (frames + length - 1) // length
-    out_shape = (rows, length) + trailing
     on_device = first.is_cuda or _lib.is_emulator()          # emulator (tests): CPU tensors run the same kernel source
     if not on_device:
-        out = torch.zeros((rows * length,) + trailing, dtype=first.dtype, device=first.device)
-        at = 0
-        for t in tensor_list:
-            out[at:at + t.shape[0]] = t
-            at += t.shape[0]
-        return out.view(out_shape)
-    ts = [t if t.is_contiguous() else t.contiguous() for t in tensor_list]
-    assert all(t.dtype == first.dtype and tuple(t.shape[1:]) == trailing for t in ts), 'utterances of one batch share dtype and feature shape'
-    row_bytes = first.element_size()
-    for d in trailing:
-        row_bytes *= int(d)
-    sizes = [int(t.shape[0]) * row_bytes for t in ts]
-    ptrs = [t.data_ptr() for t in ts]
-    total = rows * length * row_bytes
-    sig = (first.device, tuple(ptrs), tuple(sizes), total)
-    hit = _pack_tables.get(sig)
-    if hit is None:
-        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        gran = 16
-        while gran > 1 and (any(v % gran for v in sizes) or any(p % gran for p in ptrs) or total % gran):
-            gran //= 2
-        gran = 1 if gran == 2 else gran
-        table = torch.from_numpy(np.concatenate([np.asarray(ptrs, dtype=np.uint64).view(np.int64), offs])).to(first.device, non_blocking=True)
-        if len(_pack_tables) >= 16:
-            _pack_tables.clear()
-        hit = _pack_tables[sig] = (table, gran)              # the table holds exactly the pointers of the signature: valid whenever the signature matches
-    table, gran = hit
-    out = torch.empty(out_shape, dtype=first.dtype, device=first.device)
-    _lib.check(_lib.lib().ss_concat_pad(_lib.ptr(table), len(ts), _lib.ptr(out), total, gran, _lib.stream_of(out)), 'ss_concat_pad')
-    return out
+        return _host_pack(tensor_list, length)
+    from . import staging
+    job = PackJob(tensor_list, length)
+    table, = staging.upload([job.table], first.device)
+    return job.launch(table)
 
 
 def decollate_tensor(tensor, lengths):

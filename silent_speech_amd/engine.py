@@ -38,11 +38,11 @@ class Prepared(object):
 
     @staticmethod
     def layout_signature(model):
-        return (tuple(p.data_ptr() for p in model.parameters()), model.compute_dtype, str(model.w_out.weight.device))
+        return (tuple(p.data_ptr() for p in model.all_parameters()), model.compute_dtype, str(model.w_out.weight.device))
 
     @staticmethod
     def version_signature(model):
-        return (model._weights_version, tuple(p._version for p in model.parameters()))
+        return (model._weights_version, tuple(p._version for p in model.all_parameters()))
 
     def build(self, model):
         dt, dev = model.compute_dtype, model.w_out.weight.device
@@ -294,7 +294,7 @@ class PlanBinding(object):
         return t
 
     def ensure_bound(self, model, pr, gu, dev):
-        sig = (pr.layout_sig, gu.sig if gu is not None else None, tuple(b.data_ptr() for b in model.buffers()))
+        sig = (pr.layout_sig, gu.sig if gu is not None else None, tuple(b.data_ptr() for b in model.all_buffers()))
         if sig == self.sig:
             return
         table = self._table(model, pr, gu, dev)

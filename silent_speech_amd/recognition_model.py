@@ -23,7 +23,7 @@ from .pipeline import SizeAwareSampler
 from .architecture import Model
 from .flags import FLAGS
 from .optim import FusedAdamW
-from .transduction_model import _pack_batch
+from .transduction_model import prepare_batch
 
 _L = _lib.lib
 _p = _lib.ptr
@@ -166,7 +166,7 @@ def test(model, testset, device, *, batch_size=1):
         else:
             dataloader = torch.utils.data.DataLoader(testset, batch_size=batch_size, collate_fn=testset.collate_raw)
             for batch in dataloader:
-                X, X_raw, sess = _pack_batch(batch, device)
+                X, X_raw, sess = prepare_batch(batch, device, loss_plan=False)
                 pred = model(X, X_raw, sess)
                 for ints, tgt in zip(greedy_decode(pred, batch['lengths'], blank), batch['text_int']):
                     predictions.append(tt.int_to_text(ints))
@@ -206,7 +206,7 @@ def train_model(trainset, devset, device, n_epochs=200, *, compute_dtype=torch.b
         losses = []
         for batch in dataloader:
             schedule_lr(batch_idx)
-            X, X_raw, sess = _pack_batch(batch, device)
+            X, X_raw, sess = prepare_batch(batch, device, loss_plan=False)
             pred = model(X, X_raw, sess)
             loss = ctc_loss(pred, batch, blank=n_chars)
             losses.append(loss.detach())

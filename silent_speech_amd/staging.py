@@ -1,0 +1,83 @@
+"""Host -> device staging of the small per-batch tables (pointer / offset tables of combine_fixed_length, the per-utterance
+descriptors of dtw_loss).  A training step sees NEW tensors every iteration (reference transduction_model.py:196-212 iterates a
+DataLoader), so these tables cannot be cached: what can be done is to make them cheap -- everything a batch needs is laid out back
+to back in ONE pinned host buffer and crosses PCIe in ONE asynchronous copy, issued before the forward pass is enqueued.  A copy
+from pageable memory (`torch.from_numpy(x).to(device, non_blocking=True)`) is staged by the runtime inside the call and orders
+itself behind everything already queued on the stream: several of those per step in the middle of the enqueue are what this
+module replaces.
+
+Pinned buffers come from a small per-device ring; a slot is reused only after the event recorded behind its last copy has
+completed (in steady state it completed many steps ago, so the wait never blocks).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+_SLOTS = 8
+_ALIGN = 16
+_rings = {}
+
+
+class _Ring(object):
+    def __init__(self, device):
+        self.device = device
+        self.bufs = [None] * _SLOTS
+        self.events = [None] * _SLOTS
+        self.at = 0
+
+    def slot(self, nbytes):
+        i = self.at
+        self.at = (i + 1) % _SLOTS
+        ev = self.events[i]
+        if ev is not None:
+            ev.synchronize()
+        buf = self.bufs[i]
+        if buf is None or buf.numel() < nbytes:
+            cap = 1 << max(16, int(nbytes - 1).bit_length())
+            buf = self.bufs[i] = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        if ev is None:
+            ev = self.events[i] = torch.cuda.Event()
+        return buf, ev
+
+
+def upload(arrays, device):
+    """arrays: list of numpy arrays.  Returns one device tensor per array (same dtype and shape), all living in ONE device
+    buffer filled by ONE host-to-device copy on the current stream.  Emulator backend (tests): plain CPU tensors."""
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    offs, total = [], 0
+    for a in arrays:
+        offs.append(total)
+        total += (a.nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+    total = max(total, _ALIGN)
+    device = torch.device(device)
+    if device.type != 'cuda':
+        if not _lib.is_emulator():
+            raise RuntimeError('silent_speech_amd: staging to %s; the HIP kernels need an AMD GPU (no CPU fallback exists)' % device)
+        return [torch.from_numpy(a.copy()) for a in arrays]
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    ring = _rings.get(device)
+    if ring is None:
+        ring = _rings[device] = _Ring(device)
+    host, ev = ring.slot(total)
+    hv = host.numpy()
+    for a, o in zip(arrays, offs):
+        if a.nbytes:
+            hv[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
+    dev = torch.empty(total, dtype=torch.uint8, device=device)
+    dev.copy_(host[:total], non_blocking=True)
+    ev.record(torch.cuda.current_stream(device))
+    out = []
+    for a, o in zip(arrays, offs):
+        t = dev[o:o + a.nbytes].view(_TORCH_DTYPE[a.dtype.type])
+        out.append(t.view(a.shape) if a.ndim != 1 else t)
+    return out
+
+
+_TORCH_DTYPE = {np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8, np.float32: torch.float32, np.float64: torch.float64}
+
+
+def pinned_like(shape, dtype):
+    """A pinned host tensor for one bulk upload of batch data that arrives in host memory (the DataLoader's tensors)."""
+    return torch.empty(shape, dtype=dtype, pin_memory=torch.cuda.is_available())

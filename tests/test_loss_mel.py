@@ -110,6 +110,53 @@ def test_pack_roundtrip_golden():
         assert torch.equal(a, b)
 
 
+def test_pack_device_kernel_golden(dev):
+    """The DEVICE branch of combine_fixed_length (the `ss_concat_pad` gather over a freshly uploaded pointer table) against the
+    reference's own packed tensor (tests/golden/pack.npz), twice with different source tensors: nothing may be cached on addresses."""
+    z = np.load(os.path.join(GOLD, 'pack.npz'))
+    ts = [torch.from_numpy(z['t/%d' % i]).to(dev) for i in range(4)]
+    packed = data_utils.combine_fixed_length(ts, 16)
+    assert packed.device.type == dev.type and np.array_equal(packed.cpu().numpy(), z['packed'])
+    for a, b in zip(ts, data_utils.decollate_tensor(packed, [t.shape[0] for t in ts])):
+        assert torch.equal(a, b)
+    ts[1].mul_(2.0)                                             # in-place edit of a source: same pointers, new content
+    again = data_utils.combine_fixed_length(ts, 16)
+    want = data_utils.combine_fixed_length([t.cpu() for t in ts], 16)
+    if not is_emu(dev):
+        assert want.device.type == 'cpu'
+    assert torch.equal(again.cpu(), want.cpu())
+    odd = [t[:, :3].contiguous()[1:] for t in ts]               # 12-byte rows at unaligned offsets: the 4-byte granule path
+    assert torch.equal(data_utils.combine_fixed_length(odd, 5).cpu(), data_utils._host_pack([t.cpu() for t in odd], 5))
+
+
+def test_prepare_batch_then_dtw_loss_equals_standalone(dev):
+    """prepare_batch (one upload for the pack tables + the loss plan, before the forward) followed by dtw_loss on the same dict gives
+    what the separate calls give; the prepared plan is consumed by that one call; targets edited in place afterwards are honoured."""
+    z = np.load(os.path.join(GOLD, 'dtw_loss_mixed.npz'))
+    ex = _example(z, 4, dev)
+    g = torch.Generator().manual_seed(3)
+    ex['emg'] = [torch.randn(n, 112, generator=g).to(dev) for n in ex['lengths']]
+    ex['raw_emg'] = [torch.randn(8 * n, 8, generator=g).to(dev) for n in ex['lengths']]
+    ex['session_ids'] = [torch.full((n,), 2, dtype=torch.int64).to(dev) for n in ex['lengths']]
+    row = int(z['pred'].shape[1])
+    X, X_raw, sess = tm.prepare_batch(ex, dev, seq_len=row)
+    assert tm._Prepared.example is ex
+    assert torch.equal(X.cpu(), data_utils._host_pack([t.cpu() for t in ex['emg']], row))
+    assert torch.equal(X_raw.cpu(), data_utils._host_pack([t.cpu() for t in ex['raw_emg']], row * 8))
+    assert torch.equal(sess.cpu(), data_utils._host_pack([t.cpu() for t in ex['session_ids']], row))
+    pred, aux = torch.from_numpy(z['pred']).to(dev), torch.from_numpy(z['aux']).to(dev)
+    l1, a1 = tm.dtw_loss(pred, aux, ex, True, None, phoneme_loss_weight=0.5)
+    assert tm._Prepared.example is None                         # one-shot
+    l2, a2 = tm.dtw_loss(pred, aux, ex, True, None, phoneme_loss_weight=0.5)
+    assert abs(float(l1) - float(l2)) < 1e-6 * abs(float(l1)) and a1 == a2        # f32 atomics: the block sums arrive in any order
+    assert abs(float(l1) - float(z['loss_eval'])) < 2e-5 * abs(float(z['loss_eval']))
+    ex['audio_features'][0].add_(0.25)                          # the advisor's case: a write that a (pointer, version) signature may miss
+    l3, _ = tm.dtw_loss(pred, aux, ex, True, None, phoneme_loss_weight=0.5)
+    cpu = dict(ex, audio_features=[a.cpu() for a in ex['audio_features']], phonemes=[p.cpu() for p in ex['phonemes']])
+    want, _ = loss_ref.dtw_loss_ref(pred.cpu(), aux.cpu(), cpu, lam=0.5)
+    assert abs(float(l3) - float(want)) < 2e-5 * abs(float(want)) and abs(float(l3) - float(l1)) > 1e-4 * abs(float(l1))
+
+
 def test_dtw_loss_all_silent_and_degenerate_utterances(dev):
     """Edge cases of the packed layout: every utterance silent, a 1-frame utterance (1 x M and N x 1 cost matrices: no
     interior DTW cell, align.py:24 leaves results at 0), ragged rows with padding frames, targets shorter and longer than
