@@ -200,9 +200,10 @@ __global__ __launch_bounds__(NW * 64) void gemm8_dw_kernel(DwJobs jobs, int nite
 
 // ================================================================ K-contiguous LDS tiles (transpose at write time)
 namespace g8 {
-constexpr int KP = 144;                      // LDS row pitch: 128 B (64 frames of one outer row) + 16 B.  Fragment reads: 16 consecutive rows, one
-                                             // chunk -> 16-byte slots (9 row + chunk) mod 16, all distinct.  Block writes: see StageKT.
-constexpr int KT_STAGE = 512 * KP;           // A tile (256 outer rows) + B tile
+constexpr int KP = 144;                      // LDS row pitch: 128 B (64 frames of one outer row) + 16 B = 9 sixteen-byte slots
+constexpr int KS = 34;                       // outer column m = 8 c + mm (c < 32, mm < 8) lives in LDS row mm * KS + c  (see StageKT)
+constexpr int KROWS = 8 * KS;                // 272 row slots per operand tile (rows 32, 33 of every group of 34 are unused)
+constexpr int KT_STAGE = 2 * KROWS * KP;     // A tile + B tile
 
 __device__ __forceinline__ unsigned perm_lo(unsigned hi_src, unsigned lo_src) {         // {lo16(lo_src), lo16(hi_src)}
 #if defined(SS_EMU)
@@ -219,55 +220,96 @@ __device__ __forceinline__ unsigned perm_hi(unsigned hi_src, unsigned lo_src) { 
 #endif
 }
 
-// Per thread and K tile: ONE 8 x 8 block of ONE operand -- frames 8 r .. 8 r + 7 (r = lane & 7) of outer columns 8 c .. 8 c + 7
-// (c = 8 * (wave & 3) + (lane >> 3)); waves 0..3 copy A, waves 4..7 copy B (wave-uniform operand).  A load instruction of a wave
-// therefore touches 8 frames x 128 contiguous bytes (whole cache lines), and a 16-lane group of a block WRITE (same outer row
-// index inside the block, r = 0..7, two neighbouring c) lands on 16-byte slots (8 c + 9 row + r) mod 16: conflict-free.
+// Per thread and K tile: TWO 4 (frames) x 8 (outer columns) blocks of ONE operand, one per 32-frame half h of the tile -- frames
+// 32 h + 4 r .. + 3 of outer columns 8 c .. 8 c + 7, with
+//     c = (lane & 15) + 16 (wave & 1),   r = (lane >> 4) + 4 ((wave >> 1) & 1);   waves 0..3 copy A, waves 4..7 copy B.
+// Each half has its own 16 registers and its own slot in the step (write in MFMA groups 0-1 resp. 8-9, the loads of the tile after next
+// right behind), so a load has a full K step (~1 us) to arrive without a second register set, and the requests of a step leave in two
+// bursts of 4 instead of one of 8.  Both memory sides want something of the 16 lanes the hardware serves together:
+//   * the global load: whole cache lines.  16 lanes = 16 consecutive 16-byte chunks of ONE frame = 2 full lines.  (The first version dealt
+//     the lanes of a quarter-wave to 8 frames x 32 bytes: 4 x the tag look-ups, and the kernel was bound by exactly that -- without its
+//     global loads the main loop ran at 1600 TFLOP/s, with them at 830; tools/gemm_bench + SS_GEMM_DW_ABL.)
+//   * the LDS write of the transposed block (outer column 8 c + mm, 8 bytes = 4 frames at byte 64 h + 8 r of the row): with outer column m
+//     in row mm * 34 + c and 9 sixteen-byte slots per row the 16 c of a write sit 9 slots apart (all distinct), r and r + 1 share a slot's halves.
+//   * the fragment read of an MFMA operand (16 consecutive outer columns = 8 mm x 2 c, one chunk): slots 2 mm + 9 b (mod 16; 34 * 9 = 306 = 2 mod
+//     16): all distinct as well.  (mm * 32 + c would put the 8 mm of a read on the SAME slot: 32 * 9 = 0 mod 16.)
 // Requires batches of a multiple of 8 frames (a block never straddles a batch), of at least 64 frames (one wrap per K tile at most),
 // and K slices that start at multiples of 64.
 struct StageKT {
     const unsigned char* p;                  // operand base + this thread's outer column chunk (bytes)
-    unsigned off, step, wrap, rs;            // block's first frame (byte offset) / advance per 64 frames / extra per batch wrap / row stride (bytes)
-    int tt, rpb, kb;                         // frame inside its batch, frames per batch, block's first frame inside a K tile
-    unsigned wr;                             // LDS byte offset inside a stage: (operand, outer row 8 c, chunk r)
+    unsigned off[2], step, wrap, rs;         // first frame of the block of half h (byte offset) / advance per 64 frames / extra per batch wrap / row stride
+    int tt[2], rpb, kb;                      // frame inside its batch (per half), frames per batch, first frame of the h = 0 block inside a K tile
+    unsigned wr;                             // LDS byte offset inside a stage: (operand, row c of group mm = 0, byte 8 r)
     __device__ __forceinline__ void init(const DwJob& J, int opsel, int m0, int n0, int k_begin, int wave, int lane) {
-        const int r = lane & 7, c = (wave & 3) * 8 + (lane >> 3);
+        const int c = (lane & 15) + 16 * (wave & 1), r = (lane >> 4) + 4 * ((wave >> 1) & 1);
         const RowMap& map = opsel ? J.bmap : J.amap;
         const int outer = opsel ? n0 : m0, lim = opsel ? J.N : J.M;
         const int col = outer + c * 8 < lim ? outer + c * 8 : 0;         // beyond the matrix: column 0 (products land in C entries that are never stored)
         p = (const unsigned char*)((opsel ? J.B : J.A) + map.base + col);
-        rpb = map.rows_per_batch; kb = 8 * r;
+        rpb = map.rows_per_batch; kb = 4 * r;
         rs = (unsigned)(map.row_stride * 2); step = (unsigned)(map.row_stride * BK8 * 2);
         wrap = (unsigned)((map.batch_stride - (long long)rpb * map.row_stride) * 2);
-        const int rr = k_begin + kb;
-        int b_ = 0, t_ = rr;
-        if (rpb != 0x7fffffff) { b_ = rr / rpb; t_ = rr - b_ * rpb; }
-        tt = t_;
-        off = (unsigned)(((long long)b_ * map.batch_stride + (long long)t_ * map.row_stride) * 2);
-        wr = (unsigned)((opsel * 256 + c * 8) * KP + r * 16);
-    }
-    __device__ __forceinline__ void advance() {
-        tt += BK8; off += step;                                          // batches hold >= 64 frames (host-side condition): at most one wrap, no loop
-        const bool over = tt >= rpb; tt -= over ? rpb : 0; off += over ? wrap : 0u;
-    }
-    template <bool PRED>
-    __device__ __forceinline__ void load(int k0, int kend, u32x4 (&L)[8]) {
-        const unsigned char* q = p + off;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (PRED) { const u32x4 z = {0u, 0u, 0u, 0u}; L[i] = k0 + kb + i < kend ? *(const u32x4*)(q + i * rs) : z; }
-            else L[i] = *(const u32x4*)(q + i * rs);
+        for (int h = 0; h < 2; ++h) {
+            const int rr = k_begin + 32 * h + kb;
+            int b_ = 0, t_ = rr;
+            if (rpb != 0x7fffffff) { b_ = rr / rpb; t_ = rr - b_ * rpb; }
+            tt[h] = t_;
+            off[h] = (unsigned)(((long long)b_ * map.batch_stride + (long long)t_ * map.row_stride) * 2);
+        }
+        wr = (unsigned)((opsel * KROWS + c) * KP + r * 8);
+    }
+    template <int H>
+    __device__ __forceinline__ void advance() {
+        tt[H] += BK8; off[H] += step;                                    // batches hold >= 64 frames (host-side condition): at most one wrap, no loop
+        const bool over = tt[H] >= rpb; tt[H] -= over ? rpb : 0; off[H] += over ? wrap : 0u;
+    }
+    // The loads of the steady state are issued from asm and counted by hand (wait_vm): left to the compiler, its wait insertion put an
+    // s_waitcnt vmcnt(0) at the loop header (the loop-carried state of two register sets in flight merges to "everything pending"), which
+    // also drained the OTHER half's loads a few hundred cycles after their issue.  A compiler-visible load into the same registers anywhere
+    // would bring that back (it would have to guard every later use), so the predicated form (ragged last tile; prologue of short K
+    // slices) loads into temporaries and copies: the copy is where the compiler waits, L itself never carries a pending load it knows of.
+    template <int H, bool PRED>
+    __device__ __forceinline__ void load(int k0, int kend, u32x4 (&L)[4]) {
+        const unsigned char* q = p + off[H];
+        if constexpr (PRED) {
+            u32x4 T[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const u32x4 z = {0u, 0u, 0u, 0u}; T[i] = k0 + 32 * H + kb + i < kend ? *(const u32x4*)(q + i * rs) : z; }
+#if !defined(SS_EMU)
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) as a builtin: the copies below coalesce away, and without the explicit wait the
+#endif                                                   // compiler would carry "L pending" into the steady loop and wait vmcnt(0) at its header
+#pragma unroll
+            for (int i = 0; i < 4; ++i) L[i] = T[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#if defined(SS_EMU)
+                L[i] = *(const u32x4*)(q + i * rs);
+#else
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L[i]) : "v"(q + i * rs) : "memory");
+#endif
+            }
         }
     }
-    // outer rows 2 W, 2 W + 1 of the block: dword W of the 8 frames -> two K-contiguous 16-byte chunks
-    template <int W>
-    __device__ __forceinline__ void write2(unsigned char* stage, const u32x4 (&L)[8]) {
-        u32x4 o0, o1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { o0[j] = perm_lo(L[2 * j + 1][W], L[2 * j][W]); o1[j] = perm_hi(L[2 * j + 1][W], L[2 * j][W]); }
-        *(u32x4*)(stage + wr + (2 * W) * KP) = o0;
-        *(u32x4*)(stage + wr + (2 * W + 1) * KP) = o1;
+    // all but the N most recent asm loads of this wave have arrived (N = 4: the other half's loads stay in flight); ties L to this point
+    template <int N>
+    __device__ __forceinline__ static void wait_vm(u32x4 (&L)[4]) {
+#if !defined(SS_EMU)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(L[0]), "+v"(L[1]), "+v"(L[2]), "+v"(L[3]) : "n"(N));
+#endif
     }
+    // outer rows 2 W, 2 W + 1 of the block of half H: dword W of its 4 frames -> two K-contiguous 8-byte pieces
+    template <int H, int W>
+    __device__ __forceinline__ void write2(unsigned char* stage, const u32x4 (&L)[4]) {
+        u32x2 o0, o1;
+        o0[0] = perm_lo(L[1][W], L[0][W]); o0[1] = perm_lo(L[3][W], L[2][W]);
+        o1[0] = perm_hi(L[1][W], L[0][W]); o1[1] = perm_hi(L[3][W], L[2][W]);
+        *(u32x2*)(stage + wr + (2 * W) * KS * KP + 64 * H) = o0;
+        *(u32x2*)(stage + wr + (2 * W + 1) * KS * KP + 64 * H) = o1;
+    }
+    template <int H>
+    __device__ __forceinline__ void write_all(unsigned char* stage, const u32x4 (&L)[4]) { write2<H, 0>(stage, L); write2<H, 1>(stage, L); write2<H, 2>(stage, L); write2<H, 3>(stage, L); }
 };
 // wait for this wave's LDS operations only (the global loads of the tile after next stay in flight), then the workgroup barrier
 __device__ __forceinline__ void barrier_lds() {
@@ -283,9 +325,10 @@ __device__ __forceinline__ void barrier_lds() {
 
 // HR = 16-row MFMA tiles per phase (2 or 4).  Waves 2 (M) x 4 (N), 128 x 64 per wave; a K step (64 frames) is 8 / HR phases per K half;
 // every phase requests the NEXT phase's fragments from asm, issues its own HR x 4 MFMAs and closes with one lgkmcnt(0).  The tile after
-// the current one (in registers since the previous step) is transposed and written in the first four MFMA groups of a step, the loads of
-// the tile after that leave right behind the last write; the step's single barrier sits in front of its last phase.
-template <int HR>
+// the current one (in registers since the previous step) is transposed and written in two halves (MFMA groups 0-1 and 8-9 of 16), the loads
+// of the tile after that leave right behind each half; the step's single barrier sits in front of its last phase.
+// ABL: compile-time ablation mask for tuning (results wrong): 1 no global loads, 2 no transposes / LDS writes, 4 no MFMAs in the steady steps, 8 no C update
+template <int HR, int ABL, bool SHIFT = false>
 __global__ __launch_bounds__(512) void gemm8_dwk_kernel(DwJobs jobs, int nitems, int xorder)
 {
     using namespace g8;
@@ -301,9 +344,10 @@ __global__ __launch_bounds__(512) void gemm8_dwk_kernel(DwJobs jobs, int nitems,
     const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
 #endif
     const int wm = wave >> 2, wn = wave & 3, opsel = wave >> 2, G = gridDim.x;
-    const unsigned aoff = (unsigned)((wm * 128 + c) * KP + q * 16), boff = (unsigned)((256 + wn * 64 + c) * KP + q * 16);
+    // fragment of MFMA tile i: outer columns 16 i + c (c = lane & 15) = group mm = c & 7, row 2 i + (c >> 3) (+ 16 wm | 8 wn): tile i adds 2 rows
+    const unsigned aoff = (unsigned)(((c & 7) * KS + (c >> 3) + 16 * wm) * KP + q * 16), boff = (unsigned)((KROWS + (c & 7) * KS + (c >> 3) + 8 * wn) * KP + q * 16);
     StageKT st;
-    u32x4 L[8];
+    u32x4 L0[4], L1[4];                      // the two half-tile blocks in flight
     int it = blockIdx.x, ji = 0, m0, n0, k_begin, k_end, nsteps, cur = 0;
 
 #define G8K_SETUP()                                                                                                         \
@@ -321,7 +365,8 @@ __global__ __launch_bounds__(512) void gemm8_dwk_kernel(DwJobs jobs, int nitems,
         k_begin = z * J_.k_chunk; k_end = min(J_.K, k_begin + J_.k_chunk);                                                   \
         nsteps = (k_end - k_begin + BK8 - 1) / BK8;                                                                          \
         st.init(J_, opsel, m0, n0, k_begin, wave, lane);                                                                     \
-        if (nsteps == 1) st.template load<true>(k_begin, k_end, L); else if (nsteps > 1) st.template load<false>(k_begin, k_end, L); \
+        if (nsteps == 1) { st.template load<0, true>(k_begin, k_end, L0); st.template load<1, true>(k_begin, k_end, L1); }   \
+        else if (nsteps > 1) { st.template load<0, false>(0, 0, L0); st.template load<1, false>(0, 0, L1); }                 \
     } while (0)
 
     G8K_SETUP();
@@ -334,11 +379,11 @@ __global__ __launch_bounds__(512) void gemm8_dwk_kernel(DwJobs jobs, int nitems,
         bf16x8 fa[2][HR], fb[2][4];
         auto read_a = [&](auto phc, auto xc, unsigned sb) {
             constexpr int ph = phc, x = xc, kk = ph / NPK, i = (ph % NPK) * HR + x;
-            lds_read128_async<i * 16 * KP + kk * 64>(fa[ph & 1][x], lds, lbase + sb + aoff);
+            lds_read128_async<i * 2 * KP + kk * 64>(fa[ph & 1][x], lds, lbase + sb + aoff);
         };
         auto read_b = [&](auto phc, auto jc, unsigned sb) {
             constexpr int ph = phc, j = jc, kk = ph / NPK;
-            lds_read128_async<j * 16 * KP + kk * 64>(fb[kk][j], lds, lbase + sb + boff);
+            lds_read128_async<j * 2 * KP + kk * 64>(fb[kk][j], lds, lbase + sb + boff);
         };
         auto wait_frags = [&](auto phc) {
             constexpr int ph = phc;
@@ -350,10 +395,15 @@ __global__ __launch_bounds__(512) void gemm8_dwk_kernel(DwJobs jobs, int nitems,
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16_16x16x32(fa[ph & 1][x], fb[kk][j], acc[i][j]);
         };
-        // MFMA group g = ph * HR + x of step s (16 groups of 4 MFMAs): groups 0..3 write column pair g of tile s + 1 into the other stage, group 4
-        // requests tile s + 2.  STEADY (s + 3 < nsteps, compile time): every condition true, tile s + 2 is not the (possibly ragged) last one.
-        auto phase = [&](auto phc, auto steady_c, const unsigned S, const unsigned O, const int s) {
-            constexpr int ph = phc, nx = ph + 1 < NPH ? ph + 1 : 0;
+        // MFMA group g = ph * HR + x of step s (16 groups of 4 MFMAs): groups 0-1 / 8-9 transpose and write half 0 / 1 of tile s + 1 into the other
+        // stage, groups 2 / 10 request that half of tile s + 2.  STEADY (s + 3 < nsteps, compile time): every condition true, tile s + 2 is not the
+        // (possibly ragged) last one.
+        // SH (experiment, off: SHIFT = false): the copy slots of the waves that stage B (4..7) two groups behind those of the waves that stage A.
+        // Wave w and wave w + 4 share a SIMD and leave every barrier together, so both copy and both compute at the same moments; shifting
+        // one of them needs the whole step loop twice (a wave-uniform branch around it), and with two copies of the loop the allocator
+        // spilled 321 registers -- not measurable as a schedule.
+        auto phase = [&](auto phc, auto steady_c, auto shc, const unsigned S, const unsigned O, const int s) {
+            constexpr int ph = phc, nx = ph + 1 < NPH ? ph + 1 : 0, SH = shc;
             constexpr bool last = ph + 1 == NPH, STEADY = steady_c;
             bool rd = true; unsigned rst = S;
             if constexpr (last) {
@@ -366,21 +416,33 @@ __global__ __launch_bounds__(512) void gemm8_dwk_kernel(DwJobs jobs, int nitems,
                     read_a(std::integral_constant<int, nx>{}, xc, rst);
                     if constexpr (nx % NPK == 0) static_for<x * 4 / HR, (x + 1) * 4 / HR>([&](auto j) { read_b(std::integral_constant<int, nx>{}, j, rst); });
                 }
-                if constexpr (g < 4) { if (STEADY || s + 1 < nsteps) st.template write2<g>(lds + O, L); }
-                if constexpr (g == 4) {
-                    if (STEADY) { st.advance(); st.template load<false>(0, 0, L); }
-                    else if (s + 2 < nsteps) { st.advance(); st.template load<true>(k_begin + (s + 2) * BK8, k_end, L); }
+                const bool wr_ok = (STEADY && !(ABL & 2)) || (!STEADY && s + 1 < nsteps);
+                if constexpr (g == 0 + SH) { if (wr_ok) { if (STEADY) StageKT::wait_vm<4>(L0); else StageKT::wait_vm<0>(L0); st.template write2<0, 0>(lds + O, L0); st.template write2<0, 1>(lds + O, L0); } }
+                if constexpr (g == 1 + SH) { if (wr_ok) { st.template write2<0, 2>(lds + O, L0); st.template write2<0, 3>(lds + O, L0); } }
+                if constexpr (g == 8 + SH) { if (wr_ok) { if (STEADY) StageKT::wait_vm<4>(L1); else StageKT::wait_vm<0>(L1); st.template write2<1, 0>(lds + O, L1); st.template write2<1, 1>(lds + O, L1); } }
+                if constexpr (g == 9 + SH) { if (wr_ok) { st.template write2<1, 2>(lds + O, L1); st.template write2<1, 3>(lds + O, L1); } }
+                if constexpr (g == 2 + SH) {
+                    if (STEADY) { st.template advance<0>(); if (!(ABL & 1)) st.template load<0, false>(0, 0, L0); }
+                    else if (s + 2 < nsteps) { st.template advance<0>(); st.template load<0, true>(k_begin + (s + 2) * BK8, k_end, L0); }
+                }
+                if constexpr (g == 10 + SH) {
+                    if (STEADY) { st.template advance<1>(); if (!(ABL & 1)) st.template load<1, false>(0, 0, L1); }
+                    else if (s + 2 < nsteps) { st.template advance<1>(); st.template load<1, true>(k_begin + (s + 2) * BK8, k_end, L1); }
                 }
                 sched_fence();
-                mfma_row(phc, xc);
+                if (!(STEADY && (ABL & 4))) mfma_row(phc, xc);
                 sched_fence();
             });
             if (rd) wait_frags(std::integral_constant<int, nx>{});
             sched_fence();
         };
         // ---- tile 0 (in registers since the previous item's epilogue) -> stage cur, tile 1 requested, first fragments
-        if (nsteps > 0) { st.template write2<0>(lds + cur * KT_STAGE, L); st.template write2<1>(lds + cur * KT_STAGE, L); st.template write2<2>(lds + cur * KT_STAGE, L); st.template write2<3>(lds + cur * KT_STAGE, L); }
-        if (nsteps > 1) { st.advance(); if (nsteps == 2) st.template load<true>(k_begin + BK8, k_end, L); else st.template load<false>(0, 0, L); }
+        if (nsteps > 0) { StageKT::wait_vm<0>(L0); StageKT::wait_vm<0>(L1); st.template write_all<0>(lds + cur * KT_STAGE, L0); st.template write_all<1>(lds + cur * KT_STAGE, L1); }
+        if (nsteps > 1) {
+            st.template advance<0>(); st.template advance<1>();
+            if (nsteps == 2) { st.template load<0, true>(k_begin + BK8, k_end, L0); st.template load<1, true>(k_begin + BK8, k_end, L1); }
+            else { st.template load<0, false>(0, 0, L0); st.template load<1, false>(0, 0, L1); }
+        }
         barrier_lds();
         if (nsteps > 0) {
             static_for<0, HR>([&](auto x) { read_a(std::integral_constant<int, 0>{}, x, (unsigned)(cur * KT_STAGE)); });
@@ -389,9 +451,12 @@ __global__ __launch_bounds__(512) void gemm8_dwk_kernel(DwJobs jobs, int nitems,
         }
         sched_fence();
         {
-            int s = 0;
-            for (; s + 3 < nsteps; ++s) { const unsigned S = cur * KT_STAGE, O = (cur ^ 1) * KT_STAGE; static_for<0, NPH>([&](auto ph) { phase(ph, std::true_type{}, S, O, s); }); cur ^= 1; }
-            for (; s < nsteps; ++s) { const unsigned S = cur * KT_STAGE, O = (cur ^ 1) * KT_STAGE; static_for<0, NPH>([&](auto ph) { phase(ph, std::false_type{}, S, O, s); }); cur ^= 1; }
+            auto run = [&](auto shc) {
+                int s = 0;
+                for (; s + 3 < nsteps; ++s) { const unsigned S = cur * KT_STAGE, O = (cur ^ 1) * KT_STAGE; static_for<0, NPH>([&](auto ph) { phase(ph, std::true_type{}, shc, S, O, s); }); cur ^= 1; }
+                for (; s < nsteps; ++s) { const unsigned S = cur * KT_STAGE, O = (cur ^ 1) * KT_STAGE; static_for<0, NPH>([&](auto ph) { phase(ph, std::false_type{}, shc, S, O, s); }); cur ^= 1; }
+            };
+            if (SHIFT && opsel) run(std::integral_constant<int, 2>{}); else run(std::integral_constant<int, 0>{});
         }
         // `cur` now names the stage the last K tile did NOT use: free since the barrier of the last-but-one step (or never used), so the
         // next item's tile 0 may be written there without another barrier
@@ -405,7 +470,7 @@ __global__ __launch_bounds__(512) void gemm8_dwk_kernel(DwJobs jobs, int nitems,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = cn0 + (wn * 4 + j) * 16 + c, row0 = cm0 + (wm * 8 + i) * 16 + q * 4;
-                if (col < Nj) {
+                if (col < Nj && !((ABL & 8) && acc[i][j][0] != 12345.f)) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         if (row0 + reg < Mj) {
@@ -479,10 +544,19 @@ extern "C" int ss_gemm_dw_grouped(int n_jobs, const ss_dw_job* jobs, void* strea
 #define G8_DWK(HR_)                                                                                                          \
     do {                                                                                                                      \
         static bool granted = false;                                                                                          \
-        if (!granted) { if (g8_grant((const void*)gemm8_dwk_kernel<HR_>, smem)) return 1; granted = true; }                   \
-        SS_LAUNCH(SS_KERNEL(gemm8_dwk_kernel<HR_>), grid, block, smem, stream, J, nitems, g_dw_xorder);                       \
+        if (!granted) { if (g8_grant((const void*)gemm8_dwk_kernel<HR_, ABL_>, smem)) return 1; granted = true; }             \
+        SS_LAUNCH(SS_KERNEL(gemm8_dwk_kernel<HR_, ABL_>), grid, block, smem, stream, J, nitems, g_dw_xorder);                 \
     } while (0)
-        if (g_dw_kt == 2) G8_DWK(2); else G8_DWK(4);
+#define ABL_ 0
+        static const int abl = getenv("SS_GEMM_DW_ABL") ? atoi(getenv("SS_GEMM_DW_ABL")) : 0;       // tuning only (tools/gemm_bench): results are wrong when set
+        if (abl == 0) { if (g_dw_kt == 2) G8_DWK(2); else G8_DWK(4); }
+#undef ABL_
+#if defined(G8_DW_ABLATION)
+#define ABL_CASE(A_) else if (abl == A_) { constexpr int ABL_ = A_; G8_DWK(4); }
+        ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(8) ABL_CASE(11) ABL_CASE(7)
+#undef ABL_CASE
+#endif
+        else { ss_set_error("ss_gemm_dw_grouped: SS_GEMM_DW_ABL needs a -DG8_DW_ABLATION build"); return 1; }
 #undef G8_DWK
         SS_LAUNCH_CHECK("ss_gemm_dw_grouped");
         return 0;

@@ -212,10 +212,12 @@ def test_gemm8_dropout_matches_other_kernels(dev, gemm_opts):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('kt', [4, 2, 0])
 @pytest.mark.parametrize('split', [0, 1, 3])
-def test_gemm_dw_grouped(dev, split):
+def test_gemm_dw_grouped(dev, split, kt):
     """Grouped dW = dY^T X: three problems in one launch (plain maps, a ragged last K tile, conv-style overlapping rows with
-    batches of frames), accumulated onto a non-zero C; automatic / forced K split."""
+    batches of frames), accumulated onto a non-zero C; automatic / forced K split; kt = 4 / 2: the K-contiguous-tile kernel
+    (8 x 8 register transposes on the way into LDS, 4 / 2 MFMA row tiles per phase), 0: the transposing-read kernel."""
     from silent_speech_amd import _lib
     big = not is_emu(dev)
     dt = torch.bfloat16
@@ -229,7 +231,7 @@ def test_gemm_dw_grouped(dev, split):
         jobs.append((dy.to(dev), x.to(dev), dW, N, K, R, ops.rowmap(N), ops.rowmap(K), K))
         wants.append(base + dy.float().t() @ x.float()); outs.append(dW)
     # conv2-style: dY rows and the 3-tap windows of a zero-padded (B, T+2, C) input, batches of T frames
-    Bn, T, Ci, Co = (4, 200, 64, 264) if big else (3, 24, 16, 40)
+    Bn, T, Ci, Co = (4, 200, 64, 264) if big else (3, 72, 16, 40)            # batches of >= 64 frames, a multiple of 8: legal for every kernel
     dyc = torch.randn(Bn, T, Co, generator=g).to(dt)
     xc = torch.zeros(Bn, T + 2, Ci, dtype=dt); xc[:, 1:-1] = torch.randn(Bn, T, Ci, generator=g).to(dt)
     dWc = torch.zeros(Co, 3 * Ci, device=dev)
@@ -237,10 +239,12 @@ def test_gemm_dw_grouped(dev, split):
     win = torch.stack([xc[:, k:k + T].float() for k in range(3)], 2).reshape(Bn * T, 3 * Ci)
     wants.append(dyc.float().reshape(Bn * T, Co).t() @ win); outs.append(dWc)
     old = _lib.lib().ss_gemm_dw_set_option(0, split)
+    old_kt = _lib.lib().ss_gemm_dw_set_option(3, kt)
     try:
         ops.gemm_dw_grouped(jobs)
     finally:
         _lib.lib().ss_gemm_dw_set_option(0, old)
+        _lib.lib().ss_gemm_dw_set_option(3, old_kt)
     for i, (o, w) in enumerate(zip(outs, wants)):
         assert_close_robust(o, w, 1.5e-2, name='dw job %d' % i, max_outlier_frac=0)
 

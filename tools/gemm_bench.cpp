@@ -116,13 +116,14 @@ static void bench_dw(const char* tag, int rows, int n, const int (*mn)[2], int i
     }
     float t_old = time_us(iters, run_dw_old, &b);
     printf("%-10s rows=%6d jobs=%d  %-22s %8.1f us  %7.1f TF\n", tag, rows, n, "128-wide TR, per GEMM", t_old, flops / t_old / 1e6);
-    const int splits[3] = {0, 1, 2};
-    for (int pin = 0; pin < 2; ++pin) {                 // compiler order / reads fenced in front of the MFMAs of a K half
-        ss_gemm_dw_set_option(1, pin);
+    const int kts[3] = {0, 4, 2};                       // transposing-read kernel (rounds 2-3) / K-contiguous tiles, 4 or 2 MFMA row tiles per phase
+    for (int v = 0; v < 3; ++v) {
+        ss_gemm_dw_set_option(3, kts[v]);
         float t = time_us(iters, run_dw_grouped, &a);
-        char name[40]; snprintf(name, sizeof name, "grouped pin%d", pin);
+        char name[40]; snprintf(name, sizeof name, kts[v] ? "grouped KT hr%d" : "grouped TR (r3)", kts[v]);
         printf("%-10s rows=%6d jobs=%d  %-22s %8.1f us  %7.1f TF\n", tag, rows, n, name, t, flops / t / 1e6);
     }
+    ss_gemm_dw_set_option(3, -1);
     ss_gemm_dw_set_option(1, 1);
     // cross-check one accumulation of each (buffers re-zeroed)
     for (int i = 0; i < n; ++i) { CK(hipMemset(a.jobs[i].C, 0, (size_t)a.jobs[i].M * a.jobs[i].N * 4)); CK(hipMemset(b.jobs[i].C, 0, (size_t)a.jobs[i].M * a.jobs[i].N * 4)); }
