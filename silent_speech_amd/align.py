@@ -108,6 +108,6 @@ def align_from_distances(distance_matrix, debug=False, device=None):
     if t.dtype == torch.float64:
         _, res = _cumulative(t, True)
         return res.cpu().tolist()
-    # keep the caller's strides: no transposed copy is materialised, the skew kernel reads strided
-    results, _ = dtw_align_batch(t, [(N, M)], [0], [t.stride()])
-    return results[:N].cpu().tolist()
+    # keep the caller's strides: no transposed copy is materialised, the kernel reads the view in place (torch_ops.py: silent_speech::dtw_align)
+    from . import torch_ops  # noqa: F401
+    return torch.ops.silent_speech.dtw_align(t).cpu().tolist()

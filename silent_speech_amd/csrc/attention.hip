@@ -1925,6 +1925,9 @@ extern "C" int ss_relpos_attention_backward_p(int dtype, const void* qkv, const 
     SS_CHECK((qkvT && dOT) || !ss_relpos_attention_needs_transposed(dtype, T, dp, D), "ss_relpos_attention_backward: this shape runs the per-tile kernels, which need qkvT and dOT");
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
     p.qkv = qkv; p.qkvT = qkvT; p.E = E; p.ET = ET; p.out = (void*)out; p.lse = (float*)lse; p.dO = dO; p.dOT = dOT; p.Dv = Dscratch; p.dqkv = dqkv;
+    // D = rowsum(dO * O) stays a pass of its own (14.5 us, HBM-bound).  Round 4 formed it inside the image-path query-major kernel instead (from the
+    // dO fragments of a tile and the matching O rows, handed to the key-major kernel through Dscratch): bit-identical gradients, but that kernel is
+    // instruction-issue-bound and the ~200 extra instructions per tile cost it 20 us -- backward 167 -> 173 us at 880 pairs; removed.
     {
         long long blocks = ((long long)B * T + 3) / 4; if (blocks > 8192) blocks = 8192;
         if (dtype == SS_BF16) SS_LAUNCH(attn_dsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dO, (const bf16_t*)out, Dscratch, B, H, T, dp);

@@ -83,11 +83,17 @@ def _mel_basis(sampling_rate, n_fft, num_mels, fmin, fmax, device, ld):
 
 def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False):
     """y: (B, L) float32 in [-1, 1] on the GPU -> (B, num_mels, F) float32 log-mel, F = 1 + (L + n_fft - hop - n_fft)//hop.
-    (The reference's min/max range warnings (:40-43) would force a device sync and are omitted.)"""
+    (The reference's min/max range warnings (:40-43) would force a device sync and are omitted.)  Dispatches through
+    torch.ops.silent_speech.stft_logmel (torch_ops.py)."""
     if y.dim() != 2 or y.dtype != torch.float32:
         raise ValueError('y must be a float32 (B, L) tensor')
     if hop_size % 4 or n_fft % 4:
         raise ValueError('hop_size and n_fft must be multiples of 4 (16-byte f32 rows)')
+    from . import torch_ops  # noqa: F401
+    return torch.ops.silent_speech.stft_logmel(y, int(n_fft), int(num_mels), int(sampling_rate), int(hop_size), int(win_size), int(fmin), int(fmax), bool(center))
+
+
+def _mel_spectrogram_impl(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center):
     y = y.contiguous()
     B, L = y.shape
     pad = int((n_fft - hop_size) / 2)

@@ -3,7 +3,7 @@ torch.optim.Optimizer interface the reference's training loop uses (transduction
 param_groups[...]['lr'] writes, zero_grad(), step(); ReduceLROnPlateau works on it unchanged)."""
 import torch
 
-from . import ops
+from . import torch_ops  # noqa: F401  (registers torch.ops.silent_speech.*)
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -49,6 +49,6 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError('FusedAdamW updates the whole flat arena with one set of hyper-parameters: exactly one param group')
         g = self.param_groups[0]
         self._t += 1
-        ops.adamw_step(flat, gflat, self._m, self._v, n, float(g['lr']), self._t, beta1=g['betas'][0], beta2=g['betas'][1], eps=g['eps'],
-                       weight_decay=g['weight_decay'], grad_scale=grad_scale)
+        torch.ops.silent_speech.fused_adamw(flat, gflat, self._m, self._v, int(n), float(g['lr']), int(self._t), float(g['betas'][0]), float(g['betas'][1]),
+                                            float(g['eps']), float(g['weight_decay']), float(grad_scale))
         self.model.mark_weights_updated()

@@ -64,30 +64,6 @@ class _CtcPlan(object):
         self.lengths, self.tlens = lengths, tl
 
 
-class _CtcLossFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, logits, plan, V, blank):
-        dev = logits.device
-        M, ld = logits.shape
-        st = _lib.stream_of(logits)
-        lse = torch.empty(M, dtype=torch.float32, device=dev)
-        amax = torch.empty(M, dtype=torch.int32, device=dev)
-        _lib.check(_L().ss_frame_lse(_p(logits), ld, 0, V, M, _p(lse), _p(amax), st), 'ss_frame_lse')
-        ws = torch.empty(2 * max(plan.ws_floats, 1), dtype=torch.float32, device=dev)
-        nll = torch.empty(max(plan.n, 1), dtype=torch.float32, device=dev)
-        dlogits = torch.empty_like(logits)
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.check(_L().ss_ctc_loss(_p(logits), ld, V, blank, _p(lse), _p(plan.desc) if plan.n else None, plan.n, plan.max_s, M, _p(plan.targets),
-                                    _p(ws), _p(ws[max(plan.ws_floats, 1):]), _p(nll), _p(dlogits), _p(loss), st), 'ss_ctc_loss')
-        ctx.dlogits = dlogits
-        plan.nll, plan.argmax = nll[:plan.n], amax
-        return loss[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        return ctx.dlogits * g, None, None, None
-
-
 def ctc_loss(pred, example, blank=None, *, return_plan=False):
     """recognition_model.py:96-101 in one call.  pred: (rows, 200, V) raw model outputs (NOT log-softmaxed);
     example: the collate_raw batch dict ('lengths', 'text_int').  Returns the 0-dim mean loss
@@ -96,7 +72,9 @@ def ctc_loss(pred, example, blank=None, *, return_plan=False):
     blank = V - 1 if blank is None else int(blank)
     logits = pred.reshape(B * T, V).float().contiguous()
     plan = _CtcPlan(example['lengths'], example['text_int'], B * T, pred.device)
-    loss = _CtcLossFn.apply(logits, plan, V, blank)
+    loss, _, nll, amax = torch.ops.silent_speech.ctc_loss(logits, plan.desc, plan.targets, plan.n, plan.max_s, plan.ws_floats, V, blank)
+    plan.nll, plan.argmax = nll.detach()[:plan.n], amax
+    loss = loss[0]
     return (loss, plan) if return_plan else loss
 
 

@@ -14,7 +14,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.silent_speech.*)
 from .align import _workspace_layout
 from .architecture import Model
 from . import staging
@@ -78,9 +78,9 @@ class _LossPlan(object):
         """Device side: the two uploaded tables, the concatenated targets, and the per-frame index tables (one launch)."""
         dev = Y.device
         self.Y, self.phones = Y, phones
-        self.desc = desc_dev if self.n_silent else None
+        self.desc = desc_dev
         nv, ns = max(self.n_voiced, 1), max(self.n_silent_frames, 1)
-        idx = torch.empty(2 * nv + 3 * ns, dtype=torch.int32, device=dev)
+        idx = self.idx = torch.empty(2 * nv + 3 * ns, dtype=torch.int32, device=dev)
         self.vo_pred, self.vo_tgt = idx[:nv], idx[nv:2 * nv]
         self.si_tgt, self.si_base, self.si_res = idx[2 * nv:2 * nv + ns], idx[2 * nv + ns:2 * nv + 2 * ns], idx[2 * nv + 2 * ns:]
         _lib.check(_L().ss_loss_index_tables(_p(utt_dev), self.n_utt, _p(self.vo_pred), _p(self.vo_tgt), _p(self.si_tgt), _p(self.si_base), _p(self.si_res),
@@ -111,45 +111,6 @@ def _build_loss_plan(example, rows_total, device):
     if ja is not None:
         Y, ph = ja.launch(up[2]), jp.launch(up[3])
     return plan.bind(up[0], up[1], Y, ph)
-
-
-class _DtwLossFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, head, plan, n_mel, n_ph, lam, inv_total):
-        dev = head.device
-        M, ld = head.shape
-        st = _lib.stream_of(head)
-        lse = torch.empty(M, dtype=torch.float32, device=dev)
-        amax = torch.empty(M, dtype=torch.int32, device=dev)
-        dhead = torch.zeros_like(head)
-        loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        correct = torch.zeros(1, dtype=torch.int32, device=dev)
-        _lib.check(_L().ss_frame_lse(_p(head), ld, n_mel, n_ph, M, _p(lse), _p(amax), st), 'ss_frame_lse')
-        if plan.n_voiced:
-            _lib.check(_L().ss_voiced_loss(_p(head), ld, n_mel, n_ph, _p(lse), _p(amax), _p(plan.Y), _p(plan.phones), _p(plan.vo_pred), _p(plan.vo_tgt),
-                                           plan.n_voiced, lam, inv_total, _p(dhead), _p(loss), _p(correct), st), 'ss_voiced_loss')
-        results = None
-        if plan.n_silent:
-            ws = torch.empty(max(plan.ws_bytes, 256), dtype=torch.uint8, device=dev)
-            results = torch.empty(max(plan.res_total, 1), dtype=torch.int32, device=dev)
-            mx_n, mx_m = max(s[0] for s in plan.shapes), max(s[1] for s in plan.shapes)
-            cells = float(sum(a * b for a, b in plan.shapes))
-            ops.timed('silent_cost_skewed_kernel', 0, 4.0 * cells + 4.0 * (n_mel + n_ph) * sum(a + b for a, b in plan.shapes),
-                      lambda: _lib.check(_L().ss_silent_cost_skewed(_p(head), ld, n_mel, _p(lse), _p(plan.Y), _p(plan.phones), _p(plan.desc), plan.n_silent, mx_n, mx_m,
-                                                                    lam, _p(ws), _p(results), st), 'ss_silent_cost_skewed'))
-            ops.timed('dtw_kernel', 0, 8.0 * cells,         # 8 N M bytes per matrix (f32 cost in + f32 cumulative out)
-                      lambda: _lib.check(_L().ss_dtw_align_skewed(_p(plan.desc), plan.n_silent, _p(ws), _p(results), st), 'ss_dtw_align_skewed'))
-            _lib.check(_L().ss_silent_loss(_p(head), ld, n_mel, n_ph, _p(lse), _p(amax), _p(plan.Y), _p(plan.phones), _p(results), _p(plan.si_tgt),
-                                           _p(plan.si_base), _p(plan.si_res), plan.n_silent_frames, lam, inv_total, _p(dhead), _p(loss), _p(correct), st),
-                       'ss_silent_loss')
-        ctx.dhead = dhead
-        ctx.mark_non_differentiable(correct)
-        plan.results, plan.argmax = results, amax                     # the plan is this call's own object (alignment / arg-max for the evaluation extras)
-        return loss[0], correct
-
-    @staticmethod
-    def backward(ctx, gl, gc):
-        return ctx.dhead * gl, None, None, None, None, None
 
 
 class _Prepared(object):
@@ -195,8 +156,14 @@ def _dtw_loss_plan(predictions, phoneme_predictions, example, lam, total_length=
     head = _fused_head(predictions, phoneme_predictions, M, n_mel, n_ph)
     plan = _loss_plan(example, M, predictions.device)
     total = plan.total_length if total_length is None else total_length
-    loss, correct = _DtwLossFn.apply(head, plan, n_mel, n_ph, float(lam), 1.0 / float(total))
-    return loss, correct, plan
+    mx_n = max((a for a, _ in plan.shapes), default=0)
+    mx_m = max((b for _, b in plan.shapes), default=0)
+    loss, correct, _, results, amax = torch.ops.silent_speech.dtw_loss(
+        head, plan.Y, plan.phones, plan.idx, plan.desc, n_mel, n_ph, float(lam), 1.0 / float(total), plan.n_voiced, plan.n_silent_frames,
+        plan.n_silent, int(plan.ws_bytes), int(plan.res_total), mx_n, mx_m, float(sum(a * b for a, b in plan.shapes)),
+        float(sum(a + b for a, b in plan.shapes)))
+    plan.results, plan.argmax = (results if plan.n_silent else None), amax        # the plan is this call's own object (evaluation extras)
+    return loss[0], correct, plan
 
 
 def dtw_loss(predictions, phoneme_predictions, example, phoneme_eval=False, phoneme_confusion=None, *, phoneme_loss_weight=None,

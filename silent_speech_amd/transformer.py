@@ -1,7 +1,8 @@
 """Parameter containers of the relative-position Transformer encoder -- same class names, constructor
 arguments, parameter names/shapes and initialisation as the reference's transformer.py, so reference
-checkpoints load with load_state_dict().  The math runs in csrc/attention.hip / gemm.hip / norm.hip,
-sequenced by engine.py; calling one of these modules on its own raises (there is no eager fallback)."""
+checkpoints load with load_state_dict().  Inside `Model` the math is sequenced by the native plan (engine.py, csrc/plan.hip) and these
+classes only hold parameters; called on their own, their `forward` runs the same HIP kernels one C-ABI call at a time (eager.py:
+inference forwards, no autograd -- training goes through Model)."""
 import copy
 
 import torch
@@ -42,6 +43,11 @@ class MultiHeadAttention(nn.Module):
             raise NotImplementedError('the HIP attention kernel implements the relative-positional variant the reference trains')
         self.relative_positional = LearnedRelativePositionalEmbedding(relative_positional_distance, n_head, d_qkv, True)
 
+    def forward(self, x):
+        """transformer.py:87-112: x (length, batch, d_model) -> (length, batch, d_model)."""
+        from . import eager
+        return eager.mha_forward(self, x)
+
 
 class TransformerEncoderLayer(nn.Module):
     """transformer.py:7-41 (post-norm; masks accepted and ignored by the reference, :43,54)."""
@@ -59,6 +65,11 @@ class TransformerEncoderLayer(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
         self.activation = nn.ReLU()
 
+    def forward(self, src, src_mask=None, src_key_padding_mask=None, is_causal=False):
+        """transformer.py:43-60 (the mask arguments are accepted and ignored, as in the reference)."""
+        from . import eager
+        return eager.encoder_layer_forward(self, src, src_mask, src_key_padding_mask, is_causal)
+
 
 class TransformerEncoder(nn.Module):
     """Same state_dict keys as nn.TransformerEncoder(encoder_layer, num_layers) (architecture.py:54):
@@ -68,3 +79,7 @@ class TransformerEncoder(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
         self.num_layers = num_layers
+
+    def forward(self, src, mask=None, src_key_padding_mask=None):
+        from . import eager
+        return eager.encoder_forward(self, src, mask, src_key_padding_mask)
