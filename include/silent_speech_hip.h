@@ -379,8 +379,10 @@ typedef struct ss_plan ss_plan;
  * 3C) with the device pointer of the per-channel sums and the local row count; must all-reduce the sums in place on `stream`
  * and return the GLOBAL row count. */
 typedef double (*ss_reduce_hook)(void* user, float* sums_dev, int n_floats, double n_local, void* stream);
-/* Called from ss_plan_backward when a group of parameter gradients is final on `stream` (what = 0: heads + encoder + w_raw_in,
- * 1..3: ResBlock 2, 1, 0): lets the caller start a bucketed gradient all-reduce while the rest of backward still runs. */
+/* Called from ss_plan_backward when a group of parameter gradients is final on `stream`: what = 4 + l: encoder layer l (fired
+ * layer by layer, last layer first, while the backward of the earlier layers still runs), 0: the fused heads + w_raw_in (after it every
+ * non-convolutional gradient is final), 1..3: ResBlock 2, 1, 0.  Lets the caller start a bucketed gradient all-reduce while the
+ * rest of backward still runs. */
 typedef void (*ss_event_hook)(void* user, int what, void* stream);
 ss_plan* ss_plan_create(const ss_model_dims* dims);                 /* [host] NULL on error */
 void ss_plan_destroy(ss_plan* plan);                                /* [host] */

@@ -35,6 +35,7 @@ struct LayerP {
     void *wqkv = 0, *wqkvT = 0, *wo = 0, *woT = 0, *E = 0, *ET = 0, *w1 = 0, *w2 = 0, *w1T = 0, *w2T = 0;
     float *b1 = 0, *b2 = 0, *g1 = 0, *be1 = 0, *g2 = 0, *be2 = 0;
     float *dg1 = 0, *dbe1 = 0, *dg2 = 0, *dbe2 = 0, *dw1 = 0, *db1 = 0, *dw2 = 0, *db2 = 0, *wo_stage = 0, *wqkv_stage = 0;
+    PermB unpack;          // this layer's re-laid-out gradients (w_o, w_q / w_k / w_v) -> .grad arena
 };
 
 // pointers saved by forward for backward (all into the caller's workspace)
@@ -139,6 +140,7 @@ struct Plan {
             slot(p + "norm1.weight.grad", (void**)&L.dg1); slot(p + "norm1.bias.grad", (void**)&L.dbe1); slot(p + "norm2.weight.grad", (void**)&L.dg2); slot(p + "norm2.bias.grad", (void**)&L.dbe2);
             slot(p + "linear1.weight.grad", (void**)&L.dw1); slot(p + "linear1.bias.grad", (void**)&L.db1); slot(p + "linear2.weight.grad", (void**)&L.dw2); slot(p + "linear2.bias.grad", (void**)&L.db2);
             slot(p + "w_o.stage", (void**)&L.wo_stage); slot(p + "w_qkv.stage", (void**)&L.wqkv_stage);
+            slot_perm(p + "unpack", L.unpack);
         }
         slot("w_head", &w_head); slot("w_head_T", &w_head_T); slot("b_head", (void**)&b_head);
         slot("head_w.stage", (void**)&head_w_stage); slot("head_b.stage", (void**)&head_b_stage);
@@ -439,14 +441,24 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         if (!X.dry) L_(timed(X, "attn_bwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 5.0, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_backward_p(dt, s.qkv, s.qkvT, w.E, w.ET, s.o, s.lse, dO, dOT, dsc, dqkv, s.pimg, B, H, T, Tp, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
         L_(grp.add(dqkv, s.x, w.wqkv_stage, 3 * HD, d, M, RM(3 * HD), RM(d), side));
         { ss_gemm_epilogue e = EPI(); e.mode = 1; L_(gemm(X, dt, dqkv, w.wqkvT, G, M, d, 3 * HD, RM(3 * HD), RM(3 * HD), RM(d), &e)); }
-        if (l > 0) { SIDE_BEGIN(); L_(grp.launch(side)); SIDE_END(); }          // layer 0's group waits for w_raw_in's gradient
+        if (l > 0) {                                                             // layer 0's group waits for w_raw_in's gradient
+            // the layer's weight gradients, their un-layout into the .grad arena, and -- data-parallel runs -- the event that lets the caller
+            // start THIS layer's all-reduce now (what = 4 + l): 6 collectives of ~28 MB spread over the encoder backward instead of one of
+            // 170 MB after it.  (The fork makes `side` wait for everything the main stream produced for this layer: bias / LayerNorm gradients.)
+            SIDE_BEGIN(); L_(grp.launch(side)); L_(permute_batch(X, w.unpack, side)); SIDE_END();
+            if (on_event && !X.dry) on_event(event_user, 4 + l, side);
+        }
     }
     // ---- w_raw_in (architecture.py:73)
     L_(grp.add(G, c->conv_out, dw_raw_in, d, d, M, RM(d), RM(d), side));
     SIDE_BEGIN(); L_(grp.launch(side)); L_(colsum(X, G, M, d, db_raw_in, side));
-    L_(permute_batch(X, unpack_enc, side));                                      // heads + encoder layers: re-laid-out gradients -> .grad arena, under the conv backward
+    if (c->n_layers > 0) L_(permute_batch(X, layers[0].unpack, side));
+    L_(permute_batch(X, unpack_enc, side));                                      // the fused heads (and whatever else the caller put there): under the conv backward
     SIDE_END();
-    if (on_event && !X.dry) on_event(event_user, 0, side);                     // encoder gradients complete on `side` (bucketed all-reduce hook)
+    if (on_event && !X.dry) {
+        if (c->n_layers > 0) on_event(event_user, 4, side);                      // encoder layer 0
+        on_event(event_user, 0, side);                                          // heads + w_raw_in: every non-convolutional gradient is final on `side`
+    }
     void* dy = X.alloc((size_t)M * d * es);
     L_(gemm(X, dt, G, w_raw_in_T, dy, M, d, d, RM(d), RM(d), RM(d)));
 

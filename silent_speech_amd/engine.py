@@ -169,12 +169,17 @@ class GradUnpack(object):
         if n_aux:
             ub.add(hw[n_out:n_out + n_aux], model.w_aux.weight.grad, (1, n_aux, d), (0, d, 1), accumulate=True)
             ub.add(hb[n_out:n_out + n_aux], model.w_aux.bias.grad, (1, 1, n_aux), (0, 0, 1), accumulate=True)
+        self.head_batch = ub
+        # one batch per encoder layer, launched right behind the layer's weight-gradient GEMMs: the layer's gradients are then final
+        # (and, under data parallelism, on their way through the all-reduce) while the backward of the earlier layers still runs
+        self.layer_batches = []
         for l, layer in enumerate(model.transformer.layers):
             a = layer.self_attn
-            ub.add(self.buf['wo%d' % l], a.w_o.grad, (H, dh, d), (dp, 1, H * dp), accumulate=True)
+            lb = ops.PermuteBatch()
+            lb.add(self.buf['wo%d' % l], a.w_o.grad, (H, dh, d), (dp, 1, H * dp), accumulate=True)
             for i, wp in enumerate((a.w_q, a.w_k, a.w_v)):
-                ub.add(self.buf['wqkv%d' % l][i * H * dp * d:], wp.grad, (H, d, dh), (dp * d, 1, d), accumulate=True)
-        self.encoder_batch = ub
+                lb.add(self.buf['wqkv%d' % l][i * H * dp * d:], wp.grad, (H, d, dh), (dp * d, 1, d), accumulate=True)
+            self.layer_batches.append(lb)
         self.conv_batches = []
         for i, blk in enumerate(model.conv_blocks):
             O, I, _ = blk.conv1.weight.shape
@@ -286,11 +291,12 @@ class PlanBinding(object):
                     mod, attr = k.split('.')
                     t[p + k + '.grad'] = getattr(getattr(layer, mod), attr).grad
                 t[p + 'w_o.stage'], t[p + 'w_qkv.stage'] = gu.buf['wo%d' % l], gu.buf['wqkv%d' % l]
+                batch(p + 'unpack', gu.layer_batches[l])
         t['w_head'], t['w_head_T'], t['b_head'] = pr.w_head, pr.w_head_T, pr.b_head
         if g:
             t['head_w.stage'], t['head_b.stage'] = gu.buf['head_w'], gu.buf['head_b']
             t['stage_arena'], t['stage_arena.bytes'] = gu.arena, int(gu.arena.numel() * 4)
-            batch('unpack_encoder', gu.encoder_batch)
+            batch('unpack_encoder', gu.head_batch)
         return t
 
     def ensure_bound(self, model, pr, gu, dev):

@@ -289,6 +289,20 @@ def _pack_batch(batch, device, seq_len=200):
     return prepare_batch(batch, device, seq_len)
 
 
+def _lookahead(iterable):
+    """(item, next item or None): the training loop looks one batch ahead so that data-parallel bookkeeping of the next step can
+    overlap the current one."""
+    it = iter(iterable)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 def test(model, testset, device):
     """transduction_model.py:33-55: eval-mode forward on batches of 32 utterances; returns
     (mean loss, mean phoneme accuracy, confusion matrix)."""
@@ -346,12 +360,14 @@ def train_model(trainset, devset, device, save_sound_outputs=True, *, compute_dt
     for epoch_idx in range(n_epochs):
         losses = []
         sampler.set_epoch(epoch_idx)
-        for batch in dataloader:
+        for batch, upcoming in _lookahead(dataloader):
             optim.zero_grad()
             schedule_lr(batch_idx)
             X, X_raw, sess = _pack_batch(batch, device)
             if data_parallel is not None:
-                data_parallel.begin_step(X_raw.shape[0] * (X_raw.shape[1] // 8), data_parallel.local_target_frames(batch))
+                # the host-side exchange of the NEXT batch's (row, frame) counts starts now and is picked up by the next begin_step
+                nxt = None if upcoming is None else ((sum(int(n) for n in upcoming['lengths']) + 199) // 200 * 200, data_parallel.local_target_frames(upcoming))
+                data_parallel.begin_step(X_raw.shape[0] * (X_raw.shape[1] // 8), data_parallel.local_target_frames(batch), next_counts=nxt)
             pred, phoneme_pred = model(X, X_raw, sess)
             total = data_parallel.global_total(batch) if data_parallel is not None else None
             loss, _ = dtw_loss(pred, phoneme_pred, batch, total_length=total)

@@ -29,7 +29,7 @@ UTTS = [(1, 24, False), (2, 48, True), (3, 48, False), (4, 24, True), (5, 48, Fa
 # whole rows of 24 frames -> per-rank rows == global rows; 8 utterances deal evenly to 1, 2 and 4 ranks
 
 
-def run_step(model, batch, dp, seq_len=24):
+def run_step(model, batch, dp, seq_len=24, next_counts=None):
     from silent_speech_amd.data_utils import combine_fixed_length
     from silent_speech_amd.transduction_model import dtw_loss
     X_raw = combine_fixed_length(batch['raw_emg'], seq_len * 8)
@@ -39,7 +39,7 @@ def run_step(model, batch, dp, seq_len=24):
     if not zero_late:
         model.zero_grad(set_to_none=True)
     if dp is not None:
-        dp.begin_step(X_raw.shape[0] * seq_len, dp.local_target_frames(batch))
+        dp.begin_step(X_raw.shape[0] * seq_len, dp.local_target_frames(batch), next_counts=next_counts)
     pred, aux = model(X, X_raw, sess)
     total = dp.global_total(batch) if dp is not None else None
     loss, _ = dtw_loss(pred, aux, batch, phoneme_loss_weight=0.5, total_length=total)
@@ -54,7 +54,7 @@ def run_step(model, batch, dp, seq_len=24):
 def build_model():
     from silent_speech_amd.architecture import Model
     torch.manual_seed(123)
-    m = Model(112, 80, 48, model_size=16, num_layers=1, dropout=0.0, compute_dtype=torch.float32)
+    m = Model(112, 80, 48, model_size=16, num_layers=int(os.environ.get('SS_DP_LAYERS', '1')), dropout=0.0, compute_dtype=torch.float32)
     with torch.no_grad():
         for n, p in m.named_parameters():
             if p.dim() == 1 and 'bias' not in n:
@@ -117,13 +117,23 @@ def main():
             for prm in model.parameters():
                 if rank > 0:
                     prm.add_(torch.randn(prm.shape, device=prm.device) * 0.01)
-        dp = DataParallel(bucketed=os.environ.get('SS_DP_BUCKETED', '1') == '1')
+        dp = DataParallel(bucketed=os.environ.get('SS_DP_BUCKETED', '1') == '1', grad_dtype=torch.bfloat16 if os.environ.get('SS_DP_GRAD_BF16') == '1' else None)
         dp.attach(model)
         batch = make_batch(UTTS[rank::world])
     else:
         batch = make_batch([u for r in range(int(os.environ.get('SS_DP_ORDER_OF', '2'))) for u in UTTS[r::int(os.environ.get('SS_DP_ORDER_OF', '2'))]])
     batch = {k: ([t.to(dev) for t in v] if isinstance(v, list) and len(v) and torch.is_tensor(v[0]) else v) for k, v in batch.items()}
-    loss = run_step(model, batch, dp)
+    if os.environ.get('SS_DP_PREFETCH') == '1' and dp is not None:
+        # the step is run twice; the first begin_step already starts the exchange of the second step's counts (a loop that looks one batch ahead)
+        model.shift_rng = _R                         # attach() installed the ranks' shared random shift: both steps must see the same augmentation here
+        counts = (int(sum(batch['lengths'])), dp.local_target_frames(batch))
+        run_step(model, batch, dp, next_counts=counts)
+        assert dp._pending is not None
+        model.zero_grad(set_to_none=True)
+        loss = run_step(model, batch, dp)
+        assert dp._pending is None
+    else:
+        loss = run_step(model, batch, dp)
     _, gflat, n = model.flat_arenas()
     emb = model.transformer.layers[0].self_attn.relative_positional.embeddings.detach().clone().cpu()
     res = {'loss': float(loss), 'grads': gflat.clone().cpu(), 'emb': emb, 'rm': model.conv_blocks[0].bn1.running_mean.clone().cpu(), 'rv': model.conv_blocks[2].bn2.running_var.clone().cpu()}

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _ranks_vs_single(tmp_path, extra_env, world=2):
+def _ranks_vs_single(tmp_path, extra_env, world=2, tol=2e-4, check_running=True):
     worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
     env = dict(os.environ, OMP_NUM_THREADS='1', SS_DP_ORDER_OF=str(world), **extra_env)
     single = str(tmp_path / 'single.pt')
@@ -37,10 +37,12 @@ def _ranks_vs_single(tmp_path, extra_env, world=2):
     assert ga.shape == gb.shape
     assert float(ga.abs().max()) > 1e-3 and float(gb.abs().max()) > 1e-3, 'vacuous comparison: the gradient arena is empty'
     err = float((ga - gb).abs().max()) / (float(ga.abs().max()) + 1e-12)
-    assert err < 2e-4, err
-    assert torch.allclose(a['rm'], b['rm'], rtol=1e-4, atol=1e-6)
-    assert torch.allclose(a['rv'], b['rv'], rtol=1e-4, atol=1e-6)
+    assert err < tol, err
+    if check_running:                        # (a worker that runs the step twice has updated the running statistics twice)
+        assert torch.allclose(a['rm'], b['rm'], rtol=1e-4, atol=1e-6)
+        assert torch.allclose(a['rv'], b['rv'], rtol=1e-4, atol=1e-6)
     assert torch.equal(a['emb'], b['emb'])      # the never-trained relative-position embeddings were broadcast from rank 0 too
+    return err
 
 
 def _two_rank_vs_single(tmp_path, extra_env):
@@ -57,6 +59,24 @@ def test_zero_grad_between_forward_and_backward_keeps_the_arena(tmp_path):
     all-zero arena: gradients are re-homed instead."""
     _ensure_emu()
     _two_rank_vs_single(tmp_path, {'SS_DP_ZERO_LATE': '1'})
+
+
+def test_per_layer_buckets_two_layers_and_the_single_encoder_bucket(tmp_path):
+    """A 2-layer encoder fires the layer buckets from inside the backward (event 4 + 1 while layer 0 is still to come); SS_DP_LAYER_BUCKETS=0
+    is the one-bucket schedule of rounds 2-3.  Both equal the single process."""
+    _ensure_emu()
+    _ranks_vs_single(tmp_path, {'SS_DP_LAYERS': '2'}, 2)
+    _ranks_vs_single(tmp_path, {'SS_DP_LAYERS': '2', 'SS_DP_LAYER_BUCKETS': '0'}, 2)
+
+
+def test_bf16_gradient_transport_and_count_prefetch(tmp_path):
+    """grad_dtype=bfloat16 halves the bytes on the links: the rank-sums are rounded once to bf16 (measured delta recorded below, bound 2^-7 of the
+    largest gradient); next_counts starts the next step's host-side exchange during the current step."""
+    _ensure_emu()
+    err = _ranks_vs_single(tmp_path, {'SS_DP_GRAD_BF16': '1', 'SS_DP_PREFETCH': '1'}, 2, tol=8e-3, check_running=False)
+    assert err > 1e-6, 'the bf16 transport was not exercised'
+    with open(str(tmp_path / 'bf16_transport_delta.txt'), 'w') as f:
+        f.write('max |g_bf16 - g_f32| / max |g| = %.3e\n' % err)
 
 
 def test_four_rank_step_equals_single_process_unbucketed(tmp_path):
