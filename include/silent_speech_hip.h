@@ -28,9 +28,9 @@ extern "C" {
 const char* ss_last_error(void);
 /* Library/ABI version and the GPU architecture the kernels were compiled for ("gfx950"). */
 /* Bumped whenever a struct layout or an entry-point signature changes (3: ss_gemm_epilogue column-statistics fields, the plan /
- * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative; 4: ss_loss_index_tables).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
+ * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative; 4: ss_loss_index_tables; 5: gate recomputation arguments of ss_bn_backward_sums / ss_bn_backward_apply).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
  * library paired with newer headers would otherwise read garbage struct fields instead of failing. */
-#define SS_ABI_VERSION 4
+#define SS_ABI_VERSION 5
 int ss_abi_version(void);
 const char* ss_target_arch(void);
 
@@ -199,17 +199,21 @@ int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const float* inv
                 void* y, int pad_y, int B, int T, int C, int relu, void* stream);
 /* autograd backward of the above (transduction_model.py:209), again in two phases:
  * sums[3][C] = { sum g, sum g*xhat_a, sum g*xhat_b } with g = dy*1[y>0]; dgamma/dbeta are ACCUMULATED (+=);
- * apply: dx = gamma*invstd*(g - sums0/n - xhat*sums{1,2}/n). */
+ * apply: dx = gamma*invstd*(g - sums0/n - xhat*sums{1,2}/n).
+ * The ReLU gate 1[y>0] is read from the saved output y, or -- gate_beta_a != NULL -- RECOMPUTED as the sign of the forward's own
+ * expression (xa - mean_a) gamma_a invstd_a + beta_a [+ the b branch] from the inputs both passes read anyway (y may then be NULL):
+ * one tensor less per pass (the plan does this). */
 int ss_bn_backward_sums(int dtype, const void* dy, int pad_dy, const void* y, int pad_y,
                         const void* xa, int pad_xa, const float* mean_a, const float* invstd_a,
                         const void* xb, int pad_xb, const float* mean_b, const float* invstd_b,
                         float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
-                        float* scratch, float* sums, int B, int T, int C, int relu, void* stream);
+                        float* scratch, float* sums, int B, int T, int C, int relu,
+                        const float* gate_gamma_a, const float* gate_beta_a, const float* gate_gamma_b, const float* gate_beta_b, void* stream);
 int ss_bn_backward_apply(int dtype, const void* dy, int pad_dy, const void* y, int pad_y,
                          const void* xa, int pad_xa, const float* mean_a, const float* invstd_a, const float* gamma_a,
                          const void* xb, int pad_xb, const float* mean_b, const float* invstd_b, const float* gamma_b,
                          const float* sums, double n_total, void* dxa, int pad_dxa, void* dxb, int pad_dxb,
-                         int B, int T, int C, int relu, void* stream);
+                         int B, int T, int C, int relu, const float* gate_beta_a, const float* gate_beta_b, void* stream);
 /* out[c] += sum_r x[r][c]  (bias gradients of nn.Linear / nn.Conv1d) */
 int64_t ss_colsum_scratch_floats(int rows, int C); /* [host] */
 int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, float* scratch, float* out_accum, void* stream);
@@ -389,7 +393,7 @@ void ss_plan_destroy(ss_plan* plan);                                /* [host] */
 int ss_plan_slot_count(const ss_plan* plan);                        /* [host] */
 const char* ss_plan_slot_name(const ss_plan* plan, int slot);       /* [host] */
 int ss_plan_bind(ss_plan* plan, int slot, void* device_ptr_or_value); /* [host] slots named *.total / *.all_f32 / *.bytes take integers */
-int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off */
+int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off, 4 BatchNorm backward recomputes the ReLU gate (on) or reads the saved output (off) */
 int ss_plan_set_reduce_hook(ss_plan* plan, ss_reduce_hook fn, void* user); /* [host] */
 int ss_plan_set_event_hook(ss_plan* plan, ss_event_hook fn, void* user);   /* [host] */
 int64_t ss_plan_ctx_bytes(void);                                    /* [host] */

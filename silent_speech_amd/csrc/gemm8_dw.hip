@@ -464,7 +464,9 @@ __global__ __launch_bounds__(512) void gemm8_dwk_kernel(DwJobs jobs, int nitems,
         float* Cj = J.C; const long long ldc = J.ldc; const int Mj = J.M, Nj = J.N, atomic = J.atomic, cm0 = m0, cn0 = n0;
         const bool has_next = it + G < nitems;
         if (has_next) { it += G; G8K_SETUP(); }
-        // ---- epilogue: lane holds rows q*4+reg, column c of each 16x16 tile
+        // ---- epilogue: lane holds rows q*4+reg, column c of each 16x16 tile (an update instruction touches 4 rows x 64 bytes).  ~22 of the ~315 us of a
+        // layer group are these f32 atomics (SS_GEMM_DW_ABL=8).  Measured and dropped: exchanging the registers of neighbouring tiles half-wave-wise
+        // (v_permlane32_swap) so that an instruction covers 2 rows x 128 contiguous bytes -- same time: the L2 atomic units are bound per float, not per line.
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll

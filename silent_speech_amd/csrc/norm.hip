@@ -69,7 +69,7 @@ template <class T>
 __global__ __launch_bounds__(RED_THREADS) void bn_partial_kernel(const T* __restrict__ x, Seq sx, int rows, int C, int rows_per_chunk, const float* __restrict__ shift, float* __restrict__ partial)
 {
     __shared__ float red[2][RED_THREADS * 8];
-    ColMap m(C, threadIdx.x, RED_THREADS);
+    ColMap m(C, threadIdx.x, (int)blockDim.x);
     const int r0 = blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     for (int cb = 0; cb < m.CV; cb += m.CVb) {
         const int cx = cb + m.cx0;
@@ -139,6 +139,16 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
     }
 }
 
+// threads of a column-reduction workgroup: the largest multiple of the C / 8 column chunks within RED_THREADS, so that no lane idles (C = 768:
+// 96 chunks x 2 rows = 192 threads; with 256 a quarter of the lanes had no column).  SS_BN_RED_THREADS overrides (tuning).
+static int red_threads(int C) {
+    static const int forced = getenv("SS_BN_RED_THREADS") ? atoi(getenv("SS_BN_RED_THREADS")) : 0;
+    if (forced > 0) return forced < RED_THREADS ? forced : RED_THREADS;
+    const int cv = C >> 3;
+    if (cv >= RED_THREADS || cv <= 0) return RED_THREADS;
+    const int t = RED_THREADS / cv * cv;
+    return t >= 64 ? t : RED_THREADS;
+}
 // row chunks of the column reductions = workgroups: 3 per CU (SS_BN_CHUNKS; bn_bwd_sums per step: 512 -> 0.504, 768 -> 0.475, 1024 -> 0.53 ms)
 static int red_chunks(int rows) { static const int cap = getenv("SS_BN_CHUNKS") ? atoi(getenv("SS_BN_CHUNKS")) : 768; int c = (rows + 63) / 64; if (c > cap) c = cap; if (c < 1) c = 1; return c; }
 
@@ -152,10 +162,10 @@ extern "C" int ss_bn_stats_sums(int dtype, const void* x, int B, int T, int C, i
     const int rows = B * T, nch = red_chunks(rows), rpc = (rows + nch - 1) / nch;
     Seq sx = {T, pad};
     if (dtype == SS_BF16) {
-        SS_LAUNCH(bn_partial_kernel<bf16_t>, dim3(nch), dim3(RED_THREADS), 0, stream, (const bf16_t*)x, sx, rows, C, rpc, shift, scratch);
+        SS_LAUNCH(bn_partial_kernel<bf16_t>, dim3(nch), dim3(red_threads(C)), 0, stream, (const bf16_t*)x, sx, rows, C, rpc, shift, scratch);
         SS_LAUNCH(bn_sums_kernel<bf16_t>, dim3((C + 31) / 32), dim3(256), 0, stream, (const bf16_t*)x, sx, (const float*)scratch, nch, C, shift, sums);
     } else {
-        SS_LAUNCH(bn_partial_kernel<float>, dim3(nch), dim3(RED_THREADS), 0, stream, (const float*)x, sx, rows, C, rpc, shift, scratch);
+        SS_LAUNCH(bn_partial_kernel<float>, dim3(nch), dim3(red_threads(C)), 0, stream, (const float*)x, sx, rows, C, rpc, shift, scratch);
         SS_LAUNCH(bn_sums_kernel<float>, dim3((C + 31) / 32), dim3(256), 0, stream, (const float*)x, sx, (const float*)scratch, nch, C, shift, sums);
     }
     SS_LAUNCH_CHECK("ss_bn_stats_sums");
@@ -300,24 +310,35 @@ extern "C" int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const
 // =========================================================================== BatchNorm backward
 // g = dy * 1[y>0]  (ReLU of the fused output);  per branch: dgamma = sum g*xhat, dbeta = sum g,
 // dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).
-template <class T>
+template <class T, bool REGATE>
 __global__ __launch_bounds__(RED_THREADS, sizeof(T) == 2 ? 4 : 2) void bn_bwd_partial_kernel(const T* __restrict__ dy, Seq sdy, const T* __restrict__ y, Seq sy,
                                                                      const T* __restrict__ xa, Seq sa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a,
                                                                      const T* __restrict__ xb, Seq sb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b,
+                                                                     const float* __restrict__ gamma_a, const float* __restrict__ beta_a, const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
                                                                      int rows, int C, int rows_per_chunk, int relu, float* __restrict__ partial)
 {
+    // beta_a != null: the ReLU gate is RECOMPUTED from the inputs that are read anyway -- y > 0  <=>  (xa - mean_a) gamma_a invstd_a + beta_a
+    // [+ the b branch] > 0, the forward's own expression (bn_apply_kernel) -- instead of read from the saved output: one tensor less per pass
+    // (4 -> 3 reads here, 4 -> 3 of the 6 streams of bn_bwd_apply).
+    // REGATE is a template parameter: the two forms need different per-channel constants, and both in one kernel overflowed the 128-register
+    // budget of 4 workgroups per CU (the pass ran 3 x slower).  The recomputing form keeps (mean, gamma invstd) per branch + the summed betas and
+    // applies invstd to the x-hat sums once, after the row loop.
     __shared__ float red[3][RED_THREADS * 8];
-    ColMap m(C, threadIdx.x, RED_THREADS);
+    ColMap m(C, threadIdx.x, (int)blockDim.x);
     const int r0 = blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     for (int cb = 0; cb < m.CV; cb += m.CVb) {
         const int cx = cb + m.cx0;
-        float sg[8], sga[8], sgb[8], ma[8], ia[8], mb[8], ib[8];
+        float sg[8], sga[8], sgb[8], ma[8], ka[8], mb[8], kb[8], bs[8];          // ka / kb: invstd (gate from y) or gamma invstd (gate recomputed)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { sg[e] = sga[e] = sgb[e] = 0.f; ma[e] = ia[e] = mb[e] = ib[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { sg[e] = sga[e] = sgb[e] = 0.f; ma[e] = ka[e] = mb[e] = kb[e] = bs[e] = 0.f; }
         const bool cv = m.active && cx < m.CV;
         if (cv) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { ma[e] = mean_a[cx * 8 + e]; ia[e] = invstd_a[cx * 8 + e]; if (xb) { mb[e] = mean_b[cx * 8 + e]; ib[e] = invstd_b[cx * 8 + e]; } }
+            for (int e = 0; e < 8; ++e) {
+                const int c = cx * 8 + e;
+                ma[e] = mean_a[c]; ka[e] = invstd_a[c]; if (xb) { mb[e] = mean_b[c]; kb[e] = invstd_b[c]; }
+                if (REGATE) { ka[e] *= gamma_a[c]; bs[e] = beta_a[c]; if (xb) { kb[e] *= gamma_b[c]; bs[e] += beta_b[c]; } }
+            }
             // two rows per trip: up to 8 independent 16-byte loads in flight per thread (the sums keep their row order)
             for (int r = r0 + m.ry; r < r1; r += 2 * m.RY) {
                 const bool two = r + m.RY < r1;
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(RED_THREADS, sizeof(T) == 2 ? 4 : 2) void bn_bwd_pa
                 float g[2][8], o[2][8], va[2][8], vb[2][8];
                 const int b0 = r / sdy.T, t0 = r - b0 * sdy.T, b1 = rb / sdy.T, t1 = rb - b1 * sdy.T;      // ONE division per row (Seq::row costs one per tensor)
                 Vec8<T>::load(dy + sdy.at(b0, t0) * C + cx * 8, g[0]); Vec8<T>::load(dy + sdy.at(b1, t1) * C + cx * 8, g[1]);
-                if (relu) { Vec8<T>::load(y + sy.at(b0, t0) * C + cx * 8, o[0]); Vec8<T>::load(y + sy.at(b1, t1) * C + cx * 8, o[1]); }
+                if (relu && !REGATE) { Vec8<T>::load(y + sy.at(b0, t0) * C + cx * 8, o[0]); Vec8<T>::load(y + sy.at(b1, t1) * C + cx * 8, o[1]); }
                 Vec8<T>::load(xa + sa.at(b0, t0) * C + cx * 8, va[0]); Vec8<T>::load(xa + sa.at(b1, t1) * C + cx * 8, va[1]);
                 if (xb) { Vec8<T>::load(xb + sb.at(b0, t0) * C + cx * 8, vb[0]); Vec8<T>::load(xb + sb.at(b1, t1) * C + cx * 8, vb[1]); }
 #pragma unroll
@@ -333,11 +354,22 @@ __global__ __launch_bounds__(RED_THREADS, sizeof(T) == 2 ? 4 : 2) void bn_bwd_pa
                     if (u == 1 && !two) break;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float gg = (!relu || o[u][e] > 0.f) ? g[u][e] : 0.f;
-                        sg[e] += gg; sga[e] += gg * (va[u][e] - ma[e]) * ia[e];
-                        if (xb) sgb[e] += gg * (vb[u][e] - mb[e]) * ib[e];
+                        if (REGATE) {       // pre = (xa - mean_a) gamma_a invstd_a [+ b branch] + betas: the forward's expression (bn_apply_kernel)
+                            const float da = va[u][e] - ma[e], db = xb ? vb[u][e] - mb[e] : 0.f;
+                            const float gg = (!relu || da * ka[e] + db * kb[e] + bs[e] > 0.f) ? g[u][e] : 0.f;
+                            sg[e] += gg; sga[e] += gg * da;
+                            if (xb) sgb[e] += gg * db;
+                        } else {
+                            const float gg = (!relu || o[u][e] > 0.f) ? g[u][e] : 0.f;
+                            sg[e] += gg; sga[e] += gg * (va[u][e] - ma[e]) * ka[e];
+                            if (xb) sgb[e] += gg * (vb[u][e] - mb[e]) * kb[e];
+                        }
                     }
                 }
+            }
+            if (REGATE) {                   // the x-hat sums were taken without invstd: apply it once per channel
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sga[e] *= invstd_a[cx * 8 + e]; if (xb) sgb[e] *= invstd_b[cx * 8 + e]; }
             }
         }
         __syncthreads();
@@ -370,12 +402,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     if (dbeta_b) dbeta_b[c] += t[0];
 }
 
-template <class T>
+template <class T, bool REGATE>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* __restrict__ y, Seq sy,
                                     const T* __restrict__ xa, Seq sa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a, const float* __restrict__ gamma_a,
                                     const T* __restrict__ xb, Seq sb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b, const float* __restrict__ gamma_b,
-                                    const float* __restrict__ coef, float inv_n, T* __restrict__ dxa, Seq sda, T* __restrict__ dxb, Seq sdb, int B, int C, int relu)
+                                    const float* __restrict__ coef, float inv_n, T* __restrict__ dxa, Seq sda, T* __restrict__ dxb, Seq sdb, int B, int C, int relu,
+                                    const float* __restrict__ beta_a, const float* __restrict__ beta_b)
 {
+    constexpr bool regate = REGATE;                         // recompute the ReLU gate from xa / xb instead of reading the saved output (see bn_bwd_partial_kernel;
+                                                            // a template parameter for the same reason: both forms in one kernel spilled 60 registers)
     const int CV = C >> 3, TT = sdy.T;
     const int padmax = sda.pad > sdb.pad ? sda.pad : sdb.pad;
     const long long total = (long long)B * (TT + 2 * padmax) * CV;
@@ -384,13 +419,13 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* 
         // thread <-> column chunk fixed (see bn_apply_kernel): dx = k (g - c0 - (x - mean) q) with k = gamma invstd, c0 = mean(g),
         // q = invstd mean(g xhat) in registers
         RowWalk w(blockIdx.x * blockDim.x + threadIdx.x, step32, (unsigned)CV, TP);
-        float ma[8], ka[8], qa[8], c0[8], mb[8], kb[8], qb[8];
+        float ma[8], ka[8], qa[8], c0[8], mb[8], kb[8], qb[8], bs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = w.cx * 8 + e;
             ma[e] = mean_a[c]; ka[e] = gamma_a[c] * invstd_a[c]; qa[e] = invstd_a[c] * (coef[C + c] * inv_n); c0[e] = coef[c] * inv_n;
-            mb[e] = 0.f; kb[e] = 0.f; qb[e] = 0.f;
-            if (xb) { mb[e] = mean_b[c]; kb[e] = gamma_b[c] * invstd_b[c]; qb[e] = invstd_b[c] * (coef[2 * C + c] * inv_n); }
+            mb[e] = 0.f; kb[e] = 0.f; qb[e] = 0.f; bs[e] = regate ? beta_a[c] : 0.f;
+            if (xb) { mb[e] = mean_b[c]; kb[e] = gamma_b[c] * invstd_b[c]; qb[e] = invstd_b[c] * (coef[2 * C + c] * inv_n); if (regate) bs[e] += beta_b[c]; }
         }
         const unsigned rows_out = (unsigned)B * TP;
         for (; w.ro < rows_out; w.next()) {
@@ -401,10 +436,13 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* 
             if (t >= 0 && t < TT) {
                 float g[8], o[8], v[8], u[8];
                 Vec8<T>::load(dy + sdy.at(b, t) * C + cx * 8, g);
-                if (relu) Vec8<T>::load(y + sy.at(b, t) * C + cx * 8, o);
+                if (relu && !regate) Vec8<T>::load(y + sy.at(b, t) * C + cx * 8, o);
                 Vec8<T>::load(xa + sa.at(b, t) * C + cx * 8, v);
                 if (xb) Vec8<T>::load(xb + sb.at(b, t) * C + cx * 8, u);
-                if (relu) {
+                if (regate) {                                   // ka = gamma invstd is the forward's scale: (x - mean) ka + beta, both branches, as bn_apply_kernel formed it
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float pre = (v[e] - ma[e]) * ka[e] + (xb ? (u[e] - mb[e]) * kb[e] : 0.f) + bs[e]; g[e] = pre > 0.f ? g[e] : 0.f; }
+                } else if (relu) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
                 }
@@ -431,10 +469,22 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* 
         if (!halo) {
             float g[8], v[8];
             Vec8<T>::load(dy + sdy.at(b, t) * C + cx * 8, g);
-            if (relu) { float o[8]; Vec8<T>::load(y + sy.at(b, t) * C + cx * 8, o);
+            Vec8<T>::load(xa + sa.at(b, t) * C + cx * 8, v);
+            if (regate) {
+                float u[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u[e] = 0.f;
+                if (xb) Vec8<T>::load(xb + sb.at(b, t) * C + cx * 8, u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = cx * 8 + e;
+                    float pre = (v[e] - mean_a[c]) * (gamma_a[c] * invstd_a[c]) + beta_a[c];
+                    if (xb) pre += (u[e] - mean_b[c]) * (gamma_b[c] * invstd_b[c]) + beta_b[c];
+                    g[e] = pre > 0.f ? g[e] : 0.f;
+                }
+            } else if (relu) { float o[8]; Vec8<T>::load(y + sy.at(b, t) * C + cx * 8, o);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f; }
-            Vec8<T>::load(xa + sa.at(b, t) * C + cx * 8, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const int c = cx * 8 + e; const float xh = (v[e] - mean_a[c]) * invstd_a[c]; oa[e] = gamma_a[c] * invstd_a[c] * (g[e] - coef[c] * inv_n - xh * coef[C + c] * inv_n); }
             if (xb) { Vec8<T>::load(xb + sb.at(b, t) * C + cx * 8, v);
@@ -452,17 +502,23 @@ extern "C" int ss_bn_backward_sums(int dtype, const void* dy, int pad_dy, const 
                                    const void* xa, int pad_xa, const float* mean_a, const float* invstd_a,
                                    const void* xb, int pad_xb, const float* mean_b, const float* invstd_b,
                                    float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
-                                   float* scratch, float* sums, int B, int T, int C, int relu, void* stream)
+                                   float* scratch, float* sums, int B, int T, int C, int relu,
+                                   const float* gate_gamma_a, const float* gate_beta_a, const float* gate_gamma_b, const float* gate_beta_b, void* stream)
 {
     SS_CHECK(dy && xa && mean_a && invstd_a && scratch && sums, "ss_bn_backward_sums: null pointer");
-    SS_CHECK(!relu || y, "ss_bn_backward_sums: relu backward needs the saved output");
+    SS_CHECK(!relu || y || gate_beta_a, "ss_bn_backward_sums: relu backward needs the saved output or the affine parameters to recompute its sign");
+    SS_CHECK(!gate_beta_a || (gate_gamma_a && (!xb || (gate_gamma_b && gate_beta_b))), "ss_bn_backward_sums: gate recomputation needs gamma and beta of every branch");
     SS_CHECK(!xb || (mean_b && invstd_b), "ss_bn_backward_sums: second branch incomplete");
     SS_CHECK(C % 8 == 0 && C > 0 && B > 0 && T > 0, "ss_bn_backward_sums: bad shape");
     const int rows = B * T, nch = red_chunks(rows), rpc = (rows + nch - 1) / nch;
     Seq sdy = {T, pad_dy}, sy = {T, pad_y}, sa = {T, pad_xa}, sb = {T, pad_xb};
 #define SS_BNB(TT)                                                                                                                             \
-    SS_LAUNCH(bn_bwd_partial_kernel<TT>, dim3(nch), dim3(RED_THREADS), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, \
-              (const TT*)xb, sb, mean_b, invstd_b, rows, C, rpc, relu, scratch);                                                                \
+    if (relu && gate_beta_a)                                                                                                                  \
+        SS_LAUNCH(SS_KERNEL(bn_bwd_partial_kernel<TT, true>), dim3(nch), dim3(red_threads(C)), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, \
+                  (const TT*)xb, sb, mean_b, invstd_b, gate_gamma_a, gate_beta_a, gate_gamma_b, gate_beta_b, rows, C, rpc, relu, scratch);       \
+    else                                                                                                                                      \
+        SS_LAUNCH(SS_KERNEL(bn_bwd_partial_kernel<TT, false>), dim3(nch), dim3(red_threads(C)), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, \
+                  (const TT*)xb, sb, mean_b, invstd_b, gate_gamma_a, gate_beta_a, gate_gamma_b, gate_beta_b, rows, C, rpc, relu, scratch);       \
     SS_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, (const float*)scratch, nch, C, sums, dgamma_a, dbeta_a, dgamma_b, dbeta_b)
     if (dtype == SS_BF16) { SS_BNB(bf16_t); } else { SS_BNB(float); }
 #undef SS_BNB
@@ -474,10 +530,11 @@ extern "C" int ss_bn_backward_apply(int dtype, const void* dy, int pad_dy, const
                                     const void* xa, int pad_xa, const float* mean_a, const float* invstd_a, const float* gamma_a,
                                     const void* xb, int pad_xb, const float* mean_b, const float* invstd_b, const float* gamma_b,
                                     const float* sums, double n_total, void* dxa, int pad_dxa, void* dxb, int pad_dxb,
-                                    int B, int T, int C, int relu, void* stream)
+                                    int B, int T, int C, int relu, const float* gate_beta_a, const float* gate_beta_b, void* stream)
 {
     SS_CHECK(dy && xa && mean_a && invstd_a && gamma_a && dxa && sums, "ss_bn_backward_apply: null pointer");
-    SS_CHECK(!relu || y, "ss_bn_backward_apply: relu backward needs the saved output");
+    SS_CHECK(!relu || y || gate_beta_a, "ss_bn_backward_apply: relu backward needs the saved output or the affine parameters to recompute its sign");
+    SS_CHECK(!gate_beta_a || !xb || gate_beta_b, "ss_bn_backward_apply: gate recomputation needs beta of every branch");
     SS_CHECK(!xb || (mean_b && invstd_b && gamma_b && dxb), "ss_bn_backward_apply: second branch incomplete");
     SS_CHECK(C % 8 == 0 && C > 0 && B > 0 && T > 0 && n_total >= 1.0, "ss_bn_backward_apply: bad shape");
     Seq sdy = {T, pad_dy}, sy = {T, pad_y}, sa = {T, pad_xa}, sb = {T, pad_xb}, sda = {T, pad_dxa}, sdb = {T, pad_dxb};
@@ -486,8 +543,12 @@ extern "C" int ss_bn_backward_apply(int dtype, const void* dy, int pad_dy, const
     SS_CHECK(total < (1LL << 31) - (1LL << 22), "ss_bn_backward_apply: tensor too large for 32-bit chunk indices");
     const float inv_n = (float)(1.0 / n_total);
 #define SS_BNA(TT)                                                                                                                             \
-    SS_LAUNCH(bn_bwd_apply_kernel<TT>, ew_grid(total, 256, C / 8), dim3(256), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, gamma_a, \
-              (const TT*)xb, sb, mean_b, invstd_b, gamma_b, sums, inv_n, (TT*)dxa, sda, (TT*)dxb, sdb, B, C, relu)
+    if (relu && gate_beta_a)                                                                                                                  \
+        SS_LAUNCH(SS_KERNEL(bn_bwd_apply_kernel<TT, true>), ew_grid(total, 256, C / 8), dim3(256), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, gamma_a, \
+                  (const TT*)xb, sb, mean_b, invstd_b, gamma_b, sums, inv_n, (TT*)dxa, sda, (TT*)dxb, sdb, B, C, relu, gate_beta_a, gate_beta_b); \
+    else                                                                                                                                      \
+        SS_LAUNCH(SS_KERNEL(bn_bwd_apply_kernel<TT, false>), ew_grid(total, 256, C / 8), dim3(256), 0, stream, (const TT*)dy, sdy, (const TT*)y, sy, (const TT*)xa, sa, mean_a, invstd_a, gamma_a, \
+                  (const TT*)xb, sb, mean_b, invstd_b, gamma_b, sums, inv_n, (TT*)dxa, sda, (TT*)dxb, sdb, B, C, relu, gate_beta_a, gate_beta_b)
     if (dtype == SS_BF16) { SS_BNA(bf16_t); } else { SS_BNA(float); }
 #undef SS_BNA
     SS_LAUNCH_CHECK("ss_bn_backward_apply");
@@ -499,7 +560,7 @@ template <class T>
 __global__ __launch_bounds__(RED_THREADS) void colsum_partial_kernel(const T* __restrict__ x, int rows, int C, long long ld, int rows_per_chunk, float* __restrict__ partial)
 {
     __shared__ float red[RED_THREADS * 8];
-    ColMap m(C, threadIdx.x, RED_THREADS);
+    ColMap m(C, threadIdx.x, (int)blockDim.x);
     const int r0 = blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     for (int cb = 0; cb < m.CV; cb += m.CVb) {
         const int cx = cb + m.cx0;
@@ -550,8 +611,8 @@ extern "C" int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, 
     SS_CHECK(C % 8 == 0 && C > 0 && rows >= 0 && ld % 8 == 0, "ss_colsum: C and ld must be multiples of 8");
     if (rows == 0) return 0;
     const int nch = colsum_chunks(rows), rpc = (rows + nch - 1) / nch;
-    if (dtype == SS_BF16) SS_LAUNCH(colsum_partial_kernel<bf16_t>, dim3(nch), dim3(RED_THREADS), 0, stream, (const bf16_t*)x, rows, C, (long long)ld, rpc, scratch);
-    else SS_LAUNCH(colsum_partial_kernel<float>, dim3(nch), dim3(RED_THREADS), 0, stream, (const float*)x, rows, C, (long long)ld, rpc, scratch);
+    if (dtype == SS_BF16) SS_LAUNCH(colsum_partial_kernel<bf16_t>, dim3(nch), dim3(red_threads(C)), 0, stream, (const bf16_t*)x, rows, C, (long long)ld, rpc, scratch);
+    else SS_LAUNCH(colsum_partial_kernel<float>, dim3(nch), dim3(red_threads(C)), 0, stream, (const float*)x, rows, C, (long long)ld, rpc, scratch);
     SS_LAUNCH(colsum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, (const float*)scratch, nch, C, out_accum);
     SS_LAUNCH_CHECK("ss_colsum");
     return 0;

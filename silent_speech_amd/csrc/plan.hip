@@ -76,7 +76,7 @@ struct Plan {
     PermB unpack_enc;
     reduce_fn hook = 0; void* hook_user = 0;
     event_fn on_event = 0; void* event_user = 0;
-    int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1;
+    int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1, regate_on = 1;
     hipEvent_t ev_fork = 0, ev_join = 0;
     size_t esz() const { return D.dtype == SS_BF16 ? 2 : 4; }
 
@@ -462,7 +462,9 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
     void* dy = X.alloc((size_t)M * d * es);
     L_(gemm(X, dt, G, w_raw_in_T, dy, M, d, d, RM(d), RM(d), RM(d)));
 
-    // ---- ResBlocks, last to first (architecture.py:29-40)
+    // ---- ResBlocks, last to first (architecture.py:29-40).  regate: the BatchNorm backward passes recompute the ReLU gate from the convolution
+    // outputs they read anyway instead of reading the saved block output as well (option 4, SS_AMD_BN_REGATE)
+    const bool regate = regate_on != 0;
     for (int i = 2; i >= 0; --i) {
         BlockP& w = blk[i]; BlockCtx& s = c->blk[i];
         const int O = s.O, Cin = s.Cin, Tin = s.Tin, Tout = s.Tout, rows = B * Tout;
@@ -471,10 +473,10 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         void* dcr = X.alloc((size_t)rows * O * es);
         float* sums = (float*)X.alloc((size_t)3 * O * 4);
         if (!X.dry) {
-            L_(timed(X, "bn_bwd_sums", 0, (double)B * Tout * O * es * 4, stream, [&] { return ss_bn_backward_sums(dt, dy, 0, s.y, s.pad_y, s.c2, 0, s.m2, s.i2, s.cr, 0, s.mr, s.ir, w.bn2.dgamma, w.bn2.dbeta, w.bnr.dgamma, w.bnr.dbeta, s.scratch, sums, B, Tout, O, 1, stream); }));
+            L_(timed(X, "bn_bwd_sums", 0, (double)B * Tout * O * es * 4, stream, [&] { return ss_bn_backward_sums(dt, dy, 0, s.y, s.pad_y, s.c2, 0, s.m2, s.i2, s.cr, 0, s.mr, s.ir, w.bn2.dgamma, w.bn2.dbeta, w.bnr.dgamma, w.bnr.dbeta, s.scratch, sums, B, Tout, O, 1, regate ? w.bn2.gamma : nullptr, regate ? w.bn2.beta : nullptr, regate ? w.bnr.gamma : nullptr, regate ? w.bnr.beta : nullptr, stream); }));
             double n_total = (double)B * Tout;
             if (hook) n_total = hook(hook_user, sums, 3 * O, n_total, stream);
-            L_(timed(X, "bn_bwd_apply", 0, (double)B * Tout * O * es * 6, stream, [&] { return ss_bn_backward_apply(dt, dy, 0, s.y, s.pad_y, s.c2, 0, s.m2, s.i2, w.bn2.gamma, s.cr, 0, s.mr, s.ir, w.bnr.gamma, sums, n_total, dc2, 1, dcr, 0, B, Tout, O, 1, stream); }));
+            L_(timed(X, "bn_bwd_apply", 0, (double)B * Tout * O * es * 6, stream, [&] { return ss_bn_backward_apply(dt, dy, 0, s.y, s.pad_y, s.c2, 0, s.m2, s.i2, w.bn2.gamma, s.cr, 0, s.mr, s.ir, w.bnr.gamma, sums, n_total, dc2, 1, dcr, 0, B, Tout, O, 1, regate ? w.bn2.beta : nullptr, regate ? w.bnr.beta : nullptr, stream); }));
         }
         // conv2 (k3, stride 1): weight and input gradients.  d/d(bias) of a conv feeding training-mode BatchNorm is identically 0
         DwGroup cg{this, &XS, grouped};
@@ -484,10 +486,10 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         void* dc1 = X.alloc((size_t)B * (Tout + 2) * O * es);
         float* sums1 = (float*)X.alloc((size_t)3 * O * 4);
         if (!X.dry) {
-            L_(timed(X, "bn_bwd_sums", 0, (double)B * Tout * O * es * 4, stream, [&] { return ss_bn_backward_sums(dt, dh1, 0, s.h1, 1, s.c1, 0, s.m1, s.i1, nullptr, 0, nullptr, nullptr, w.bn1.dgamma, w.bn1.dbeta, nullptr, nullptr, s.scratch, sums1, B, Tout, O, 1, stream); }));
+            L_(timed(X, "bn_bwd_sums", 0, (double)B * Tout * O * es * 4, stream, [&] { return ss_bn_backward_sums(dt, dh1, 0, s.h1, 1, s.c1, 0, s.m1, s.i1, nullptr, 0, nullptr, nullptr, w.bn1.dgamma, w.bn1.dbeta, nullptr, nullptr, s.scratch, sums1, B, Tout, O, 1, regate ? w.bn1.gamma : nullptr, regate ? w.bn1.beta : nullptr, nullptr, nullptr, stream); }));
             double n_total = (double)B * Tout;
             if (hook) n_total = hook(hook_user, sums1, 3 * O, n_total, stream);
-            L_(timed(X, "bn_bwd_apply", 0, (double)B * Tout * O * es * 6, stream, [&] { return ss_bn_backward_apply(dt, dh1, 0, s.h1, 1, s.c1, 0, s.m1, s.i1, w.bn1.gamma, nullptr, 0, nullptr, nullptr, nullptr, sums1, n_total, dc1, 1, nullptr, 0, B, Tout, O, 1, stream); }));
+            L_(timed(X, "bn_bwd_apply", 0, (double)B * Tout * O * es * 6, stream, [&] { return ss_bn_backward_apply(dt, dh1, 0, s.h1, 1, s.c1, 0, s.m1, s.i1, w.bn1.gamma, nullptr, 0, nullptr, nullptr, nullptr, sums1, n_total, dc1, 1, nullptr, 0, B, Tout, O, 1, regate ? w.bn1.beta : nullptr, nullptr, stream); }));
         }
         // conv1 (k3, stride 2) and the 1x1 stride-2 residual path
         const long long in_bs = (long long)(Tin + 2) * Cin;
@@ -550,6 +552,7 @@ extern "C" int ss_plan_set_option(ss_plan* h, int what, int value)
     else if (what == 1) { old = h->p->dw_grouped; h->p->dw_grouped = value; }
     else if (what == 2) { old = h->p->side_blocks; h->p->side_blocks = value >= 1 && value <= 2 ? value : 2; }
     else if (what == 3) { old = h->p->fuse_stats; h->p->fuse_stats = value; }
+    else if (what == 4) { old = h->p->regate_on; h->p->regate_on = value; }
     return old;
 }
 extern "C" int ss_plan_set_reduce_hook(ss_plan* h, ss_reduce_hook fn, void* user) { SS_CHECK(h, "null plan"); h->p->hook = (reduce_fn)fn; h->p->hook_user = user; return 0; }

@@ -433,6 +433,7 @@ def backward(model, ctx, dhead):
     L = pb.lib
     L.ss_plan_set_option(pb.handle, 1, int(os.environ.get('SS_AMD_DW_GROUPED', '1') != '0'))
     L.ss_plan_set_option(pb.handle, 2, int(os.environ.get('SS_AMD_SIDE_BLOCKS', '2')))
+    L.ss_plan_set_option(pb.handle, 4, int(os.environ.get('SS_AMD_BN_REGATE', '1') != '0'))
     rc = L.ss_plan_backward(pb.handle, ctx.buf, _lib.ptr(dhead), _lib.stream_of(dhead), ctypes.c_void_p(side.cuda_stream) if side is not None else None)
     pb.raise_callback_error()
     _lib.check(rc, 'ss_plan_backward')

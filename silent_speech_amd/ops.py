@@ -191,20 +191,22 @@ def bn_apply(xa, sa, pad_xa, y, pad_y, B, T, C, relu, xb=None, sb=None, pad_xb=0
 
 
 def bn_backward(dy, pad_dy, y, pad_y, xa, pad_xa, sa, dxa, pad_dxa, dgamma_a, dbeta_a, scratch, B, T, C, relu,
-                xb=None, pad_xb=0, sb=None, dxb=None, pad_dxb=0, dgamma_b=None, dbeta_b=None, reduce_fn=None):
-    """sa/sb = (mean, invstd, gamma).  reduce_fn as in bn_stats (all-reduces the [3][C] gradient sums)."""
+                xb=None, pad_xb=0, sb=None, dxb=None, pad_dxb=0, dgamma_b=None, dbeta_b=None, reduce_fn=None, beta_a=None, beta_b=None):
+    """sa/sb = (mean, invstd, gamma).  reduce_fn as in bn_stats (all-reduces the [3][C] gradient sums).  beta_a [, beta_b]: recompute
+    the ReLU gate from xa / xb and the affine parameters instead of reading the saved output y (which may then be None)."""
     b3 = sb if sb is not None else [None] * 3
+    gate = (sa[2], beta_a, b3[2], beta_b) if beta_a is not None else (None, None, None, None)
     sums = torch.empty(3 * C, dtype=torch.float32, device=dy.device)
     rc = _L().ss_bn_backward_sums(_dt(dy), _p(dy), pad_dy, _p(y), pad_y, _p(xa), pad_xa, _p(sa[0]), _p(sa[1]),
                                   _p(xb), pad_xb, _p(b3[0]), _p(b3[1]), _p(dgamma_a), _p(dbeta_a), _p(dgamma_b), _p(dbeta_b),
-                                  _p(scratch), _p(sums), B, T, C, int(relu), _s(dy))
+                                  _p(scratch), _p(sums), B, T, C, int(relu), _p(gate[0]), _p(gate[1]), _p(gate[2]), _p(gate[3]), _s(dy))
     _lib.check(rc, 'ss_bn_backward_sums')
     n_total = float(B * T)
     if reduce_fn is not None:
         n_total = reduce_fn(sums, n_total)
     rc = _L().ss_bn_backward_apply(_dt(dy), _p(dy), pad_dy, _p(y), pad_y, _p(xa), pad_xa, _p(sa[0]), _p(sa[1]), _p(sa[2]),
                                    _p(xb), pad_xb, _p(b3[0]), _p(b3[1]), _p(b3[2]), _p(sums), n_total, _p(dxa), pad_dxa, _p(dxb), pad_dxb,
-                                   B, T, C, int(relu), _s(dy))
+                                   B, T, C, int(relu), _p(gate[1]), _p(gate[3]), _s(dy))
     _lib.check(rc, 'ss_bn_backward_apply')
 
 

@@ -68,6 +68,17 @@ def test_batchnorm_resblock_tail_fwd_bwd(dev, dt, shape):
     assert_close_robust(dxb, xb_r.grad, _tol(dt, 5e-5, 3e-2), name='dxb', max_outlier_frac=0 if dt == torch.float32 else 5e-3)
     for got, want, n in ((dga, ga_r.grad, 'dgamma_a'), (dba, ba_r.grad, 'dbeta_a'), (dgb, gb_r.grad, 'dgamma_b'), (dbb, bb_r.grad, 'dbeta_b')):
         assert_close_robust(got, want, _tol(dt, 5e-5, 2e-2), name=n, max_outlier_frac=0)
+    # the same backward with the ReLU gate RECOMPUTED from xa / xb and the affine parameters (what the plan runs): the saved output is not read
+    dxa2 = torch.full((B, T + 2, C), 5.0, dtype=dt, device=dev); dxb2 = torch.empty(B, T, C, dtype=dt, device=dev)
+    g2 = [torch.zeros(C, device=dev) for _ in range(4)]
+    ops.bn_backward(dy.to(dev), 0, None, 1, xa_d, 1, (ma, ia, ga.to(dev)), dxa2, 1, g2[0], g2[1], scratch, B, T, C, True,
+                    xb=xb_d, pad_xb=0, sb=(mb, ib, gb.to(dev)), dxb=dxb2, pad_dxb=0, dgamma_b=g2[2], dbeta_b=g2[3], beta_a=ba.to(dev), beta_b=bb.to(dev))
+    assert_close_robust(dxa2[:, 1:-1], xa_r.grad, _tol(dt, 5e-5, 3e-2), name='dxa (gate recomputed)', max_outlier_frac=0 if dt == torch.float32 else 5e-3)
+    assert_close_robust(dxb2, xb_r.grad, _tol(dt, 5e-5, 3e-2), name='dxb (gate recomputed)', max_outlier_frac=0 if dt == torch.float32 else 5e-3)
+    for got, want, n in zip(g2, (ga_r.grad, ba_r.grad, gb_r.grad, bb_r.grad), ('dgamma_a', 'dbeta_a', 'dgamma_b', 'dbeta_b')):
+        assert_close_robust(got, want, _tol(dt, 5e-5, 2e-2), name=n + ' (gate recomputed)', max_outlier_frac=0)
+    flips = int(((dxa2[:, 1:-1].float() == 0) != (dxa[:, 1:-1].float() == 0)).sum())       # gates that differ between the two forms (pre-activations within rounding of 0)
+    assert flips <= (3 if dt == torch.float32 else B * T * C // 500), flips          # f32: only pre-activations within an ulp of 0 can differ
 
 
 def test_batchnorm_eval_mode(dev):
