@@ -19,16 +19,25 @@ def _free_port():
     return p
 
 
+_single_cache = {}
+
+
 def _ranks_vs_single(tmp_path, extra_env, world=2, tol=2e-4, check_running=True):
     worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
     env = dict(os.environ, OMP_NUM_THREADS='1', SS_DP_ORDER_OF=str(world), **extra_env)
-    single = str(tmp_path / 'single.pt')
-    p0 = subprocess.Popen([sys.executable, worker, single], env=dict(env, WORLD_SIZE='1', RANK='0'))
+    # the single-process reference depends on the model and the utterance order only: computed once per (layers, world), next to the ranks
+    key = (extra_env.get('SS_DP_LAYERS', '1'), world, extra_env.get('SS_DP_DEVICE', 'cpu'))
+    single, p0 = _single_cache.get(key), None
+    if single is None or not os.path.exists(single):
+        import tempfile
+        single = _single_cache[key] = os.path.join(tempfile.mkdtemp(prefix='ss_dp_single_'), 'single.pt')
+        senv = {k: v for k, v in env.items() if k not in ('SS_DP_ZERO_LATE', 'SS_DP_GRAD_BF16', 'SS_DP_PREFETCH', 'SS_DP_LAYER_BUCKETS', 'SS_DP_BUCKETED')}
+        p0 = subprocess.Popen([sys.executable, worker, single], env=dict(senv, WORLD_SIZE='1', RANK='0'))
     port = str(_free_port())
     multi = str(tmp_path / 'multi.pt')
     procs = [subprocess.Popen([sys.executable, worker, multi], env=dict(env, WORLD_SIZE=str(world), RANK=str(r), MASTER_PORT=port, MASTER_ADDR='127.0.0.1'))
              for r in range(world)]
-    for p in [p0] + procs:
+    for p in ([p0] if p0 is not None else []) + procs:
         assert p.wait(timeout=900) == 0
     a, b = torch.load(single), torch.load(multi)
     # loss: each rank reports sum(local losses)/global frames; the single-process loss is the sum over ranks
@@ -56,24 +65,18 @@ def test_two_rank_step_equals_single_process(tmp_path):
 
 def test_zero_grad_between_forward_and_backward_keeps_the_arena(tmp_path):
     """model.zero_grad(set_to_none=True) after the forward pass used to leave the fused optimiser / the all-reduce with a stale,
-    all-zero arena: gradients are re-homed instead."""
+    all-zero arena: gradients are re-homed instead.  Run on a 2-layer encoder, so that a layer bucket is fired from INSIDE the backward
+    (event 4 + 1 while layer 0 is still to come)."""
     _ensure_emu()
-    _two_rank_vs_single(tmp_path, {'SS_DP_ZERO_LATE': '1'})
+    _two_rank_vs_single(tmp_path, {'SS_DP_ZERO_LATE': '1', 'SS_DP_LAYERS': '2'})
 
 
-def test_per_layer_buckets_two_layers_and_the_single_encoder_bucket(tmp_path):
-    """A 2-layer encoder fires the layer buckets from inside the backward (event 4 + 1 while layer 0 is still to come); SS_DP_LAYER_BUCKETS=0
-    is the one-bucket schedule of rounds 2-3.  Both equal the single process."""
+def test_single_encoder_bucket_bf16_transport_and_count_prefetch(tmp_path):
+    """SS_DP_LAYER_BUCKETS=0 is the one-bucket schedule of rounds 2-3; grad_dtype=bfloat16 halves the bytes on the links: the rank-sums are
+    rounded once to bf16 (measured delta recorded below, bound 2^-7 of the largest gradient); next_counts starts the next step's host-side
+    exchange during the current step."""
     _ensure_emu()
-    _ranks_vs_single(tmp_path, {'SS_DP_LAYERS': '2'}, 2)
-    _ranks_vs_single(tmp_path, {'SS_DP_LAYERS': '2', 'SS_DP_LAYER_BUCKETS': '0'}, 2)
-
-
-def test_bf16_gradient_transport_and_count_prefetch(tmp_path):
-    """grad_dtype=bfloat16 halves the bytes on the links: the rank-sums are rounded once to bf16 (measured delta recorded below, bound 2^-7 of the
-    largest gradient); next_counts starts the next step's host-side exchange during the current step."""
-    _ensure_emu()
-    err = _ranks_vs_single(tmp_path, {'SS_DP_GRAD_BF16': '1', 'SS_DP_PREFETCH': '1'}, 2, tol=8e-3, check_running=False)
+    err = _ranks_vs_single(tmp_path, {'SS_DP_LAYER_BUCKETS': '0', 'SS_DP_GRAD_BF16': '1', 'SS_DP_PREFETCH': '1'}, 2, tol=8e-3, check_running=False)
     assert err > 1e-6, 'the bf16 transport was not exercised'
     with open(str(tmp_path / 'bf16_transport_delta.txt'), 'w') as f:
         f.write('max |g_bf16 - g_f32| / max |g| = %.3e\n' % err)
