@@ -607,7 +607,7 @@ def main():
             for k, v in prof.summary().items():
                 table[k] = v
             pmc, pmc_src, pmc_stale = {}, None, None
-            for fn in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            for fn in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
                 try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py)
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
                     pmc_src = 'profiles/' + fn
@@ -622,9 +622,9 @@ def main():
             if pmc_stale:
                 pmc = {}
             hints = {'gemm8_kc_kernel (288x256)': 'gemm8_kc_kernel<unsigned short, 9', 'gemm8_kc_kernel (256x256)': 'gemm8_kc_kernel<unsigned short, 8',
-                     'gemm_dw_grouped': 'gemm8_dw_kernel', 'gemm_smallk_kernel (K <= 32, first conv)': 'gemm_smallk_kernel', 'gemm_w2_kernel (128|144 x 128)': 'gemm_w2_kernel', 'gemm_glds_kernel (128x128)': 'gemm_glds_kernel',
+                     'gemm_dw_grouped': 'gemm8_dwk_kernel', 'gemm_smallk_kernel (K <= 32, first conv)': 'gemm_smallk_kernel', 'gemm_w2_kernel (128|144 x 128)': 'gemm_w2_kernel', 'gemm_glds_kernel (128x128)': 'gemm_glds_kernel',
                      'attn_fwd': 'attn_fwd_res2_kernel', 'attn_bwd': ('attn_bwd_kv2_kernel', 'attn_bwd_q2_kernel', 'attn_dsum_kernel'), 'bn_stats': 'bn_partial_kernel', 'bn_apply': 'bn_apply_kernel',
-                     'bn_bwd_sums': 'bn_bwd_partial_kernel', 'bn_bwd_apply': 'bn_bwd_apply_kernel', 'add_dropout_ln_fwd': 'add_dropout_ln_fwd_kernel',
+                     'bn_bwd_sums': ('bn_bwd_partial_kernel', 'bn_bwd_finalize_kernel'), 'bn_bwd_apply': 'bn_bwd_apply_kernel', 'add_dropout_ln_fwd': 'add_dropout_ln_fwd_kernel',
                      'ln_bwd': ('ln_bwd2_kernel<', 'ln_bwd2_finalize_kernel'), 'adamw_kernel': 'adamw_kernel', 'dtw_kernel': 'dtw_kernel', 'silent_cost_skewed_kernel': 'silent_cost_skewed_kernel',
                      'colsum': 'colsum_partial_kernel', 'permute3d_batch (weight re-layout)': 'permute3d_batch_kernel', 'grad_unlayout': 'permute3d_batch_f32_kernel'}
 
@@ -670,7 +670,7 @@ def main():
                                'serial_kernel_ms_per_step': total_s / psteps * 1e3,
                                'timing': 'HIP events around every kernel launch (inside the native plan: ss_plan_profile; Python-launched kernels: '
                                          'torch events on the launch stream) on every 5th timed step; those steps run without the side stream '
-                                         '(exclusive durations); rocprofv3 counterpart: profiles/r03_serial_kernel_stats.txt',
+                                         '(exclusive durations); rocprofv3 counterpart: profiles/r04_serial_kernel_stats.txt',
                                'kernels': kernels[:16]}
         if world == 1 and args.cpu_rows > 0:
             base, sub, ref_pred = cpu_baseline(batch_cpu, args.cpu_rows, args.cpu_warmup, args.cpu_steps, init_sd, dev)

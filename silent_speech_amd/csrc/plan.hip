@@ -73,7 +73,7 @@ struct Plan {
     void *w_raw_in = 0, *w_raw_in_T = 0, *w_head = 0, *w_head_T = 0;
     float *b_raw_in = 0, *dw_raw_in = 0, *db_raw_in = 0, *b_head = 0, *head_w_stage = 0, *head_b_stage = 0, *stage_arena = 0;
     long long stage_arena_bytes = 0;
-    PermB unpack_enc;
+    PermB unpack_enc, unpack_all;          // heads only | heads + every encoder layer (one launch: runs without the per-layer events)
     reduce_fn hook = 0; void* hook_user = 0;
     event_fn on_event = 0; void* event_user = 0;
     int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1, regate_on = 1;
@@ -145,7 +145,7 @@ struct Plan {
         slot("w_head", &w_head); slot("w_head_T", &w_head_T); slot("b_head", (void**)&b_head);
         slot("head_w.stage", (void**)&head_w_stage); slot("head_b.stage", (void**)&head_b_stage);
         slot("stage_arena", (void**)&stage_arena); slot("stage_arena.bytes", (void**)&stage_arena_bytes);
-        slot_perm("unpack_encoder", unpack_enc);
+        slot_perm("unpack_encoder", unpack_enc); slot_perm("unpack_encoder_all", unpack_all);
     }
 
     // ---------------------------------------------------------------- small launch helpers (all return non-zero on error)
@@ -406,6 +406,8 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
     // scratch of the LayerNorm backward (per-workgroup column sums): one buffer, the launches are stream-ordered
     const int64_t ln_floats = ss_layernorm_backward_scratch_floats(M, d);
     float* ln_scratch = ln_floats ? (float*)X.alloc((size_t)ln_floats * 4) : nullptr;
+    // per-layer gradient un-layout (7 small launches instead of 1) only when someone listens to the per-layer events (data parallel) or no combined table is bound
+    const bool per_layer = on_event != nullptr || !unpack_all.jobs;
     // ---- encoder layers, last to first (transformer.py:54-59)
     for (int l = c->n_layers - 1; l >= 0; --l) {
         LayerP& w = layers[l]; LayerCtx& s = c->layer[l];
@@ -445,15 +447,17 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
             // the layer's weight gradients, their un-layout into the .grad arena, and -- data-parallel runs -- the event that lets the caller
             // start THIS layer's all-reduce now (what = 4 + l): 6 collectives of ~28 MB spread over the encoder backward instead of one of
             // 170 MB after it.  (The fork makes `side` wait for everything the main stream produced for this layer: bias / LayerNorm gradients.)
-            SIDE_BEGIN(); L_(grp.launch(side)); L_(permute_batch(X, w.unpack, side)); SIDE_END();
+            SIDE_BEGIN(); L_(grp.launch(side)); if (per_layer) L_(permute_batch(X, w.unpack, side)); SIDE_END();
             if (on_event && !X.dry) on_event(event_user, 4 + l, side);
         }
     }
     // ---- w_raw_in (architecture.py:73)
     L_(grp.add(G, c->conv_out, dw_raw_in, d, d, M, RM(d), RM(d), side));
     SIDE_BEGIN(); L_(grp.launch(side)); L_(colsum(X, G, M, d, db_raw_in, side));
-    if (c->n_layers > 0) L_(permute_batch(X, layers[0].unpack, side));
-    L_(permute_batch(X, unpack_enc, side));                                      // the fused heads (and whatever else the caller put there): under the conv backward
+    if (per_layer) {
+        if (c->n_layers > 0) L_(permute_batch(X, layers[0].unpack, side));
+        L_(permute_batch(X, unpack_enc, side));                                  // the fused heads: under the conv backward
+    } else L_(permute_batch(X, unpack_all, side));                               // no listener for per-layer events: heads + all layers in ONE launch
     SIDE_END();
     if (on_event && !X.dry) {
         if (c->n_layers > 0) on_event(event_user, 4, side);                      // encoder layer 0

@@ -170,6 +170,13 @@ class GradUnpack(object):
             ub.add(hw[n_out:n_out + n_aux], model.w_aux.weight.grad, (1, n_aux, d), (0, d, 1), accumulate=True)
             ub.add(hb[n_out:n_out + n_aux], model.w_aux.bias.grad, (1, 1, n_aux), (0, 0, 1), accumulate=True)
         self.head_batch = ub
+        ua = ops.PermuteBatch()                     # heads + every layer in one table: the launch of a run without per-layer listeners
+        ua.add(hw[:n_out], model.w_out.weight.grad, (1, n_out, d), (0, d, 1), accumulate=True)
+        ua.add(hb[:n_out], model.w_out.bias.grad, (1, 1, n_out), (0, 0, 1), accumulate=True)
+        if n_aux:
+            ua.add(hw[n_out:n_out + n_aux], model.w_aux.weight.grad, (1, n_aux, d), (0, d, 1), accumulate=True)
+            ua.add(hb[n_out:n_out + n_aux], model.w_aux.bias.grad, (1, 1, n_aux), (0, 0, 1), accumulate=True)
+        self.all_batch = ua
         # one batch per encoder layer, launched right behind the layer's weight-gradient GEMMs: the layer's gradients are then final
         # (and, under data parallelism, on their way through the all-reduce) while the backward of the earlier layers still runs
         self.layer_batches = []
@@ -180,6 +187,9 @@ class GradUnpack(object):
             for i, wp in enumerate((a.w_q, a.w_k, a.w_v)):
                 lb.add(self.buf['wqkv%d' % l][i * H * dp * d:], wp.grad, (H, d, dh), (dp * d, 1, d), accumulate=True)
             self.layer_batches.append(lb)
+            ua.add(self.buf['wo%d' % l], a.w_o.grad, (H, dh, d), (dp, 1, H * dp), accumulate=True)
+            for i, wp in enumerate((a.w_q, a.w_k, a.w_v)):
+                ua.add(self.buf['wqkv%d' % l][i * H * dp * d:], wp.grad, (H, d, dh), (dp * d, 1, d), accumulate=True)
         self.conv_batches = []
         for i, blk in enumerate(model.conv_blocks):
             O, I, _ = blk.conv1.weight.shape
@@ -297,6 +307,7 @@ class PlanBinding(object):
             t['head_w.stage'], t['head_b.stage'] = gu.buf['head_w'], gu.buf['head_b']
             t['stage_arena'], t['stage_arena.bytes'] = gu.arena, int(gu.arena.numel() * 4)
             batch('unpack_encoder', gu.head_batch)
+            batch('unpack_encoder_all', gu.all_batch)
         return t
 
     def ensure_bound(self, model, pr, gu, dev):

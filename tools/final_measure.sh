@@ -5,22 +5,25 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
-python -m pytest tests -m gpu -q -x 2>&1 | tail -3 > $O/pytest_gpu.log
-rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --steps 6 --warmup 2 --cpu-rows 0 --no-legs --no-profile > $O/kt_bench.log 2>&1
-python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -1) 8 > $O/kernel_stats.txt
-SS_AMD_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -d $O/ks -o ks -- python bench.py --steps 6 --warmup 2 --cpu-rows 0 --no-legs --no-profile > $O/ks_bench.log 2>&1
-python tools/rocprof_summary.py $(find $O/ks -name "*.db" | head -1) 8 > $O/serial_kernel_stats.txt
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o pf -- python bench.py --steps 2 --warmup 1 --cpu-rows 0 --no-legs --no-profile > $O/pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o pw -- python bench.py --steps 2 --warmup 1 --cpu-rows 0 --no-legs --no-profile > $O/pw.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -3 > $O/pytest_gpu.log
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --steps 8 --warmup 4 --cpu-rows 0 --no-legs --no-profile --no-same > $O/kt_bench.log 2>&1
+python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -1) 12 > $O/kernel_stats.txt
+python tools/gpu_idle.py $(find $O/kt -name "*.db" | head -1) 0.5 > $O/gpu_idle_rotated.txt
+SS_AMD_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats -d $O/ks -o ks -- python bench.py --steps 8 --warmup 4 --cpu-rows 0 --no-legs --no-profile --no-same > $O/ks_bench.log 2>&1
+python tools/rocprof_summary.py $(find $O/ks -name "*.db" | head -1) 12 > $O/serial_kernel_stats.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o pf -- python bench.py --steps 4 --warmup 1 --cpu-rows 0 --no-legs --no-profile --no-same > $O/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o pw -- python bench.py --steps 4 --warmup 1 --cpu-rows 0 --no-legs --no-profile --no-same > $O/pw.log 2>&1
 python tools/pmc_summary.py $(find $O/pf -name "*.db" | head -1) $(find $O/pw -name "*.db" | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt
 rm -rf $O/kt $O/ks $O/pf $O/pw
-cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json            # the bench line's `traffic` fields come from THIS run's counters
+cp $O/pmc_traffic.json profiles/r04_pmc_traffic.json            # the bench line's `traffic` fields come from THIS run's counters
 python bench.py > $O/bench.json.log 2>$O/bench.err
+for ss in 1 0; do SS_AMD_SIDE_STREAM=$ss python bench.py --no-profile --no-legs --cpu-rows 0 --steps 20 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('side_stream=$ss', d['ms_per_step'], d['config']['unprofiled'])"; done > $O/side_stream_ab.txt 2>&1
 bash tools/attn_trace.sh > /dev/null 2>&1; cp gpurun_out/attn_trace/kernel_stats.txt $O/attention_kernel_stats.txt
 bash tools/attn_pmc.sh > /dev/null 2>&1; cp gpurun_out/attn_pmc/table.txt $O/attention_sq_counters.txt
 ./tools/bin/attn_bench > $O/attention_bench.txt 2>&1
 ./tools/bin/mfma_peak 4000 > $O/mfma_peak.txt 2>&1
 ./tools/bin/gemm_bench 20 > $O/gemm_bench.txt 2>&1
 ./tools/bin/gemm_bench 20 epi >> $O/gemm_bench.txt 2>&1
+timeout 300 python tools/host_profile.py 12 > $O/host_profile.txt 2>&1
 (./tools/bin/dtw_bench 64 1000 10; ./tools/bin/dtw_bench 256 1000 10; SS_DTW_DEBUG=8 ./tools/bin/dtw_bench 64 1000 10; SS_DTW_DEBUG=8 ./tools/bin/dtw_bench 256 1000 10; ./tools/bin/ta_probe) > $O/dtw_bench.txt 2>&1
-cat $O/pytest_gpu.log; cat $O/mfma_peak.txt; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/attention_bench.txt; cat $O/dtw_bench.txt
+cat $O/pytest_gpu.log; cat $O/side_stream_ab.txt; cat $O/mfma_peak.txt; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/gpu_idle_rotated.txt; cat $O/attention_bench.txt; cat $O/dtw_bench.txt

@@ -6,15 +6,20 @@ db = sqlite3.connect(sys.argv[1])
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if t.startswith('rocpd_kernel_dispatch')][0]
-rows = sorted(db.execute('select start, end from %s' % kd).fetchall())
+try:
+    rows = sorted(db.execute('select start, end, name from kernels').fetchall())
+except Exception:
+    rows = sorted((a, b, '?') for a, b in db.execute('select start, end from %s' % kd).fetchall())
 rows = rows[int(len(rows) * skip):]                 # drop model set-up and warm-up: the second half is steady-state steps
 span = rows[-1][1] - rows[0][0]
-busy, cur_s, cur_e, gaps = 0, rows[0][0], rows[0][1], []
-for s, e in rows[1:]:
+busy, cur_s, cur_e, gaps, where, last = 0, rows[0][0], rows[0][1], [], [], rows[0][2]
+for s, e, nm in rows[1:]:
     if s > cur_e:
-        busy += cur_e - cur_s; gaps.append(s - cur_e); cur_s, cur_e = s, e
+        busy += cur_e - cur_s; gaps.append(s - cur_e); where.append((s - cur_e, last, nm)); cur_s, cur_e = s, e
     else:
         cur_e = max(cur_e, e)
+    if e >= cur_e:
+        last = nm
 busy += cur_e - cur_s
 gaps.sort()
 print('kernels %d  span %.3f ms  busy %.3f ms  idle %.3f ms (%.1f %%)  gaps %d  median gap %.2f us  p90 %.2f us  max %.1f us' %
@@ -22,3 +27,6 @@ print('kernels %d  span %.3f ms  busy %.3f ms  idle %.3f ms (%.1f %%)  gaps %d  
        gaps[len(gaps) // 2] / 1e3 if gaps else 0, gaps[int(len(gaps) * 0.9)] / 1e3 if gaps else 0, gaps[-1] / 1e3 if gaps else 0))
 big = [g for g in gaps if g > 20e3]
 print('gaps > 20 us: %d, total %.3f ms' % (len(big), sum(big) / 1e6))
+
+for g, a, b in sorted(where, reverse=True)[:12]:
+    print('  %8.1f us  after %-60s before %s' % (g / 1e3, a[:60], b[:60]))
