@@ -26,6 +26,7 @@ def make_batch(seed_list):
 
 
 UTTS = [(1, 24, False), (2, 48, True), (3, 48, False), (4, 24, True), (5, 48, False), (6, 24, True), (7, 24, False), (8, 48, True)]
+UTTS = UTTS[:int(os.environ.get('SS_DP_UTTS', '8'))]      # 2-rank tests use the first four (voiced + silent on both ranks): half the emulator time
 # whole rows of 24 frames -> per-rank rows == global rows; 8 utterances deal evenly to 1, 2 and 4 ranks
 
 

@@ -24,7 +24,7 @@ _single_cache = {}
 
 def _ranks_vs_single(tmp_path, extra_env, world=2, tol=2e-4, check_running=True):
     worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
-    env = dict(os.environ, OMP_NUM_THREADS='1', SS_DP_ORDER_OF=str(world), **extra_env)
+    env = dict(os.environ, OMP_NUM_THREADS='1', SS_DP_ORDER_OF=str(world), SS_DP_UTTS='4' if world == 2 else '8', **extra_env)
     # the single-process reference depends on the model and the utterance order only: computed once per (layers, world), next to the ranks
     key = (extra_env.get('SS_DP_LAYERS', '1'), world, extra_env.get('SS_DP_DEVICE', 'cpu'))
     single, p0 = _single_cache.get(key), None
