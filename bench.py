@@ -518,10 +518,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host_enqueue = 0.0
+    pstride = max(5, args.steps // 2)              # per-launch events on two steps of the timed region (every 5th for short runs): they run serially (no side stream)
     timed_frames = 0
     for i in range(args.steps):
         timed_frames += frames_of[it[0] % len(batches)]
-        profiled = prof is not None and i % 5 == 0
+        profiled = prof is not None and i % pstride == 0
         if prof is not None:
             # every 5th timed step carries the per-launch HIP events (roofline numerator); those steps run serially (no side stream):
             # a duration taken while a second stream shares the CUs is not a per-kernel quantity
@@ -534,7 +535,7 @@ def main():
             host_enqueue += time.perf_counter() - th
     engine.SIDE_STREAM_ENABLED = True
     L.ss_plan_profile(plan.handle, 0)
-    n_plain = args.steps - (len(range(0, args.steps, 5)) if prof is not None else 0)
+    n_plain = args.steps - (len(range(0, args.steps, pstride)) if prof is not None else 0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -543,7 +544,7 @@ def main():
     final_loss = float(loss.detach())
 
     # the same loop on ONE batch (what rounds 1-3 timed), un-profiled: how much of a step is per-batch host work / uploads
-    # Un-profiled comparison loops after the timed one (the timed loop carries per-launch events on every 5th step, which run
+    # Un-profiled comparison loops after the timed one (the timed loop carries per-launch events on two of its steps, which run
     # without the side stream): the SAME loop rotating the batches, and the loop rounds 1-3 reported (batch 0 every step).
     same_ms = rot_ms = float('nan')
     n_same, rot_frames = 0, 0
@@ -592,13 +593,13 @@ def main():
                        'unprofiled': None if n_same == 0 else {
                            'steps': n_same, 'ms_per_step_rotated': rot_ms, 'frames_per_s_rotated': rot_frames / rot_ms * 1e3,
                            'ms_per_step_same_batch': same_ms, 'frames_per_s_same_batch': frames / same_ms * 1e3,
-                           'note': 'after the timed loop, no per-launch events (the timed loop runs every 5th step serially for the roofline table): '
+                           'note': 'after the timed loop, no per-launch events (the timed loop runs two of its steps serially for the roofline table): '
                                    'the rotating loop again, and batch 0 on every step (what rounds 1-3 timed)'},
                        'host_enqueue_ms_per_step': host_enqueue / max(n_plain, 1) * 1e3,
                        'host_enqueue_note': 'host time to enqueue one un-profiled step (forward and backward are one native call each)'},
         }
         if prof is not None:
-            psteps = len(range(0, args.steps, 5))
+            psteps = len(range(0, args.steps, pstride))
             rows_buf = (_lib.ProfileRow * 64)()
             nrows = L.ss_plan_profile_read(plan.handle, rows_buf, 64)
             table = {}
@@ -669,7 +670,7 @@ def main():
                                'algorithmic_per_launch': top['algorithmic_per_launch'], 'event_timed_steps': psteps,
                                'serial_kernel_ms_per_step': total_s / psteps * 1e3,
                                'timing': 'HIP events around every kernel launch (inside the native plan: ss_plan_profile; Python-launched kernels: '
-                                         'torch events on the launch stream) on every 5th timed step; those steps run without the side stream '
+                                         'torch events on the launch stream) on every 5th (runs of <= 10 steps) / every (steps/2)-th timed step; those steps run without the side stream '
                                          '(exclusive durations); rocprofv3 counterpart: profiles/r04_serial_kernel_stats.txt',
                                'kernels': kernels[:16]}
         if world == 1 and args.cpu_rows > 0:

@@ -10,7 +10,14 @@ try:
     rows = sorted(db.execute('select start, end, name from kernels').fetchall())
 except Exception:
     rows = sorted((a, b, '?') for a, b in db.execute('select start, end from %s' % kd).fetchall())
-rows = rows[int(len(rows) * skip):]                 # drop model set-up and warm-up: the second half is steady-state steps
+steps = [e for _, e, nm in rows if nm.startswith('adamw_kernel')]        # one optimiser launch per training step
+if len(steps) >= 4 and skip >= 0:
+    nwin = min(6, len(steps) - 2)                    # window: the last `nwin` whole steps (between the ends of two AdamW launches): no set-up, no warm-up / timed-loop sync
+    lo, hi = steps[-1 - nwin], steps[-1]
+    rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
+    print('window: the last %d training steps (%.3f ms per step)' % (nwin, (hi - lo) / 1e6 / nwin))
+else:
+    rows = rows[int(len(rows) * abs(skip)):]         # no optimiser in the trace: drop the first part (set-up, warm-up)
 span = rows[-1][1] - rows[0][0]
 busy, cur_s, cur_e, gaps, where, last = 0, rows[0][0], rows[0][1], [], [], rows[0][2]
 for s, e, nm in rows[1:]:
