@@ -183,8 +183,11 @@ class DeviceBatchBuilder(object):
     The 112-d hand-crafted EMG features (`emg`, data_utils.py:92-136) are not inputs of the model (architecture.py:61 ignores
     x_feat) and are emitted as zeros of the right shape unless the recording brings `emg_features`."""
 
-    def __init__(self, device, mfcc_norm=None, emg_norm=None, limit_length=False, sil_index=0):
+    def __init__(self, device, mfcc_norm=None, emg_norm=None, limit_length=False, sil_index=0, remove_channels=()):
+        """remove_channels: the reference's FLAGS.remove_channels (read_emg.py:73-75): those raw-EMG columns are zeroed after the
+        filtering / resampling and before the soft clip, exactly where load_utterance does it."""
         self.device, self.mfcc_norm, self.emg_norm, self.limit_length, self.sil_index = torch.device(device), mfcc_norm, emg_norm, limit_length, sil_index
+        self.remove_channels = tuple(int(c) for c in remove_channels)
 
     # ---- EMG: every recording of the batch through ONE filter / resample launch sequence
     def _filtered_689(self, recordings):
@@ -219,9 +222,9 @@ class DeviceBatchBuilder(object):
         n_own = [self._frames(r, mframes[i], self.limit_length) for i, r in enumerate(recordings)]
         # raw EMG: filter every recording, gather rows 8 .. 8 + 8 n into ONE buffer, soft-clip it in one launch
         e689 = self._filtered_689(recordings)
-        for e, n in zip(e689, n_own):
-            if e.shape[0] < 8 + 8 * n:
-                raise ValueError('recording too short: %d model-rate samples for %d frames' % (e.shape[0], n))
+        # a resampled signal that ends before row 8 + 8 n: the reference's slice raw_emg[8:8+8n] (read_emg.py:90) silently comes out shorter;
+        # here the frame count of that recording follows the samples that exist (whole frames), so every downstream length stays consistent
+        n_own = [min(n, max(0, (int(e.shape[0]) - 8) // 8)) for e, n in zip(e689, n_own)]
         # rows 8 .. 8 + 8 n of every recording (read_emg.py:90), as f32 (:100), gathered into ONE buffer by one launch
         e32 = e689[0]._base.to(torch.float32) if e689[0]._base is not None else torch.cat(e689, 0).to(torch.float32)
         offs = np.concatenate([[0], np.cumsum([int(e.shape[0]) for e in e689])])
@@ -231,6 +234,8 @@ class DeviceBatchBuilder(object):
         for n in n_own:
             raw_views.append(raw[off:off + 8 * n])
             off += 8 * n
+        for ch in self.remove_channels:                                                     # read_emg.py:73-75 (on the model-rate signal; zero stays zero through the clip)
+            raw[:, ch].zero_()
         _soft_clip(raw, raw, 8, None, None, 20.0, 50.0)                                     # read_emg.py:227-228
         out = {k: [] for k in ('audio_features', 'audio_feature_lengths', 'emg', 'raw_emg', 'parallel_voiced_emg', 'phonemes', 'session_ids',
                                'lengths', 'silent', 'text_int', 'text_int_lengths')}
@@ -256,7 +261,13 @@ class DeviceBatchBuilder(object):
             text = torch.as_tensor(r.get('text_int', np.zeros(0, dtype=np.int64)), dtype=torch.int64)
             out['audio_features'].append(feats); out['audio_feature_lengths'].append(nt)
             out['emg'].append(emg); out['raw_emg'].append(raw_views[i])
-            out['parallel_voiced_emg'].append(np.zeros(1))
+            # read_emg.py:250-257: for a silent example the voiced twin's (normalised, soft-clipped) EMG features; np.zeros(1) otherwise.  The
+            # 112-d hand-crafted features are not computed here (not model inputs): the twin's are passed through when the recording brings them.
+            pv = np.zeros(1)
+            if r['silent'] and r['parallel'].get('emg_features') is not None:
+                pv = torch.as_tensor(r['parallel']['emg_features'], dtype=torch.float32).to(dev)
+                pv = normalize_features(pv, self.emg_norm, 8.0) if self.emg_norm is not None else pv
+            out['parallel_voiced_emg'].append(pv)
             out['phonemes'].append(ph.to(dev)); out['session_ids'].append(torch.full((n,), int(r.get('session_index', 0)), dtype=torch.int64, device=dev))
             out['lengths'].append(n); out['silent'].append(bool(r['silent']))
             out['text_int'].append(text); out['text_int_lengths'].append(int(text.shape[0]))

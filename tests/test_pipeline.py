@@ -184,6 +184,14 @@ def test_device_batch_builder_matches_the_per_utterance_chain(dev):
         assert float(np.abs(d).mean()) < 1e-4 and float(np.abs(d).max()) < 2e-2, (i, float(np.abs(d).mean()))
         assert np.array_equal(b['phonemes'][i].cpu().numpy(), ph)
         assert int(b['session_ids'][i][0]) == 3 and b['text_int_lengths'][i] == 5
+    # FLAGS.remove_channels (read_emg.py:73-75): those electrode columns are zero, the others unchanged; the voiced twin's EMG features ride along
+    recs[1]['parallel']['emg_features'] = np.ones((b['audio_feature_lengths'][1], 112), dtype=np.float32)
+    b2 = pipeline.DeviceBatchBuilder(dev, mfcc_norm=norm, remove_channels=(2, 5)).build(recs)
+    for i in range(len(recs)):
+        g0, g2 = b['raw_emg'][i].cpu(), b2['raw_emg'][i].cpu()
+        assert float(g2[:, [2, 5]].abs().max()) == 0.0 and torch.equal(g2[:, [0, 1, 3, 4, 6, 7]], g0[:, [0, 1, 3, 4, 6, 7]])
+    assert torch.is_tensor(b2['parallel_voiced_emg'][1]) and tuple(b2['parallel_voiced_emg'][1].shape) == (b['audio_feature_lengths'][1], 112)
+    assert isinstance(b2['parallel_voiced_emg'][0], np.ndarray)
 
 
 @pytest.mark.gpu
