@@ -17,6 +17,13 @@ struct Seq {            // logical row r of a (B, T + 2*pad, C) buffer
     __device__ __forceinline__ long long at(int b, int t) const { return (long long)b * (T + 2 * pad) + pad + t; }     // the division of row() done once by the caller
 };
 
+// 8 consecutive per-channel f32 constants as TWO 16-byte loads.  Element-wise (and conditional) they became 8 dword loads each behind its own
+// wait: with 6..8 such arrays a workgroup spent its first ~8 us in a chain of dependent round trips before touching the data.
+__device__ __forceinline__ void ld8(const float* __restrict__ p, float (&v)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
 // thread -> (vector column cx0 (+k*CVb), row lane ry) for column reductions over a [rows][C] matrix
 struct ColMap {
     int CV, CVb, RY, cx0, ry; bool active;
@@ -216,11 +223,17 @@ __global__ void bn_apply_kernel(const T* __restrict__ xa, Seq sa, const float* _
         RowWalk w(blockIdx.x * blockDim.x + threadIdx.x, step32, (unsigned)CV, TP);
         float ma[8], sca[8], ba[8], mb[8], scb[8], bb[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = w.cx * 8 + e;
-            ma[e] = mean_a[c]; sca[e] = gamma_a[c] * invstd_a[c]; ba[e] = beta_a[c];
-            mb[e] = 0.f; scb[e] = 0.f; bb[e] = 0.f;
-            if (xb) { mb[e] = mean_b[c]; scb[e] = gamma_b[c] * invstd_b[c]; bb[e] = beta_b[c]; }
+        for (int e = 0; e < 8; ++e) { mb[e] = 0.f; scb[e] = 0.f; bb[e] = 0.f; }
+        {
+            float t[8];
+            ld8(mean_a + w.cx * 8, ma); ld8(gamma_a + w.cx * 8, sca); ld8(invstd_a + w.cx * 8, t); ld8(beta_a + w.cx * 8, ba);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sca[e] *= t[e];
+            if (xb) {
+                ld8(mean_b + w.cx * 8, mb); ld8(gamma_b + w.cx * 8, scb); ld8(invstd_b + w.cx * 8, t); ld8(beta_b + w.cx * 8, bb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) scb[e] *= t[e];
+            }
         }
         for (; w.ro < rows_out; w.next()) {
             const int t = (int)w.tp - sy.pad;
@@ -311,7 +324,7 @@ extern "C" int ss_bn_apply(int dtype, const void* xa, const float* mean_a, const
 // g = dy * 1[y>0]  (ReLU of the fused output);  per branch: dgamma = sum g*xhat, dbeta = sum g,
 // dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)).
 template <class T, bool REGATE>
-__global__ __launch_bounds__(RED_THREADS, sizeof(T) == 2 ? 4 : 2) void bn_bwd_partial_kernel(const T* __restrict__ dy, Seq sdy, const T* __restrict__ y, Seq sy,
+__global__ __launch_bounds__(RED_THREADS, sizeof(T) == 2 ? 3 : 2) void bn_bwd_partial_kernel(const T* __restrict__ dy, Seq sdy, const T* __restrict__ y, Seq sy,
                                                                      const T* __restrict__ xa, Seq sa, const float* __restrict__ mean_a, const float* __restrict__ invstd_a,
                                                                      const T* __restrict__ xb, Seq sb, const float* __restrict__ mean_b, const float* __restrict__ invstd_b,
                                                                      const float* __restrict__ gamma_a, const float* __restrict__ beta_a, const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
@@ -333,36 +346,57 @@ __global__ __launch_bounds__(RED_THREADS, sizeof(T) == 2 ? 4 : 2) void bn_bwd_pa
         for (int e = 0; e < 8; ++e) { sg[e] = sga[e] = sgb[e] = 0.f; ma[e] = ka[e] = mb[e] = kb[e] = bs[e] = 0.f; }
         const bool cv = m.active && cx < m.CV;
         if (cv) {
+            {   // all per-channel constants as 16-byte loads, issued together (the b-branch arrays fall back to the a-branch ones when absent: no branch)
+                float t0[8], t1[8], t2[8], t3[8];
+                ld8(mean_a + cx * 8, ma); ld8(invstd_a + cx * 8, ka);
+                ld8((xb ? mean_b : mean_a) + cx * 8, mb); ld8((xb ? invstd_b : invstd_a) + cx * 8, kb);
+                if (REGATE) {
+                    ld8(gamma_a + cx * 8, t0); ld8(beta_a + cx * 8, t1); ld8((xb ? gamma_b : gamma_a) + cx * 8, t2); ld8((xb ? beta_b : beta_a) + cx * 8, t3);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = cx * 8 + e;
-                ma[e] = mean_a[c]; ka[e] = invstd_a[c]; if (xb) { mb[e] = mean_b[c]; kb[e] = invstd_b[c]; }
-                if (REGATE) { ka[e] *= gamma_a[c]; bs[e] = beta_a[c]; if (xb) { kb[e] *= gamma_b[c]; bs[e] += beta_b[c]; } }
+                    for (int e = 0; e < 8; ++e) { ka[e] *= t0[e]; kb[e] *= t2[e]; bs[e] = t1[e] + (xb ? t3[e] : 0.f); }
+                }
+                if (!xb) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { mb[e] = 0.f; kb[e] = 0.f; }
+                }
             }
-            // two rows per trip: up to 8 independent 16-byte loads in flight per thread (the sums keep their row order)
+            // Two rows per trip, SOFTWARE-PIPELINED: the raw 16-byte chunks of trip k + 1 are requested before trip k is unpacked and summed, so the
+            // loads of one trip travel under the ~200 VALU instructions of the previous one.  (Round 3 issued a trip's loads, waited for all of them and
+            // computed: ~30 dependent round trips per thread, 2.6 TB/s of real traffic for an "HBM-bound" pass.)  Rows past the chunk re-load its last
+            // row and are skipped at the use; the sums keep their row order.
+            typedef typename RawVec8<T>::type Raw;
+            Raw ng[2], no[2], na[2], nb[2];
+            auto fetch = [&](int r, Raw (&fg)[2], Raw (&fo)[2], Raw (&fa)[2], Raw (&fb)[2]) {
+                const int rc0 = r < r1 ? r : r1 - 1, rc1 = r + m.RY < r1 ? r + m.RY : r1 - 1;
+                const int b0 = rc0 / sdy.T, t0 = rc0 - b0 * sdy.T, b1 = rc1 / sdy.T, t1 = rc1 - b1 * sdy.T;      // ONE division per row (Seq::row costs one per tensor)
+                fg[0] = RawVec8<T>::load(dy + sdy.at(b0, t0) * C + cx * 8); fg[1] = RawVec8<T>::load(dy + sdy.at(b1, t1) * C + cx * 8);
+                if (relu && !REGATE) { fo[0] = RawVec8<T>::load(y + sy.at(b0, t0) * C + cx * 8); fo[1] = RawVec8<T>::load(y + sy.at(b1, t1) * C + cx * 8); }
+                fa[0] = RawVec8<T>::load(xa + sa.at(b0, t0) * C + cx * 8); fa[1] = RawVec8<T>::load(xa + sa.at(b1, t1) * C + cx * 8);
+                if (xb) { fb[0] = RawVec8<T>::load(xb + sb.at(b0, t0) * C + cx * 8); fb[1] = RawVec8<T>::load(xb + sb.at(b1, t1) * C + cx * 8); }
+            };
+            if (r0 + m.ry < r1) fetch(r0 + m.ry, ng, no, na, nb);
             for (int r = r0 + m.ry; r < r1; r += 2 * m.RY) {
                 const bool two = r + m.RY < r1;
-                const int rb = two ? r + m.RY : r;
-                float g[2][8], o[2][8], va[2][8], vb[2][8];
-                const int b0 = r / sdy.T, t0 = r - b0 * sdy.T, b1 = rb / sdy.T, t1 = rb - b1 * sdy.T;      // ONE division per row (Seq::row costs one per tensor)
-                Vec8<T>::load(dy + sdy.at(b0, t0) * C + cx * 8, g[0]); Vec8<T>::load(dy + sdy.at(b1, t1) * C + cx * 8, g[1]);
-                if (relu && !REGATE) { Vec8<T>::load(y + sy.at(b0, t0) * C + cx * 8, o[0]); Vec8<T>::load(y + sy.at(b1, t1) * C + cx * 8, o[1]); }
-                Vec8<T>::load(xa + sa.at(b0, t0) * C + cx * 8, va[0]); Vec8<T>::load(xa + sa.at(b1, t1) * C + cx * 8, va[1]);
-                if (xb) { Vec8<T>::load(xb + sb.at(b0, t0) * C + cx * 8, vb[0]); Vec8<T>::load(xb + sb.at(b1, t1) * C + cx * 8, vb[1]); }
+                Raw cg[2] = {ng[0], ng[1]}, co[2] = {no[0], no[1]}, ca[2] = {na[0], na[1]}, cb[2] = {nb[0], nb[1]};
+                if (r + 2 * m.RY < r1) fetch(r + 2 * m.RY, ng, no, na, nb);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if (u == 1 && !two) break;
+                    float g[8], o[8], va[8], vb[8];
+                    RawVec8<T>::unpack(cg[u], g); RawVec8<T>::unpack(ca[u], va);
+                    if (relu && !REGATE) RawVec8<T>::unpack(co[u], o);
+                    if (xb) RawVec8<T>::unpack(cb[u], vb);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         if (REGATE) {       // pre = (xa - mean_a) gamma_a invstd_a [+ b branch] + betas: the forward's expression (bn_apply_kernel)
-                            const float da = va[u][e] - ma[e], db = xb ? vb[u][e] - mb[e] : 0.f;
-                            const float gg = (!relu || da * ka[e] + db * kb[e] + bs[e] > 0.f) ? g[u][e] : 0.f;
+                            const float da = va[e] - ma[e], db = xb ? vb[e] - mb[e] : 0.f;
+                            const float gg = (!relu || da * ka[e] + db * kb[e] + bs[e] > 0.f) ? g[e] : 0.f;
                             sg[e] += gg; sga[e] += gg * da;
                             if (xb) sgb[e] += gg * db;
                         } else {
-                            const float gg = (!relu || o[u][e] > 0.f) ? g[u][e] : 0.f;
-                            sg[e] += gg; sga[e] += gg * (va[u][e] - ma[e]) * ka[e];
-                            if (xb) sgb[e] += gg * (vb[u][e] - mb[e]) * kb[e];
+                            const float gg = (!relu || o[e] > 0.f) ? g[e] : 0.f;
+                            sg[e] += gg; sga[e] += gg * (va[e] - ma[e]) * ka[e];
+                            if (xb) sgb[e] += gg * (vb[e] - mb[e]) * kb[e];
                         }
                     }
                 }
@@ -421,11 +455,23 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, Seq sdy, const T* 
         RowWalk w(blockIdx.x * blockDim.x + threadIdx.x, step32, (unsigned)CV, TP);
         float ma[8], ka[8], qa[8], c0[8], mb[8], kb[8], qb[8], bs[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = w.cx * 8 + e;
-            ma[e] = mean_a[c]; ka[e] = gamma_a[c] * invstd_a[c]; qa[e] = invstd_a[c] * (coef[C + c] * inv_n); c0[e] = coef[c] * inv_n;
-            mb[e] = 0.f; kb[e] = 0.f; qb[e] = 0.f; bs[e] = regate ? beta_a[c] : 0.f;
-            if (xb) { mb[e] = mean_b[c]; kb[e] = gamma_b[c] * invstd_b[c]; qb[e] = invstd_b[c] * (coef[2 * C + c] * inv_n); if (regate) bs[e] += beta_b[c]; }
+        for (int e = 0; e < 8; ++e) { mb[e] = 0.f; kb[e] = 0.f; qb[e] = 0.f; bs[e] = 0.f; }
+        {
+            float ia[8], t[8];
+            ld8(mean_a + w.cx * 8, ma); ld8(gamma_a + w.cx * 8, ka); ld8(invstd_a + w.cx * 8, ia); ld8(coef + C + w.cx * 8, qa); ld8(coef + w.cx * 8, c0);
+            if (regate) ld8(beta_a + w.cx * 8, bs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ka[e] *= ia[e]; qa[e] = ia[e] * (qa[e] * inv_n); c0[e] *= inv_n; }
+            if (xb) {
+                ld8(mean_b + w.cx * 8, mb); ld8(gamma_b + w.cx * 8, kb); ld8(invstd_b + w.cx * 8, ia); ld8(coef + 2 * C + w.cx * 8, qb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kb[e] *= ia[e]; qb[e] = ia[e] * (qb[e] * inv_n); }
+                if (regate) {
+                    ld8(beta_b + w.cx * 8, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bs[e] += t[e];
+                }
+            }
         }
         const unsigned rows_out = (unsigned)B * TP;
         for (; w.ro < rows_out; w.next()) {

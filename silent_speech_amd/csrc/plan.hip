@@ -301,7 +301,7 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         if (training && hook && f1 && fr == f1 + 2 * d && O == d && !X.dry) nred = hook(hook_user, f1, 4 * O, (double)B * Tout, stream);
         L_(bn_stats(X, c1, B, Tout, O, s.scratch, w.bn1, training, &s.m1, &s.i1, f1, nred));
         void* h1 = X.alloc((size_t)B * (Tout + 2) * O * es);
-        if (!X.dry) L_(timed(X, "bn_apply", 0, (double)B * Tout * O * es * 3, stream, [&] { return ss_bn_apply(dt, c1, s.m1, s.i1, w.bn1.gamma, w.bn1.beta, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h1, 1, B, Tout, O, 1, stream); }));
+        if (!X.dry) L_(timed(X, "bn_apply", 0, (double)B * Tout * O * es * 2, stream, [&] { return ss_bn_apply(dt, c1, s.m1, s.i1, w.bn1.gamma, w.bn1.beta, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h1, 1, B, Tout, O, 1, stream); }));
         void* c2 = X.alloc((size_t)rows * O * es);
         float* f2 = conv_gemm(X, h1, w.w2f, c2, rows, O, 3 * O, RM(O, Tout, (long long)(Tout + 2) * O), RM(3 * O), w.b2, w.bn2, slot ? slot + 4 * d : nullptr, &rc); L_(rc);
         L_(bn_stats(X, c2, B, Tout, O, s.scratch, w.bn2, training, &s.m2, &s.i2, f2));
@@ -477,10 +477,10 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         void* dcr = X.alloc((size_t)rows * O * es);
         float* sums = (float*)X.alloc((size_t)3 * O * 4);
         if (!X.dry) {
-            L_(timed(X, "bn_bwd_sums", 0, (double)B * Tout * O * es * 4, stream, [&] { return ss_bn_backward_sums(dt, dy, 0, s.y, s.pad_y, s.c2, 0, s.m2, s.i2, s.cr, 0, s.mr, s.ir, w.bn2.dgamma, w.bn2.dbeta, w.bnr.dgamma, w.bnr.dbeta, s.scratch, sums, B, Tout, O, 1, regate ? w.bn2.gamma : nullptr, regate ? w.bn2.beta : nullptr, regate ? w.bnr.gamma : nullptr, regate ? w.bnr.beta : nullptr, stream); }));
+            L_(timed(X, "bn_bwd_sums", 0, (double)B * Tout * O * es * (regate ? 3 : 4), stream, [&] { return ss_bn_backward_sums(dt, dy, 0, s.y, s.pad_y, s.c2, 0, s.m2, s.i2, s.cr, 0, s.mr, s.ir, w.bn2.dgamma, w.bn2.dbeta, w.bnr.dgamma, w.bnr.dbeta, s.scratch, sums, B, Tout, O, 1, regate ? w.bn2.gamma : nullptr, regate ? w.bn2.beta : nullptr, regate ? w.bnr.gamma : nullptr, regate ? w.bnr.beta : nullptr, stream); }));
             double n_total = (double)B * Tout;
             if (hook) n_total = hook(hook_user, sums, 3 * O, n_total, stream);
-            L_(timed(X, "bn_bwd_apply", 0, (double)B * Tout * O * es * 6, stream, [&] { return ss_bn_backward_apply(dt, dy, 0, s.y, s.pad_y, s.c2, 0, s.m2, s.i2, w.bn2.gamma, s.cr, 0, s.mr, s.ir, w.bnr.gamma, sums, n_total, dc2, 1, dcr, 0, B, Tout, O, 1, regate ? w.bn2.beta : nullptr, regate ? w.bnr.beta : nullptr, stream); }));
+            L_(timed(X, "bn_bwd_apply", 0, (double)B * Tout * O * es * (regate ? 5 : 6), stream, [&] { return ss_bn_backward_apply(dt, dy, 0, s.y, s.pad_y, s.c2, 0, s.m2, s.i2, w.bn2.gamma, s.cr, 0, s.mr, s.ir, w.bnr.gamma, sums, n_total, dc2, 1, dcr, 0, B, Tout, O, 1, regate ? w.bn2.beta : nullptr, regate ? w.bnr.beta : nullptr, stream); }));
         }
         // conv2 (k3, stride 1): weight and input gradients.  d/d(bias) of a conv feeding training-mode BatchNorm is identically 0
         DwGroup cg{this, &XS, grouped};
@@ -490,10 +490,10 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         void* dc1 = X.alloc((size_t)B * (Tout + 2) * O * es);
         float* sums1 = (float*)X.alloc((size_t)3 * O * 4);
         if (!X.dry) {
-            L_(timed(X, "bn_bwd_sums", 0, (double)B * Tout * O * es * 4, stream, [&] { return ss_bn_backward_sums(dt, dh1, 0, s.h1, 1, s.c1, 0, s.m1, s.i1, nullptr, 0, nullptr, nullptr, w.bn1.dgamma, w.bn1.dbeta, nullptr, nullptr, s.scratch, sums1, B, Tout, O, 1, regate ? w.bn1.gamma : nullptr, regate ? w.bn1.beta : nullptr, nullptr, nullptr, stream); }));
+            L_(timed(X, "bn_bwd_sums", 0, (double)B * Tout * O * es * (regate ? 2 : 3), stream, [&] { return ss_bn_backward_sums(dt, dh1, 0, s.h1, 1, s.c1, 0, s.m1, s.i1, nullptr, 0, nullptr, nullptr, w.bn1.dgamma, w.bn1.dbeta, nullptr, nullptr, s.scratch, sums1, B, Tout, O, 1, regate ? w.bn1.gamma : nullptr, regate ? w.bn1.beta : nullptr, nullptr, nullptr, stream); }));
             double n_total = (double)B * Tout;
             if (hook) n_total = hook(hook_user, sums1, 3 * O, n_total, stream);
-            L_(timed(X, "bn_bwd_apply", 0, (double)B * Tout * O * es * 6, stream, [&] { return ss_bn_backward_apply(dt, dh1, 0, s.h1, 1, s.c1, 0, s.m1, s.i1, w.bn1.gamma, nullptr, 0, nullptr, nullptr, nullptr, sums1, n_total, dc1, 1, nullptr, 0, B, Tout, O, 1, regate ? w.bn1.beta : nullptr, nullptr, stream); }));
+            L_(timed(X, "bn_bwd_apply", 0, (double)B * Tout * O * es * (regate ? 3 : 4), stream, [&] { return ss_bn_backward_apply(dt, dh1, 0, s.h1, 1, s.c1, 0, s.m1, s.i1, w.bn1.gamma, nullptr, 0, nullptr, nullptr, nullptr, sums1, n_total, dc1, 1, nullptr, 0, B, Tout, O, 1, regate ? w.bn1.beta : nullptr, nullptr, stream); }));
         }
         // conv1 (k3, stride 2) and the 1x1 stride-2 residual path
         const long long in_bs = (long long)(Tin + 2) * Cin;
