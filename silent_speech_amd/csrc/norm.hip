@@ -235,15 +235,33 @@ __global__ void bn_apply_kernel(const T* __restrict__ xa, Seq sa, const float* _
                 for (int e = 0; e < 8; ++e) scb[e] *= t[e];
             }
         }
+        // the raw chunks of the thread's NEXT row are requested before the current row is converted and stored (one row per trip otherwise means
+        // load -> wait -> store with a single 16-byte load or two in flight per thread)
+        typedef typename RawVec8<T>::type Raw;
+        Raw nv = RawVec8<T>::zero(), nu = RawVec8<T>::zero();
+        auto fetch = [&](unsigned b, unsigned tp) {
+            const int t = (int)tp - sy.pad;
+            if (t >= 0 && t < TT) {
+                nv = RawVec8<T>::load(xa + sa.at((int)b, t) * C + w.cx * 8);
+                if (xb) nu = RawVec8<T>::load(xb + sb.at((int)b, t) * C + w.cx * 8);
+            }
+        };
+        if (w.ro < rows_out) fetch(w.b, w.tp);
         for (; w.ro < rows_out; w.next()) {
             const int t = (int)w.tp - sy.pad;
+            const Raw cv = nv, cu = nu;
+            {   // position of the next row of this thread (RowWalk::next without committing it)
+                unsigned nb = w.b + w.db, ntp = w.tp + w.dtp;
+                if (ntp >= w.TP) { ntp -= w.TP; ++nb; }
+                if (w.ro + w.rstep < rows_out) fetch(nb, ntp);
+            }
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = 0.f;                 // zero halo rows
             if (t >= 0 && t < TT) {
                 float v[8], u[8];
-                Vec8<T>::load(xa + sa.at((int)w.b, t) * C + w.cx * 8, v);
-                if (xb) Vec8<T>::load(xb + sb.at((int)w.b, t) * C + w.cx * 8, u);
+                RawVec8<T>::unpack(cv, v);
+                if (xb) RawVec8<T>::unpack(cu, u);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (v[e] - ma[e]) * sca[e] + ba[e];
                 if (xb) {
@@ -401,9 +419,11 @@ __global__ __launch_bounds__(RED_THREADS, sizeof(T) == 2 ? 3 : 2) void bn_bwd_pa
                     }
                 }
             }
-            if (REGATE) {                   // the x-hat sums were taken without invstd: apply it once per channel
+            if (REGATE) {                   // the x-hat sums were taken without invstd: apply it once per channel (16-byte loads, no branch)
+                float ia[8], ib[8];
+                ld8(invstd_a + cx * 8, ia); ld8((xb ? invstd_b : invstd_a) + cx * 8, ib);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { sga[e] *= invstd_a[cx * 8 + e]; if (xb) sgb[e] *= invstd_b[cx * 8 + e]; }
+                for (int e = 0; e < 8; ++e) { sga[e] *= ia[e]; sgb[e] *= ib[e]; }
             }
         }
         __syncthreads();
@@ -414,12 +434,9 @@ __global__ __launch_bounds__(RED_THREADS, sizeof(T) == 2 ? 3 : 2) void bn_bwd_pa
             for (int yy = 1; yy < m.RY; ++yy)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const int o = (yy * m.CVb + m.cx0) * 8 + e; sg[e] += red[0][o]; sga[e] += red[1][o]; sgb[e] += red[2][o]; }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                partial[((long long)blockIdx.x * 3 + 0) * C + cx * 8 + e] = sg[e];
-                partial[((long long)blockIdx.x * 3 + 1) * C + cx * 8 + e] = sga[e];
-                partial[((long long)blockIdx.x * 3 + 2) * C + cx * 8 + e] = sgb[e];
-            }
+            Vec8<float>::store(partial + ((long long)blockIdx.x * 3 + 0) * C + cx * 8, sg);
+            Vec8<float>::store(partial + ((long long)blockIdx.x * 3 + 1) * C + cx * 8, sga);
+            Vec8<float>::store(partial + ((long long)blockIdx.x * 3 + 2) * C + cx * 8, sgb);
         }
     }
 }
@@ -672,7 +689,36 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __rest
                                                                  unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id)
 {
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, CV = C >> 3;
-    for (int r = blockIdx.x * wpb + (threadIdx.x >> 6); r < rows; r += gridDim.x * wpb) {
+    // gamma / beta of this lane's chunks stay in registers for all of its rows (they were re-read -- 4 x 16 bytes per chunk -- behind their own wait on
+    // every row), and the raw chunks of the NEXT row are requested before the current row is reduced: a wave otherwise runs load -> wait -> reduce -> load
+    // -> wait -> store, three dependent round trips per row.
+    typedef typename RawVec8<T>::type Raw;
+    constexpr bool HOIST = NV <= 2;                     // wide rows (NV = 8: 128 registers of constants) keep the per-row loads
+    float gm[HOIST ? NV : 1][8], bt[HOIST ? NV : 1][8];
+    if (HOIST) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int cx = lane + 64 * i, cc = cx < CV ? cx : CV - 1;
+            ld8(gamma + cc * 8, gm[HOIST ? i : 0]); ld8(beta + cc * 8, bt[HOIST ? i : 0]);
+        }
+    }
+    const int rstep = gridDim.x * wpb;
+    int r = blockIdx.x * wpb + (threadIdx.x >> 6);
+    Raw nx[NV], na[NV];
+    auto fetch = [&](int row) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int cx = lane + 64 * i;
+            if (cx < CV) { nx[i] = RawVec8<T>::load(x + (long long)row * C + cx * 8); na[i] = RawVec8<T>::load(a_z + (long long)row * C + cx * 8); }
+            else { nx[i] = RawVec8<T>::zero(); na[i] = RawVec8<T>::zero(); }
+        }
+    };
+    if (r < rows) fetch(r);
+    for (; r < rows; r += rstep) {
+        Raw cx_[NV], ca_[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { cx_[i] = nx[i]; ca_[i] = na[i]; }
+        if (r + rstep < rows) fetch(r + rstep);
         float z[NV][8];
         float s = 0.f;
 #pragma unroll
@@ -680,8 +726,7 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __rest
             const int cx = lane + 64 * i;
             if (cx < CV) {
                 float xv[8], av[8];
-                Vec8<T>::load(x + (long long)r * C + cx * 8, xv);
-                Vec8<T>::load(a_z + (long long)r * C + cx * 8, av);
+                RawVec8<T>::unpack(cx_[i], xv); RawVec8<T>::unpack(ca_[i], av);
                 bool kp[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) kp[e] = true;
@@ -719,8 +764,9 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __rest
             const int cx = lane + 64 * i;
             if (cx < CV) {
                 float o[8];
+                if (!HOIST) { ld8(gamma + cx * 8, gm[0]); ld8(beta + cx * 8, bt[0]); }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (z[i][e] - mu) * rs * gamma[cx * 8 + e] + beta[cx * 8 + e];
+                for (int e = 0; e < 8; ++e) o[e] = (z[i][e] - mu) * rs * gm[HOIST ? i : 0][e] + bt[HOIST ? i : 0][e];
                 Vec8<T>::store(y + (long long)r * C + cx * 8, o);
             }
         }
