@@ -246,7 +246,7 @@ def make_step(model, optim, batches, dp, it):
         if i <= 500:
             for gp in optim.param_groups:
                 gp['lr'] = i * 1e-3 / 500                                       # transduction_model.py:186-189
-        X, X_raw, sess = prepare_batch(batch, X_dev(batch))                     # the three combine_fixed_length calls + the loss plan, one upload
+        X, X_raw, sess = prepare_batch(batch, batch['raw_emg'][0].device)       # the three combine_fixed_length calls + the loss plan, one upload
         if dp is not None:
             dp.begin_step(X_raw.shape[0] * 200, dp.local_target_frames(batch))
         pred, aux = model(X, X_raw, sess)
@@ -259,10 +259,6 @@ def make_step(model, optim, batches, dp, it):
         it[0] += 1
         return loss
     return step
-
-
-def X_dev(batch):
-    return batch['raw_emg'][0].device
 
 
 def _time_steps(step, warm, timed):

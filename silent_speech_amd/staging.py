@@ -76,8 +76,3 @@ def upload(arrays, device):
 
 
 _TORCH_DTYPE = {np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8, np.float32: torch.float32, np.float64: torch.float64}
-
-
-def pinned_like(shape, dtype):
-    """A pinned host tensor for one bulk upload of batch data that arrives in host memory (the DataLoader's tensors)."""
-    return torch.empty(shape, dtype=dtype, pin_memory=torch.cuda.is_available())
