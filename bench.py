@@ -119,9 +119,9 @@ def parity_entry(sub, ref_pred, model_sd, dev, dropout_p=0.2):
     out = {'rows': int(ref_pred.shape[0]), 'dropout': dropout_p,
            'reference': 'oracle/model_ref.py (fp32 torch restatement pinned to the reference by tests/golden), dropout masks replayed by oracle/dropout_ref.py'}
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model_sd.items()}
-    for name, dt in (('bf16', torch.bfloat16), ('fp32', torch.float32)):
+    for name, dt, mm in (('bf16', torch.bfloat16, 'exact'), ('fp32', torch.float32, 'exact'), ('fp32_bf16x3', torch.float32, 'bf16x3')):
         for p in (0.0, dropout_p):
-            m = Model(112, 80, 48, model_size=768, num_layers=6, dropout=p, compute_dtype=dt)
+            m = Model(112, 80, 48, model_size=768, num_layers=6, dropout=p, compute_dtype=dt, f32_matmul=mm)
             m.load_state_dict(model_sd, strict=True)
             m.to(dev)
             m.shift_rng = _R
@@ -272,16 +272,21 @@ def _time_steps(step, warm, timed):
     return (time.perf_counter() - t0) / timed, loss
 
 
-def fp32_mode_leg(batch, init_sd, dev, frames, warm=2, timed=4):
-    """The SAME step in exact-f32 kernels (compute_dtype=float32: f32 MFMA 16x16x4, f32 activations): the mode whose `pred` sits within
-    north_star's 1e-4 mel-L1 of the reference (parity.mel_l1_fp32*), timed by the driver like the bf16 line."""
+def fp32_mode_leg(batch, init_sd, dev, frames, warm=2, timed=4, f32_matmul='exact'):
+    """The SAME step with f32 activations / weights between the kernels (compute_dtype=float32), timed by the driver like the bf16 line:
+    f32_matmul='exact' = f32 MFMA 16x16x4 (the mode of parity.mel_l1_fp32*), 'bf16x3' = every GEMM / attention product on three bf16
+    MFMAs over operands split hi + lo in registers (parity.mel_l1_fp32_bf16x3*: the parity-grade FAST mode, still inside north_star's
+    1e-4 mel-L1 of the reference)."""
     from silent_speech_amd.architecture import Model
     from silent_speech_amd.optim import FusedAdamW
-    model = Model(112, 80, 48, model_size=768, num_layers=6, dropout=0.2, compute_dtype=torch.float32)
+    model = Model(112, 80, 48, model_size=768, num_layers=6, dropout=0.2, compute_dtype=torch.float32, f32_matmul=f32_matmul)
     model.load_state_dict(init_sd, strict=True)
     model.to(dev).train()
     optim = FusedAdamW(model, weight_decay=1e-7)
     dt, loss = _time_steps(make_step(model, optim, batch, None, [0]), warm, timed)
+    if f32_matmul == 'bf16x3':
+        return {'dtype': 'fp32 storage, bf16x3 MFMA', 'ms_per_step': dt * 1e3, 'frames_per_s': frames / dt, 'steps': timed, 'warmup': warm, 'final_loss': float(loss.detach()),
+                'roofline_note': '3 bf16 MFMAs per product: 3 x 398 MFLOP/frame issued => %.0f %% of the bf16 MFMA peak' % (100.0 * frames * 3 * 398e6 / dt / 1e12 / PEAK_BF16_TFLOPS)}
     return {'dtype': 'fp32', 'ms_per_step': dt * 1e3, 'frames_per_s': frames / dt, 'steps': timed, 'warmup': warm, 'final_loss': float(loss.detach()),
             'roofline_note': 'f32 MFMA peak is %.1f TFLOP/s: 398 MFLOP/frame => %.0f %% of it' % (PEAK_F32_TFLOPS, 100.0 * frames * 398e6 / dt / 1e12 / PEAK_F32_TFLOPS)}
 
@@ -426,7 +431,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp32x3'], help="fp32x3: f32 storage, every matmul product on three bf16 MFMAs (Model(f32_matmul='bf16x3'))")
     ap.add_argument('--cpu-rows', type=int, default=16, help='packed rows of the batch given to the CPU baseline (0 = skip baseline and parity)')
     ap.add_argument('--cpu-steps', type=int, default=5)
     ap.add_argument('--cpu-warmup', type=int, default=3)
@@ -470,7 +475,7 @@ def main():
 
     dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     torch.manual_seed(0)
-    model = Model(112, 80, 48, model_size=768, num_layers=6, dropout=0.2, compute_dtype=dt).to(dev)
+    model = Model(112, 80, 48, model_size=768, num_layers=6, dropout=0.2, compute_dtype=dt, f32_matmul='bf16x3' if args.dtype == 'fp32x3' else 'exact').to(dev)
     model.train()
     init_sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     dp = DataParallel() if world > 1 else None
@@ -682,6 +687,7 @@ def main():
             out['dtw']['saturating'] = {k: v for k, v in dtw_leg(dev, nb=256).items() if k in ('workload', 'hip_ms', 'matrices_per_s', 'roofline', 'bit_exact_vs_oracle')}
             out['mel'] = mel_leg(dev)
             out['fp32_mode'] = fp32_mode_leg(batch, init_sd, dev, frames)
+            out['fp32_bf16x3_mode'] = fp32_mode_leg(batch, init_sd, dev, frames, warm=3, timed=8, f32_matmul='bf16x3')
             out['ctc'] = ctc_leg(dev)
             out['eval'] = eval_leg(dev)
             out['pipeline'] = pipeline_leg(dev)

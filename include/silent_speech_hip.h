@@ -24,6 +24,8 @@ extern "C" {
 
 #define SS_F32 0
 #define SS_BF16 1
+#define SS_F32X3 3   /* ss_gemm dtype_in only: f32 operands in memory, arithmetic on three bf16 MFMAs per product (operands split
+                        hi + lo in registers, f32 accumulate: 16-17 significant bits per operand instead of 24 / 8) */
 
 const char* ss_last_error(void);
 /* Library/ABI version and the GPU architecture the kernels were compiled for ("gfx950"). */
@@ -84,7 +86,9 @@ typedef struct ss_gemm_epilogue {
  * activation buffers; nn.Linear (architecture.py:51,55,59; transformer.py:32,34); the per-head
  * einsum projections 'tbf,hfa->bhta' / 'bhta,haf->tbf' (transformer.py:96-98,111); and the autograd
  * backward of all of them (transduction_model.py:209): dX = dY.W (b_mode = OC), dW = dY^T.X
- * (a_mode = b_mode = OC, split_k > 1 with atomic f32 accumulation). */
+ * (a_mode = b_mode = OC, split_k > 1 with atomic f32 accumulation).
+ * dtype_in: SS_BF16 (bf16 MFMA), SS_F32 (exact f32 MFMA 16x16x4) or SS_F32X3 (f32 operands, bf16 x 3 MFMA: ~5x the f32 rate at
+ * ~1e-5 relative error per product, the "parity-grade fast mode" of the training plan, ss_plan_set_option 5). */
 int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, const void* B, void* C,
             int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap,
             const ss_gemm_epilogue* epilogue, int split_k, void* stream);
@@ -393,7 +397,7 @@ void ss_plan_destroy(ss_plan* plan);                                /* [host] */
 int ss_plan_slot_count(const ss_plan* plan);                        /* [host] */
 const char* ss_plan_slot_name(const ss_plan* plan, int slot);       /* [host] */
 int ss_plan_bind(ss_plan* plan, int slot, void* device_ptr_or_value); /* [host] slots named *.total / *.all_f32 / *.bytes take integers */
-int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off, 4 BatchNorm backward recomputes the ReLU gate (on) or reads the saved output (off) */
+int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off, 4 BatchNorm backward recomputes the ReLU gate (on) or reads the saved output (off), 5 an SS_F32 plan runs its GEMMs as SS_F32X3 (bf16 x 3 MFMA on f32 operands) on/off (default off = exact f32) */
 int ss_plan_set_reduce_hook(ss_plan* plan, ss_reduce_hook fn, void* user); /* [host] */
 int ss_plan_set_event_hook(ss_plan* plan, ss_event_hook fn, void* user);   /* [host] */
 int64_t ss_plan_ctx_bytes(void);                                    /* [host] */

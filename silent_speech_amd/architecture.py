@@ -48,7 +48,7 @@ class ResBlock(nn.Module):
 
 class Model(nn.Module):
     def __init__(self, num_features, num_outs, num_aux_outs=None, *, model_size=None, num_layers=None, dropout=None,
-                 compute_dtype=torch.bfloat16):
+                 compute_dtype=torch.bfloat16, f32_matmul='exact'):
         super().__init__()
         model_size = FLAGS.model_size if model_size is None else model_size
         num_layers = FLAGS.num_layers if num_layers is None else num_layers
@@ -72,7 +72,10 @@ class Model(nn.Module):
         self.num_outs, self.num_aux_outs = num_outs, num_aux_outs
         if compute_dtype not in (torch.bfloat16, torch.float32):
             raise ValueError('compute_dtype must be torch.bfloat16 or torch.float32')
+        if f32_matmul not in ('exact', 'bf16x3'):
+            raise ValueError("f32_matmul must be 'exact' (f32 MFMA) or 'bf16x3' (f32 storage, three bf16 MFMAs per product)")
         self.compute_dtype = compute_dtype
+        self.f32_matmul = f32_matmul                      # read by the plan when compute_dtype is float32 (engine.py)
         self._weights_version = 0
         self._bn_reduce_fn = None                         # set by the data-parallel wrapper (SyncBN-equivalent statistics)
         self._seed_base, self._step = 0x5EED, 0

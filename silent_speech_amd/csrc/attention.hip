@@ -57,11 +57,30 @@ constexpr int PT_LD = 256 + 8;  // probability tile row length (elements)
 template <class T> struct Frag;
 template <> struct Frag<bf16_t> { bf16x8 v; };
 template <> struct Frag<float> { f32x4 lo, hi; };
+// f32 storage, bf16 x 3 arithmetic (dtype SS_F32X3, per-tile kernels): a fragment is split into hi = bf16(x) and lo = bf16(x - hi) when
+// it is loaded; a product is a_lo.b_hi + a_hi.b_lo + a_hi.b_hi on three bf16 MFMAs (f32 accumulate), see gemm.hip: split_bf16x3.
+struct x3_t;
+template <> struct Frag<x3_t> { bf16x8 hi, lo; };
+template <class MT> struct StorageOf { typedef MT type; };
+template <> struct StorageOf<x3_t> { typedef float type; };
 
 __device__ __forceinline__ void frag_zero(Frag<bf16_t>& f) { bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; f.v = z; }
 __device__ __forceinline__ void frag_zero(Frag<float>& f) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; f.lo = z; f.hi = z; }
 __device__ __forceinline__ void frag_load(Frag<bf16_t>& f, const bf16_t* p) { f.v = *(const bf16x8*)p; }
 __device__ __forceinline__ void frag_load(Frag<float>& f, const float* p) { f.lo = *(const f32x4*)p; f.hi = *(const f32x4*)(p + 4); }
+__device__ __forceinline__ void frag_zero(Frag<x3_t>& f) { bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; f.hi = z; f.lo = z; }
+__device__ __forceinline__ void frag_load(Frag<x3_t>& f, const float* p) {
+    const f32x4 x0 = *(const f32x4*)p, x1 = *(const f32x4*)(p + 4);
+    const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned hp = pack_bf16(v[2 * e], v[2 * e + 1]);
+        h[e] = hp;
+        l[e] = pack_bf16(v[2 * e] - __uint_as_float(hp << 16), v[2 * e + 1] - __uint_as_float(hp & 0xffff0000u));
+    }
+    f.hi = __builtin_bit_cast(bf16x8, h); f.lo = __builtin_bit_cast(bf16x8, l);
+}
 // keep only the first n (0..8) elements
 __device__ __forceinline__ void frag_keep(Frag<bf16_t>& f, int n) {
 #pragma unroll
@@ -71,7 +90,16 @@ __device__ __forceinline__ void frag_keep(Frag<float>& f, int n) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { if (e >= n) f.lo[e] = 0.f; if (e + 4 >= n) f.hi[e] = 0.f; }
 }
+__device__ __forceinline__ void frag_keep(Frag<x3_t>& f, int n) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (e >= n) { f.hi[e] = 0; f.lo[e] = 0; }
+}
 __device__ __forceinline__ f32x4 mma32(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x4 c) { return mfma_bf16_16x16x32(a.v, b.v, c); }
+__device__ __forceinline__ f32x4 mma32(const Frag<x3_t>& a, const Frag<x3_t>& b, f32x4 c) {
+    c = mfma_bf16_16x16x32(a.lo, b.hi, c);
+    c = mfma_bf16_16x16x32(a.hi, b.lo, c);
+    return mfma_bf16_16x16x32(a.hi, b.hi, c);
+}
 __device__ __forceinline__ f32x4 mma32(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) c = mfma_f32_16x16x4(a.lo[e], b.lo[e], c);
@@ -81,17 +109,18 @@ __device__ __forceinline__ f32x4 mma32(const Frag<float>& a, const Frag<float>& 
 }
 
 // fragments of one matrix row (8 consecutive d per lane per 32-deep step); zero if !valid
-template <class T, int DPK>
-__device__ __forceinline__ void row_frags(Frag<T> (&f)[DPK], const T* rowp, bool valid, int lane) {
+template <class T, int DPK, class F>
+__device__ __forceinline__ void row_frags(F (&f)[DPK], const T* rowp, bool valid, int lane) {
 #pragma unroll
     for (int kk = 0; kk < DPK; ++kk) { if (valid) frag_load(f[kk], rowp + kk * 32 + (lane >> 4) * 8); else frag_zero(f[kk]); }
 }
 __device__ __forceinline__ void frag_select(Frag<bf16_t>& f, bool keep) { bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; f.v = keep ? f.v : z; }
 __device__ __forceinline__ void frag_select(Frag<float>& f, bool keep) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; f.lo = keep ? f.lo : z; f.hi = keep ? f.hi : z; }
+__device__ __forceinline__ void frag_select(Frag<x3_t>& f, bool keep) { bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; f.hi = keep ? f.hi : z; f.lo = keep ? f.lo : z; }
 // branch-free variant: always loads (row clamped into [0, nrows)), zeroes by select -> no control flow, so the
 // compiler can hoist the loads of later key blocks above the MFMAs of earlier ones (memory-level parallelism)
-template <class T, int DPK>
-__device__ __forceinline__ void row_frags_nb(Frag<T> (&f)[DPK], const T* base, long long stride, int row, int nrows, int lane) {
+template <class T, int DPK, class F>
+__device__ __forceinline__ void row_frags_nb(F (&f)[DPK], const T* base, long long stride, int row, int nrows, int lane) {
     const bool ok = row >= 0 && row < nrows;
     const int r = row < 0 ? 0 : (row >= nrows ? nrows - 1 : row);
     const T* rowp = base + (long long)r * stride + (lane >> 4) * 8;
@@ -100,22 +129,22 @@ __device__ __forceinline__ void row_frags_nb(Frag<T> (&f)[DPK], const T* base, l
 }
 // 8 consecutive time steps t0..t0+7 of one row of a [..][Tp] transposed copy, zero beyond T
 // branch-free variant (t0 is a multiple of 8, Tp a multiple of 8 and >= Tlen)
-template <class T>
-__device__ __forceinline__ void time_frag_nb(Frag<T>& f, const T* rowp, int t0, int Tlen, int Tp) {
+template <class F, class T>
+__device__ __forceinline__ void time_frag_nb(F& f, const T* rowp, int t0, int Tlen, int Tp) {
     const int tc = t0 > Tp - 8 ? Tp - 8 : t0;
     frag_load(f, rowp + tc);
     int n = Tlen - t0; n = n < 0 ? 0 : (n > 8 ? 8 : n);
     frag_keep(f, tc == t0 ? n : 0);
 }
-template <class T>
-__device__ __forceinline__ void time_frag(Frag<T>& f, const T* rowp, int t0, int Tlen) {
+template <class F, class T>
+__device__ __forceinline__ void time_frag(F& f, const T* rowp, int t0, int Tlen) {
     if (t0 >= Tlen || t0 < 0) { frag_zero(f); return; }
     frag_load(f, rowp + t0);
     if (t0 + 8 > Tlen) frag_keep(f, Tlen - t0);
 }
 
-template <class T, int DPK>
-__device__ __forceinline__ f32x4 dot_frags(const Frag<T> (&a)[DPK], const Frag<T> (&b)[DPK]) {
+template <class T, int DPK, class F>
+__device__ __forceinline__ f32x4 dot_frags(const F (&a)[DPK], const F (&b)[DPK]) {
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < DPK; ++kk) c = mma32(a[kk], b[kk], c);
@@ -160,9 +189,10 @@ __device__ __forceinline__ void finish_logits(const f32x4& s, const float (&pos)
 }  // namespace
 
 // =========================================================================== forward
-template <class T, int DPK>
+template <class MT, int DPK>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p)
 {
+    typedef typename StorageOf<MT>::type T;
     __shared__ __attribute__((aligned(16))) T ptile[4][16][PT_LD];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     int bxi, h, b; attn_block_coord(p.gx, p.H, bxi, h, b);
@@ -180,19 +210,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p)
     const int nb = tile_ok ? (kend - kstart + 15) / 16 : 0;
     const int m_org = kstart - q0 - 15 + (D - 1);
 
-    Frag<T> qf[DPK];
+    Frag<MT> qf[DPK];
     { int qr = q0 + c; qr = qr < Tn ? qr : Tn - 1; row_frags<T, DPK>(qf, Q + (long long)qr * ldq, tile_ok, lane); }
 
     float lg[NB_MAX][4];
     f32x4 rprev;
-    { Frag<T> ef[DPK]; row_frags_nb<T, DPK>(ef, E, dp, m_org + c, 2 * D - 1, lane); rprev = dot_frags<T, DPK>(qf, ef); }
+    { Frag<MT> ef[DPK]; row_frags_nb<T, DPK>(ef, E, dp, m_org + c, 2 * D - 1, lane); rprev = dot_frags<T, DPK>(qf, ef); }
     // All NB_MAX key blocks are computed unconditionally and branch-free (blocks beyond the band are masked to -inf):
     // with no control flow between them the scheduler overlaps the fragment loads of later blocks with the MFMAs,
     // shuffles and softmax prologue of earlier ones.
 #pragma unroll
     for (int j = 0; j < NB_MAX; ++j) {
         const int k0 = kstart + 16 * j;
-        Frag<T> kf[DPK], ef[DPK];
+        Frag<MT> kf[DPK], ef[DPK];
         row_frags_nb<T, DPK>(kf, K, ldq, k0 + c, Tn, lane);
         row_frags_nb<T, DPK>(ef, E, dp, m_org + 16 * (j + 1) + c, 2 * D - 1, lane);
         const f32x4 s = dot_frags<T, DPK>(qf, kf);
@@ -239,10 +269,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p)
     for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; o[n] = z; }
 #pragma unroll
     for (int kc = 0; kc < NB_MAX / 2; ++kc) {
-        Frag<T> pa; frag_load(pa, &ptile[w][c][kc * 32 + g * 8]);
+        Frag<MT> pa; frag_load(pa, &ptile[w][c][kc * 32 + g * 8]);
 #pragma unroll
         for (int n = 0; n < 2 * DPK; ++n) {
-            Frag<T> vb; time_frag_nb(vb, VT + (long long)(n * 16 + c) * p.Tp, kstart + kc * 32 + g * 8, Tn, p.Tp);
+            Frag<MT> vb; time_frag_nb(vb, VT + (long long)(n * 16 + c) * p.Tp, kstart + kc * 32 + g * 8, Tn, p.Tp);
             o[n] = mma32(pa, vb, o[n]);
         }
     }
@@ -301,9 +331,10 @@ __device__ __forceinline__ void prob_ds(const float (&lgt)[4], const f32x4& dpv,
 }
 
 // =========================================================================== backward: query-major (dQ)
-template <class T, int DPK>
+template <class MT, int DPK>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p)
 {
+    typedef typename StorageOf<MT>::type T;
     SS_DYN_SMEM(smem_raw);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
     int bxi, h, b; attn_block_coord(p.gx, p.H, bxi, h, b);
@@ -331,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p)
     // zero the relative-position tile
     for (int i = lane; i < 16 * ldb; i += 64) stf(tileB + i, 0.f);
 
-    Frag<T> qf[DPK], dof[DPK];
+    Frag<MT> qf[DPK], dof[DPK];
     { int qr = q0 + c; qr = qr < Tn ? qr : Tn - 1;
       row_frags<T, DPK>(qf, Q + (long long)qr * ldq, tile_ok, lane);
       row_frags<T, DPK>(dof, dO + (long long)qr * (H * dp), tile_ok, lane); }
@@ -344,13 +375,13 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p)
     }
     wave_lds_sync();
     f32x4 rprev;
-    { Frag<T> ef[DPK]; row_frags_nb<T, DPK>(ef, E, dp, m_org + c, 2 * D - 1, lane); rprev = dot_frags<T, DPK>(qf, ef); }
+    { Frag<MT> ef[DPK]; row_frags_nb<T, DPK>(ef, E, dp, m_org + c, 2 * D - 1, lane); rprev = dot_frags<T, DPK>(qf, ef); }
     // all NB_MAX key blocks, unconditional and branch-free (see attn_fwd_kernel); dS of blocks beyond the band is 0
 #pragma unroll
     for (int j = 0; j < NB_MAX; ++j) {
         const int k0 = kstart + 16 * j;
         float ds[4], pd[4], pos[4], lgt[4];
-        Frag<T> kf[DPK], ef[DPK], vf[DPK];
+        Frag<MT> kf[DPK], ef[DPK], vf[DPK];
         row_frags_nb<T, DPK>(kf, K, ldq, k0 + c, Tn, lane);
         row_frags_nb<T, DPK>(vf, V, ldq, k0 + c, Tn, lane);
         row_frags_nb<T, DPK>(ef, E, dp, m_org + 16 * (j + 1) + c, 2 * D - 1, lane);
@@ -375,9 +406,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p)
     for (int n = 0; n < 2 * DPK; ++n) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[n] = z; }
 #pragma unroll
     for (int kc = 0; kc < NB_MAX / 2; ++kc) {                               // content term: dS . K
-        Frag<T> a; frag_load(a, tileA + c * PT_LD + kc * 32 + g * 8);
+        Frag<MT> a; frag_load(a, tileA + c * PT_LD + kc * 32 + g * 8);
 #pragma unroll
-        for (int n = 0; n < 2 * DPK; ++n) { Frag<T> kb; time_frag_nb(kb, KT + (long long)(n * 16 + c) * p.Tp, kstart + kc * 32 + g * 8, Tn, p.Tp); acc[n] = mma32(a, kb, acc[n]); }
+        for (int n = 0; n < 2 * DPK; ++n) { Frag<MT> kb; time_frag_nb(kb, KT + (long long)(n * 16 + c) * p.Tp, kstart + kc * 32 + g * 8, Tn, p.Tp); acc[n] = mma32(a, kb, acc[n]); }
     }
 #pragma unroll
     for (int n = 0; n < 2 * DPK; ++n) acc[n] = acc[n] * p.scale;
@@ -385,9 +416,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p)
     for (int mc = 0; mc < 7; ++mc) {                                        // positional term: dR . E (unscaled Q); MPt <= 224
         const bool on = mc * 32 < MPt;
         const int mo = on ? mc * 32 : 0;
-        Frag<T> a; frag_load(a, tileB + c * ldb + mo + g * 8); frag_select(a, on);
+        Frag<MT> a; frag_load(a, tileB + c * ldb + mo + g * 8); frag_select(a, on);
 #pragma unroll
-        for (int n = 0; n < 2 * DPK; ++n) { Frag<T> eb; frag_load(eb, ET + (long long)(n * 16 + c) * MPt + mo + g * 8); acc[n] = mma32(a, eb, acc[n]); }
+        for (int n = 0; n < 2 * DPK; ++n) { Frag<MT> eb; frag_load(eb, ET + (long long)(n * 16 + c) * MPt + mo + g * 8); acc[n] = mma32(a, eb, acc[n]); }
     }
     if (tile_ok) {
         T* dQ = (T*)p.dqkv + (long long)b * Tn * ldq + h * dp;
@@ -399,9 +430,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnP p)
 }
 
 // =========================================================================== backward: key-major (dK, dV)
-template <class T, int DPK>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p)
+template <class MT, int DPK>
+__global__ __launch_bounds__(256, DPK <= 3 ? 2 : 1) void attn_bwd_kv_kernel(AttnP p)      // <= 256 registers up to d_head 96: two waves per SIMD (the bf16 x 3 fragments would otherwise take 296)
 {
+    typedef typename StorageOf<MT>::type T;
     __shared__ __attribute__((aligned(16))) T tP[4][16][40];     // [key][32 queries (+pad)]  P~^T
     __shared__ __attribute__((aligned(16))) T tS[4][16][40];     //                           dS^T
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
@@ -423,7 +455,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p)
     const int nqb = tile_ok ? (qend - qstart + 15) / 16 : 0;
     const int npair = (nqb + 1) / 2;
 
-    Frag<T> kf[DPK], vf[DPK];
+    Frag<MT> kf[DPK], vf[DPK];
     { int kr = k0 + c; const bool ok = tile_ok && kr < Tn; kr = kr < Tn ? kr : Tn - 1;
       row_frags<T, DPK>(kf, K + (long long)kr * ldq, ok, lane);
       row_frags<T, DPK>(vf, V + (long long)kr * ldq, ok, lane); }
@@ -439,7 +471,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p)
         for (int half = 0; half < 2; ++half) {
             const int jq = 2 * pr + half, qb0 = qstart + 16 * jq;
             float pd[4], ds[4], pos[4], lgt[4], lse[4], dv[4]; bool rowok[4];
-            Frag<T> qf[DPK], dof[DPK], e0[DPK], e1[DPK];
+            Frag<MT> qf[DPK], dof[DPK], e0[DPK], e1[DPK];
             row_frags_nb<T, DPK>(qf, Q, ldq, qb0 + c, Tn, lane);
             row_frags_nb<T, DPK>(dof, dO, (long long)H * dp, qb0 + c, Tn, lane);
             const int m0 = k0 - qb0 - 15 + (D - 1);
@@ -465,11 +497,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnP p)
         }
         wave_lds_sync();
         {
-            Frag<T> pa, sa; frag_load(pa, &tP[w][c][g * 8]); frag_load(sa, &tS[w][c][g * 8]);
+            Frag<MT> pa, sa; frag_load(pa, &tP[w][c][g * 8]); frag_load(sa, &tS[w][c][g * 8]);
             const int t0 = qstart + 32 * pr + g * 8;
 #pragma unroll
             for (int n = 0; n < 2 * DPK; ++n) {
-                Frag<T> db, qb;
+                Frag<MT> db, qb;
                 time_frag_nb(db, dOT + (long long)(n * 16 + c) * p.Tp, t0, Tn, p.Tp);
                 time_frag_nb(qb, QT + (long long)(n * 16 + c) * p.Tp, t0, Tn, p.Tp);
                 dvv[n] = mma32(pa, db, dvv[n]);
@@ -1743,7 +1775,7 @@ __global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv_res_kernel(AttnP p
 // =========================================================================== host side
 static int attn_check(const char* what, int dtype, int B, int H, int T, int Tp, int dp, int D, float dropout_p)
 {
-    SS_CHECK(dtype == SS_F32 || dtype == SS_BF16, "%s: bad dtype", what);
+    SS_CHECK(dtype == SS_F32 || dtype == SS_BF16 || dtype == SS_F32X3, "%s: bad dtype", what);
     SS_CHECK(B > 0 && H > 0 && T > 0, "%s: empty problem", what);
     SS_CHECK(dp % 32 == 0 && dp >= 32 && dp <= 128, "%s: padded head dim %d must be 32, 64, 96 or 128", what, dp);
     SS_CHECK(H <= 64 && H * dp <= 1024, "%s: H=%d heads x padded dim %d exceeds 1024 columns", what, H, dp);
@@ -1770,6 +1802,11 @@ static void attn_fill(AttnP& p, int B, int H, int T, int Tp, int dp, int D, floa
             else if (dpk == 2) SS_LAUNCH(SS_KERNEL(KERNEL<bf16_t, 2>), grid, dim3(BLK), smem, stream, p);       \
             else if (dpk == 3) SS_LAUNCH(SS_KERNEL(KERNEL<bf16_t, 3>), grid, dim3(BLK), smem, stream, p);       \
             else SS_LAUNCH(SS_KERNEL(KERNEL<bf16_t, 4>), grid, dim3(BLK), smem, stream, p);                     \
+        } else if (dtype == SS_F32X3) {                                                                         \
+            if (dpk == 1) SS_LAUNCH(SS_KERNEL(KERNEL<x3_t, 1>), grid, dim3(BLK), smem, stream, p);              \
+            else if (dpk == 2) SS_LAUNCH(SS_KERNEL(KERNEL<x3_t, 2>), grid, dim3(BLK), smem, stream, p);         \
+            else if (dpk == 3) SS_LAUNCH(SS_KERNEL(KERNEL<x3_t, 3>), grid, dim3(BLK), smem, stream, p);         \
+            else SS_LAUNCH(SS_KERNEL(KERNEL<x3_t, 4>), grid, dim3(BLK), smem, stream, p);                       \
         } else {                                                                                                \
             if (dpk == 1) SS_LAUNCH(SS_KERNEL(KERNEL<float, 1>), grid, dim3(BLK), smem, stream, p);             \
             else if (dpk == 2) SS_LAUNCH(SS_KERNEL(KERNEL<float, 2>), grid, dim3(BLK), smem, stream, p);        \

@@ -34,7 +34,7 @@ int ss_upload_table(void* dst_dev, const void* src_host, size_t bytes, void* str
 
 // ------------------------------------------------------------------ element types
 typedef unsigned short bf16_t;   // raw bfloat16 bits
-enum { SS_F32 = 0, SS_BF16 = 1, SS_F64 = 2 };
+enum { SS_F32 = 0, SS_BF16 = 1, SS_F64 = 2, SS_F32X3 = 3 };
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

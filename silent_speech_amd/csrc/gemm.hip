@@ -247,11 +247,50 @@ struct TileMma<float> {
     }
 };
 
+// f32 operands, bf16 x 3 arithmetic (dtype_in = SS_F32X3): x = hi + lo with hi = bf16(x), lo = bf16(x - hi), and
+//   a.b ~ a_lo.b_hi + a_hi.b_lo + a_hi.b_hi          (the a_lo.b_lo term, 2^-18 of the product, is dropped)
+// on three bf16 MFMAs with f32 accumulation: every product is exact in f32, the operands carry 16-17 significant bits instead of 24.
+// The LDS image stays the f32 one (all four staging modes and the global->LDS copy are unchanged): lane (r, q) reads the same 8
+// consecutive k of its row as the exact kernel, which is precisely the A / B fragment of one 16x16x32 bf16 MFMA; the split is done on
+// the fragments (3 VALU per element: one packed conversion per pair and operand half, the widening and the subtraction).
+__device__ __forceinline__ void split_bf16x3(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
+    const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    u32x4 h, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned hp = pack_bf16(v[2 * p], v[2 * p + 1]);
+        h[p] = hp;
+        l[p] = pack_bf16(v[2 * p] - __uint_as_float(hp << 16), v[2 * p + 1] - __uint_as_float(hp & 0xffff0000u));
+    }
+    hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
+}
+struct TileMmaX3 {
+    static __device__ __forceinline__ void run(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+        const int r = lane & 15, q = lane >> 4;
+        bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            split_bf16x3(*(const f32x4*)(As + swz(wm * 64 + i * 16 + r, q * 2)), *(const f32x4*)(As + swz(wm * 64 + i * 16 + r, q * 2 + 1)), ah[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            split_bf16x3(*(const f32x4*)(Bs + swz(wn * 64 + j * 16 + r, q * 2)), *(const f32x4*)(Bs + swz(wn * 64 + j * 16 + r, q * 2 + 1)), bh[j], bl[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = mfma_bf16_16x16x32(al[i], bh[j], acc[i][j]);        // small terms first
+                acc[i][j] = mfma_bf16_16x16x32(ah[i], bl[j], acc[i][j]);
+                acc[i][j] = mfma_bf16_16x16x32(ah[i], bh[j], acc[i][j]);
+            }
+    }
+};
+
 
 template <bool TR, class S> struct TrSel { typedef S type; };
 template <class S> struct TrSel<true, S> { typedef StageTR type; };
-template <bool TR, class T> struct MmaSel { typedef TileMma<T> type; };
-template <class T> struct MmaSel<true, T> { typedef TileMmaTR type; };
+template <bool TR, class T, int X3> struct MmaSel { typedef TileMma<T> type; };
+template <class T> struct MmaSel<true, T, 0> { typedef TileMmaTR type; };
+template <> struct MmaSel<false, float, 1> { typedef TileMmaX3 type; };
 
 // Work item `it` (tile x K-slice) of a persistent block.  Items are taken G at a time; inside each batch of G the
 // XCD-aware bijective remap keeps consecutive tile ids (which share an A row panel) on one XCD's L2.
@@ -270,7 +309,7 @@ __device__ __forceinline__ void item_coord(int it, int G, int nitems, int ntiles
 // PERSISTENT kernel: gridDim.x = min(#items, 2 blocks x #CUs); each block walks items it, it+G, ...  The global loads of
 // the NEXT item's first K-tiles are issued before the current item's epilogue, so the C-tile store burst, the next
 // tile's cold loads and the launch ramp overlap instead of serialising once per "round" of tiles.
-template <class T, class TO, int AMODE, int BMODE>
+template <class T, class TO, int AMODE, int BMODE, int X3 = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C,
                                                       int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi,
                                                       int k_chunk, int tiles_m, int tiles_n, int nitems)
@@ -285,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
     const int G = gridDim.x, ntiles = tiles_m * tiles_n;
     typedef typename TrSel<TR, typename StagerSel<T, AMODE>::type>::type SA;
     typedef typename TrSel<TR, typename StagerSel<T, BMODE>::type>::type SB;
-    typedef typename MmaSel<TR, T>::type MMA;
+    typedef typename MmaSel<TR, T, X3>::type MMA;
     SA sa; SB sb;
     typename SA::Regs ra0, ra1;
     typename SB::Regs rb0, rb1;
@@ -413,7 +452,7 @@ struct StageG {
     }
 };
 
-template <class T, class TO>
+template <class T, class TO, int X3 = 0>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const T* __restrict__ A, const T* __restrict__ B, TO* __restrict__ C,
                                                            int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi,
                                                            int k_chunk, int tiles_m, int tiles_n, int nitems)
@@ -437,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const T* __restrict__
         for (int s = 0; s < nsteps; ++s) {
             __syncthreads();                                  // tile s has landed in stage `cur`; stage cur^1 is free
             if (s + 1 < nsteps) { sa.issue(lds[cur ^ 1][0]); sb.issue(lds[cur ^ 1][1]); }
-            if (!(epi.debug & 4)) TileMma<T>::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
+            if (!(epi.debug & 4)) MmaSel<false, T, X3>::type::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
             cur ^= 1;
         }
         // `cur` now names the stage NOT read by the last K-tile: the next item's first tile goes there
@@ -720,7 +759,7 @@ static bool pick_gemm8(bool bf16_in, int a_mode, int b_mode, int M, int N, int K
     return true;
 }
 
-template <class T, class TO>
+template <class T, class TO, int X3 = 0>
 static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, void* C, int M, int N, int K,
                        const RowMap& am, const RowMap& bm, const GemmEpi& epi, int split_k, void* stream)
 {
@@ -785,7 +824,7 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
         }
     }
     if (a_mode == OP_KC && b_mode == OP_KC && epi.fast && K % BK == 0 && k_chunk % BK == 0 && !(epi.debug & 8)) {
-        SS_LAUNCH(SS_KERNEL(gemm_glds_kernel<T, TO>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems);
+        SS_LAUNCH(SS_KERNEL(gemm_glds_kernel<T, TO, X3>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems);
         SS_LAUNCH_CHECK("ss_gemm(glds)");
         g_last_kernel = 1;
         return 0;
@@ -793,7 +832,7 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     // (measured: a global_load_lds + XOR-swizzled ds_read_b64_tr_b16 variant of the OC x OC kernel is ~7 % SLOWER than the
     //  register-staged, 288-byte-pitch one below -- the transpose read's banking is not fixed by address swizzles.)
 #define SS_GEMM_CASE(AM, BMD)                                                                                     \
-    SS_LAUNCH(SS_KERNEL(gemm_kernel<T, TO, AM, BMD>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems)
+    SS_LAUNCH(SS_KERNEL(gemm_kernel<T, TO, AM, BMD, X3>), grid, block, 0, stream, (const T*)A, (const T*)B, (TO*)C, M, N, K, am, bm, epi, k_chunk, tiles_m, tiles_n, nitems)
     if (a_mode == OP_KC && b_mode == OP_KC) SS_GEMM_CASE(OP_KC, OP_KC);
     else if (a_mode == OP_KC && b_mode == OP_OC) SS_GEMM_CASE(OP_KC, OP_OC);
     else if (a_mode == OP_OC && b_mode == OP_OC) SS_GEMM_CASE(OP_OC, OP_OC);
@@ -851,9 +890,9 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
     SS_CHECK(A && B && C && amap && bmap && cmap, "ss_gemm: null pointer");
     SS_CHECK(M >= 0 && N >= 0 && K >= 0, "ss_gemm: negative size");
     if (M == 0 || N == 0) return 0;
-    SS_CHECK(dtype_in == SS_F32 || dtype_in == SS_BF16, "ss_gemm: bad input dtype %d", dtype_in);
+    SS_CHECK(dtype_in == SS_F32 || dtype_in == SS_BF16 || dtype_in == SS_F32X3, "ss_gemm: bad input dtype %d", dtype_in);
     SS_CHECK(dtype_out == SS_F32 || dtype_out == SS_BF16, "ss_gemm: bad output dtype %d", dtype_out);
-    SS_CHECK(!(dtype_in == SS_F32 && dtype_out == SS_BF16), "ss_gemm: f32 inputs with bf16 output is not a supported combination");
+    SS_CHECK(!(dtype_in != SS_BF16 && dtype_out == SS_BF16), "ss_gemm: f32 inputs with bf16 output is not a supported combination");
     const int epc = dtype_in == SS_BF16 ? 8 : 4;
     const size_t esz = dtype_in == SS_BF16 ? 2 : 4;
     // 16-byte vector staging: reduction extent (KC) / outer extent (OC) and all strides in whole chunks
@@ -874,6 +913,7 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
     RowMap am = to_rowmap(amap), bm = to_rowmap(bmap);
     if (dtype_in == SS_BF16 && dtype_out == SS_BF16) return launch_gemm<bf16_t, bf16_t>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
     if (dtype_in == SS_BF16 && dtype_out == SS_F32) return launch_gemm<bf16_t, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
+    if (dtype_in == SS_F32X3) return launch_gemm<float, float, 1>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
     return launch_gemm<float, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
 }
 

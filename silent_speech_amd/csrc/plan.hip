@@ -76,7 +76,7 @@ struct Plan {
     PermB unpack_enc, unpack_all;          // heads only | heads + every encoder layer (one launch: runs without the per-layer events)
     reduce_fn hook = 0; void* hook_user = 0;
     event_fn on_event = 0; void* event_user = 0;
-    int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1, regate_on = 1;
+    int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1, regate_on = 1, f32_x3 = 0;
     hipEvent_t ev_fork = 0, ev_join = 0;
     size_t esz() const { return D.dtype == SS_BF16 ? 2 : 4; }
 
@@ -155,7 +155,7 @@ struct Plan {
         void* st = stream ? stream : X.stream;
         const double ob = dt_out == SS_BF16 ? 2.0 : 4.0;
         return timed(X, a_mode == SS_OP_OC && b_mode == SS_OP_OC ? "gemm_dw" : "gemm", 2.0 * M * N * K, ((double)M * K + (double)N * K) * esz() + (double)M * N * ob, st,
-                     [&] { return ss_gemm(D.dtype, dt_out, a_mode, b_mode, A, B, C, M, N, K, &am, &bm, &cm, e, split, st); }, true);
+                     [&] { return ss_gemm(D.dtype == SS_F32 && f32_x3 ? SS_F32X3 : D.dtype, dt_out, a_mode, b_mode, A, B, C, M, N, K, &am, &bm, &cm, e, split, st); }, true);
     }
     int colsum(Exec& X, const void* x, int rows, int C, float* out, void* stream) {
         float* scratch = (float*)X.alloc((size_t)ss_colsum_scratch_floats(rows, C) * 4);
@@ -342,7 +342,7 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         // training: the resident forward leaves its probabilities for the backward kernels (no recomputation of the logits there)
         const size_t pimg_bytes = training ? (size_t)ss_relpos_attention_saved_bytes(dt, B, H, T, dp, Dr) : 0;
         void* pimg = pimg_bytes ? X.alloc(pimg_bytes) : nullptr;
-        if (!X.dry) L_(timed(X, "attn_fwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 3.0, (double)M * 4 * HD * es, stream, [&] { return ss_relpos_attention_forward_p(dt, qkv, qkvT, w.E, o, lse, pimg, B, H, T, Tp, dp, Dr, scale, p_drop, seed, 4 * l, stream); }));
+        if (!X.dry) L_(timed(X, "attn_fwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 3.0, (double)M * 4 * HD * es, stream, [&] { return ss_relpos_attention_forward_p(dt == SS_F32 && f32_x3 ? SS_F32X3 : dt, qkv, qkvT, w.E, o, lse, pimg, B, H, T, Tp, dp, Dr, scale, p_drop, seed, 4 * l, stream); }));
         s.pimg = pimg;
         void* a = X.alloc((size_t)M * d * es);
         L_(gemm(X, dt, o, w.wo, a, M, d, HD, RM(HD), RM(HD), RM(d)));
@@ -440,7 +440,7 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         } else L_(gemm(X, dt, dA, w.woT, dO, M, HD, d, RM(d), RM(d), RM(HD)));
         void* dqkv = X.alloc((size_t)M * 3 * HD * es);
         float* dsc = (float*)X.alloc((size_t)B * H * T * 4);
-        if (!X.dry) L_(timed(X, "attn_bwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 5.0, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_backward_p(dt, s.qkv, s.qkvT, w.E, w.ET, s.o, s.lse, dO, dOT, dsc, dqkv, s.pimg, B, H, T, Tp, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
+        if (!X.dry) L_(timed(X, "attn_bwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 5.0, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_backward_p(dt == SS_F32 && f32_x3 ? SS_F32X3 : dt, s.qkv, s.qkvT, w.E, w.ET, s.o, s.lse, dO, dOT, dsc, dqkv, s.pimg, B, H, T, Tp, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
         L_(grp.add(dqkv, s.x, w.wqkv_stage, 3 * HD, d, M, RM(3 * HD), RM(d), side));
         { ss_gemm_epilogue e = EPI(); e.mode = 1; L_(gemm(X, dt, dqkv, w.wqkvT, G, M, d, 3 * HD, RM(3 * HD), RM(3 * HD), RM(d), &e)); }
         if (l > 0) {                                                             // layer 0's group waits for w_raw_in's gradient
@@ -557,6 +557,7 @@ extern "C" int ss_plan_set_option(ss_plan* h, int what, int value)
     else if (what == 2) { old = h->p->side_blocks; h->p->side_blocks = value >= 1 && value <= 2 ? value : 2; }
     else if (what == 3) { old = h->p->fuse_stats; h->p->fuse_stats = value; }
     else if (what == 4) { old = h->p->regate_on; h->p->regate_on = value; }
+    else if (what == 5) { old = h->p->f32_x3; h->p->f32_x3 = value != 0; }
     return old;
 }
 extern "C" int ss_plan_set_reduce_hook(ss_plan* h, ss_reduce_hook fn, void* user) { SS_CHECK(h, "null plan"); h->p->hook = (reduce_fn)fn; h->p->hook_user = user; return 0; }

@@ -420,6 +420,7 @@ def forward(model, x_raw, training, shift_r, seed):
     shifted = torch.empty_like(x_raw) if (training and shift_r > 0) else None
     buf = ctypes.create_string_buffer(pb.ctx_bytes)
     pb.ws = ws
+    L.ss_plan_set_option(pb.handle, 5, int(model.f32_matmul == 'bf16x3'))
     p_drop = model.dropout_p if training else 0.0
     rc = L.ss_plan_forward(pb.handle, _lib.ptr(x_raw), _lib.ptr(shifted), _lib.ptr(ws), nbytes, B, T0, int(training), int(shift_r if training else 0),
                            float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(head), buf, _lib.stream_of(x_raw))
@@ -445,6 +446,7 @@ def backward(model, ctx, dhead):
     L.ss_plan_set_option(pb.handle, 1, int(os.environ.get('SS_AMD_DW_GROUPED', '1') != '0'))
     L.ss_plan_set_option(pb.handle, 2, int(os.environ.get('SS_AMD_SIDE_BLOCKS', '2')))
     L.ss_plan_set_option(pb.handle, 4, int(os.environ.get('SS_AMD_BN_REGATE', '1') != '0'))
+    L.ss_plan_set_option(pb.handle, 5, int(model.f32_matmul == 'bf16x3'))
     rc = L.ss_plan_backward(pb.handle, ctx.buf, _lib.ptr(dhead), _lib.stream_of(dhead), ctypes.c_void_p(side.cuda_stream) if side is not None else None)
     pb.raise_callback_error()
     _lib.check(rc, 'ss_plan_backward')

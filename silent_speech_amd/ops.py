@@ -99,8 +99,9 @@ def gemm_ex(A, B, C, M, N, K, amap, bmap, cmap, **kw):
 
 
 def _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, extras, a_mode=OP_KC, b_mode=OP_KC, bias=None, relu=False, gate=None,
-               gate_scale=1.0, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0, mode=0, split_k=1, col_perm=None, col_stats=None):
-    """col_stats = (col_sum, col_sumsq or None, col_shift or None): f32 [N] tensors accumulated by the 8-wave kernel's epilogue
+               gate_scale=1.0, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0, mode=0, split_k=1, col_perm=None, col_stats=None, f32_math='exact'):
+    """f32_math (f32 operands only): 'exact' = f32 MFMA, 'bf16x3' = SS_F32X3 (three bf16 MFMAs per product).
+    col_stats = (col_sum, col_sumsq or None, col_shift or None): f32 [N] tensors accumulated by the 8-wave kernel's epilogue
     (RuntimeError when another kernel would run: ask ss_gemm_fuses_column_stats first)."""
     epi = GemmEpilogue()
     if col_stats is not None:
@@ -125,8 +126,14 @@ def _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, extras, a_mode=OP_KC, b_mode=
     if gate is not None:
         assert gate.dtype == C.dtype
 
+    dt_in = _dt(A)
+    if f32_math != 'exact':
+        if f32_math != 'bf16x3' or A.dtype != torch.float32:
+            raise ValueError("f32_math is 'exact' or 'bf16x3', and 'bf16x3' needs float32 operands")
+        dt_in = _lib.SS_F32X3
+
     def launch():
-        rc = _L().ss_gemm(_dt(A), _dt(C), a_mode, b_mode, _p(A), _p(B), _p(C), M, N, K, ctypes.byref(amap), ctypes.byref(bmap),
+        rc = _L().ss_gemm(dt_in, _dt(C), a_mode, b_mode, _p(A), _p(B), _p(C), M, N, K, ctypes.byref(amap), ctypes.byref(bmap),
                           ctypes.byref(cmap), ctypes.byref(epi), split_k, _s(C))
         _lib.check(rc, 'ss_gemm')
     if PROFILER is not None and C.is_cuda:
@@ -262,14 +269,23 @@ def relpos_attention_saved_bytes(dtype, B, H, T, dp, D):
     return int(_L().ss_relpos_attention_saved_bytes(dtype if isinstance(dtype, int) else _lib.dtype_code(dtype), B, H, T, dp, D))
 
 
-def relpos_attention_forward(qkv, qkvT, E, out, lse, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0, saved=None):
-    rc = _L().ss_relpos_attention_forward_p(_dt(qkv), _p(qkv), _p(qkvT), _p(E), _p(out), _p(lse), _p(saved), B, H, T, Tp, dp, D, scale, p,
+def _attn_dt(qkv, f32_math):
+    if f32_math == 'exact':
+        return _dt(qkv)
+    if f32_math != 'bf16x3' or qkv.dtype != torch.float32:
+        raise ValueError("f32_math is 'exact' or 'bf16x3', and 'bf16x3' needs float32 tensors")
+    return _lib.SS_F32X3
+
+
+def relpos_attention_forward(qkv, qkvT, E, out, lse, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0, saved=None, f32_math='exact'):
+    rc = _L().ss_relpos_attention_forward_p(_attn_dt(qkv, f32_math), _p(qkv), _p(qkvT), _p(E), _p(out), _p(lse), _p(saved), B, H, T, Tp, dp, D, scale, p,
                                             int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
     _lib.check(rc, 'ss_relpos_attention_forward')
 
 
-def relpos_attention_backward(qkv, qkvT, E, ET, out, lse, dO, dOT, dscratch, dqkv, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0, saved=None):
-    rc = _L().ss_relpos_attention_backward_p(_dt(qkv), _p(qkv), _p(qkvT), _p(E), _p(ET), _p(out), _p(lse), _p(dO), _p(dOT), _p(dscratch),
+def relpos_attention_backward(qkv, qkvT, E, ET, out, lse, dO, dOT, dscratch, dqkv, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0, saved=None,
+                              f32_math='exact'):
+    rc = _L().ss_relpos_attention_backward_p(_attn_dt(qkv, f32_math), _p(qkv), _p(qkvT), _p(E), _p(ET), _p(out), _p(lse), _p(dO), _p(dOT), _p(dscratch),
                                              _p(dqkv), _p(saved), B, H, T, Tp, dp, D, scale, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
     _lib.check(rc, 'ss_relpos_attention_backward')
 

@@ -78,10 +78,10 @@ def _oracle(cfg2, p, resident, seed, storage=False):
     return out
 
 
-def _step(cfg2, dt, dev, p=0.0):
+def _step(cfg2, dt, dev, p=0.0, f32_matmul='exact'):
     from silent_speech_amd.architecture import Model
     from silent_speech_amd.transduction_model import _pack_batch, dtw_loss
-    m = Model(112, 80, 48, model_size=768, num_layers=6, dropout=p, compute_dtype=dt)
+    m = Model(112, 80, 48, model_size=768, num_layers=6, dropout=p, compute_dtype=dt, f32_matmul=f32_matmul)
     m.load_state_dict(cfg2['sd'], strict=True)
     m.to(dev)
     m.shift_rng = _FixedShift
@@ -134,12 +134,12 @@ def _grad_figures(m, want, yard=None):
     return rows
 
 
-def _full_step_check(cfg2, cuda, dt, p, tag):
+def _full_step_check(cfg2, cuda, dt, p, tag, f32_matmul='exact'):
     """fp32 kernels: north_star's bar (mel-L1 of `pred` < 1e-4 vs the reference function), loss 1e-4 relative, every gradient tensor
     within 2e-3 relative L2 and cosine >= 0.99999.  bf16 kernels (the bench dtype): recorded, and bounded tensor by tensor by twice
     the deviation of the oracle itself under bf16 storage (the yardstick; see tests/test_dropout_parity.py)."""
     f32 = dt == torch.float32
-    m, pred, aux, loss = _step(cfg2, dt, cuda, p)
+    m, pred, aux, loss = _step(cfg2, dt, cuda, p, f32_matmul)
     resident = _lib.lib().ss_relpos_attention_needs_transposed(_lib.dtype_code(dt), 200, m.dp, m.max_rel) == 0
     ref = _oracle(cfg2, p, resident, m.last_seed)
     yard = None if f32 else _oracle(cfg2, p, resident, m.last_seed, storage=True)
@@ -155,13 +155,14 @@ def _full_step_check(cfg2, cuda, dt, p, tag):
                        yard_worst_rel_l2=max(r['yard_rel_l2'] for r in rows.values()),
                        yard_worst_max_err_over_max=max(r['yard_max_err_over_max'] for r in rows.values()))
     _record(tag, payload)
+    g_l2, g_cos = (2e-3, 0.99999) if f32_matmul == 'exact' else (1e-2, 0.9999)
     if f32:
         assert l1 < 1e-4, 'mel-L1 %g' % l1
         assert_close_robust(pred, ref['pred'], 2e-4, name='pred', max_outlier_frac=0)
         assert_close_robust(aux, ref['aux'], 2e-4, name='aux', max_outlier_frac=0)
         assert abs(loss - ref['loss']) < 1e-4 * abs(ref['loss']), (loss, ref['loss'])
         for n, r in rows.items():
-            assert r['rel_l2'] <= 2e-3 and r['cos'] >= 0.99999, (n, r)
+            assert r['rel_l2'] <= g_l2 and r['cos'] >= g_cos, (n, r)
     else:
         assert l1 <= 2.0 * payload['yard_mel_l1'] + 1e-3, (l1, payload['yard_mel_l1'])
         assert_close_robust(pred, ref['pred'], 6e-2, name='pred', max_outlier_frac=1e-3)
@@ -178,6 +179,19 @@ def test_full_step_fp32_vs_oracle(cfg2, cuda):
 def test_full_step_fp32_dropout_vs_oracle(cfg2, cuda):
     """The benchmarked mode (dropout 0.2) in exact-f32 kernels: same bars, masks restated by oracle/dropout_ref.py."""
     _full_step_check(cfg2, cuda, torch.float32, DROP_P, 'fp32_dropout')
+
+
+def test_full_step_fp32_storage_bf16x3_matmul_vs_oracle(cfg2, cuda):
+    """The parity-grade FAST mode (f32 storage between the kernels, every GEMM / attention product on three bf16 MFMAs, f32 accumulate;
+    Model(f32_matmul='bf16x3')): held to north_star's bar like the exact-f32 kernels -- mel-L1 < 1e-4, pred 2e-4, loss 1e-4 -- and every gradient
+    tensor within 1e-2 relative L2 / cosine 0.9999.  Measured: mel-L1 7.9e-6 (exact f32 9e-7, bf16 5.7e-3), median gradient tensor 3.9e-5
+    (1.3e-5 / 4e-3), worst tensor conv_blocks.0.conv1.weight 5.1e-3 (1.5e-3 / 0.15): the 2^-17 operand rounding is amplified by the same
+    path (three BatchNorms, the DTW alignment) that amplifies the f32 rounding of the exact kernels to 1.5e-3."""
+    _full_step_check(cfg2, cuda, torch.float32, 0.0, 'fp32_bf16x3', f32_matmul='bf16x3')
+
+
+def test_full_step_fp32_storage_bf16x3_matmul_dropout_vs_oracle(cfg2, cuda):
+    _full_step_check(cfg2, cuda, torch.float32, DROP_P, 'fp32_bf16x3_dropout', f32_matmul='bf16x3')
 
 
 def test_full_step_bf16_dropout_vs_oracle(cfg2, cuda):

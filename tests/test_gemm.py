@@ -31,6 +31,33 @@ def test_gemm_modes(dev, dt, modes):
     assert_close_robust(C, want, rtol=_tol(dt), name='gemm', max_outlier_frac=0)
 
 
+@pytest.mark.parametrize('modes', [(OP_KC, OP_KC), (OP_KC, OP_OC), (OP_OC, OP_OC), (OP_OC, OP_KC)])
+def test_gemm_f32_operands_bf16x3_arithmetic(dev, modes):
+    """SS_F32X3: f32 operands split hi + lo in registers, three bf16 MFMAs per product.  Measured against the f64 product: the error
+    must sit between the exact-f32 kernel's and 2^-16 of sum |a||b| (an accidental plain-bf16 path would be ~100 x worse: asserted too)."""
+    am, bm = modes
+    big = not is_emu(dev)
+    M, N, K = (520, 264, 328) if big else (136, 72, 104)
+    g = torch.Generator().manual_seed(77 + am * 2 + bm)
+    a = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))       # row scales: the split must hold across magnitudes
+    b = torch.randn(N, K, generator=g)
+    want = a.double() @ b.double().t()
+    scale = a.abs().double() @ b.abs().double().t()
+    A = (a if am == OP_KC else a.t().contiguous()).to(dev)
+    B = (b if bm == OP_KC else b.t().contiguous()).to(dev)
+    errs = {}
+    for math in ('exact', 'bf16x3'):
+        C = torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+        ops.gemm(A, B, C, M, N, K, ops.rowmap(K if am == OP_KC else M), ops.rowmap(K if bm == OP_KC else N), ops.rowmap(N), a_mode=am, b_mode=bm, f32_math=math)
+        errs[math] = float(((C.cpu().double() - want).abs() / scale).max())
+    bf = float(((a.bfloat16().double() @ b.bfloat16().double().t() - want).abs() / scale).max())
+    assert errs['exact'] < 1e-6
+    assert errs['bf16x3'] < 2.0 ** -16, errs
+    assert errs['bf16x3'] < bf / 30, (errs, bf)
+    with pytest.raises(ValueError):
+        ops.gemm(A.bfloat16(), B.bfloat16(), torch.empty(M, N, dtype=torch.bfloat16, device=dev), M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), f32_math='bf16x3')
+
+
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 def test_gemm_epilogue_bias_relu_gate_accumulate(dev, dt):
     M, N, K = 70, 40, 64
