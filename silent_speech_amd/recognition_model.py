@@ -153,12 +153,12 @@ def test(model, testset, device, *, batch_size=1):
     return wer(references, predictions)
 
 
-def train_model(trainset, devset, device, n_epochs=200, *, compute_dtype=torch.bfloat16, max_steps=None):
+def train_model(trainset, devset, device, n_epochs=200, *, compute_dtype=torch.bfloat16, f32_matmul='exact', max_steps=None):
     """:61-117 on the MI355X: batches under a 128 000-sample budget, AdamW (lr 3e-4 in the reference's flags), linear
     warm-up, an optimiser step every SECOND batch (gradients accumulate in the flat .grad arena), MultiStepLR."""
     dataloader = torch.utils.data.DataLoader(trainset, collate_fn=devset.collate_raw, num_workers=0, batch_sampler=SizeAwareSampler(trainset, 128000))
     n_chars = len(devset.text_transform.chars)
-    model = Model(devset.num_features, n_chars + 1, compute_dtype=compute_dtype).to(device)
+    model = Model(devset.num_features, n_chars + 1, compute_dtype=compute_dtype, f32_matmul=f32_matmul).to(device)
     # flag defaults of recognition_model.py:20-28 (they differ from the transduction trainer's)
     lr0, warmup, l2 = FLAGS.lookup('learning_rate', 3e-4), FLAGS.lookup('learning_rate_warmup', 1000), FLAGS.lookup('l2', 0.0)
     out_dir, start = FLAGS.lookup('output_directory', 'output'), FLAGS.lookup('start_training_from', None)

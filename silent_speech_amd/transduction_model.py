@@ -321,7 +321,7 @@ def test(model, testset, device):
     return np.mean(losses), np.mean(accuracies), phoneme_confusion
 
 
-def train_model(trainset, devset, device, save_sound_outputs=True, *, compute_dtype=torch.bfloat16, max_steps=None, data_parallel=None):
+def train_model(trainset, devset, device, save_sound_outputs=True, *, compute_dtype=torch.bfloat16, f32_matmul='exact', max_steps=None, data_parallel=None):
     """transduction_model.py:159-227 on the MI355X.  trainset/devset follow the reference's EMGDataset protocol
     (collate_raw, num_features, num_speech_features, size-aware batches -- see synthetic.SyntheticEMGDataset).
     The vocoder / ASR tail (:175-176,218-225) is outside the hot path: save_sound_outputs is accepted for
@@ -336,7 +336,7 @@ def train_model(trainset, devset, device, save_sound_outputs=True, *, compute_dt
     sampler = SizeAwareSampler(training_subset, 256000, rank=dp.rank, world=dp.world, seed=0) if dp is not None else SizeAwareSampler(training_subset, 256000)
     dataloader = torch.utils.data.DataLoader(training_subset, collate_fn=devset.collate_raw, num_workers=0, batch_sampler=sampler)
     n_phones = len(phoneme_inventory)
-    model = Model(devset.num_features, devset.num_speech_features, n_phones, compute_dtype=compute_dtype).to(device)
+    model = Model(devset.num_features, devset.num_speech_features, n_phones, compute_dtype=compute_dtype, f32_matmul=f32_matmul).to(device)
     if FLAGS.start_training_from is not None:
         model.load_state_dict(torch.load(FLAGS.start_training_from), strict=False)
     if data_parallel is not None:

@@ -27,21 +27,21 @@ def _load(name):
     return z, sd
 
 
-def _build(z, sd, dev, dt):
+def _build(z, sd, dev, dt, f32_matmul='exact'):
     d = sd['w_raw_in.weight'].shape[0]
     L = 0
     while 'transformer.layers.%d.linear1.weight' % L in sd:
         L += 1
-    m = Model(112, 80, 48, model_size=d, num_layers=L, dropout=0.0, compute_dtype=dt)
+    m = Model(112, 80, 48, model_size=d, num_layers=L, dropout=0.0, compute_dtype=dt, f32_matmul=f32_matmul)
     missing, unexpected = m.load_state_dict(sd, strict=True), None      # reference checkpoint loads strictly
     m.to(dev)
     m.shift_rng = _FixedShift(int(z['r']))
     return m
 
 
-def _check(name, dev, dt):
+def _check(name, dev, dt, f32_matmul='exact', keep=None):
     z, sd = _load(name)
-    m = _build(z, sd, dev, dt)
+    m = _build(z, sd, dev, dt, f32_matmul)
     training = bool(z['training'])
     m.train(training)
     x_raw = torch.from_numpy(z['x_raw']).clone().to(dev)
@@ -52,6 +52,8 @@ def _check(name, dev, dt):
     assert_close_robust(pred, z['pred'], ft, name=name + ':pred', max_outlier_frac=0 if f32 else 1e-3)
     assert_close_robust(aux, z['aux'], ft, name=name + ':aux', max_outlier_frac=0 if f32 else 1e-3)
     l1 = float((pred.detach().float().cpu() - torch.from_numpy(z['pred'])).abs().mean())
+    if keep is not None:
+        keep['pred'] = pred.detach().float().cpu().clone()
     if f32:
         assert l1 < 1e-4, 'mel-L1 %g' % l1            # north_star: mel-L1 within 1e-4 of the reference (fp32 kernels)
     if not training:
@@ -83,6 +85,19 @@ def test_model_tiny_fp32(dev):
     _check('model_d16_L1_train_r3_T40', dev, torch.float32)
 
 
+def test_model_tiny_fp32_storage_bf16x3_matmul(dev):
+    """Model(f32_matmul='bf16x3') -- f32 tensors, every GEMM / attention product on three bf16 MFMAs -- against the REFERENCE golden with the
+    exact-f32 bars (forward 2e-4 and mel-L1 < 1e-4, gradients 3e-3, running statistics 1e-4); and the mode is really engaged: its
+    output is not bit-identical to the exact kernels'."""
+    a, b = {}, {}
+    _check('model_d16_L1_train_r3_T40', dev, torch.float32, keep=a)
+    _check('model_d16_L1_train_r3_T40', dev, torch.float32, f32_matmul='bf16x3', keep=b)
+    assert not torch.equal(a['pred'], b['pred'])
+    assert float((a['pred'] - b['pred']).abs().max()) < 1e-3
+    with pytest.raises(ValueError):
+        Model(112, 80, 48, model_size=16, num_layers=1, f32_matmul='tf32')
+
+
 def test_model_tiny_bf16(dev):
     _check('model_d16_L1_train_r3_T40', dev, torch.bfloat16)
 
@@ -90,11 +105,14 @@ def test_model_tiny_bf16(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['model_d8_L1_eval', 'model_d8_L1_train_r0', 'model_d16_L2_train_r3', 'model_d16_L2_train_r7_T120',
                                   'model_d32_L1_train_r5_T200'])
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, 'fp32_bf16x3'])
 def test_model_golden_gpu(name, dt):
     from silent_speech_amd import _lib
     _lib.load()
-    _check(name, torch.device('cuda'), dt)
+    if dt == 'fp32_bf16x3':
+        _check(name, torch.device('cuda'), torch.float32, f32_matmul='bf16x3')
+    else:
+        _check(name, torch.device('cuda'), dt)
 
 
 def test_state_dict_keys_match_reference(dev):

@@ -25,5 +25,9 @@ bash tools/attn_pmc.sh > /dev/null 2>&1; cp gpurun_out/attn_pmc/table.txt $O/att
 ./tools/bin/gemm_bench 20 > $O/gemm_bench.txt 2>&1
 ./tools/bin/gemm_bench 20 epi >> $O/gemm_bench.txt 2>&1
 timeout 300 python tools/host_profile.py 12 > $O/host_profile.txt 2>&1
+# the f32-storage / bf16 x 3 mode: serial kernel trace of its step, and its GEMM against the exact-f32 / bf16 kernels and its own copy floor
+SS_AMD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kx -o kx -- python bench.py --dtype fp32x3 --steps 3 --warmup 1 --cpu-rows 0 --no-legs --no-profile --no-same > $O/kx_bench.log 2>&1
+python tools/rocprof_summary.py $(find $O/kx -name "*.db" | head -1) 4 > $O/x3_kernel_stats.txt; rm -rf $O/kx
+PYTHONPATH=. timeout 300 python tools/x3_gemm_probe.py > $O/x3_gemm_probe.txt 2>&1
 (./tools/bin/dtw_bench 64 1000 10; ./tools/bin/dtw_bench 256 1000 10; SS_DTW_DEBUG=8 ./tools/bin/dtw_bench 64 1000 10; SS_DTW_DEBUG=8 ./tools/bin/dtw_bench 256 1000 10; ./tools/bin/ta_probe) > $O/dtw_bench.txt 2>&1
 cat $O/pytest_gpu.log; cat $O/side_stream_ab.txt; cat $O/mfma_peak.txt; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/gpu_idle_rotated.txt; cat $O/attention_bench.txt; cat $O/dtw_bench.txt
