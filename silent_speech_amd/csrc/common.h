@@ -209,6 +209,14 @@ __device__ __forceinline__ void barrier_keep_vm() {
 #endif
 }
 
+// hand-counted wait on this wave's vector-memory operations (they retire in issue order): at most N still outstanding afterwards
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+#if !defined(SS_EMU)
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+#endif
+}
+
 // LDS transpose read (ds_read_b64_tr_b16): see tools/emu/hipemu.h for the lane map (verified on gfx950)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_ptr) {

@@ -265,23 +265,31 @@ __device__ __forceinline__ void split_bf16x3(const f32x4& x0, const f32x4& x1, b
     hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
 }
 struct TileMmaX3 {
-    static __device__ __forceinline__ void run(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+    struct Frags { bf16x8 ah[4], al[4], bh[4], bl[4]; };
+    // every byte this wave needs from the staged K tile, split: after load() the LDS stage is not touched again by this wave
+    static __device__ __forceinline__ void load(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane, Frags& f) {
         const int r = lane & 15, q = lane >> 4;
-        bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            split_bf16x3(*(const f32x4*)(As + swz(wm * 64 + i * 16 + r, q * 2)), *(const f32x4*)(As + swz(wm * 64 + i * 16 + r, q * 2 + 1)), ah[i], al[i]);
+            split_bf16x3(*(const f32x4*)(As + swz(wm * 64 + i * 16 + r, q * 2)), *(const f32x4*)(As + swz(wm * 64 + i * 16 + r, q * 2 + 1)), f.ah[i], f.al[i]);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            split_bf16x3(*(const f32x4*)(Bs + swz(wn * 64 + j * 16 + r, q * 2)), *(const f32x4*)(Bs + swz(wn * 64 + j * 16 + r, q * 2 + 1)), bh[j], bl[j]);
+            split_bf16x3(*(const f32x4*)(Bs + swz(wn * 64 + j * 16 + r, q * 2)), *(const f32x4*)(Bs + swz(wn * 64 + j * 16 + r, q * 2 + 1)), f.bh[j], f.bl[j]);
+    }
+    static __device__ __forceinline__ void mma(const Frags& f, f32x4 (&acc)[4][4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[i][j] = mfma_bf16_16x16x32(al[i], bh[j], acc[i][j]);        // small terms first
-                acc[i][j] = mfma_bf16_16x16x32(ah[i], bl[j], acc[i][j]);
-                acc[i][j] = mfma_bf16_16x16x32(ah[i], bh[j], acc[i][j]);
+                acc[i][j] = mfma_bf16_16x16x32(f.al[i], f.bh[j], acc[i][j]);        // small terms first
+                acc[i][j] = mfma_bf16_16x16x32(f.ah[i], f.bl[j], acc[i][j]);
+                acc[i][j] = mfma_bf16_16x16x32(f.ah[i], f.bh[j], acc[i][j]);
             }
+    }
+    static __device__ __forceinline__ void run(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
+        Frags f;
+        load(As, Bs, wm, wn, lane, f);
+        mma(f, acc);
     }
 };
 
@@ -473,11 +481,37 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const T* __restrict__
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
-        for (int s = 0; s < nsteps; ++s) {
-            __syncthreads();                                  // tile s has landed in stage `cur`; stage cur^1 is free
-            if (s + 1 < nsteps) { sa.issue(lds[cur ^ 1][0]); sb.issue(lds[cur ^ 1][1]); }
-            if (!(epi.debug & 4)) MmaSel<false, T, X3>::type::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
-            cur ^= 1;
+        if constexpr (X3) {
+            // bf16 x 3: a wave's split fragments of a K tile ARE its whole share of the tile (64 registers), so the stage is handed back to the copy
+            // engine as soon as every wave holds them -- BEFORE the 48 MFMAs -- and the copy of tile s + 2 goes into the stage tile s was just read
+            // from: two K tiles in flight per workgroup on two LDS stages.  Worth 3-8 % (22 000 x 3072 x 768: 458 -> 436 us): the copies are bound by
+            // CU <-> L2 THROUGHPUT, not latency -- the launch with the MMA removed takes 276 us either way (tools/x3_gemm_probe.py: 3.2 GB of tile
+            // bytes = 11.5 TB/s; FETCH_SIZE says 0.4 GB of it misses L2), because a 128 x 128 tile of f32 operands is 32 flop per byte.
+            // Vector-memory operations retire in issue order: with tiles s and s + 1 outstanding (8 copies per thread each), vmcnt(8) is "tile s has landed".
+            for (int s = 0; s < nsteps; ++s) {
+                if (s == 0) {
+                    __syncthreads();                          // tile 0 (requested by the prologue / under the previous item's epilogue) has landed; stage cur^1 is free
+                    if (nsteps > 1) { sa.issue(lds[cur ^ 1][0]); sb.issue(lds[cur ^ 1][1]); }
+                } else {
+                    if (s + 1 < nsteps) wait_vmcnt<8>(); else wait_vmcnt<0>();
+                    barrier_keep_vm();
+                }
+                TileMmaX3::Frags f;
+                TileMmaX3::load(lds[cur][0], lds[cur][1], wm, wn, lane, f);
+                if (s + 2 < nsteps) {
+                    barrier_keep_vm();                        // every wave holds its fragments of tile s
+                    sa.issue(lds[cur][0]); sb.issue(lds[cur][1]);
+                }
+                if (!(epi.debug & 4)) TileMmaX3::mma(f, acc);
+                cur ^= 1;
+            }
+        } else {
+            for (int s = 0; s < nsteps; ++s) {
+                __syncthreads();                              // tile s has landed in stage `cur`; stage cur^1 is free
+                if (s + 1 < nsteps) { sa.issue(lds[cur ^ 1][0]); sb.issue(lds[cur ^ 1][1]); }
+                if (!(epi.debug & 4)) MmaSel<false, T, X3>::type::run(lds[cur][0], lds[cur][1], wm, wn, lane, acc);
+                cur ^= 1;
+            }
         }
         // `cur` now names the stage NOT read by the last K-tile: the next item's first tile goes there
         const int cm0 = m0, cn0 = n0;

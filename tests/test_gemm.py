@@ -58,6 +58,25 @@ def test_gemm_f32_operands_bf16x3_arithmetic(dev, modes):
         ops.gemm(A.bfloat16(), B.bfloat16(), torch.empty(M, N, dtype=torch.bfloat16, device=dev), M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), f32_math='bf16x3')
 
 
+@pytest.mark.parametrize('K', [32, 64, 160])
+def test_gemm_bf16x3_copy_pipeline(dev, K):
+    """The KC x KC bf16 x 3 kernel keeps TWO K tiles in flight on its two LDS stages (a stage is handed back once every wave holds its split
+    fragments): 1, 2 and 5 K steps, more tiles than workgroup slots (the persistent loop's hand-over between items), ragged M / N, bias + ReLU
+    through the LDS-staged epilogue.  Must run the global->LDS kernel (ss_gemm_last_kernel == 1)."""
+    from silent_speech_amd import _lib
+    big = not is_emu(dev)
+    M, N = (70000, 392) if big else (520, 72)
+    g = torch.Generator().manual_seed(K)
+    a = torch.randn(M, K, generator=g); b = torch.randn(N, K, generator=g); bias = torch.randn(N, generator=g)
+    want = torch.relu(a.double() @ b.double().t() + bias.double())
+    scale = a.abs().double() @ b.abs().double().t() + bias.abs().double()
+    C = torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+    ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), bias=bias.to(dev), relu=True, f32_math='bf16x3')
+    assert _lib.lib().ss_gemm_last_kernel() == 1
+    err = float(((C.cpu().double() - want).abs() / scale).max())
+    assert err < 2.0 ** -16, err
+
+
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 def test_gemm_epilogue_bias_relu_gate_accumulate(dev, dt):
     M, N, K = 70, 40, 64
