@@ -81,16 +81,20 @@ def _check(name, dev, dt, f32_matmul='exact', keep=None):
     return l1
 
 
+_exact_pred = {}
+
+
 def test_model_tiny_fp32(dev):
-    _check('model_d16_L1_train_r3_T40', dev, torch.float32)
+    _check('model_d16_L1_train_r3_T40', dev, torch.float32, keep=_exact_pred)
 
 
 def test_model_tiny_fp32_storage_bf16x3_matmul(dev):
     """Model(f32_matmul='bf16x3') -- f32 tensors, every GEMM / attention product on three bf16 MFMAs -- against the REFERENCE golden with the
     exact-f32 bars (forward 2e-4 and mel-L1 < 1e-4, gradients 3e-3, running statistics 1e-4); and the mode is really engaged: its
     output is not bit-identical to the exact kernels'."""
-    a, b = {}, {}
-    _check('model_d16_L1_train_r3_T40', dev, torch.float32, keep=a)
+    a, b = _exact_pred, {}
+    if 'pred' not in a:                                  # (run on its own: the exact kernels' output is needed for the comparison)
+        _check('model_d16_L1_train_r3_T40', dev, torch.float32, keep=a)
     _check('model_d16_L1_train_r3_T40', dev, torch.float32, f32_matmul='bf16x3', keep=b)
     assert not torch.equal(a['pred'], b['pred'])
     assert float((a['pred'] - b['pred']).abs().max()) < 1e-3
