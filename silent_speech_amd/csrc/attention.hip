@@ -47,6 +47,7 @@ struct AttnP {
     float scale;
     unsigned drop_thresh; float drop_scale; unsigned long long seed; unsigned stream;
     int h1;         // hand-scheduled kernels: half-workgroups dispatched FIRST (see res2_block)
+    int persist;    // > 0: persistent schedule of the kernels that stage E -- this many workgroups per head, each walks several sequences of ITS head (see res2_item)
     int tail;       // hand-scheduled kernels: bytes behind the last table (chunk buffers / room for reads that run past the E table)
     int debug;      // SS_ATTN_DEBUG (measurement only): bit 0 skips the operand staging, bit 1 the tile loop of the hand-scheduled forward
 };
@@ -931,6 +932,56 @@ __device__ __forceinline__ void res2_block(const AttnP& p, int& pair, int& half)
     else if (bid < p.h1 + p.gx) { pair = bid - p.h1; half = -1; }
     else { const int hb = bid - p.gx; pair = p.gx + (hb >> 1); half = hb & 1; }
 }
+// The launch parameters re-read from the kernel-argument segment (AttnP is these kernels' only argument).  What the item loop needs to find its next
+// sequence (B, H, the schedule, the operand base pointers) would otherwise stay in scalar registers across the hand-scheduled tile loop, which has none
+// to spare: 48-62 scalars spilled to VGPR lanes and 26 more VGPRs to scratch, + 4 / + 17 us per launch.  An s_load per field and item costs nothing.
+// an opaque copy of a per-thread value: what is computed from it inside a loop stays inside (staging addresses hoisted out of the item loop
+// would live through the tile loop, which has no registers to spare)
+__device__ __forceinline__ int opaque_v(int x) {
+#if !defined(SS_EMU)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+#if defined(SS_EMU)
+typedef const AttnP* AttnArgs;
+__device__ __forceinline__ AttnArgs fresh_args(const AttnP& p) { return &p; }
+#else
+typedef const __attribute__((address_space(4))) AttnP* AttnArgs;
+__device__ __forceinline__ AttnArgs fresh_args(const AttnP&) {
+    AttnArgs k = (AttnArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));                     // opaque: the loads below cannot be hoisted out of the item loop and kept alive
+    return k;
+}
+#endif
+// Persistent schedule (forward, query-major backward: the kernels that keep the embedding table E of a HEAD in LDS).  The grid is H x S workgroups,
+// one per CU: workgroup (h, u) stages E once and walks the sequences b = u, u + S, ... of head h, restaging only K and V -- E is 46 of the 115 KB a
+// (sequence, head) pair needs, and with H = 8 all workgroups of a head sit on one XCD (blocks are dealt round-robin), so its E stays in that L2.
+// The B % S sequences of the last, partial round are split into half-pairs as before (two workgroups share one: each stages K / V and takes every
+// second tile); the first S / 2 workgroups of a head run their half FIRST, the others last, which keeps the two populations half a round apart
+// (they stage in each other's compute phases, see res2_block).  k = 0, 1, ...: the k-th item of this workgroup; false when it has none left.
+template <class A>
+__device__ __forceinline__ bool res2_item(A a, int k, int& pair, int& half) {
+    const int S = a->persist;
+    if (S <= 0) {
+        if (k > 0) return false;
+        const int bid = blockIdx.x, h1 = a->h1, gx = a->gx;                     // res2_block
+        if (bid < h1) { pair = gx + (bid >> 1); half = bid & 1; }
+        else if (bid < h1 + gx) { pair = bid - h1; half = -1; }
+        else { const int hb = bid - gx; pair = gx + (hb >> 1); half = hb & 1; }
+        return true;
+    }
+    const int H = a->H, B = a->B, h = (int)blockIdx.x % H, u = (int)blockIdx.x / H;
+    const int r = B % S, nsplit = (B > S && 2 * r <= S) ? r : 0;                // sequences of the partial round that are split in halves
+    const int Bfull = B - nsplit;                                               // sequences taken whole: b = u, u + S, ... < Bfull
+    const int nfull = u < Bfull ? (Bfull - u + S - 1) / S : 0;
+    const bool has_half = u < 2 * nsplit, half_first = has_half && u < S / 2;
+    int kk = k;
+    if (half_first) { if (kk == 0) { pair = (Bfull + (u >> 1)) * H + h; half = u & 1; return true; } --kk; }
+    if (kk < nfull) { pair = (u + kk * S) * H + h; half = -1; return true; }
+    if (has_half && !half_first && kk == nfull) { pair = (Bfull + (u >> 1)) * H + h; half = u & 1; return true; }
+    return false;
+}
 constexpr int F2_PTB = 32 * 20 * 2;       // bytes of one P~ chunk buffer: [32 keys][16 queries + 4] bf16
 constexpr float MASKED_NAT = -1e8f;       // transformer.py:256-261
 
@@ -1094,26 +1145,33 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res2_kernel(AttnP p)
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + RES2_PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    int pair, half; res2_block(p, pair, half);
-    const int H = p.H, h = pair % H, b = pair / H;
+    const int H = p.H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1;
     unsigned char* lds = (unsigned char*)smem;
     const unsigned VS = 0, KS = VS + Tr * PK, ES = KS + Tr * PK, PT = ES + NE * PK, CT = PT + (unsigned)p.tail;      // tail: chunk buffers, and room for reads past the E table
     int* ctr = (int*)(lds + CT);
     const long long ldq = 3LL * H * dp;
-    const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
-    if (!(p.debug & 1)) {
-        stage_rows<DPK>(lds + KS, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W_FWD * 64);
-        stage_rows<DPK>(lds + VS, PK, Q + 2 * H * dp, ldq, Tn, Tr, tid, RES_W_FWD * 64);
-        stage_rows<DPK>(lds + ES, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE, tid, RES_W_FWD * 64);
-    }
-    if (tid == 0) *ctr = (p.debug & 2) ? nb : 0;
-    __syncthreads();
 #if defined(SS_EMU)
     const unsigned lbase = 0;
 #else
     const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
 #endif
+    int pair, half;
+    for (int item = 0;; ++item) {                                           // one (sequence, head) pair, or the sequences of this workgroup's head (res2_item)
+    const AttnArgs a = fresh_args(p);
+    if (!res2_item(a, item, pair, half)) break;
+    const int h = pair % H, b = pair / H;
+    const RT* Q = (const RT*)a->qkv + (long long)b * Tn * ldq + h * dp;
+    if (item > 0) __syncthreads();                                          // every wave has left the tile loop of the previous sequence: K, V and the counter are free
+    if (!(p.debug & 1)) {
+        const int ts = opaque_v(tid);
+        stage_rows<DPK>(lds + KS, PK, Q + H * dp, ldq, Tn, Tr, ts, RES_W_FWD * 64);
+        stage_rows<DPK>(lds + VS, PK, Q + 2 * H * dp, ldq, Tn, Tr, ts, RES_W_FWD * 64);
+        if (item == 0) stage_rows<DPK>(lds + ES, PK, (const RT*)a->E + (long long)h * NE * dp, dp, NE, NE, ts, RES_W_FWD * 64);      // the head's table: once per workgroup
+    }
+    if (tid == 0) *ctr = (p.debug & 2) ? nb : 0;
+    __syncthreads();
+    const int lane = opaque_v(tid) & 63, c = lane & 15, g = lane >> 4;       // the tile loop's lane constants are formed per item: nothing of them lives through the staging
     unsigned srcb[4]; bool sel[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) { const int r = g * 4 + reg; srcb[reg] = (unsigned)((((c - r + 15) & 15) + 16 * g) * 4); sel[reg] = c + r >= 15; }
@@ -1143,6 +1201,7 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res2_kernel(AttnP p)
         it = itn;
 #pragma unroll
         for (int kk = 0; kk < DPK; ++kk) qf[kk] = qn[kk];
+    }
     }
 }
 
@@ -1288,34 +1347,43 @@ __global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q2_kernel(AttnP p)
     SS_DYN_SMEM(smem);
     constexpr int dp = DPK * 32, PK = dp * 2 + RES2_PAD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
-    int pair, half; res2_block(p, pair, half);
-    const int H = p.H, h = pair % H, b = pair / H;
+    const int H = p.H;
     const int Tn = p.T, D = p.D, nb = (Tn + 15) >> 4, Tr = nb * 16, NE = 2 * D - 1;
     unsigned char* lds = (unsigned char*)smem;
     // [K | V | E | chunk buffers]: V rows past the band continue into E, E rows outside the table into V resp. the (zeroed) buffers: always finite, always met by dS' = 0
     const unsigned KS = 0, VS = KS + Tr * PK, ES = VS + Tr * PK, PT = ES + NE * PK, CT = PT + (unsigned)p.tail;
     int* ctr = (int*)(lds + CT);
     const long long ldq = 3LL * H * dp;
-    const RT* Q = (const RT*)p.qkv + (long long)b * Tn * ldq + h * dp;
-    const RT* dO = (const RT*)p.dO + (long long)b * Tn * (H * dp) + h * dp;
-    {
-        stage_rows<DPK>(lds + KS, PK, Q + H * dp, ldq, Tn, Tr, tid, RES_W_BQ * 64);
-        stage_rows<DPK>(lds + VS, PK, Q + 2 * H * dp, ldq, Tn, Tr, tid, RES_W_BQ * 64);
-        stage_rows<DPK>(lds + ES, PK, (const RT*)p.E + (long long)h * NE * dp, dp, NE, NE, tid, RES_W_BQ * 64);
-        for (unsigned i = PT + tid * 16; i < CT; i += RES_W_BQ * 64 * 16) { u32x4 z = {0u, 0u, 0u, 0u}; *(u32x4*)(lds + i) = z; }
-        if (tid == 0) *ctr = 0;
-    }
-    __syncthreads();
 #if defined(SS_EMU)
     const unsigned lbase = 0;
 #else
     const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
 #endif
+    const float sdrop = p.drop_scale, inv_s = 1.f / sdrop;
+    int pair, half;
+    for (int item = 0;; ++item) {                                           // one (sequence, head) pair, or the sequences of this workgroup's head (res2_item)
+    const AttnArgs a = fresh_args(p);
+    if (!res2_item(a, item, pair, half)) break;
+    const int h = pair % H, b = pair / H;
+    const RT* Q = (const RT*)a->qkv + (long long)b * Tn * ldq + h * dp;
+    const RT* dO = (const RT*)a->dO + (long long)b * Tn * (H * dp) + h * dp;
+    if (item > 0) __syncthreads();                                          // every wave has left the tile loop of the previous sequence
+    {
+        const int ts = opaque_v(tid);
+        stage_rows<DPK>(lds + KS, PK, Q + H * dp, ldq, Tn, Tr, ts, RES_W_BQ * 64);
+        stage_rows<DPK>(lds + VS, PK, Q + 2 * H * dp, ldq, Tn, Tr, ts, RES_W_BQ * 64);
+        if (item == 0) {                                                    // the head's table and the zeroed buffers: once per workgroup
+            stage_rows<DPK>(lds + ES, PK, (const RT*)a->E + (long long)h * NE * dp, dp, NE, NE, ts, RES_W_BQ * 64);
+            for (unsigned i = PT + ts * 16; i < CT; i += RES_W_BQ * 64 * 16) { u32x4 z = {0u, 0u, 0u, 0u}; *(u32x4*)(lds + i) = z; }
+        }
+        if (tid == 0) *ctr = 0;
+    }
+    __syncthreads();
+    const int lane = opaque_v(tid) & 63, c = lane & 15, g = lane >> 4;       // the tile loop's lane constants are formed per item: nothing of them lives through the staging
     unsigned srcb[4]; bool sel[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) { const int r = g * 4 + reg; srcb[reg] = (unsigned)((((c + r + 1) & 15) + 16 * g) * 4); sel[reg] = c <= r; }
     const unsigned ptw = lbase + PT + w * 2 * F2_PTB + (c * 20 + g * 4) * 2, ptr_ = lbase + PT + w * 2 * F2_PTB + (g * 4 + (c >> 2)) * 40 + (c & 3) * 8;
-    const float sdrop = p.drop_scale, inv_s = 1.f / sdrop;
     int it = res_split_index(res_next(ctr, lane), half);
     bf16x8 dof[DPK], don[DPK];
     if (it < nb) { int qr = res_tile_of(it, nb) * 16 + c; qr = qr < Tn ? qr : Tn - 1; glb_row_frags<DPK>(dof, dO + (long long)qr * (H * dp), true, g); }
@@ -1341,6 +1409,7 @@ __global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q2_kernel(AttnP p)
         it = itn;
 #pragma unroll
         for (int kk = 0; kk < DPK; ++kk) dof[kk] = don[kk];
+    }
     }
 }
 
@@ -1856,7 +1925,7 @@ static bool fwd2_enabled() {
     return !(e && e[0] == '0');
 }
 typedef void (*ResKernel)(AttnP);
-static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, void* stream, AttnP p, bool stagger = false) {
+static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, void* stream, AttnP p, bool stagger = false, bool per_head = false) {
     // one workgroup per CU at a time: pairs beyond the last full round of #CU are split in two halves when that shortens it
     static int cus = 0;
     if (!cus) {
@@ -1869,9 +1938,13 @@ static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, 
     const int rem = pairs % cus;
     const bool split = pairs > cus && rem > 0 && 2 * rem <= cus;
     p.gx = split ? pairs - rem : pairs;
-    const int blocks = split ? pairs + rem : pairs;
-    p.h1 = 0;
-    if (stagger && split) { const char* e = getenv("SS_ATTN_STAGGER"); if (!(e && e[0] == '0')) { p.h1 = 2 * rem < cus / 2 ? 2 * rem : (cus / 2) & ~1; } }
+    int blocks = split ? pairs + rem : pairs;
+    p.h1 = 0; p.persist = 0;
+    if (per_head && pairs > cus && cus % p.H == 0 && cus / p.H >= 2) {          // more than one round: one persistent workgroup per CU, S = cus / H per head (res2_item)
+        const char* e = getenv("SS_ATTN_PERSIST");                                // "0": one workgroup per pair (A/B measurements, tests of both)
+        if (!(e && e[0] == '0')) { p.persist = cus / p.H; blocks = cus; }
+    }
+    if (stagger && split && !p.persist) { const char* e = getenv("SS_ATTN_STAGGER"); if (!(e && e[0] == '0')) { p.h1 = 2 * rem < cus / 2 ? 2 * rem : (cus / 2) & ~1; } }
 #if !defined(SS_EMU)
     static size_t granted[48] = {0};
     if (granted[slot] < smem) {
@@ -1935,7 +2008,7 @@ extern "C" int ss_relpos_attention_forward_p(int dtype, const void* qkv, const v
     if (!ss_relpos_attention_needs_transposed(dtype, T, dp, D)) {
         if (fwd2_enabled() && res_smem(3, T, dp, D) <= RES_LDS_MAX) {
             p.tail = (int)res2_tail(3, T, dp, D);
-            if (res_launch(res_pick(3, dp / 32, p.drop_thresh != 0), 24 + dp / 32 + (p.drop_thresh ? 4 : 0), B * H, RES_W_FWD, res_smem(3, T, dp, D), stream, p, true)) return 1;
+            if (res_launch(res_pick(3, dp / 32, p.drop_thresh != 0), 24 + dp / 32 + (p.drop_thresh ? 4 : 0), B * H, RES_W_FWD, res_smem(3, T, dp, D), stream, p, true, true)) return 1;
         } else if (res_launch(res_pick(0, dp / 32, p.drop_thresh != 0), dp / 32 + (p.drop_thresh ? 12 : 0), B * H, RES_W_FWD, res_smem(0, T, dp, D), stream, p)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_forward");
         return 0;
@@ -1974,7 +2047,7 @@ extern "C" int ss_relpos_attention_backward_p(int dtype, const void* qkv, const 
         SS_CHECK(ss_relpos_attention_saved_bytes(dtype, B, H, T, dp, D) > 0, "ss_relpos_attention_backward_p: this shape has no saved probabilities");
         p.pimg = (void*)pimg;
         p.tail = (int)res2_tail(4, T, dp, D);
-        if (res_launch(res_pick(4, dp / 32), 32 + dp / 32, B * H, RES_W_BQ, res_smem(4, T, dp, D), stream, p, true)) return 1;
+        if (res_launch(res_pick(4, dp / 32), 32 + dp / 32, B * H, RES_W_BQ, res_smem(4, T, dp, D), stream, p, true, true)) return 1;
         if (res_launch(res_pick(5, dp / 32), 36 + dp / 32, B * H, RES_W_BKV, res_smem(5, T, dp, D), stream, p, true)) return 1;
         SS_LAUNCH_CHECK("ss_relpos_attention_backward_p");
         return 0;

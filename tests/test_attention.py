@@ -200,6 +200,36 @@ def test_resident_forward_generations_agree(dev, monkeypatch, T, D, dh, p):
     assert_close_robust(res['1'][0], res['0'][0], 2e-2, name='O', max_outlier_frac=0)
 
 
+@pytest.mark.parametrize('p', [0.0, 0.2])
+def test_persistent_per_head_schedule_equals_one_workgroup_per_pair(dev, monkeypatch, p):
+    """More (sequence, head) pairs than CUs: the forward and the query-major backward run ONE persistent workgroup per CU that keeps its
+    head's embedding table in LDS and walks several sequences (whole ones, and a half of one of the last, partial round); SS_ATTN_PERSIST=0
+    is the old one-workgroup-per-pair launch.  Same arithmetic per pair: output, lse, the probability image and dqkv must be bit-identical."""
+    B, H, T, dh, D = (5, 2, 40, 32, 9) if is_emu(dev) else (110, 8, 200, 96, 100)      # emulator: 4 "CUs" -> 2 workgroups per head, 5 = 2 x 2 + a split one
+    dt, dp, Tp = torch.bfloat16, (dh + 31) // 32 * 32, (T + 7) // 8 * 8
+    g = torch.Generator().manual_seed(17)
+    qkv = (torch.randn(B * T, 3 * H * dp, generator=g) * 0.7).to(dt).to(dev)
+    E = (torch.randn(H, 2 * D - 1, dp, generator=g) * dh ** -0.5).to(dt)
+    MPt = (2 * D - 1 + 31) // 32 * 32
+    ET = torch.zeros(H, dp, MPt, dtype=dt); ET[:, :, :2 * D - 1] = E.transpose(1, 2)
+    E, ET = E.to(dev), ET.to(dev)
+    dO = torch.randn(B * T, H * dp, generator=g).to(dt).to(dev)
+    nsaved = ops.relpos_attention_saved_bytes(dt, B, H, T, dp, D)
+    assert nsaved > 0
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('SS_ATTN_PERSIST', mode)
+        out = torch.zeros(B * T, H * dp, dtype=dt, device=dev); lse = torch.zeros(B, H, T, device=dev)
+        saved = torch.zeros(nsaved, dtype=torch.uint8, device=dev)
+        ops.relpos_attention_forward(qkv, None, E, out, lse, B, H, T, Tp, dp, D, 1.0 / math.sqrt(dh), p=p, seed=5, rng_stream=2, saved=saved)
+        dqkv = torch.zeros(B * T, 3 * H * dp, dtype=dt, device=dev); dsc = torch.empty(B, H, T, device=dev)
+        ops.relpos_attention_backward(qkv, None, E, ET, out, lse, dO, None, dsc, dqkv, B, H, T, Tp, dp, D, 1.0 / math.sqrt(dh), p=p, seed=5, rng_stream=2, saved=saved)
+        res[mode] = [t.cpu() for t in (out.view(torch.int16), lse, saved, dqkv.view(torch.int16))]
+    for a, b, name in zip(res['0'], res['1'], ('O', 'lse', 'image', 'dqkv')):
+        assert torch.equal(a, b), name
+    assert float(res['1'][0].float().abs().max()) > 0 and float(res['1'][3].float().abs().max()) > 0
+
+
 def test_transposed_copies_only_needed_by_the_per_tile_kernels(dev):
     """ss_relpos_attention_needs_transposed: bf16 rows of <= 208 frames run the LDS-resident kernels (qkvT / dOT may be NULL);
     f32 and long sequences run the per-tile kernels, which refuse to start without them."""
