@@ -327,6 +327,33 @@ def test_gemm8_column_statistics(dev, gemm_opts, ni, out_dt):
         ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), col_stats=(cs, None, None))
 
 
+@pytest.mark.parametrize('colsum', [False, True])
+def test_gemm8_gate_is_a_sign_test_of_the_saved_activation(dev, gemm_opts, colsum):
+    """The bf16 gate epilogue of the 8-wave kernel (out = gate > 0 ? v * gate_scale : 0, the ReLU / dropout backward of the FFN) with gates of
+    every kind: positive, negative, +0, -0, tiny, huge; bias + ReLU in front and, optionally, the column sums of the stored values
+    (linear1.bias.grad) -- the one gated launch of the training step."""
+    from silent_speech_amd import _lib
+    gemm_opts(ops.GEMM_OPT_G8, 2); gemm_opts(ops.GEMM_OPT_G8_NI, 9)
+    M, N, K = (300, 264, 64) if is_emu(dev) else (5000, 776, 256)
+    g = torch.Generator().manual_seed(21)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16); b = (torch.randn(N, K, generator=g) * 0.2).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    gate = torch.randn(M, N, generator=g)
+    gate[::3, ::5] = 0.0; gate[1::3, ::7] = -0.0; gate[2::5, 1::4] = 1e-30; gate[::7, 2::9] = 3e38; gate[3::11] *= -1
+    gate = gate.to(torch.bfloat16)
+    C = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=dev)
+    cs = torch.full((N,), 2.0, device=dev)
+    kw = dict(col_stats=(cs, None, None)) if colsum else {}
+    ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), bias=bias.to(dev), relu=True, alpha=0.5, gate=gate.to(dev), gate_scale=1.25, **kw)
+    assert _lib.lib().ss_gemm_last_kernel() == 4
+    want = torch.relu(0.5 * (a.float() @ b.float().t()) + bias) * 1.25 * (gate.float() > 0).float()
+    stored = C.float().cpu()
+    assert_close_robust(stored, want, 1.5e-2, name='gated', max_outlier_frac=0)
+    assert torch.equal(stored == 0, (want == 0) | (stored == 0)) and bool(((stored != 0) <= (gate.float() > 0)).all())      # nothing leaks through a closed gate
+    if colsum:
+        assert_close_robust(cs.cpu() - 2.0, stored.sum(0), 2e-5, name='col_sum', max_outlier_frac=0)
+
+
 # ------------------------------------------------------------------ K <= 32: the LDS-free kernel of the first convolution (csrc/gemm_smallk.hip)
 @pytest.mark.parametrize('ktaps', [3, 1])
 @pytest.mark.parametrize('stats', [False, True])

@@ -168,6 +168,16 @@ static void bench_epi(int iters) {
         double cks = 0; for (size_t i = 0; i < hc.size(); i += 7) cks += fabs((double)bf2f(hc[i]));
         printf("epilogue   M=%6d N=%5d K=%5d  %-18s kernel %d  %8.1f us  %7.1f TF   checksum %.9e\n", M, N, K, names[v], ss_gemm_last_kernel(), t, flops / t / 1e6, cks);
     }
+    // where the gate's cost comes from: the same two launches with every output row mapped onto row 0 (the C stores and the gate loads then hit L2:
+    // what is left of the difference is instruction / latency cost, what disappeared was HBM traffic of the epilogue bursts)
+    for (int v = 0; v < 2; ++v) {
+        memset(&a.epi, 0, sizeof(a.epi)); a.epi.alpha = 1.f; a.epi.gate_scale = 1.f;
+        if (v == 1) { a.epi.gate = gate; a.epi.gate_scale = 1.25f; }
+        a.cm = plain(0);
+        const float t = time_us(iters, run_kc, &a);
+        printf("epilogue   M=%6d N=%5d K=%5d  %-18s kernel %d  %8.1f us  %7.1f TF   (timing only: all output rows aliased)\n", M, N, K, v ? "gate, rows -> 0" : "plain, rows -> 0", ss_gemm_last_kernel(), t, flops / t / 1e6);
+        a.cm = plain(N);
+    }
     CK(hipFree(a.A)); CK(hipFree(a.B)); CK(hipFree(a.C)); CK(hipFree(gate)); CK(hipFree(bias)); CK(hipFree(cs));
     // the output map of a convolution: (B, T + 2, C) with a zero halo row at each end of every sequence -> a division per output row
     {
