@@ -200,12 +200,16 @@ def test_resident_forward_generations_agree(dev, monkeypatch, T, D, dh, p):
     assert_close_robust(res['1'][0], res['0'][0], 2e-2, name='O', max_outlier_frac=0)
 
 
-@pytest.mark.parametrize('p', [0.0, 0.2])
-def test_persistent_per_head_schedule_equals_one_workgroup_per_pair(dev, monkeypatch, p):
+@pytest.mark.parametrize('p,BH', [(0.0, (5, 2)), (0.2, (5, 2)), (0.2, (6, 2)), (0.0, (5, 1)), (0.0, (7, 1))])
+def test_persistent_per_head_schedule_equals_one_workgroup_per_pair(dev, monkeypatch, p, BH):
     """More (sequence, head) pairs than CUs: the forward and the query-major backward run ONE persistent workgroup per CU that keeps its
     head's embedding table in LDS and walks several sequences (whole ones, and a half of one of the last, partial round); SS_ATTN_PERSIST=0
     is the old one-workgroup-per-pair launch.  Same arithmetic per pair: output, lse, the probability image and dqkv must be bit-identical."""
-    B, H, T, dh, D = (5, 2, 40, 32, 9) if is_emu(dev) else (110, 8, 200, 96, 100)      # emulator: 4 "CUs" -> 2 workgroups per head, 5 = 2 x 2 + a split one
+    # emulator: 4 "CUs".  (5, 2): 2 workgroups per head, 2 whole sequences each + one split in halves; (6, 2): no partial round; (5, 1): 4 workgroups,
+    # two of them without a half; (7, 1): 3 left over of 4 -> not split (a second whole round for three workgroups).  GPU: the benchmarked launch.
+    if not is_emu(dev) and BH != (5, 2):
+        pytest.skip('emulator-size schedules')
+    B, H, T, dh, D = (BH[0], BH[1], 40, 32, 9) if is_emu(dev) else (110, 8, 200, 96, 100)
     dt, dp, Tp = torch.bfloat16, (dh + 31) // 32 * 32, (T + 7) // 8 * 8
     g = torch.Generator().manual_seed(17)
     qkv = (torch.randn(B * T, 3 * H * dp, generator=g) * 0.7).to(dt).to(dev)
