@@ -167,7 +167,8 @@ def test_recognition_step_at_full_size_vs_oracle():
     """BASELINE configs[4] at its real size: 768-d / 6-layer encoder with a 38-way output on one 128 000-sample batch (~55 rows of 200
     frames, ~20 utterances of up to 860 frames with ~T/6 labels each).  Oracle: oracle/model_ref.model_forward + the reference's own
     loss lines on torch CPU (recognition_model.py:96-101), two of the utterances re-checked with the f64 recursion of oracle/ctc_ref.py.
-    f32 kernels: logits 2e-4, loss 1e-4, every gradient tensor 3e-3 relative L2 / cosine 0.99999; bf16: loss within 2 %, recorded."""
+    f32 kernels: logits 2e-4, loss 1e-4, every gradient tensor 3e-3 relative L2 / cosine 0.99999; f32 storage with bf16 x 3 products: the same
+    forward bars, gradients 1.5e-2 / 0.9999; bf16: loss within 2 %, recorded."""
     import json
     import torch.nn.functional as F
     from oracle import ctc_ref, loss_ref, model_ref
@@ -205,8 +206,8 @@ def test_recognition_step_at_full_size_vs_oracle():
             assert abs(nll - want) < 1e-6 * abs(want)
         off += T
     rec = {}
-    for name, dt in (('fp32', torch.float32), ('bf16', torch.bfloat16)):
-        m = Model(112, 38, model_size=768, num_layers=6, dropout=0.0, compute_dtype=dt)
+    for name, dt, mm in (('fp32', torch.float32, 'exact'), ('fp32_bf16x3', torch.float32, 'bf16x3'), ('bf16', torch.bfloat16, 'exact')):
+        m = Model(112, 38, model_size=768, num_layers=6, dropout=0.0, compute_dtype=dt, f32_matmul=mm)
         m.load_state_dict(sd, strict=True)
         m.to(dev).train()
         m.shift_rng = _FixedShift(3)
@@ -223,8 +224,9 @@ def test_recognition_step_at_full_size_vs_oracle():
         if dt == torch.float32:
             assert_close_robust(pred, logits_ref.detach(), 2e-4, name='logits', max_outlier_frac=0)
             assert abs(float(loss) - float(loss_ref_v)) < 1e-4 * abs(float(loss_ref_v))
+            g_l2, g_cos = (3e-3, 0.99999) if mm == 'exact' else (1.5e-2, 0.9999)          # bf16 x 3 products: the conv-stack tensors sit 3-4 x above the exact kernels
             for n, (rl2, cos) in figs.items():     # 3e-3: half as many frames as the transduction batch average the ReLU-kink flips of the conv stack less (measured 2.1e-3 on conv_blocks.0.conv1)
-                assert rl2 <= 3e-3 and cos >= 0.99999, (n, rl2, cos)
+                assert rl2 <= g_l2 and cos >= g_cos, (n, rl2, cos)
         else:
             assert abs(float(loss) - float(loss_ref_v)) < 2e-2 * abs(float(loss_ref_v))
     out = os.path.join(os.path.dirname(__file__), '..', 'gpurun_out')
