@@ -426,6 +426,92 @@ def pipeline_leg(dev, n_utt=24):
             'cpu_frames_per_s': frames / t_cpu, 'cpu_kind': 'oracle/filter_ref.py + oracle/mel_ref.py (numpy, 1 process; %d of %d recordings timed, scaled)' % (k, n_utt)}
 
 
+def n1_comparison(args, local_rank):
+    """The same command on ONE GPU (this rank's), run by rank 0 after the process group is gone: the N = 1 figure the N-GPU line is read against,
+    measured on the same node in the same call.  No legs, no CPU baseline, no per-launch events."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_PORT', 'GROUP_RANK', 'ROLE_RANK',
+                                                           'TORCHELASTIC_RUN_ID', 'SS_BENCH_LAUNCHER', 'SS_BENCH_SCHEDULE')}
+    env['HIP_VISIBLE_DEVICES'] = env.get('HIP_VISIBLE_DEVICES', '').split(',')[local_rank] if env.get('HIP_VISIBLE_DEVICES') else str(local_rank)
+    if os.environ.get('SS_BENCH_BACKEND', 'nccl') != 'nccl':
+        env.pop('HIP_VISIBLE_DEVICES', None)          # gloo ranks shared the GPUs that exist
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(args.steps), '--warmup', str(args.warmup), '--dtype', args.dtype,
+           '--batches', str(args.batches), '--no-legs', '--no-profile', '--no-same', '--cpu-rows', '0']
+    try:
+        outp = subprocess.check_output(cmd, env=env, timeout=900).decode(errors='replace')
+        d = json.loads([l for l in outp.splitlines() if l.startswith('{')][-1])
+        return {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'n_gpus': 1,
+                'note': 'the same loop on one GPU of this node, run by rank 0 after the N-rank measurement (no legs, no per-launch events)'}
+    except Exception as e:          # noqa: BLE001
+        return {'value': None, 'error': repr(e)[:300]}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun around it: this process becomes the launcher.  It starts N copies of this
+    script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT in the environment, exactly what
+    torch.distributed.run would export), forwards rank 0's JSON line and returns the worst exit code.  Backend: RCCL ('nccl') when the node
+    has a GPU per rank, otherwise gloo ranks sharing the GPUs that exist (a functional run of the N > 1 path; the line says which).
+    Should the two-communicator schedule (gradient buckets on their own RCCL communicator, BatchNorm exchanges on the default one) fail
+    on this RCCL build, the run is repeated ONCE with SS_DP_SINGLE_GROUP=1 and the line records which schedule produced the number."""
+    import socket
+    import subprocess
+    n = args.gpus
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev == 0:
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
+    backend = os.environ.get('SS_BENCH_BACKEND') or ('nccl' if ndev >= n else 'gloo')
+    schedules = [('two_communicators', {})]
+    if os.environ.get('SS_DP_SINGLE_GROUP', '0') == '1':
+        schedules = [('single_communicator', {'SS_DP_SINGLE_GROUP': '1'})]
+    elif backend == 'nccl':
+        schedules.append(('single_communicator', {'SS_DP_SINGLE_GROUP': '1'}))
+    limit = float(os.environ.get('SS_BENCH_LAUNCH_TIMEOUT', '1500'))
+    failures = []
+    for name, extra in schedules:
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                       SS_BENCH_BACKEND=backend, SS_BENCH_SCHEDULE=name, SS_BENCH_LAUNCHER='self', SS_BENCH_FAILED_SCHEDULES=';'.join(failures), **extra)
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        t0, rc, out0 = time.time(), None, b''
+        import threading
+        def drain():                                  # rank 0's stdout is read while it runs (a full pipe would block it)
+            nonlocal out0
+            out0 = procs[0].stdout.read()
+        th = threading.Thread(target=drain, daemon=True); th.start()
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                rc = next(c for c in codes if c not in (None, 0))
+                break
+            if all(c == 0 for c in codes):
+                rc = 0
+                break
+            if time.time() - t0 > limit:
+                rc = 124
+                break
+            time.sleep(0.2)
+        for p in procs:                               # exactly the processes started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill(); p.wait()
+        th.join(timeout=5)
+        lines = [l for l in out0.decode(errors='replace').splitlines() if l.startswith('{')]
+        if rc == 0 and lines:
+            print(lines[-1], flush=True)
+            return 0
+        failures.append('%s: rc %s' % (name, rc))
+        sys.stderr.write('bench.py launcher: schedule %s failed (rc %s)%s\n' % (name, rc, '; retrying with one communicator' if name != schedules[-1][0] else ''))
+    return 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -448,8 +534,10 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args))          # plain `python bench.py --gpus N`: start the N ranks from here
     if args.gpus > 1 and world == 1:
-        raise SystemExit('for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...')
+        raise SystemExit('--gpus %d but WORLD_SIZE=1' % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
     if os.environ.get('SS_BENCH_BACKEND', 'nccl') != 'nccl':
@@ -465,7 +553,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from silent_speech_amd import _lib, engine, ops
+    from silent_speech_amd import _lib, engine, ops, staging
     from silent_speech_amd.architecture import Model
     from silent_speech_amd.data_utils import combine_fixed_length
     from silent_speech_amd.distributed import DataParallel
@@ -514,11 +602,14 @@ def main():
     if not args.no_profile:
         prof = ops.LaunchProfiler()
         ops.PROFILER = prof
+    if dp is not None:
+        dp.measure_exposed = True                  # events on both sides of sync_gradients' waits: the un-hidden part of the gradient all-reduce
+        dp._exposed = []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    host_enqueue = 0.0
+    host_enqueue = ring_wait = 0.0
     pstride = max(5, args.steps // 2)              # per-launch events on two steps of the timed region (every 5th for short runs): they run serially (no side stream)
     timed_frames = 0
     for i in range(args.steps):
@@ -530,10 +621,11 @@ def main():
             prof.enabled = profiled
             L.ss_plan_profile(plan.handle, int(profiled))
             engine.SIDE_STREAM_ENABLED = not profiled
-        th = time.perf_counter()
+        th, tw = time.perf_counter(), staging.WAIT_SECONDS[0]
         loss = step()
         if not profiled:
             host_enqueue += time.perf_counter() - th
+            ring_wait += staging.WAIT_SECONDS[0] - tw
     engine.SIDE_STREAM_ENABLED = True
     L.ss_plan_profile(plan.handle, 0)
     n_plain = args.steps - (len(range(0, args.steps, pstride)) if prof is not None else 0)
@@ -543,6 +635,35 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.PROFILER = None
     final_loss = float(loss.detach())
+    comm = None
+    if dp is not None:
+        exposed = dp.exposed_ms()
+        dp.measure_exposed = False
+        prop = torch.cuda.get_device_properties(dev)
+        mine = {'rank': rank, 'local_rank': local_rank, 'device': dev.index, 'name': prop.name, 'pci_bus_id': getattr(prop, 'pci_bus_id', None),
+                'exposed_ms': exposed, 'pid': os.getpid()}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=dp.host_group)          # host-side (gloo) group: no device traffic
+        backend_used = DataParallel._backend_of(None)
+        nbytes, ncoll = dp.bucket_bytes()
+        rccl_version = None
+        if backend_used == 'nccl':
+            try:
+                rccl_version = '.'.join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:          # noqa: BLE001
+                pass
+        comm = {'rccl': {'backend': backend_used + (' (= RCCL on ROCm)' if backend_used == 'nccl' else ' (ranks share the GPUs that exist: functional run of the N > 1 path, not a scaling figure)'),
+                         'world_size': dist.get_world_size(), 'rccl_version': rccl_version, 'ranks': [{k: e[k] for k in ('rank', 'local_rank', 'device', 'name', 'pci_bus_id')} for e in everyone],
+                         'distinct_devices': len({(e['device'], e['pci_bus_id']) for e in everyone}),
+                         'communicators': {'gradient_buckets': 'own communicator' if dp.bucket_group is not dp.group else 'default communicator',
+                                           'batchnorm_sums': 'default communicator', 'host_counts': 'gloo side group' if dp.host_group is not None else 'default group',
+                                           'count': 2 if dp.bucket_group is not dp.group else 1},
+                         'schedule': dp.schedule, 'launcher': os.environ.get('SS_BENCH_LAUNCHER', 'torch.distributed.run'),
+                         'failed_schedules': [x for x in os.environ.get('SS_BENCH_FAILED_SCHEDULES', '').split(';') if x]},
+                'allreduce': {'bytes_per_step': nbytes, 'buckets': ncoll, 'dtype': 'bf16' if dp.grad_dtype is not None else 'f32',
+                              'layer_buckets': bool(dp.layer_buckets), 'batchnorm_collectives_per_step': 12,
+                              'exposed_ms': max((e['exposed_ms'] or 0.0) for e in everyone), 'exposed_ms_per_rank': [e['exposed_ms'] for e in everyone],
+                              'exposed_note': 'device time the main stream waits in sync_gradients (HIP events on both sides of the waits), mean over the timed steps, max over ranks'}}
 
     # the same loop on ONE batch (what rounds 1-3 timed), un-profiled: how much of a step is per-batch host work / uploads
     # Un-profiled comparison loops after the timed one (the timed loop carries per-launch events on two of its steps, which run
@@ -596,9 +717,14 @@ def main():
                            'ms_per_step_same_batch': same_ms, 'frames_per_s_same_batch': frames / same_ms * 1e3,
                            'note': 'after the timed loop, no per-launch events (the timed loop runs two of its steps serially for the roofline table): '
                                    'the rotating loop again, and batch 0 on every step (what rounds 1-3 timed)'},
-                       'host_enqueue_ms_per_step': host_enqueue / max(n_plain, 1) * 1e3,
-                       'host_enqueue_note': 'host time to enqueue one un-profiled step (forward and backward are one native call each)'},
+                       'host_enqueue_ms_per_step': (host_enqueue - ring_wait) / max(n_plain, 1) * 1e3,
+                       'host_ring_wait_ms_per_step': ring_wait / max(n_plain, 1) * 1e3,
+                       'host_enqueue_note': 'host time to enqueue one un-profiled step (forward and backward are one native call each), EXCLUDING the time the host '
+                                            'sat blocked on the staging ring (a host more than 8 batches ahead of the GPU waits for a slot: back-pressure, reported '
+                                            'separately as host_ring_wait_ms_per_step)'},
         }
+        if comm is not None:
+            out.update(comm)
         if prof is not None:
             psteps = len(range(0, args.steps, pstride))
             rows_buf = (_lib.ProfileRow * 64)()
@@ -679,7 +805,7 @@ def main():
             out['cpu_baseline'] = base
             out['parity'] = parity_entry(sub, ref_pred, init_sd, dev)
             if args.cpu_full:        # SURVEY 8d asks for the identical batch: the whole 110-row step is the headline CPU figure, the bounded
-                full, _, _ = cpu_baseline(batch_cpu, 10 ** 9, 1, 2, init_sd, dev, want_pred=False)        # sample (faster per frame: it fits the caches) rides along
+                full, _, _ = cpu_baseline(batch_cpu, 10 ** 9, 2, 5, init_sd, dev, want_pred=False)        # sample (faster per frame: it fits the caches) rides along
                 full['bounded_sample'] = {k: base[k] for k in ('value', 'unit', 'cores', 'sample')}
                 out['cpu_baseline'] = full
         if world == 1 and not args.no_legs:
@@ -691,9 +817,15 @@ def main():
             out['ctc'] = ctc_leg(dev)
             out['eval'] = eval_leg(dev)
             out['pipeline'] = pipeline_leg(dev)
-        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and os.environ.get('SS_BENCH_N1', '1') != '0':
+            out['n1_comparison'] = n1_comparison(args, local_rank)
+            if out['n1_comparison'].get('value'):
+                out['n1_comparison']['speedup_of_this_line'] = out['value'] / out['n1_comparison']['value']
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -143,7 +143,7 @@ def _declare(lib):
     return lib
 
 
-def load(path=None):
+def load(path=None, _testing=False):
     global _lib, _is_emulator
     path = path or _LIB_PATH
     if not os.path.exists(path):
@@ -156,14 +156,21 @@ def load(path=None):
     if have != ABI_VERSION:
         raise RuntimeError('silent_speech_amd: %s has ABI version %d, this binding needs %d -- rebuild it '
                            '(make -C silent_speech_amd/csrc); struct layouts differ between versions' % (path, have, ABI_VERSION))
+    cdll.ss_target_arch.restype = ctypes.c_char_p
+    arch = cdll.ss_target_arch()
+    if arch != b'gfx950' and not _testing:
+        # the product path has ONE backend; the host-emulator build of the kernel sources is test infrastructure and only enters through
+        # use_library_for_testing (tests/backend.py) -- never through SS_AMD_LIBRARY or a default path
+        raise RuntimeError('silent_speech_amd: %s targets %r, not gfx950 -- the package only loads the MI355X build '
+                           '(SS_AMD_LIBRARY selects between gfx950 builds; the emulator library is for tests/ only)' % (path, arch))
     _lib = _declare(cdll)
-    _is_emulator = _lib.ss_target_arch() != b'gfx950'
+    _is_emulator = arch != b'gfx950'
     return _lib
 
 
 def use_library_for_testing(path):
     """tests/ only: run the same kernel sources on the host emulator (CPU tensors)."""
-    return load(path)
+    return load(path, _testing=True)
 
 
 def lib():

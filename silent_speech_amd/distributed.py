@@ -8,7 +8,8 @@ the contract here is "N-GPU step == 1-GPU step on the concatenated batch":
     collective is enqueued there, under the remaining backward kernels.  The 8 GPUs are fully connected by 7 xGMI links each, so a
     collective of tens of MB drives all links at once; there is no per-parameter bucket traffic.  SS_DP_LAYER_BUCKETS=0 restores the
     single 176 MB encoder bucket of rounds 2-3 (fired after the whole encoder backward); `grad_dtype=torch.bfloat16` halves the bytes
-    on the links (the bucket is cast, all-reduced and added back in f32: one rounding of each rank-sum, 2^-9 relative).
+    on the links (the bucket is cast to bf16, all-reduced in bf16 and copied back into the f32 arena: a ring / tree all-reduce rounds at EVERY hop,
+    so the error grows with the world size -- 1.3e-3 of max|g| measured at 2 gloo ranks, unmeasured on RCCL at 8; off by default).
   * BatchNorm : the reference's batch statistics span the whole batch (architecture.py:19,21,25), so the
     per-channel sums of every BatchNorm (forward: sum, sum-of-squares; backward: sum g, sum g*xhat) are
     all-reduced between the two phases of the HIP kernels (ss_bn_stats_sums/ss_bn_finalize, ss_bn_backward_*).
@@ -58,8 +59,14 @@ class DataParallel(object):
         # gradient buckets on their own communicator: with one group the async buckets and the blocking BatchNorm exchanges
         # share one collective stream, and the main stream's conv backward would stall behind a bucket
         self.bucket_group = group
+        self.schedule = 'single_communicator'
         if self.world > 1 and bucketed and os.environ.get('SS_DP_SINGLE_GROUP', '0') != '1':
             self.bucket_group = dist.new_group(ranks=None if group is None else dist.get_process_group_ranks(group), backend=backend)
+            self.schedule = 'two_communicators'
+        # bench.py: time the main stream spends blocked in sync_gradients (events on both sides of the waits) = the part of the
+        # gradient all-reduce that the backward did not hide
+        self.measure_exposed = False
+        self._exposed = []
 
     @staticmethod
     def _backend_of(group):
@@ -117,13 +124,18 @@ class DataParallel(object):
             self._frames_total = float(local_target_frames) if local_target_frames is not None else None
             return
         pend, self._pending = self._pending, None
-        if pend is not None and pend[0] == local:
+        if pend is not None:
+            # A prefetched exchange is ALWAYS consumed (every rank started it, so every rank waits for it) and never replaced by a
+            # rank-local extra collective: whether the announced counts match is only known locally, and a rank that re-exchanged on its
+            # own would issue a collective nobody joins while the others silently kept a sum containing its stale announcement.
             if pend[1] is not None:
                 pend[1].wait()
+            if pend[0] != local:
+                raise RuntimeError('DataParallel.begin_step: rank %d announced next_counts=%r for this step but was called with %r; next_counts '
+                                   'must be exactly the (rows x frames, target frames) pair of the next begin_step on every rank (pass '
+                                   'next_counts=None when the next batch is not known)' % (self.rank, pend[0], local))
             t = pend[2]
         else:
-            if pend is not None and pend[1] is not None:
-                pend[1].wait()                        # a prefetch for a batch that did not come: drain it (every rank does), then exchange
             t = self._host_sum(torch.tensor(local, dtype=torch.float64))
         self._ratio = float(t[0]) / float(local_rows_b_times_t)
         self._frames_total = float(t[1]) if local_target_frames is not None else None
@@ -195,10 +207,15 @@ class DataParallel(object):
         if self.world == 1:
             return
         _, gflat, n = model.flat_arenas()
+        ev = None
+        if self.measure_exposed and gflat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w, back in self._works:
             w.wait()                                               # the current stream waits for the collective
             if back is not None:
                 a, b, tmp = back
+                tmp.record_stream(torch.cuda.current_stream(gflat.device)) if tmp.is_cuda else None      # allocated under the producing (external) stream, read here
                 gflat[a:b].copy_(tmp)                              # bf16 transport: the rank-sum back into the f32 arena
         # whatever the events did not cover (bucketing off, a model variant without the hook): one more collective
         todo, pos = [], 0
@@ -210,7 +227,24 @@ class DataParallel(object):
             todo.append((pos, n))
         for a, b in todo:
             dist.all_reduce(gflat[a:b], group=self.group)           # losses are already divided by the GLOBAL frame count
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
         self._works, self._covered = [], []
+
+    def exposed_ms(self):
+        """Mean device time per step the main stream sat in sync_gradients (call after a device synchronize); None if never measured."""
+        ms = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return sum(ms) / len(ms) if ms else None
+
+    def bucket_bytes(self):
+        """(bytes all-reduced per step and rank-buffer, number of gradient collectives per step) as attach() laid the buckets out."""
+        if not self._buckets:
+            return 0, 0
+        el = 2 if self.grad_dtype is not None else 4
+        spans = [x for v in self._buckets.values() for x in v]
+        return sum((b - a) * el for a, b in spans), len(spans)
 
     def broadcast_scalars(self, *values):
         """Rank 0's values on every rank (validation loss / accuracy before the LR scheduler: kernels with f32 atomics can differ

@@ -14,9 +14,12 @@ import torch
 
 from . import _lib
 
+import time
+
 _SLOTS = 8
 _ALIGN = 16
 _rings = {}
+WAIT_SECONDS = [0.0]          # host time spent blocked on a slot's event (back-pressure of a host that runs > 8 steps ahead), for bench.py's enqueue figure
 
 
 class _Ring(object):
@@ -30,8 +33,10 @@ class _Ring(object):
         i = self.at
         self.at = (i + 1) % _SLOTS
         ev = self.events[i]
-        if ev is not None:
+        if ev is not None and not ev.query():
+            t0 = time.perf_counter()
             ev.synchronize()
+            WAIT_SECONDS[0] += time.perf_counter() - t0
         buf = self.bufs[i]
         if buf is None or buf.numel() < nbytes:
             cap = 1 << max(16, int(nbytes - 1).bit_length())

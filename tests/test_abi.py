@@ -68,6 +68,19 @@ def test_missing_library_fails_loudly(tmp_path):
     _lib.load()
 
 
+def test_emulator_library_is_refused_by_the_product_loader():
+    """Only tests may run the host-emulator build (use_library_for_testing); load() -- and therefore SS_AMD_LIBRARY -- takes gfx950 builds only."""
+    from silent_speech_amd import _lib
+    from tests.backend import EMU, _ensure_emu
+    _ensure_emu()
+    with pytest.raises(RuntimeError, match='not gfx950'):
+        _lib.load(EMU)
+    _lib.use_library_for_testing(EMU)
+    assert _lib.is_emulator()
+    _lib.load()
+    assert not _lib.is_emulator()
+
+
 def test_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, 'silent_speech_amd')
     for dp, _, fs in os.walk(pkg):

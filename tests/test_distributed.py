@@ -82,6 +82,21 @@ def test_single_encoder_bucket_bf16_transport_and_count_prefetch(tmp_path):
         f.write('max |g_bf16 - g_f32| / max |g| = %.3e\n' % err)
 
 
+def test_wrong_next_counts_raise_on_the_announcing_rank_only(tmp_path):
+    """The prefetched count exchange is always consumed; a rank whose announced next_counts do not match what it is called with raises
+    instead of issuing a rank-local extra collective (round-4 advisor finding: that collective had no partner and the job hung)."""
+    _ensure_emu()
+    worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
+    port = str(_free_port())
+    out = str(tmp_path / 'bad')
+    env = dict(os.environ, OMP_NUM_THREADS='1', SS_DP_BAD_PREFETCH='1', SS_DP_DEVICE='none')
+    procs = [subprocess.Popen([sys.executable, worker, out], env=dict(env, WORLD_SIZE='2', RANK=str(r), MASTER_PORT=port, MASTER_ADDR='127.0.0.1')) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    assert open(out + '.rank0').read() == 'ok'
+    assert open(out + '.rank1').read().startswith('raised: DataParallel.begin_step: rank 1 announced')
+
+
 def test_four_rank_step_equals_single_process_unbucketed(tmp_path):
     _ensure_emu()
     _ranks_vs_single(tmp_path, {'SS_DP_BUCKETED': '0'}, 4)

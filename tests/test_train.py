@@ -114,3 +114,31 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
         d = json.loads(line)
         assert d['n_gpus'] == 2 and d['scaling'] == scaling and d['steps'] == 3 and d['value'] > 0
         assert d['config']['parallelism'] == 'dp2' and d['config']['final_loss'] == d['config']['final_loss']
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT torchrun: bench.py starts its own ranks (free port, MASTER_ADDR 127.0.0.1, LOCAL_RANK -> device; gloo ranks
+    sharing the GPU when the box has fewer GPUs than ranks) and the rank-0 line carries what an N > 1 line is judged on: the backend and devices as the
+    process group reports them, the communicators, the all-reduce bytes / bucket count / exposed time, and an N = 1 figure from the same call.
+    `--gpus 1` goes through the same entry."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    if torch.cuda.device_count() < 2:
+        env['SS_BENCH_BACKEND'] = 'gloo'
+    out = subprocess.check_output([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-profile', '--no-legs'],
+                                  env=env, timeout=900).decode()
+    d = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0 and d['config']['parallelism'] == 'dp2'
+    assert d['rccl']['world_size'] == 2 and len(d['rccl']['ranks']) == 2 and d['rccl']['launcher'] == 'self'
+    assert d['rccl']['schedule'] in ('two_communicators', 'single_communicator') and d['rccl']['communicators']['count'] in (1, 2)
+    assert d['allreduce']['buckets'] >= 10 and 2.0e8 < d['allreduce']['bytes_per_step'] < 2.3e8          # the 53 M-float gradient arena in f32
+    assert d['allreduce']['exposed_ms'] is not None and d['allreduce']['exposed_ms'] >= 0.0
+    assert d['n1_comparison']['value'] and d['n1_comparison']['n_gpus'] == 1 and d['n1_comparison']['speedup_of_this_line'] > 0
+    out = subprocess.check_output([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-legs', '--cpu-rows', '0'],
+                                  env=env, timeout=600).decode()
+    d1 = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+    assert d1['n_gpus'] == 1 and 'rccl' not in d1 and d1['roofline']['frac'] > 0
