@@ -277,6 +277,12 @@ int ss_silent_loss(const float* head, int64_t ld, int n_mel, int n_phone, const 
                    const int64_t* phones, const int32_t* results, const int32_t* tgt_row, const int32_t* pred_base,
                    const int32_t* res_idx, int nframes, float lam, float inv_total, float* dhead, float* loss_accum,
                    int32_t* correct_accum, void* stream);
+/* Phoneme confusion matrix of the evaluation path (transduction_model.py:130-137 silent, :147-152 voiced), accumulated ON the device:
+ * confusion[pred * n_phone + target] += 1 for every target frame, pred = argmax (ss_frame_lse) of the aligned prediction row -- through
+ * `results` (ss_dtw_align_skewed) for silent utterances.  Index tables as produced by ss_loss_index_tables; int32 matrix, += . */
+int ss_phoneme_confusion(const int32_t* argmax, const int64_t* phones, const int32_t* results, const int32_t* vo_pred, const int32_t* vo_tgt,
+                         int n_voiced, const int32_t* si_tgt, const int32_t* si_base, const int32_t* si_res, int n_silent_frames,
+                         int32_t* confusion, int n_phone, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CTC loss of the recognition trainer ("next" row N1): replaces F.log_softmax + pad_sequence(decollate_tensor(...))

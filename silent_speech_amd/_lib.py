@@ -85,6 +85,7 @@ SIGNATURES = {
     'ss_voiced_loss': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],
     'ss_silent_cost_skewed': [_P, _L, _I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
     'ss_silent_loss': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P],
+    'ss_phoneme_confusion': [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _P],
     'ss_ctc_loss': [_P, _L, _I, _I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P],
     'ss_adamw_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     'ss_cast_f32': [_P, _P, _I, _L, _P],

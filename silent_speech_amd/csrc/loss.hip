@@ -301,3 +301,36 @@ extern "C" int ss_silent_loss(const float* head, int64_t ld, int n_mel, int n_ph
     SS_LAUNCH_CHECK("ss_silent_loss");
     return 0;
 }
+
+// ---------------------------------------------------------------- phoneme confusion matrix (evaluation), accumulated on the device
+// transduction_model.py:130-137 (silent: predictions gathered through the DTW alignment) and :147-152 (voiced): confusion[pred][target] += 1
+// per target frame.  One thread per frame of the two index tables, one integer atomic each; the matrix stays on the device across batches,
+// so test() reads it back ONCE per epoch (the reference calls .item() / .cpu() per utterance).
+__global__ void phoneme_confusion_kernel(const int* __restrict__ amax, const long long* __restrict__ phones, const int* __restrict__ results,
+                                         const int* __restrict__ vo_pred, const int* __restrict__ vo_tgt, int n_voiced,
+                                         const int* __restrict__ si_tgt, const int* __restrict__ si_base, const int* __restrict__ si_res, int n_silent,
+                                         int* __restrict__ conf, int n_phone)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_voiced + n_silent; i += gridDim.x * blockDim.x) {
+        int p, t;
+        if (i < n_voiced) { p = amax[vo_pred[i]]; t = (int)phones[vo_tgt[i]]; }
+        else { const int k = i - n_voiced; p = amax[si_base[k] + results[si_res[k]]]; t = (int)phones[si_tgt[k]]; }
+        if ((unsigned)p < (unsigned)n_phone && (unsigned)t < (unsigned)n_phone) atomicAdd(conf + p * n_phone + t, 1);
+    }
+}
+
+extern "C" int ss_phoneme_confusion(const int32_t* argmax, const int64_t* phones, const int32_t* results, const int32_t* vo_pred, const int32_t* vo_tgt,
+                                    int n_voiced, const int32_t* si_tgt, const int32_t* si_base, const int32_t* si_res, int n_silent_frames,
+                                    int32_t* confusion, int n_phone, void* stream)
+{
+    SS_CHECK(argmax && phones && confusion, "ss_phoneme_confusion: null pointer");
+    SS_CHECK(n_voiced == 0 || (vo_pred && vo_tgt), "ss_phoneme_confusion: voiced tables missing");
+    SS_CHECK(n_silent_frames == 0 || (results && si_tgt && si_base && si_res), "ss_phoneme_confusion: silent tables missing");
+    const int n = n_voiced + n_silent_frames;
+    if (n <= 0) return 0;
+    int blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+    SS_LAUNCH(phoneme_confusion_kernel, dim3(blocks), dim3(256), 0, stream, argmax, (const long long*)phones, results, vo_pred, vo_tgt, n_voiced,
+              si_tgt, si_base, si_res, n_silent_frames, confusion, n_phone);
+    SS_LAUNCH_CHECK("ss_phoneme_confusion");
+    return 0;
+}

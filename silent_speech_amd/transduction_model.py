@@ -176,21 +176,39 @@ def dtw_loss(predictions, phoneme_predictions, example, phoneme_eval=False, phon
     loss, correct, plan = _dtw_loss_plan(predictions, phoneme_predictions, example, lam, total_length)
     if not phoneme_eval:
         return loss, correct[0].float() / plan.total_length
-    # ---- evaluation extras: host-side confusion matrix (transduction_model.py:130-137,147-152)
+    # ---- evaluation extras: the confusion matrix (transduction_model.py:130-137,147-152)
+    if isinstance(phoneme_confusion, DeviceConfusion):
+        # accumulated on the device (one launch, integer atomics), no synchronisation: test() reads the matrix back once per epoch,
+        # and the accuracy stays a device scalar until then
+        phoneme_confusion.add(plan)
+        return loss, correct[0].float() / plan.total_length
     acc = float(correct.item()) / plan.total_length
     if phoneme_confusion is not None:
-        amax = plan.argmax.cpu().numpy()
-        res = plan.results.cpu().numpy() if plan.results is not None else None
-        ro = 0
-        for u, (n1, n2, s) in enumerate(zip(plan.lengths, plan.t2, plan.silent)):
-            tgt = example['phonemes'][u].cpu().numpy()
-            if s:
-                p = amax[plan.pred_off[u] + res[ro:ro + n2]]
-                ro += n2
-            else:
-                p = amax[plan.pred_off[u]:plan.pred_off[u] + n1]
-            np.add.at(phoneme_confusion, (p, tgt), 1)
+        # a numpy matrix handed in by a caller written against the reference: filled through the same device kernel, one copy back
+        dc = DeviceConfusion(phoneme_confusion.shape[0], predictions.device)
+        dc.add(plan)
+        phoneme_confusion += dc.numpy().astype(phoneme_confusion.dtype)
     return loss, acc
+
+
+class DeviceConfusion(object):
+    """The phoneme confusion matrix of an evaluation pass, kept on the device (int32, [predicted][target]); dtw_loss(..., phoneme_eval=True,
+    phoneme_confusion=<this>) adds a batch with one kernel launch and without a host synchronisation."""
+
+    def __init__(self, n_phone, device):
+        self.n = int(n_phone)
+        self.mat = torch.zeros(self.n * self.n, dtype=torch.int32, device=device)
+
+    def add(self, plan):
+        L = _lib.lib()
+        res = plan.results if plan.results is not None else None
+        _lib.check(L.ss_phoneme_confusion(_lib.ptr(plan.argmax), _lib.ptr(plan.phones), _lib.ptr(res), _lib.ptr(plan.vo_pred), _lib.ptr(plan.vo_tgt),
+                                          plan.n_voiced, _lib.ptr(plan.si_tgt), _lib.ptr(plan.si_base), _lib.ptr(plan.si_res),
+                                          plan.n_silent_frames if res is not None else 0, _lib.ptr(self.mat), self.n, _lib.stream_of(self.mat)),
+                   'ss_phoneme_confusion')
+
+    def numpy(self):
+        return self.mat.view(self.n, self.n).cpu().numpy()
 
 
 class EnsembleModel(torch.nn.Module):
@@ -309,14 +327,17 @@ def test(model, testset, device):
     model.eval()
     dataloader = torch.utils.data.DataLoader(testset, batch_size=32, collate_fn=testset.collate_raw)
     losses, accuracies = [], []
-    phoneme_confusion = np.zeros((len(phoneme_inventory), len(phoneme_inventory)))
+    confusion = DeviceConfusion(len(phoneme_inventory), device)      # accumulated on the device: ONE read-back per epoch
     with torch.no_grad():
         for batch in dataloader:
             X, X_raw, sess = _pack_batch(batch, device)
             pred, phoneme_pred = model(X, X_raw, sess)
-            loss, phon_acc = dtw_loss(pred, phoneme_pred, batch, True, phoneme_confusion)
-            losses.append(loss.item())
-            accuracies.append(phon_acc)
+            loss, phon_acc = dtw_loss(pred, phoneme_pred, batch, True, confusion)
+            losses.append(loss.detach().reshape(1))
+            accuracies.append(phon_acc.reshape(1))
+    phoneme_confusion = confusion.numpy().astype(np.float64)          # the reference's matrix is np.zeros(...) float64
+    losses = torch.cat(losses).cpu().numpy() if losses else np.zeros(0)
+    accuracies = torch.cat(accuracies).cpu().numpy() if accuracies else np.zeros(0)
     model.train()
     return np.mean(losses), np.mean(accuracies), phoneme_confusion
 

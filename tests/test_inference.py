@@ -69,6 +69,46 @@ def test_get_aligned_prediction_silent_and_voiced(dev):
     assert_close_robust(out, norm.inverse(want[0][align]), 2e-4, name='silent', max_outlier_frac=0)
 
 
+def test_confusion_matrix_on_the_device_equals_the_host_loop(dev):
+    """transduction_model.py:130-137,147-152: confusion[pred][target] += 1 per target frame, through the DTW alignment for silent utterances.
+    The device kernel (ss_phoneme_confusion; what test() accumulates into, one read-back per epoch) against the reference's per-utterance host
+    loop on a mixed silent / voiced batch, and the numpy-matrix form of the dtw_loss argument."""
+    from oracle import loss_ref
+    from silent_speech_amd.synthetic import SyntheticEMGDataset, make_utterance
+    m, sd = _model(dev)
+    m.eval()
+    rng = np.random.default_rng(11)
+    batch = SyntheticEMGDataset.collate_raw([make_utterance(rng, 30, False), make_utterance(rng, 26, True), make_utterance(rng, 41, True),
+                                             make_utterance(rng, 23, False)])
+    batch = {k: ([t.to(dev) for t in v] if isinstance(v, list) and len(v) and torch.is_tensor(v[0]) else v) for k, v in batch.items()}
+    dc = tm.DeviceConfusion(48, dev)
+    host = np.zeros((48, 48))
+    with torch.no_grad():
+        for rep in range(2):                                # two batches accumulate into one device matrix
+            X, X_raw, sess = tm._pack_batch(batch, dev, seq_len=40)
+            pred, aux = m(X, X_raw, sess)
+            loss, acc = tm.dtw_loss(pred, aux, batch, True, dc, phoneme_loss_weight=0.5)
+            assert torch.is_tensor(acc)                     # no host synchronisation on this path
+            X, X_raw, sess = tm._pack_batch(batch, dev, seq_len=40)
+            pred, aux = m(X, X_raw, sess)
+            loss2, acc2 = tm.dtw_loss(pred, aux, batch, True, host, phoneme_loss_weight=0.5)
+            assert isinstance(acc2, float) and abs(acc2 - float(acc)) < 1e-6
+        # the reference's loop on the oracle's predictions
+        cpu = {k: ([t.cpu() for t in v] if isinstance(v, list) and len(v) and torch.is_tensor(v[0]) else v) for k, v in batch.items()}
+        xr = loss_ref.combine_fixed_length(cpu['raw_emg'], 320)
+        pr, ar = model_ref.model_forward(sd, xr, training=False)
+        want = np.zeros((48, 48))
+        _, _, aligns = loss_ref.dtw_loss_ref(pr, ar, cpu, lam=0.5, return_alignments=True)
+        pps = loss_ref.decollate_tensor(ar, cpu['lengths'])
+        for pp, yp, al in zip(pps, cpu['phonemes'], aligns):            # transduction_model.py:130-137 (silent: through the alignment), :147-152
+            p = pp.argmax(-1).numpy()
+            np.add.at(want, (p[al] if al is not None else p, yp.numpy()), 1)
+    got = dc.numpy()
+    assert got.sum() == 2 * sum(int(a.shape[0]) for a in cpu['audio_features'])
+    assert np.array_equal(got, host.astype(np.int64))
+    assert np.array_equal(got, 2 * want.astype(np.int64))
+
+
 def test_ensemble_model_averages(dev):
     m1, sd1 = _model(dev)
     m2, sd2 = _model(dev, seed_shift=0.02)
