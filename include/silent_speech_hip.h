@@ -32,7 +32,7 @@ const char* ss_last_error(void);
 /* Bumped whenever a struct layout or an entry-point signature changes (3: ss_gemm_epilogue column-statistics fields, the plan /
  * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative; 4: ss_loss_index_tables; 5: gate recomputation arguments of ss_bn_backward_sums / ss_bn_backward_apply).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
  * library paired with newer headers would otherwise read garbage struct fields instead of failing. */
-#define SS_ABI_VERSION 5
+#define SS_ABI_VERSION 6
 int ss_abi_version(void);
 const char* ss_target_arch(void);
 
@@ -335,10 +335,19 @@ int ss_stft_magnitude(const float* spec, int64_t ld_spec, int n_bins, float* mag
  * 0 if the LDS-resident kernels run (bf16, T <= 208, operands fit the 160 KB LDS): then qkvT and dOT may be NULL and the
  * producing GEMMs need not emit them. */
 int ss_relpos_attention_needs_transposed(int dtype, int T, int dp, int D); /* [host] */
-int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse,
+/* Which kernels (dtype, T, dp, D) runs: 0 = per-tile (qkvT / dOT needed), 1 = LDS-resident 16 x 16 tiles, 2 = transposed 32 x 32 score
+ * tiles (bf16, T <= 224: csrc/attention_t.hip).  Family 2 reads the embeddings from a prepared table instead of E / ET:
+ * ss_relpos_attention_table_bytes() bytes, filled by ss_relpos_attention_prepare_tables from the f32 parameter
+ * (transformer.py:172-176 `embeddings`, [H][2D-1][dh] contiguous; scale = 1/sqrt(d_qkv) as in the calls below) -- E / scale in
+ * MFMA-fragment order, so that Q.E accumulates in the same accumulator as Q.K and the table streams from L2 as whole KiB.
+ * `tab` may be NULL for families 0 and 1; E / ET / qkvT / dOT may be NULL for family 2. */
+int ss_relpos_attention_family(int dtype, int T, int dp, int D); /* [host] */
+int64_t ss_relpos_attention_table_bytes(int H, int dp, int D); /* [host] */
+int ss_relpos_attention_prepare_tables(const float* emb, void* tab, int H, int D, int dh, int dp, float scale, void* stream);
+int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, const void* tab, void* out, float* lse,
                                 int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
                                 uint32_t rng_stream, void* stream);
-int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* out,
+int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* tab, const void* out,
                                  const float* lse, const void* dO, const void* dOT, float* Dscratch, void* dqkv,
                                  int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
                                  uint32_t rng_stream, void* stream);
@@ -346,12 +355,13 @@ int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, c
 /* The same with SAVED PROBABILITIES: the LDS-resident forward can leave its normalised probabilities (bf16, accumulator layout,
  * dropout decision in the sign bit; csrc/attention.hip "the P image") in `pimg`, ss_relpos_attention_saved_bytes() bytes; the
  * backward then reads them instead of recomputing both logit products, the skew, the exponentials and the dropout draws.
- * saved_bytes is 0 for shapes that run the per-tile kernels; pimg may be NULL in both calls (= the functions above). */
+ * saved_bytes is 0 for shapes that run the per-tile kernels; pimg may be NULL in both calls (= the functions above), except that the
+ * family-2 backward works ONLY from the saved probabilities (its forward may still run without pimg: inference). */
 int64_t ss_relpos_attention_saved_bytes(int dtype, int B, int H, int T, int dp, int D); /* [host] */
-int ss_relpos_attention_forward_p(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse, void* pimg,
+int ss_relpos_attention_forward_p(int dtype, const void* qkv, const void* qkvT, const void* E, const void* tab, void* out, float* lse, void* pimg,
                                   int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
                                   uint32_t rng_stream, void* stream);
-int ss_relpos_attention_backward_p(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* out,
+int ss_relpos_attention_backward_p(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* tab, const void* out,
                                    const float* lse, const void* dO, const void* dOT, float* Dscratch, void* dqkv, const void* pimg,
                                    int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
                                    uint32_t rng_stream, void* stream);

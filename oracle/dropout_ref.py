@@ -99,11 +99,39 @@ def attention_mask_resident(seed, stream, B, H, T, p):
         return kp.reshape(B, H, Tq, T)[:, :, :T]
 
 
+def attention_mask_transposed(seed, stream, B, H, T, p):
+    """Transposed-score attention kernels (bf16 rows of <= 224 frames; csrc/attention_t.hip `drop_key` / `drop_signs`): the 4 consecutive
+    keys 4g..4g+3 of query q draw 16 bits each from ONE 32 x 32 -> 64-bit product of x = key(pair, q) + g * 0x632BE5AB with 0x9E3779B1
+    (keys 4g, 4g+1: the halves of lo ^ hi; 4g+2, 4g+3: the halves of hi); an entry is dropped iff its draw, read as a SIGNED 16-bit
+    number, is below t16 - 32768 (saturating subtract, sign bit), t16 = threshold >> 16.  -> bool (B, H, T, T)."""
+    with np.errstate(over='ignore'):
+        Tk = (T + 3) // 4 * 4
+        sd = U32(_seed_fold(seed, stream))
+        row = (np.arange(B * H, dtype=np.uint64)[:, None] * np.uint64(T) + np.arange(T, dtype=np.uint64)[None, :]).astype(U32)
+        key = mix32((row * U32(0x9E3779B1)) ^ sd) + sd                                         # (BH, T)
+        g = np.arange(Tk // 4, dtype=np.uint64).astype(U32)
+        x = (key[:, :, None] + g[None, None, :] * U32(0x632BE5AB)).astype(np.uint64)
+        prod = x * np.uint64(0x9E3779B1)
+        lo, hi = (prod & np.uint64(_M32)).astype(U32), (prod >> np.uint64(32)).astype(U32)
+        a = lo ^ hi
+        draws = np.stack([a & U32(0xffff), a >> U32(16), hi & U32(0xffff), hi >> U32(16)], -1).astype(np.uint16).view(np.int16).astype(np.int32)   # (BH, T, Tk/4, 4)
+        ts = int(dropout_threshold(p) >> 16) - 32768
+        keep = draws >= ts
+        return keep.reshape(B, H, T, Tk)[..., :T]
+
+
+def attention_mask(family, seed, stream, B, H, T, p):
+    """Keep mask of the attention probabilities for the kernel family ss_relpos_attention_family reports (0 per-tile, 1 LDS-resident
+    16 x 16, 2 transposed 32 x 32)."""
+    return (attention_mask_tiled, attention_mask_resident, attention_mask_transposed)[family](seed, stream, B, H, T, p)
+
+
 def layer_masks(seed, num_layers, B, T, d_model, n_head, ff, p, resident_attention):
     """Keep masks of one training forward as torch float tensors in the shapes `model_ref.encoder_layer` applies them:
     [{'attn': (B,H,T,T), 'res1': (B,T,d), 'ffn': (B,T,ff), 'res2': (B,T,d)} for each layer]."""
     import torch
-    att = attention_mask_resident if resident_attention else attention_mask_tiled
+    # resident_attention: bool of the earlier rounds (False = per-tile, True = LDS-resident 16 x 16) or the family number 0 / 1 / 2
+    att = (attention_mask_tiled, attention_mask_resident, attention_mask_transposed)[int(resident_attention)]
     out = []
     for l in range(num_layers):
         out.append({

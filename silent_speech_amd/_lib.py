@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('SS_AMD_LIBRARY') or os.path.join(_HERE, 'lib', 'libsilent_speech_hip.so')      # override: A/B runs of two builds on one box
 
 SS_F32, SS_BF16, SS_F64, SS_F32X3 = 0, 1, 2, 3
-ABI_VERSION = 5          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
+ABI_VERSION = 6          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
 OP_KC, OP_OC = 0, 1
 
 
@@ -64,10 +64,11 @@ SIGNATURES = {
     'ss_reflect_pad_ragged': [_P, _P, _P, _P, _I, _I, _I, _L, _I, _P],
     'ss_concat_pad': [_P, _I, _P, _L, _I, _P],
     'ss_dtw_cumulative': [_I, _P, _L, _L, _I, _I, _P, _P, _P],
-    'ss_relpos_attention_forward': [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
-    'ss_relpos_attention_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
-    'ss_relpos_attention_forward_p': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
-    'ss_relpos_attention_backward_p': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_relpos_attention_forward': [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_relpos_attention_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_relpos_attention_forward_p': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_relpos_attention_backward_p': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_relpos_attention_prepare_tables': [_P, _P, _I, _I, _I, _I, _F, _P],
     'ss_bn_stats_sums': [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     'ss_bn_finalize': [_P, ctypes.c_double, _I, _P, _P, _P, _P, _F, _F, _I, _P],
     'ss_bn_finalize_shift': [_P, _P, ctypes.c_double, _I, _P, _P, _P, _P, _F, _F, _I, _P],
@@ -120,6 +121,8 @@ _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int6
                'ss_counters_add': ([_I, _P, _L, _P], ctypes.c_int),
                'ss_plan_profile': ([_P, _I], ctypes.c_int), 'ss_plan_profile_read': ([_P, _P, _I], ctypes.c_int),
                'ss_relpos_attention_needs_transposed': ([_I, _I, _I, _I], ctypes.c_int),
+               'ss_relpos_attention_family': ([_I, _I, _I, _I], ctypes.c_int),
+               'ss_relpos_attention_table_bytes': ([_I, _I, _I], ctypes.c_int64),
                'ss_relpos_attention_saved_bytes': ([_I, _I, _I, _I, _I, _I], ctypes.c_int64),
                'ss_layernorm_backward_scratch_floats': ([_I, _I], ctypes.c_int64)}
 _RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}

@@ -22,6 +22,7 @@
 //             key-major kernel (dK, dV); both recompute P from the saved log-sum-exp.
 #include "common.h"
 #include "silent_speech_hip.h"
+#include "attention_t.h"
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -1974,9 +1975,38 @@ static ResKernel res_pick(int which, int dpk, bool drop = false) {
     return dpk >= 1 && dpk <= 3 ? tab[which][dpk - 1] : (ResKernel)0;
 }
 
+// Which kernels a problem runs: 0 = per-tile (any T, f32 / bf16 x 3; read the transposed copies qkvT / dOT), 1 = LDS-resident 16 x 16 tiles
+// (rounds 1-4, attention.hip), 2 = transposed 32 x 32 score tiles (attention_t.hip; need the prepared embedding tables).
+static bool family_t(int dtype, int T, int dp, int D) {
+    if (dtype != SS_BF16 || !attn_t_supported(T, dp, D)) return false;
+    const char* e = getenv("SS_ATTN_T");                  // "0": keep the 16 x 16 resident kernels (A/B measurements, tests of both)
+    if (e && e[0] == '0') return false;
+    const char* r = getenv("SS_ATTN_RESIDENT");
+    return !(r && r[0] == '0');
+}
+extern "C" int ss_relpos_attention_family(int dtype, int T, int dp, int D)
+{
+    if (family_t(dtype, T, dp, D)) return 2;
+    return ss_relpos_attention_needs_transposed(dtype, T, dp, D) ? 0 : 1;
+}
+extern "C" int64_t ss_relpos_attention_table_bytes(int H, int dp, int D)
+{
+    (void)D;
+    return (H > 0 && dp % 32 == 0 && dp >= 32 && dp <= 96) ? attn_t_table_bytes(H, dp) : 0;
+}
+extern "C" int ss_relpos_attention_prepare_tables(const float* emb, void* tab, int H, int D, int dh, int dp, float scale, void* stream)
+{
+    SS_CHECK(emb && tab, "ss_relpos_attention_prepare_tables: null pointer");
+    SS_CHECK(H > 0 && D >= 1 && D <= 100 && dh >= 1 && dh <= dp && dp % 32 == 0 && dp <= 96 && scale > 0.f, "ss_relpos_attention_prepare_tables: bad shape");
+    if (attn_t_prepare_tables(emb, H, D, dh, dp, scale, tab, stream)) return 1;
+    SS_LAUNCH_CHECK("ss_relpos_attention_prepare_tables");
+    return 0;
+}
+
 // 1 if this problem runs the per-tile kernels (which read the transposed copies qkvT / dOT), 0 if the LDS-resident ones do
 extern "C" int ss_relpos_attention_needs_transposed(int dtype, int T, int dp, int D)
 {
+    if (family_t(dtype, T, dp, D)) return 0;
     const int dpk = dp / 32;
     const bool resident = res_enabled(dtype, T) && dp % 32 == 0 && dpk >= 1 && dpk <= 3 && res_smem(0, T, dp, D) <= RES_LDS_MAX && res_smem(1, T, dp, D) <= RES_LDS_MAX &&
                           res_smem(2, T, dp, D) <= RES_LDS_MAX;
@@ -1987,6 +2017,7 @@ extern "C" int ss_relpos_attention_needs_transposed(int dtype, int T, int dp, in
 extern "C" int64_t ss_relpos_attention_saved_bytes(int dtype, int B, int H, int T, int dp, int D)
 {
     if (B <= 0 || H <= 0 || T <= 0 || dp % 32 != 0 || dp < 32 || dp > 96 || D < 1 || D > 100) return 0;
+    if (family_t(dtype, T, dp, D)) return attn_t_saved_bytes(B, H, T);
     if (ss_relpos_attention_needs_transposed(dtype, T, dp, D) || !fwd2_enabled()) return 0;
     if (res_smem(3, T, dp, D) > RES_LDS_MAX || res_smem(4, T, dp, D) > RES_LDS_MAX || res_smem(5, T, dp, D) > RES_LDS_MAX) return 0;
     const char* e = getenv("SS_ATTN_SAVE_P");             // "0": backward recomputes the probabilities (A/B measurements, tests of both paths)
@@ -1995,10 +2026,24 @@ extern "C" int64_t ss_relpos_attention_saved_bytes(int dtype, int B, int H, int 
     return (int64_t)B * H * nb * pimg_slots((int)nb) * 512;
 }
 
-extern "C" int ss_relpos_attention_forward_p(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse, void* pimg,
+static void attn_t_args(AttnTArgs& a, const void* qkv, const void* tab, int B, int H, int T, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream)
+{
+    memset(&a, 0, sizeof(a));
+    a.qkv = qkv; a.tab = tab; a.B = B; a.H = H; a.T = T; a.dp = dp; a.D = D; a.scale = scale; a.dropout_p = dropout_p; a.seed = seed; a.stream_id = rng_stream;
+}
+
+extern "C" int ss_relpos_attention_forward_p(int dtype, const void* qkv, const void* qkvT, const void* E, const void* tab, void* out, float* lse, void* pimg,
                                            int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
     if (attn_check("ss_relpos_attention_forward", dtype, B, H, T, Tp, dp, D, dropout_p)) return 1;
+    if (family_t(dtype, T, dp, D)) {
+        SS_CHECK(qkv && tab && out && lse, "ss_relpos_attention_forward: null pointer (this shape runs the transposed-score kernels, which read the prepared tables: ss_relpos_attention_prepare_tables)");
+        AttnTArgs a; attn_t_args(a, qkv, tab, B, H, T, dp, D, scale, dropout_p, seed, rng_stream);
+        a.out = out; a.lse = lse; a.pimg = pimg;
+        if (attn_t_forward(a, stream)) return 1;
+        SS_LAUNCH_CHECK("ss_relpos_attention_forward");
+        return 0;
+    }
     SS_CHECK(qkv && E && out && lse, "ss_relpos_attention_forward: null pointer");
     SS_CHECK(qkvT || !ss_relpos_attention_needs_transposed(dtype, T, dp, D), "ss_relpos_attention_forward: this shape runs the per-tile kernels, which need the transposed copy qkvT");
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
@@ -2020,17 +2065,26 @@ extern "C" int ss_relpos_attention_forward_p(int dtype, const void* qkv, const v
     return 0;
 }
 
-extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, void* out, float* lse,
+extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, const void* tab, void* out, float* lse,
                                            int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
-    return ss_relpos_attention_forward_p(dtype, qkv, qkvT, E, out, lse, nullptr, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream, stream);
+    return ss_relpos_attention_forward_p(dtype, qkv, qkvT, E, tab, out, lse, nullptr, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream, stream);
 }
 
-extern "C" int ss_relpos_attention_backward_p(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* out, const float* lse,
+extern "C" int ss_relpos_attention_backward_p(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* tab, const void* out, const float* lse,
                                             const void* dO, const void* dOT, float* Dscratch, void* dqkv, const void* pimg,
                                             int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
     if (attn_check("ss_relpos_attention_backward", dtype, B, H, T, Tp, dp, D, dropout_p)) return 1;
+    if (family_t(dtype, T, dp, D)) {
+        SS_CHECK(qkv && tab && out && dO && Dscratch && dqkv, "ss_relpos_attention_backward: null pointer (this shape runs the transposed-score kernels, which read the prepared tables)");
+        SS_CHECK(pimg, "ss_relpos_attention_backward: the transposed-score kernels work from the saved probabilities of the forward (pimg, ss_relpos_attention_saved_bytes)");
+        AttnTArgs a; attn_t_args(a, qkv, tab, B, H, T, dp, D, scale, dropout_p, seed, rng_stream);
+        a.O = out; a.dO = dO; a.Dv = Dscratch; a.dqkv = dqkv; a.pimg = (void*)pimg;
+        if (attn_t_backward(a, stream)) return 1;
+        SS_LAUNCH_CHECK("ss_relpos_attention_backward");
+        return 0;
+    }
     SS_CHECK(qkv && E && ET && out && lse && dO && Dscratch && dqkv, "ss_relpos_attention_backward: null pointer");
     SS_CHECK((qkvT && dOT) || !ss_relpos_attention_needs_transposed(dtype, T, dp, D), "ss_relpos_attention_backward: this shape runs the per-tile kernels, which need qkvT and dOT");
     AttnP p; attn_fill(p, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream);
@@ -2072,9 +2126,9 @@ extern "C" int ss_relpos_attention_backward_p(int dtype, const void* qkv, const 
     return 0;
 }
 
-extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* out, const float* lse,
+extern "C" int ss_relpos_attention_backward(int dtype, const void* qkv, const void* qkvT, const void* E, const void* ET, const void* tab, const void* out, const float* lse,
                                             const void* dO, const void* dOT, float* Dscratch, void* dqkv,
                                             int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
-    return ss_relpos_attention_backward_p(dtype, qkv, qkvT, E, ET, out, lse, dO, dOT, Dscratch, dqkv, nullptr, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream, stream);
+    return ss_relpos_attention_backward_p(dtype, qkv, qkvT, E, ET, tab, out, lse, dO, dOT, Dscratch, dqkv, nullptr, B, H, T, Tp, dp, D, scale, dropout_p, seed, rng_stream, stream);
 }

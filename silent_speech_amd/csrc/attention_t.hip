@@ -1,0 +1,581 @@
+// attention_t.hip -- relative-position self-attention on the TRANSPOSED score tile (gfx950, bf16, rows of <= 224 frames).
+// Reference: transformer.py:87-112 (MultiHeadAttention.forward) and :229-297 (relative -> absolute indexing), closed form as in
+// attention.hip:   logits[q][k] = scale * Q[q].K[k] + ( |k-q| <= D-1 ?  Q[q].E[k-q+D-1]  :  -1e8 ),   P = softmax_k,   O = dropout(P) V.
+//
+// What is different from the 16x16 kernels of attention.hip (rounds 1-4): the score tile is computed TRANSPOSED, S^T = K Q^T on
+// v_mfma_f32_32x32x16_bf16, so that a LANE owns one query (accumulator column) and its registers run over the keys:
+//   * row maximum, row sum and the normalisation are in-lane (one exchange between the two half-waves per tile);
+//   * the accumulator registers ARE the B operand of the next product (O^T = V^T P^T, dQ^T = K^T dS^T): no LDS round trip for P;
+//   * the relative -> absolute "skew" (transformer.py:272-297) runs along the registers of a lane, i.e. through LDS with a per-lane
+//     offset: R^T = E' Q^T is written with row stride SKP + 1 and read back with row stride SKP (the reference's pad / view trick),
+//     one ds_write_b32 per logit and one ds_read_b128 per four, no VALU;
+//   * E' = E / scale is a prepared table in MFMA-fragment order (ss_relpos_attention_prepare_tables): the positional logits are
+//     accumulated in the SAME accumulator as Q.K (the skewed R' is its initial value), the softmax scale is folded into the exp2
+//     argument, the table streams from L2 as whole KiB (no LDS space, no LDS reads);
+//   * interior key blocks (|32 (jb - w)| + 31 <= D - 1, all keys < T) skip the band test.
+// One workgroup per (sequence, head); wave w owns the 32 queries [32 w, 32 w + 32); K and V rows live in LDS.
+// The backward reads the saved probabilities (the P image: bf16, sign bit = dropped) in two kernels: query-major (dQ; also emits
+// D = rowsum(dO * O) from its own fragments) and key-major (dK, dV), the latter on the mirrored tile (lane = key).
+#include "common.h"
+#include "attention_t.h"
+#include "silent_speech_hip.h"
+#include <math.h>
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NTM = 7;                  // 32-row tiles per sequence (T <= 224)
+constexpr int NU = 2 * NTM;             // R-blocks u in [-(NTM-1), NTM]
+constexpr int UOFF = NTM - 1;
+constexpr int SKP = 68;                 // skew buffer: read row stride (words); written with SKP + 1
+constexpr int SK_WORDS = 2400;          // 31 * (SKP + 1) + 32 * NTM + 32 + 1, rounded up
+constexpr int KPAD = 16;                // row pitch dp * 2 + 16 bytes: conflict-free ds_read_b128 of 32 rows (A operand, row per lane)
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+#if defined(SS_EMU)
+    return hipemu::mfma_32x32x16_bf16(a, b, c);
+#else
+    typedef __bf16 bf16x8_hw __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_hw, a), __builtin_bit_cast(bf16x8_hw, b), c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x16 zero16() { f32x16 z; for (int i = 0; i < 16; ++i) z[i] = 0.f; return z; }
+__device__ __forceinline__ bf16x8 zero8() { bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; return z; }
+__device__ __forceinline__ int rho(int r, int h) { return 8 * (r >> 2) + 4 * h + (r & 3); }       // accumulator row of register r (cdna_hip_programming.md section 3)
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }                       // the other half-wave's value for the same query / key
+
+struct KP {
+    const bf16_t* qkv; const bf16_t* tab; bf16_t* out; float* lse; unsigned char* pimg;
+    const bf16_t* dO; const bf16_t* O; float* Dv; bf16_t* dqkv;
+    int B, H, T, dp, D, nt;
+    float c1, scale, oscale;            // scale * log2(e); scale; 1 / (1 - p)
+    unsigned ts2, seedfold;             // packed signed 16-bit dropout thresholds (0x80008000 = keep everything); folded seed
+    int drop;
+};
+
+// ---- dropout of this kernel family: the 4 consecutive keys 4g..4g+3 of query q draw 16 bits each from ONE 32x32 -> 64-bit product
+// (lo ^ hi | hi); an entry is dropped iff its draw, read as a signed 16-bit number, is below ts = t16 - 32768.  oracle/dropout_ref.py
+// (attention_mask_transposed) restates it.
+__device__ __forceinline__ unsigned drop_key(const KP& p, int bh, int q) {
+    return mix32(((unsigned)bh * (unsigned)p.T + (unsigned)q) * 0x9E3779B1u ^ p.seedfold) + p.seedfold;
+}
+__device__ __forceinline__ void drop_signs(unsigned key, int g, unsigned ts2, unsigned& s01, unsigned& s23) {
+    const unsigned x = key + (unsigned)g * 0x632BE5ABu;
+    const unsigned lo = x * 0x9E3779B1u, hi = __umulhi(x, 0x9E3779B1u);
+    const s16x2 t = __builtin_bit_cast(s16x2, ts2);
+    s01 = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, lo ^ hi), t));     // bit 15 of a half set <=> dropped
+    s23 = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, hi), t));
+}
+__device__ __forceinline__ unsigned keep_pos(unsigned img) {        // signed bf16 pair -> the kept probabilities (negative = dropped -> 0)
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, img), z));
+}
+
+// ---- the P image.  Per (pair, query tile w, key block jb): 32 x 32 probabilities as bf16 (normalised, BEFORE dropout, sign bit set iff
+// dropout removed the entry), 2 KiB, in four 512-byte segments rg = 0..3; the 8 bytes of (query n, keys 8 rg + 4 h + 0..3) sit at slot
+//   (n & 3) + 4 * ((2 rg + h + 2 ((n >> 2) & 3)) & 7) + 32 * (n >> 4)
+// of their segment: any bijection keeps the forward's stores (one segment per instruction) whole lines, and this one makes the
+// transposing LDS reads of the key-major backward (which copies a block into LDS as it is) bank-conflict free.
+__device__ __forceinline__ int pimg_slot(int n, int h, int rg) { return (n & 3) + 4 * ((2 * rg + h + 2 * ((n >> 2) & 3)) & 7) + 32 * (n >> 4); }
+__device__ __forceinline__ long long pimg_block(int pair, int nt, int w, int jb) { return (((long long)pair * nt + w) * nt + jb) * 2048; }
+
+// band of query tile w: key blocks jlo .. jlo + nblk - 1
+__device__ __forceinline__ void tile_band(int w, int T, int D, int& jlo, int& nblk) {
+    const int lo = 32 * w - (D - 1), hi = 32 * w + 31 + (D - 1);
+    jlo = lo < 0 ? 0 : lo >> 5;
+    const int jhi = (hi > T - 1 ? T - 1 : hi) >> 5;
+    nblk = jhi - jlo + 1;
+}
+
+// cooperative copy of T rows of dp bf16 (row stride ld elements) into an LDS table of row pitch `pitch` bytes
+template <int DPK>
+__device__ __forceinline__ void stage_table(unsigned char* dst, int pitch, const bf16_t* src, long long ld, int T, int tid, int nthr) {
+    constexpr int CPR = DPK * 4, U = 4;
+    const int total = T * CPR;
+    for (int base = tid; base < total; base += nthr * U) {
+        u32x4 v[U]; int off[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * nthr, r = i / CPR, ch = i - r * CPR;
+            off[u] = i < total ? r * pitch + ch * 16 : -1;
+            if (i < total) v[u] = *(const u32x4*)(src + (long long)r * ld + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (off[u] >= 0) *(u32x4*)(dst + off[u]) = v[u];
+    }
+}
+
+// 32 x dp f32 accumulator tile held TRANSPOSED (lane = row n, registers = columns) -> rows of `ld` elements in global memory,
+// through a per-wave LDS tile (8-byte pieces in, whole 16-byte chunks of a row out)
+template <int DPK>
+__device__ __forceinline__ void store_rows_t(unsigned char* tile, const f32x16 (&acc)[DPK], float sc, bf16_t* dst, long long ld, int nrows, int lane) {
+    constexpr int TP = DPK * 64 + 16;
+    const int n = lane & 31, h = lane >> 5;
+    wave_lds_sync();
+#pragma unroll
+    for (int db = 0; db < DPK; ++db)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            u32x2 v = {pack_bf16(acc[db][4 * rg] * sc, acc[db][4 * rg + 1] * sc), pack_bf16(acc[db][4 * rg + 2] * sc, acc[db][4 * rg + 3] * sc)};
+            *(u32x2*)(tile + n * TP + (32 * db + 8 * rg + 4 * h) * 2) = v;
+        }
+    wave_lds_sync();
+    constexpr int CPR = DPK * 4;
+#pragma unroll
+    for (int t = 0; t < (32 * CPR + 63) / 64; ++t) {
+        const int c = lane + 64 * t, r = c / CPR, ch = c - r * CPR;
+        if (c < 32 * CPR && r < nrows) *(u32x4*)(dst + (long long)r * ld + ch * 8) = *(const u32x4*)(tile + r * TP + ch * 16);
+    }
+    wave_lds_sync();
+}
+
+// =========================================================================== forward
+// LDS: [K rows, pitch dp*2+16 | V rows, pitch dp*2 | per-wave skew buffers of SK_WORDS floats]
+template <int DPK, bool DROP>
+__global__ __launch_bounds__(NTM * 64) void attn_t_fwd_kernel(KP p)
+{
+    constexpr int KS = 2 * DPK, KPB = DPK * 64 + KPAD, VPB = DPK * 64;
+    SS_DYN_SMEM(lds);
+    const int T = p.T, D = p.D, nt = p.nt, H = p.H;
+    const int pair = blockIdx.x, b = pair / H, hd = pair - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, h = lane >> 5;
+    const long long ld = 3LL * H * p.dp;
+    unsigned char* Ks = (unsigned char*)lds;
+    unsigned char* Vs = Ks + (size_t)T * KPB;
+    float* sk = (float*)(Vs + (((size_t)T * VPB + 15) & ~(size_t)15)) + (size_t)w * SK_WORDS;
+    const bf16_t* base = p.qkv + (long long)b * T * ld + hd * p.dp;
+    stage_table<DPK>(Ks, KPB, base + (long long)H * p.dp, ld, T, tid, blockDim.x);
+    stage_table<DPK>(Vs, VPB, base + 2LL * H * p.dp, ld, T, tid, blockDim.x);
+
+    // this lane's query row as B fragments (zero beyond the sequence)
+    const int i0 = 32 * w, qi = i0 + n;
+    bf16x8 qf[KS];
+    {
+        const bf16_t* qrow = base + (long long)(qi < T ? qi : T - 1) * ld + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { const bf16x8 v = *(const bf16x8*)(qrow + 16 * s); qf[s] = qi < T ? v : zero8(); }
+    }
+    int jlo, nblk; tile_band(w, T, D, jlo, nblk);
+    const int dlo = jlo - w;
+    __syncthreads();
+
+    // ---- logits, transposed: acc[ub][r] = (Q.K + Q.E / scale) of key 32 (jlo + ub) + rho(r, h), query qi
+    f32x16 acc[NTM];
+    const bf16_t* tabF = p.tab + ((long long)hd * NU + (dlo + UOFF)) * (KS * 512) + lane * 8;
+    float* skw = sk + (SKP + 1) * n + 4 * h + 1;                 // + 32 ub + 8 (r >> 2) + (r & 3)
+    const float* skr = sk + SKP * n + 4 * h + 32;                // + 32 ub + 8 rg
+    const int krow = 32 * jlo + n;
+#pragma unroll
+    for (int ub = 0; ub <= NTM; ++ub) {
+        if (ub <= nblk) {
+            f32x16 rt = zero16();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) rt = mfma32(*(const bf16x8*)(tabF + (ub * KS + s) * 512), qf[s], rt);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) skw[32 * ub + 8 * (r >> 2) + (r & 3)] = rt[r];
+        }
+        if (ub >= 1 && ub <= nblk) {
+            const int kb = ub - 1;
+            wave_lds_sync();
+            f32x16 a;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) { const f32x4 v = *(const f32x4*)(skr + 32 * kb + 8 * rg); a[4 * rg] = v[0]; a[4 * rg + 1] = v[1]; a[4 * rg + 2] = v[2]; a[4 * rg + 3] = v[3]; }
+            int row = krow + 32 * kb; row = row < T ? row : T - 1;
+            const unsigned char* kp = Ks + row * KPB + 16 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a = mfma32(*(const bf16x8*)(kp + 32 * s), qf[s], a);
+            acc[kb] = a;
+        }
+    }
+
+    // ---- band / sequence mask of the edge blocks, row maximum
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NTM; ++kb) {
+        if (kb < nblk) {
+            const int dj = 32 * (dlo + kb), j0 = 32 * (jlo + kb);
+            const bool edge = (dj < 0 ? -dj : dj) + 31 > D - 1 || j0 + 31 >= T;
+            if (edge) {
+                const int rel0 = dj + 4 * h - n + (D - 1), lim = 2 * (D - 1), jl = T - j0 - 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = 8 * (r >> 2) + (r & 3);
+                    if ((unsigned)(rel0 + e) > (unsigned)lim || e >= jl) acc[kb][r] = -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[kb][r]);
+        }
+    }
+    mx = fmaxf(fmaxf(mx, xhalf(mx)), -1e30f);                     // a row without a single key inside the sequence (queries beyond T): no inf - inf
+    const float mc = mx * p.c1;
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NTM; ++kb)
+        if (kb < nblk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = fast_exp2(acc[kb][r] * p.c1 - mc); acc[kb][r] = e; sum += e; }
+        }
+    sum += xhalf(sum);
+    const float inv = qi < T ? fast_rcp(sum) : 0.f;              // rows beyond the sequence leave an all-zero image (the backward relies on it)
+    if (h == 0 && qi < T) p.lse[((long long)b * H + hd) * T + qi] = mc * LN2 + logf(sum);
+
+    // ---- probabilities -> bf16 (+ dropout decision in the sign bit) -> image, O^T += V^T P~^T
+    f32x16 o[DPK];
+#pragma unroll
+    for (int db = 0; db < DPK; ++db) o[db] = zero16();
+    const unsigned dkey = DROP ? drop_key(p, pair, qi) : 0u;
+    unsigned char* img = p.pimg ? p.pimg + pimg_block(pair, nt, w, jlo) : nullptr;
+    int slot8[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) slot8[rg] = rg * 512 + pimg_slot(n, h, rg) * 8;
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int vlane = 4 * h + (i16 >> 2), vcol = (16 * g16 + 4 * (i16 & 3)) * 2;
+#pragma unroll
+    for (int kb = 0; kb < NTM; ++kb) {
+        if (kb < nblk) {
+            unsigned pv[8];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                unsigned w0 = pack_bf16(acc[kb][4 * rg] * inv, acc[kb][4 * rg + 1] * inv), w1 = pack_bf16(acc[kb][4 * rg + 2] * inv, acc[kb][4 * rg + 3] * inv);
+                if (DROP) {
+                    unsigned s01, s23; drop_signs(dkey, 8 * (jlo + kb) + 2 * rg + h, p.ts2, s01, s23);
+                    w0 |= s01 & 0x80008000u; w1 |= s23 & 0x80008000u;
+                }
+                if (img) { u32x2 v = {w0, w1}; *(u32x2*)(img + (long long)kb * 2048 + slot8[rg]) = v; }
+                pv[2 * rg] = DROP ? keep_pos(w0) : w0; pv[2 * rg + 1] = DROP ? keep_pos(w1) : w1;
+            }
+            const int j0 = 32 * (jlo + kb);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = __builtin_bit_cast(bf16x8, (u32x4){pv[4 * s2], pv[4 * s2 + 1], pv[4 * s2 + 2], pv[4 * s2 + 3]});
+                int r0 = j0 + 16 * s2 + vlane, r1 = r0 + 8;
+                r0 = r0 < T ? r0 : T - 1; r1 = r1 < T ? r1 : T - 1;
+                const unsigned char* v0 = Vs + r0 * VPB + vcol; const unsigned char* v1 = Vs + r1 * VPB + vcol;
+#pragma unroll
+                for (int db = 0; db < DPK; ++db) {
+                    const s16x4 lo = lds_read_tr16(v0 + 64 * db), hi = lds_read_tr16(v1 + 64 * db);
+                    const bf16x8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[db] = mfma32(va, pb, o[db]);
+                }
+            }
+        }
+    }
+    store_rows_t<DPK>((unsigned char*)sk, o, p.oscale, p.out + ((long long)b * T + i0) * ((long long)H * p.dp) + hd * p.dp, (long long)H * p.dp, T - i0 < 32 ? T - i0 : 32, lane);
+}
+
+
+// =========================================================================== backward helpers
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c) {
+#if defined(SS_EMU)
+    return c + __uint_as_float(a << 16) * __uint_as_float(b << 16) + __uint_as_float(a & 0xffff0000u) * __uint_as_float(b & 0xffff0000u);
+#else
+    typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, a), __builtin_bit_cast(bf16x2_hw, b), c, false);
+#endif
+}
+// With pf = the stored probability as a float (negative iff dropout removed the entry), s = 1 / (1 - p) and D' = D / s:
+//     dS' = max(pf, 0) * dP - |pf| * D'            (dS = s * dS',  P~ = s * max(pf, 0),  dP = dO . V)
+// in: the two image words of 4 consecutive entries, their 4 dP values and D' (per entry); out: dS' as two packed bf16 words
+__device__ __forceinline__ void ds_words(unsigned w0, unsigned w1, float dp0, float dp1, float dp2, float dp3, float d0, float d1, float d2, float d3, unsigned& o0, unsigned& o1) {
+    const float p0 = __uint_as_float(w0 << 16), p1 = __uint_as_float(w0 & 0xffff0000u), p2 = __uint_as_float(w1 << 16), p3 = __uint_as_float(w1 & 0xffff0000u);
+    o0 = pack_bf16(fmaxf(p0, 0.f) * dp0 - fabsf(p0) * d0, fmaxf(p1, 0.f) * dp1 - fabsf(p1) * d1);
+    o1 = pack_bf16(fmaxf(p2, 0.f) * dp2 - fabsf(p2) * d2, fmaxf(p3, 0.f) * dp3 - fabsf(p3) * d3);
+}
+// A operand A[m][k] = tab[row0 + k'][col0 + m] of a row-major LDS table through two transposing reads (k' in the accumulator order of the B operand:
+// contraction element 8 h + e <-> row 4 h + e (e < 4) resp. 8 + 4 h + e - 4); a0 / a1: this lane's two read addresses (rows row0 + 4 h + (lane & 15) / 4 [+ 8])
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* a0, const unsigned char* a1) {
+    const s16x4 lo = lds_read_tr16(a0), hi = lds_read_tr16(a1);
+    const bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+
+// =========================================================================== backward, query-major: dQ (and D)
+// LDS: [K rows, pitch dp*2 (transposing reads) | V rows, pitch dp*2+16 (row fragments) | per-wave buffer: un-skew (bf16) / output staging]
+constexpr int BW_BUF = 6656 + 64;       // per-wave buffer bytes of both backward kernels (32 x (96*2+16) staging; >= 2 * SK_WORDS resp. 2048)
+template <int DPK>
+__global__ __launch_bounds__(NTM * 64) void attn_t_bwd_q_kernel(KP p)
+{
+    constexpr int KS = 2 * DPK, KPB = DPK * 64, VPB = DPK * 64 + KPAD;
+    SS_DYN_SMEM(lds);
+    const int T = p.T, D = p.D, nt = p.nt, H = p.H;
+    const int pair = blockIdx.x, b = pair / H, hd = pair - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, h = lane >> 5;
+    const long long ld = 3LL * H * p.dp, ldo = (long long)H * p.dp;
+    unsigned char* Ks = (unsigned char*)lds;
+    unsigned char* Vs = Ks + (((size_t)T * KPB + 15) & ~(size_t)15);
+    unsigned char* buf = Vs + (size_t)T * VPB + (size_t)w * BW_BUF;
+    bf16_t* us = (bf16_t*)buf;
+    const bf16_t* base = p.qkv + (long long)b * T * ld + hd * p.dp;
+    stage_table<DPK>(Ks, KPB, base + (long long)H * p.dp, ld, T, tid, blockDim.x);
+    stage_table<DPK>(Vs, VPB, base + 2LL * H * p.dp, ld, T, tid, blockDim.x);
+
+    const int i0 = 32 * w, qi = i0 + n;
+    bf16x8 dof[KS];
+    float Dp = 0.f;
+    {
+        const long long ro = ((long long)b * T + (qi < T ? qi : T - 1)) * ldo + hd * p.dp + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const u32x4 a = *(const u32x4*)(p.dO + ro + 16 * s), o = *(const u32x4*)(p.O + ro + 16 * s);
+            dof[s] = qi < T ? __builtin_bit_cast(bf16x8, a) : zero8();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Dp = dot2_bf16(a[e], o[e], Dp);
+        }
+        Dp += xhalf(Dp);
+        Dp = qi < T ? Dp / p.oscale : 0.f;                        // D' = D / s
+        if (h == 0 && qi < T) p.Dv[((long long)b * H + hd) * T + qi] = Dp;
+    }
+    int jlo, nblk; tile_band(w, T, D, jlo, nblk);
+    const int dlo = jlo - w;
+    f32x16 dq[DPK];
+#pragma unroll
+    for (int db = 0; db < DPK; ++db) dq[db] = zero16();
+    const unsigned char* img = p.pimg + pimg_block(pair, nt, w, jlo);
+    int slot8[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) slot8[rg] = rg * 512 + pimg_slot(n, h, rg) * 8;
+    const bf16_t* tabB = p.tab + (long long)H * NU * KS * 512 + ((long long)hd * NU + (dlo + UOFF)) * (2 * DPK * 512) + lane * 8;
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int klane = 4 * h + (i16 >> 2), kcol = (16 * g16 + 4 * (i16 & 3)) * 2;
+    bf16_t* usw = us + SKP * n + 4 * h + 32;                     // + 32 kb + 8 rg      (aligned 8-byte pieces, row stride SKP)
+    const bf16_t* usr = us + (SKP + 1) * n + 8 * h + 1;          // + 32 ub + 16 s2 + e (row stride SKP + 1: the un-skew)
+    const u32x2 z2 = {0u, 0u};
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) *(u32x2*)(usw - 32 + 8 * rg) = z2;        // key block "-1" (before the band): read by R-block 0, never written
+    __syncthreads();
+
+#pragma unroll
+    for (int kb = 0; kb < NTM; ++kb) {
+        if (kb < nblk) {
+            // dP^T = V dO^T
+            f32x16 dp_ = zero16();
+            int row = 32 * (jlo + kb) + n; row = row < T ? row : T - 1;
+            const unsigned char* vp = Vs + row * VPB + 16 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) dp_ = mfma32(*(const bf16x8*)(vp + 32 * s), dof[s], dp_);
+            unsigned ds[8];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const u32x2 iw = *(const u32x2*)(img + (long long)kb * 2048 + slot8[rg]);
+                ds_words(iw[0], iw[1], dp_[4 * rg], dp_[4 * rg + 1], dp_[4 * rg + 2], dp_[4 * rg + 3], Dp, Dp, Dp, Dp, ds[2 * rg], ds[2 * rg + 1]);
+                const u32x2 v = {ds[2 * rg], ds[2 * rg + 1]};
+                *(u32x2*)(usw + 32 * kb + 8 * rg) = v;
+            }
+            // dQ^T += K^T dS'^T
+            const int j0 = 32 * (jlo + kb);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 sb = __builtin_bit_cast(bf16x8, (u32x4){ds[4 * s2], ds[4 * s2 + 1], ds[4 * s2 + 2], ds[4 * s2 + 3]});
+                int r0 = j0 + 16 * s2 + klane, r1 = r0 + 8;
+                r0 = r0 < T ? r0 : T - 1; r1 = r1 < T ? r1 : T - 1;
+                const unsigned char* k0 = Ks + r0 * KPB + kcol; const unsigned char* k1 = Ks + r1 * KPB + kcol;
+#pragma unroll
+                for (int db = 0; db < DPK; ++db) dq[db] = mfma32(tr_frag(k0 + 64 * db, k1 + 64 * db), sb, dq[db]);
+            }
+            wave_lds_sync();
+            // dQ^T += E'^T dR'^T: R-block ub = kb is complete (key blocks kb - 1 and kb), and so is ub = nblk after the last key block
+#pragma unroll
+            for (int last = 0; last < 2; ++last) {
+                if (last == 0 || kb == nblk - 1) {
+                    const int ub = kb + last;
+                    if (last) {         // key block "nblk" (past the band) is read by the last R-block and never written: zeros.  Only now -- its
+#pragma unroll                          // words are those of the NEXT row's key blocks nblk - 2 / nblk - 3, which R-block nblk - 1 has just read
+                        for (int rg = 0; rg < 4; ++rg) *(u32x2*)(usw + 32 * (kb + 1) + 8 * rg) = z2;
+                        wave_lds_sync();
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        unsigned rw[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rw[e] = (unsigned)usr[32 * ub + 16 * s2 + 2 * e] | ((unsigned)usr[32 * ub + 16 * s2 + 2 * e + 1] << 16);
+                        const bf16x8 rb = __builtin_bit_cast(bf16x8, (u32x4){rw[0], rw[1], rw[2], rw[3]});
+#pragma unroll
+                        for (int db = 0; db < DPK; ++db) dq[db] = mfma32(*(const bf16x8*)(tabB + ((ub * 2 + s2) * DPK + db) * 512), rb, dq[db]);
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+    store_rows_t<DPK>(buf, dq, p.scale * p.oscale, p.dqkv + ((long long)b * T + i0) * ld + hd * p.dp, ld, T - i0 < 32 ? T - i0 : 32, lane);
+}
+
+// =========================================================================== backward, key-major: dK, dV
+// The mirrored tile: wave w owns the 32 KEYS [32 w, 32 w + 32) (lane = key), its registers run over the queries of a block.
+// LDS: [Q rows, pitch dp*2 (transposing reads) | dO rows, pitch dp*2+16 (row fragments AND transposing reads) | D' | per-wave buffer: image block / output staging]
+template <int DPK>
+__global__ __launch_bounds__(NTM * 64) void attn_t_bwd_kv_kernel(KP p)
+{
+    constexpr int KS = 2 * DPK, QPB = DPK * 64, OPB = DPK * 64 + KPAD;
+    SS_DYN_SMEM(lds);
+    const int T = p.T, D = p.D, nt = p.nt, H = p.H;
+    const int pair = blockIdx.x, b = pair / H, hd = pair - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, h = lane >> 5;
+    const long long ld = 3LL * H * p.dp, ldo = (long long)H * p.dp;
+    unsigned char* Qs = (unsigned char*)lds;
+    unsigned char* Os = Qs + (((size_t)T * QPB + 15) & ~(size_t)15);
+    float* Ds = (float*)(Os + (size_t)T * OPB);
+    unsigned char* buf = (unsigned char*)(Ds + 32 * nt) + (size_t)w * BW_BUF;
+    const bf16_t* base = p.qkv + (long long)b * T * ld + hd * p.dp;
+    stage_table<DPK>(Qs, QPB, base, ld, T, tid, blockDim.x);
+    stage_table<DPK>(Os, OPB, p.dO + (long long)b * T * ldo + hd * p.dp, ldo, T, tid, blockDim.x);
+    for (int i = tid; i < 32 * nt; i += blockDim.x) Ds[i] = i < T ? p.Dv[((long long)b * H + hd) * T + i] : 0.f;
+
+    const int j0 = 32 * w, kj = j0 + n;
+    bf16x8 vf[KS];
+    {
+        const bf16_t* vrow = base + 2LL * H * p.dp + (long long)(kj < T ? kj : T - 1) * ld + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { const bf16x8 v = *(const bf16x8*)(vrow + 16 * s); vf[s] = kj < T ? v : zero8(); }
+    }
+    int ilo, nblk; tile_band(w, T, D, ilo, nblk);
+    f32x16 dk[DPK], dv[DPK];
+#pragma unroll
+    for (int db = 0; db < DPK; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int qlane = 4 * h + (i16 >> 2), qcol = (16 * g16 + 4 * (i16 & 3)) * 2;
+    // this lane's four addresses into an image block copied to LDS as it is: piece (query 8 rg + 4 h + (i16 >> 2), keys 4 (4 g16 + (i16 & 3)) ..)
+    int ioff[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) { const int nq = 8 * rg + 4 * h + (i16 >> 2), kg = 4 * g16 + (i16 & 3); ioff[rg] = (kg >> 1) * 512 + pimg_slot(nq, kg & 1, kg >> 1) * 8; }
+    __syncthreads();
+
+#pragma unroll
+    for (int qb = 0; qb < NTM; ++qb) {
+        if (qb < nblk) {
+            const int ib = ilo + qb, q0 = 32 * ib;
+            // the image block of (query tile ib, key block w) -> LDS, as it is
+            const unsigned char* src = p.pimg + pimg_block(pair, nt, ib, w);
+            const u32x4 c0 = *(const u32x4*)(src + lane * 16), c1 = *(const u32x4*)(src + 1024 + lane * 16);
+            // dP = dO V^T (rows = queries)
+            f32x16 dp_ = zero16();
+            int row = q0 + n; row = row < T ? row : T - 1;
+            const unsigned char* op = Os + row * OPB + 16 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) dp_ = mfma32(*(const bf16x8*)(op + 32 * s), vf[s], dp_);
+            *(u32x4*)(buf + lane * 16) = c0; *(u32x4*)(buf + 1024 + lane * 16) = c1;
+            wave_lds_sync();
+            unsigned pw[8], ds[8];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const s16x4 t4 = lds_read_tr16(buf + ioff[rg]);
+                const u32x2 iw = __builtin_bit_cast(u32x2, t4);
+                const f32x4 dd = *(const f32x4*)(Ds + q0 + 8 * rg + 4 * h);
+                ds_words(iw[0], iw[1], dp_[4 * rg], dp_[4 * rg + 1], dp_[4 * rg + 2], dp_[4 * rg + 3], dd[0], dd[1], dd[2], dd[3], ds[2 * rg], ds[2 * rg + 1]);
+                pw[2 * rg] = keep_pos(iw[0]); pw[2 * rg + 1] = keep_pos(iw[1]);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = __builtin_bit_cast(bf16x8, (u32x4){pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]});
+                const bf16x8 sb = __builtin_bit_cast(bf16x8, (u32x4){ds[4 * s2], ds[4 * s2 + 1], ds[4 * s2 + 2], ds[4 * s2 + 3]});
+                int r0 = q0 + 16 * s2 + qlane, r1 = r0 + 8;
+                r0 = r0 < T ? r0 : T - 1; r1 = r1 < T ? r1 : T - 1;
+#pragma unroll
+                for (int db = 0; db < DPK; ++db) {
+                    dv[db] = mfma32(tr_frag(Os + r0 * OPB + qcol + 64 * db, Os + r1 * OPB + qcol + 64 * db), pb, dv[db]);
+                    dk[db] = mfma32(tr_frag(Qs + r0 * QPB + qcol + 64 * db, Qs + r1 * QPB + qcol + 64 * db), sb, dk[db]);
+                }
+            }
+        }
+    }
+    const int nrows = T - j0 < 32 ? T - j0 : 32;
+    bf16_t* drow = p.dqkv + ((long long)b * T + j0) * ld + hd * p.dp;
+    store_rows_t<DPK>(buf, dk, p.scale * p.oscale, drow + (long long)H * p.dp, ld, nrows, lane);
+    store_rows_t<DPK>(buf, dv, p.oscale, drow + 2LL * H * p.dp, ld, nrows, lane);
+}
+
+// =========================================================================== tables
+// E' = E / scale (transformer.py:172-176 embeddings, f32 [H][2D-1][dh]) in MFMA-fragment order, zero outside [0, 2D-2] and beyond dh:
+//   part F  [H][NU][2 DPK][64][8]      A[m = rel][k = d]:  rel = 32 u + D - 32 + (lane & 31),              d = 16 s + 8 (lane >> 5) + e
+//   part B  [H][NU][2][DPK][64][8]     A[m = d][k = rel]:  rel = 32 u + D - 32 + 16 s2 + 8 (lane >> 5) + e, d = 32 db + (lane & 31)
+__global__ void attn_t_tables_kernel(const float* __restrict__ emb, int H, int D, int dh, int DPK, float inv_scale, bf16_t* __restrict__ tab)
+{
+    const int KS = 2 * DPK;
+    const long long partF = (long long)H * NU * KS * 512, total = 2 * partF;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long j = i < partF ? i : i - partF;
+        const int e = j & 7, lane = (j >> 3) & 63; j >>= 9;
+        int rel, d, hd;
+        if (i < partF) { const int s = j % KS; j /= KS; const int ui = j % NU; hd = (int)(j / NU); rel = 32 * (ui - UOFF) + D - 32 + (lane & 31); d = 16 * s + 8 * (lane >> 5) + e; }
+        else { const int db = j % DPK; j /= DPK; const int s2 = j & 1; j >>= 1; const int ui = j % NU; hd = (int)(j / NU); rel = 32 * (ui - UOFF) + D - 32 + 16 * s2 + 8 * (lane >> 5) + e; d = 32 * db + (lane & 31); }
+        float v = 0.f;
+        if (rel >= 0 && rel <= 2 * D - 2 && d < dh) v = emb[((long long)hd * (2 * D - 1) + rel) * dh + d] * inv_scale;
+        tab[i] = f2bf(v);
+    }
+}
+
+size_t bwd_smem(int T, int dp, int waves) { return (((size_t)T * dp * 2 + 15) & ~(size_t)15) + (size_t)T * (dp * 2 + KPAD) + (size_t)waves * (32 * 4 + BW_BUF) + 16; }
+size_t fwd_smem(int T, int dp, int waves) { return (size_t)T * (dp * 2 + KPAD) + (((size_t)T * dp * 2 + 15) & ~(size_t)15) + (size_t)waves * SK_WORDS * 4; }
+const size_t LDS_MAX = 160 * 1024;
+
+void fill(KP& p, const AttnTArgs& a)
+{
+    memset(&p, 0, sizeof(p));
+    p.qkv = (const bf16_t*)a.qkv; p.tab = (const bf16_t*)a.tab; p.out = (bf16_t*)a.out; p.lse = a.lse; p.pimg = (unsigned char*)a.pimg;
+    p.dO = (const bf16_t*)a.dO; p.O = (const bf16_t*)a.O; p.Dv = a.Dv; p.dqkv = (bf16_t*)a.dqkv;
+    p.B = a.B; p.H = a.H; p.T = a.T; p.dp = a.dp; p.D = a.D; p.nt = (a.T + 31) / 32;
+    p.scale = a.scale; p.c1 = a.scale * LOG2E;
+    p.drop = a.dropout_p > 0.f;
+    const unsigned t16 = p.drop ? dropout_threshold(a.dropout_p) >> 16 : 0u;
+    const unsigned ts = (t16 - 32768u) & 0xffffu;
+    p.ts2 = ts | (ts << 16);
+    p.oscale = p.drop ? 1.f / (1.f - a.dropout_p) : 1.f;
+    p.seedfold = (unsigned)a.seed ^ ((unsigned)(a.seed >> 32) * 0x9E3779B9u) ^ (a.stream_id * 0x85EBCA6Bu);
+}
+
+typedef void (*Kern)(KP);
+int launch(Kern k, int slot, int blocks, int waves, size_t smem, void* stream, const KP& p)
+{
+#if !defined(SS_EMU)
+    static size_t granted[16] = {0};
+    if (granted[slot] < smem) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("attention (transposed): cannot reserve %zu bytes of LDS", smem); return 1; }
+        granted[slot] = smem;
+    }
+#endif
+    SS_LAUNCH(k, dim3(blocks), dim3(waves * 64), smem, stream, p);
+    return 0;
+}
+}  // namespace
+
+bool attn_t_supported(int T, int dp, int D)
+{
+    if (T < 1 || T > 32 * NTM || dp % 32 != 0 || dp < 32 || dp > 96 || D < 1 || D > 100) return false;
+    return fwd_smem(T, dp, (T + 31) / 32) <= LDS_MAX && bwd_smem(T, dp, (T + 31) / 32) <= LDS_MAX;
+}
+int64_t attn_t_saved_bytes(int B, int H, int T) { const int64_t nt = (T + 31) / 32; return (int64_t)B * H * nt * nt * 2048; }
+int64_t attn_t_table_bytes(int H, int dp) { return 2LL * H * NU * (dp / 16) * 512 * 2; }
+
+int attn_t_prepare_tables(const float* emb, int H, int D, int dh, int dp, float scale, void* tab, void* stream)
+{
+    const long long total = attn_t_table_bytes(H, dp) / 2;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    SS_LAUNCH(attn_t_tables_kernel, dim3(blocks), dim3(256), 0, stream, emb, H, D, dh, dp / 32, 1.f / scale, (bf16_t*)tab);
+    return 0;
+}
+
+int attn_t_forward(const AttnTArgs& a, void* stream)
+{
+    KP p; fill(p, a);
+    const int dpk = a.dp / 32, waves = p.nt;
+    static const Kern tab[2][3] = {{attn_t_fwd_kernel<1, false>, attn_t_fwd_kernel<2, false>, attn_t_fwd_kernel<3, false>},
+                                   {attn_t_fwd_kernel<1, true>, attn_t_fwd_kernel<2, true>, attn_t_fwd_kernel<3, true>}};
+    return launch(tab[p.drop][dpk - 1], p.drop * 3 + dpk - 1, a.B * a.H, waves, fwd_smem(a.T, a.dp, waves), stream, p);
+}
+
+int attn_t_backward(const AttnTArgs& a, void* stream)
+{
+    KP p; fill(p, a);
+    const int dpk = a.dp / 32, waves = p.nt;
+    static const Kern bq[3] = {attn_t_bwd_q_kernel<1>, attn_t_bwd_q_kernel<2>, attn_t_bwd_q_kernel<3>};
+    static const Kern bkv[3] = {attn_t_bwd_kv_kernel<1>, attn_t_bwd_kv_kernel<2>, attn_t_bwd_kv_kernel<3>};
+    const size_t smem = bwd_smem(a.T, a.dp, waves);
+    if (launch(bq[dpk - 1], 6 + dpk - 1, a.B * a.H, waves, smem, stream, p)) return 1;      // also writes D' for the key-major kernel
+    return launch(bkv[dpk - 1], 9 + dpk - 1, a.B * a.H, waves, smem, stream, p);
+}

@@ -32,7 +32,7 @@ struct BlockP {
     int O = 0, I = 0;
 };
 struct LayerP {
-    void *wqkv = 0, *wqkvT = 0, *wo = 0, *woT = 0, *E = 0, *ET = 0, *w1 = 0, *w2 = 0, *w1T = 0, *w2T = 0;
+    void *wqkv = 0, *wqkvT = 0, *wo = 0, *woT = 0, *E = 0, *ET = 0, *EF = 0, *w1 = 0, *w2 = 0, *w1T = 0, *w2T = 0;
     float *b1 = 0, *b2 = 0, *g1 = 0, *be1 = 0, *g2 = 0, *be2 = 0;
     float *dg1 = 0, *dbe1 = 0, *dg2 = 0, *dbe2 = 0, *dw1 = 0, *db1 = 0, *dw2 = 0, *db2 = 0, *wo_stage = 0, *wqkv_stage = 0;
     PermB unpack;          // this layer's re-laid-out gradients (w_o, w_q / w_k / w_v) -> .grad arena
@@ -133,7 +133,7 @@ struct Plan {
         for (int l = 0; l < D.n_layers; ++l) {
             const std::string p = "transformer.layers." + std::to_string(l) + ".";
             LayerP& L = layers[l];
-            slot(p + "wqkv", &L.wqkv); slot(p + "wqkvT", &L.wqkvT); slot(p + "wo", &L.wo); slot(p + "woT", &L.woT); slot(p + "E", &L.E); slot(p + "ET", &L.ET);
+            slot(p + "wqkv", &L.wqkv); slot(p + "wqkvT", &L.wqkvT); slot(p + "wo", &L.wo); slot(p + "woT", &L.woT); slot(p + "E", &L.E); slot(p + "ET", &L.ET); slot(p + "EF", &L.EF);
             slot(p + "w1", &L.w1); slot(p + "w2", &L.w2); slot(p + "w1T", &L.w1T); slot(p + "w2T", &L.w2T);
             slot(p + "linear1.bias", (void**)&L.b1); slot(p + "linear2.bias", (void**)&L.b2);
             slot(p + "norm1.weight", (void**)&L.g1); slot(p + "norm1.bias", (void**)&L.be1); slot(p + "norm2.weight", (void**)&L.g2); slot(p + "norm2.bias", (void**)&L.be2);
@@ -342,7 +342,7 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         // training: the resident forward leaves its probabilities for the backward kernels (no recomputation of the logits there)
         const size_t pimg_bytes = training ? (size_t)ss_relpos_attention_saved_bytes(dt, B, H, T, dp, Dr) : 0;
         void* pimg = pimg_bytes ? X.alloc(pimg_bytes) : nullptr;
-        if (!X.dry) L_(timed(X, "attn_fwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 3.0, (double)M * 4 * HD * es, stream, [&] { return ss_relpos_attention_forward_p(dt == SS_F32 && f32_x3 ? SS_F32X3 : dt, qkv, qkvT, w.E, o, lse, pimg, B, H, T, Tp, dp, Dr, scale, p_drop, seed, 4 * l, stream); }));
+        if (!X.dry) L_(timed(X, "attn_fwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 3.0, (double)M * 4 * HD * es, stream, [&] { return ss_relpos_attention_forward_p(dt == SS_F32 && f32_x3 ? SS_F32X3 : dt, qkv, qkvT, w.E, w.EF, o, lse, pimg, B, H, T, Tp, dp, Dr, scale, p_drop, seed, 4 * l, stream); }));
         s.pimg = pimg;
         void* a = X.alloc((size_t)M * d * es);
         L_(gemm(X, dt, o, w.wo, a, M, d, HD, RM(HD), RM(HD), RM(d)));
@@ -440,7 +440,7 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         } else L_(gemm(X, dt, dA, w.woT, dO, M, HD, d, RM(d), RM(d), RM(HD)));
         void* dqkv = X.alloc((size_t)M * 3 * HD * es);
         float* dsc = (float*)X.alloc((size_t)B * H * T * 4);
-        if (!X.dry) L_(timed(X, "attn_bwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 5.0, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_backward_p(dt == SS_F32 && f32_x3 ? SS_F32X3 : dt, s.qkv, s.qkvT, w.E, w.ET, s.o, s.lse, dO, dOT, dsc, dqkv, s.pimg, B, H, T, Tp, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
+        if (!X.dry) L_(timed(X, "attn_bwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 5.0, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_backward_p(dt == SS_F32 && f32_x3 ? SS_F32X3 : dt, s.qkv, s.qkvT, w.E, w.ET, w.EF, s.o, s.lse, dO, dOT, dsc, dqkv, s.pimg, B, H, T, Tp, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
         L_(grp.add(dqkv, s.x, w.wqkv_stage, 3 * HD, d, M, RM(3 * HD), RM(d), side));
         { ss_gemm_epilogue e = EPI(); e.mode = 1; L_(gemm(X, dt, dqkv, w.wqkvT, G, M, d, 3 * HD, RM(3 * HD), RM(3 * HD), RM(d), &e)); }
         if (l > 0) {                                                             // layer 0's group waits for w_raw_in's gradient

@@ -84,7 +84,10 @@ def mha_forward(m, x):
     out = torch.empty(M, H * dp, dtype=dt, device=dev)
     lse = torch.empty(B, H, T, dtype=torch.float32, device=dev)
     p = float(m.dropout.p) if m.training else 0.0
-    ops.relpos_attention_forward(qkv, qkvT, E, out, lse, B, H, T, Tp, dp, D, 1.0 / math.sqrt(dh), p=p, seed=_next_seed(), rng_stream=1)
+    tab = None
+    if ops.relpos_attention_family(dt, T, dp, D) == 2:                           # the transposed-score kernels read E / scale in fragment order, from the f32 parameter
+        tab = ops.relpos_attention_tables(emb, dp, 1.0 / math.sqrt(dh))
+    ops.relpos_attention_forward(qkv, qkvT, E, out, lse, B, H, T, Tp, dp, D, 1.0 / math.sqrt(dh), p=p, seed=_next_seed(), rng_stream=1, tab=tab)
     wo = torch.zeros(d, H * dp, dtype=dt, device=dev)                             # (H, dh, d) -> [f][h][a (padded)]
     ops.permute3d(m.w_o.detach(), wo, (d, H, dp), (1, dh * d, d), valid2=dh)
     y = torch.empty(M, d, dtype=dt, device=dev)

@@ -13,6 +13,7 @@ in (B, T+2, C) buffers with a zero halo row at both ends of every sequence, so a
 contiguous 3C-wide row and conv == GEMM with an overlapping-row RowMap (csrc/gemm.hip).
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -96,6 +97,11 @@ class Prepared(object):
             emb = a.relative_positional.embeddings.detach()    # (H, 2D-1, dh, 1)
             e['E'] = b1.add(emb, new(H, 2 * D - 1, dp), (H, 2 * D - 1, dp), ((2 * D - 1) * dh, dh, 1), valid2=dh)
             e['ET'] = b1.add(emb, new(H, dp, MPt), (H, dp, MPt), ((2 * D - 1) * dh, 1, dh), valid1=dh, valid2=2 * D - 1)
+            # transposed-score attention kernels (bf16 rows of <= 224 frames): E / scale in MFMA-fragment order (ss_relpos_attention_prepare_tables);
+            # the embeddings are never trained (transformer.py:214-218), so the table is rebuilt only when their version counter moves
+            nb = int(_lib.lib().ss_relpos_attention_table_bytes(H, dp, D)) if dt == torch.bfloat16 else 0
+            e['EF'] = new(max(nb // 2, 8), dtype=torch.bfloat16)
+            e['EF.src'], e['EF.version'], e['EF.scale'] = a.relative_positional.embeddings, None, 1.0 / math.sqrt(dh)
             e['w1'] = cast(layer.linear1.weight)
             e['w2'] = cast(layer.linear2.weight)
             e['w1T'] = transposed(e['w1'], layer.linear1.weight.shape[0], d)
@@ -119,6 +125,11 @@ class Prepared(object):
     def refresh(self, model):
         self.b1.run(self.dev)
         self.b2.run(self.dev)
+        for e in self.layers:
+            src = e['EF.src']
+            if e['EF'].numel() > 8 and e['EF.version'] != (src._version, src.data_ptr()):
+                ops.relpos_attention_tables(src, model.dp, e['EF.scale'], out=e['EF'])
+                e['EF.version'] = (src._version, src.data_ptr())
         self.version_sig = self.version_signature(model)
 
 
@@ -292,7 +303,7 @@ class PlanBinding(object):
             t['w_raw_in.weight.grad'], t['w_raw_in.bias.grad'] = model.w_raw_in.weight.grad, model.w_raw_in.bias.grad
         for l, (layer, w) in enumerate(zip(model.transformer.layers, pr.layers)):
             p = 'transformer.layers.%d.' % l
-            for k in ('wqkv', 'wqkvT', 'wo', 'woT', 'E', 'ET', 'w1', 'w2', 'w1T', 'w2T'):
+            for k in ('wqkv', 'wqkvT', 'wo', 'woT', 'E', 'ET', 'EF', 'w1', 'w2', 'w1T', 'w2T'):
                 t[p + k] = w[k]
             t[p + 'linear1.bias'], t[p + 'linear2.bias'] = layer.linear1.bias, layer.linear2.bias
             t[p + 'norm1.weight'], t[p + 'norm1.bias'], t[p + 'norm2.weight'], t[p + 'norm2.bias'] = layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias

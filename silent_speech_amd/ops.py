@@ -277,15 +277,43 @@ def _attn_dt(qkv, f32_math):
     return _lib.SS_F32X3
 
 
-def relpos_attention_forward(qkv, qkvT, E, out, lse, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0, saved=None, f32_math='exact'):
-    rc = _L().ss_relpos_attention_forward_p(_attn_dt(qkv, f32_math), _p(qkv), _p(qkvT), _p(E), _p(out), _p(lse), _p(saved), B, H, T, Tp, dp, D, scale, p,
+def relpos_attention_family(dtype, T, dp, D):
+    """0 = per-tile kernels (need qkvT / dOT), 1 = LDS-resident 16 x 16 tiles, 2 = transposed 32 x 32 score tiles (need the prepared tables)"""
+    return int(_L().ss_relpos_attention_family(dtype if isinstance(dtype, int) else _lib.dtype_code(dtype), T, dp, D))
+
+
+def relpos_attention_tables(emb, dp, scale, out=None):
+    """The embedding table of the transposed-score kernels (family 2): E / scale in MFMA-fragment order (ss_relpos_attention_prepare_tables).
+    emb: [H][2D-1][dh] (any float dtype; the f32 parameter of transformer.py:172-176, or a compute-dtype copy with dh <= dp columns)."""
+    emb = emb.detach().reshape(emb.shape[0], emb.shape[1], -1).float().contiguous()
+    H, NE, dh = emb.shape
+    D = (NE + 1) // 2
+    nbytes = int(_L().ss_relpos_attention_table_bytes(H, dp, D))
+    if nbytes <= 0:
+        raise ValueError('no transposed-score attention tables for H=%d dp=%d' % (H, dp))
+    if out is None:
+        out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=emb.device)
+    _lib.check(_L().ss_relpos_attention_prepare_tables(_p(emb), _p(out), H, D, dh, dp, scale, _s(emb)), 'ss_relpos_attention_prepare_tables')
+    return out
+
+
+def _attn_tab(qkv, E, T, dp, D, scale, f32_math, tab):
+    if tab is None and f32_math == 'exact' and relpos_attention_family(_dt(qkv), T, dp, D) == 2:
+        tab = relpos_attention_tables(E, dp, scale)           # convenience of the per-kernel callers (tests, eager sub-modules); the plan binds a prepared table
+    return tab
+
+
+def relpos_attention_forward(qkv, qkvT, E, out, lse, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0, saved=None, f32_math='exact', tab=None):
+    tab = _attn_tab(qkv, E, T, dp, D, scale, f32_math, tab)
+    rc = _L().ss_relpos_attention_forward_p(_attn_dt(qkv, f32_math), _p(qkv), _p(qkvT), _p(E), _p(tab), _p(out), _p(lse), _p(saved), B, H, T, Tp, dp, D, scale, p,
                                             int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
     _lib.check(rc, 'ss_relpos_attention_forward')
 
 
 def relpos_attention_backward(qkv, qkvT, E, ET, out, lse, dO, dOT, dscratch, dqkv, B, H, T, Tp, dp, D, scale, p=0.0, seed=0, rng_stream=0, saved=None,
-                              f32_math='exact'):
-    rc = _L().ss_relpos_attention_backward_p(_attn_dt(qkv, f32_math), _p(qkv), _p(qkvT), _p(E), _p(ET), _p(out), _p(lse), _p(dO), _p(dOT), _p(dscratch),
+                              f32_math='exact', tab=None):
+    tab = _attn_tab(qkv, E, T, dp, D, scale, f32_math, tab)
+    rc = _L().ss_relpos_attention_backward_p(_attn_dt(qkv, f32_math), _p(qkv), _p(qkvT), _p(E), _p(ET), _p(tab), _p(out), _p(lse), _p(dO), _p(dOT), _p(dscratch),
                                              _p(dqkv), _p(saved), B, H, T, Tp, dp, D, scale, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(qkv))
     _lib.check(rc, 'ss_relpos_attention_backward')
 

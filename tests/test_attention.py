@@ -42,8 +42,8 @@ def _run(dev, dt, B, H, T, dh, D, seed, tol_f, tol_b, p=0.0, f32_math='exact'):
     if p > 0:
         from oracle import dropout_ref
         from silent_speech_amd import _lib
-        resident = _lib.lib().ss_relpos_attention_needs_transposed(_lib.dtype_code(dt), T, dp, D) == 0
-        mask = (dropout_ref.attention_mask_resident if resident else dropout_ref.attention_mask_tiled)(seed + 1000, 8, B, H, T, p)
+        family = _lib.lib().ss_relpos_attention_family(_lib.dtype_code(dt), T, dp, D) if f32_math == 'exact' else 0
+        mask = dropout_ref.attention_mask(family, seed + 1000, 8, B, H, T, p)
         drop = torch.from_numpy(mask).float() / (1.0 - p)
         kw.update(p=p, seed=seed + 1000, rng_stream=8)
     O_ref, lse_ref = _reference(q, k, v, E, D, dh, drop=drop)
@@ -72,7 +72,9 @@ def _run(dev, dt, B, H, T, dh, D, seed, tol_f, tol_b, p=0.0, f32_math='exact'):
     dOT = torch.zeros(B, H * dp, Tp, dtype=dt); dOT[:, :, :T] = dOd.view(B, T, H * dp).transpose(1, 2)
     dqkv = torch.full((B * T, 3 * H * dp), 7.0, dtype=dt, device=dev)
     dsc = torch.empty(B, H, T, device=dev)
-    for sv in ([saved, None] if saved is not None else [None]):              # backward from the saved probabilities, and recomputing them
+    family = ops.relpos_attention_family(dt, T, dp, D) if f32_math == 'exact' else 0
+    # backward from the saved probabilities, and recomputing them (the transposed-score kernels, family 2, work from the image only)
+    for sv in ([saved] if family == 2 else [saved, None] if saved is not None else [None]):
         dqkv.fill_(7.0)
         ops.relpos_attention_backward(qkv_d, qkvT_d, E_d, ET_d, out, lse, dOd.to(dev), dOT.to(dev), dsc, dqkv, B, H, T, Tp, dp, D, scale, saved=sv, **kw)
         dq, dk, dv = [dqkv.view(B, T, 3, H, dp)[:, :, i, :, :dh].permute(0, 2, 1, 3) for i in range(3)]
@@ -98,6 +100,31 @@ def test_attention_no_band(dev, dt):
     """T <= D: no masking at all (transformer.py:256 branch not taken)."""
     T = 20 if is_emu(dev) else 50
     _run(dev, dt, B=1, H=1, T=T, dh=32, D=100 if not is_emu(dev) else 24, seed=2, tol_f=2e-5 if dt == torch.float32 else 2e-2, tol_b=5e-5 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize('case', [(37, 8, 9), (70, 32, 100), (65, 32, 20), (97, 64, 33)])
+@pytest.mark.parametrize('p', [0.0, 0.25])
+def test_attention_transposed_score_kernels(dev, case, p):
+    """Family 2 (csrc/attention_t.hip): one wave per 32-query tile, S^T = K Q^T on 32 x 32 x 16 MFMAs, the skew through LDS with a per-lane
+    offset, the embedding table E / scale in fragment order, the backward from the saved probabilities (query-major: dQ and D; key-major: dK,
+    dV).  Ragged T, several tiles, banded and unbanded, padded head dims, with and without dropout (the kernels' own mask, restated in
+    oracle/dropout_ref.attention_mask_transposed)."""
+    T, dh, D = case
+    if not is_emu(dev):
+        T, dh, D = {37: (200, 96, 100), 70: (224, 96, 100), 65: (209, 64, 40), 97: (131, 96, 17)}[T]
+    dp = (dh + 31) // 32 * 32
+    assert ops.relpos_attention_family(torch.bfloat16, T, dp, D) == 2
+    _run(dev, torch.bfloat16, B=2, H=2 if is_emu(dev) else 8, T=T, dh=dh, D=D, seed=T + D, tol_f=2e-2, tol_b=3e-2, p=p)
+
+
+@pytest.mark.parametrize('dt_old', [torch.bfloat16])
+def test_attention_resident_16x16_kernels_still_agree(dev, monkeypatch, dt_old):
+    """SS_ATTN_T=0 keeps the LDS-resident 16 x 16 kernels of rounds 1-4 reachable (A/B measurements): same function."""
+    monkeypatch.setenv('SS_ATTN_T', '0')
+    if is_emu(dev):
+        _run(dev, dt_old, B=1, H=2, T=37, dh=8, D=9, seed=1, tol_f=2e-2, tol_b=3e-2, p=0.25)
+    else:
+        _run(dev, dt_old, B=2, H=8, T=200, dh=96, D=100, seed=1, tol_f=2e-2, tol_b=3e-2, p=0.2)
 
 
 @pytest.mark.parametrize('p', [0.0, 0.25])
@@ -170,7 +197,7 @@ def test_attention_backward_uses_the_forward_dropout_mask(dev, dt):
     dOT = dOd.view(B, T, H * dp).transpose(1, 2).contiguous()
     dqkv = torch.zeros(B * T, 3 * H * dp, dtype=dt, device=dev); dsc = torch.empty(B, H, T, device=dev)
     assert (saved is not None) == bf
-    for sv in ([saved, None] if saved is not None else [None]):
+    for sv in ([saved] if ops.relpos_attention_family(dt, T, dp, D) == 2 else [saved, None] if saved is not None else [None]):
         dqkv.zero_()
         ops.relpos_attention_backward(qkv_d, qkvT_d, E_d, ET_d, out, lse, dOd.to(dev), dOT.to(dev), dsc, dqkv, B, H, T, Tp, dp, D, scale, p=p, seed=99, rng_stream=4, saved=sv)
         dq, dk, dv = [dqkv.float().view(B, T, 3, H, dp)[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
@@ -185,6 +212,7 @@ def test_resident_forward_generations_agree(dev, monkeypatch, T, D, dh, p):
     same log-sum-exp, same dropped set, outputs equal up to the bf16 rounding of the probabilities (normalised before vs after P~V)."""
     if is_emu(dev) and T > 100:
         pytest.skip('full-size rows: gpu tier')
+    monkeypatch.setenv('SS_ATTN_T', '0')                 # the 16 x 16 resident kernels (rounds 1-4), kept behind this switch
     B, H, dt = 2, 2, torch.bfloat16
     dp, Tp = (dh + 31) // 32 * 32, (T + 7) // 8 * 8
     g = torch.Generator().manual_seed(7)
@@ -209,6 +237,7 @@ def test_persistent_per_head_schedule_equals_one_workgroup_per_pair(dev, monkeyp
     # two of them without a half; (7, 1): 3 left over of 4 -> not split (a second whole round for three workgroups).  GPU: the benchmarked launch.
     if not is_emu(dev) and BH != (5, 2):
         pytest.skip('emulator-size schedules')
+    monkeypatch.setenv('SS_ATTN_T', '0')                 # a schedule of the 16 x 16 resident kernels
     B, H, T, dh, D = (BH[0], BH[1], 40, 32, 9) if is_emu(dev) else (110, 8, 200, 96, 100)
     dt, dp, Tp = torch.bfloat16, (dh + 31) // 32 * 32, (T + 7) // 8 * 8
     g = torch.Generator().manual_seed(17)
@@ -242,7 +271,10 @@ def test_transposed_copies_only_needed_by_the_per_tile_kernels(dev):
     BF16, F32 = _lib.dtype_code(torch.bfloat16), _lib.dtype_code(torch.float32)
     assert L.ss_relpos_attention_needs_transposed(BF16, 200, 96, 100) == 0
     assert L.ss_relpos_attention_needs_transposed(BF16, 40, 32, 100) == 0
-    assert L.ss_relpos_attention_needs_transposed(BF16, 209, 96, 100) == 1
+    assert L.ss_relpos_attention_needs_transposed(BF16, 224, 96, 100) == 0
+    assert L.ss_relpos_attention_needs_transposed(BF16, 225, 96, 100) == 1
+    assert L.ss_relpos_attention_family(BF16, 200, 96, 100) == 2 and L.ss_relpos_attention_family(BF16, 225, 96, 100) == 0
+    assert L.ss_relpos_attention_family(F32, 40, 32, 100) == 0
     assert L.ss_relpos_attention_needs_transposed(F32, 40, 32, 100) == 1
     assert L.ss_relpos_attention_needs_transposed(BF16, 200, 128, 100) == 1          # operands do not fit the LDS
     B, H, T, dp, D = 1, 2, 24, 32, 9

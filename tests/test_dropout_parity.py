@@ -66,9 +66,9 @@ def test_attention_mask(dev, dt):
     out = torch.zeros(B * T, H * dp, dtype=dt, device=dev); lse = torch.zeros(B, H, T, device=dev)
     ops.relpos_attention_forward(qkv.to(dev), qkvT.to(dev), E.to(dev), out, lse, B, H, T, Tp, dp, D, 1 / math.sqrt(dh), p=p, seed=seed, rng_stream=stream)
     keep = (out.float().cpu().view(B, T, H, dp).permute(0, 2, 1, 3) != 0).numpy()
-    resident = _lib.lib().ss_relpos_attention_needs_transposed(_lib.dtype_code(dt), T, dp, D) == 0
-    assert resident == (dt == torch.bfloat16)
-    want = (dropout_ref.attention_mask_resident if resident else dropout_ref.attention_mask_tiled)(seed, stream, B, H, T, p)
+    family = _lib.lib().ss_relpos_attention_family(_lib.dtype_code(dt), T, dp, D)
+    assert (family > 0) == (dt == torch.bfloat16)
+    want = dropout_ref.attention_mask(family, seed, stream, B, H, T, p)
     band = np.abs(np.arange(T)[None, :] - np.arange(T)[:, None]) <= D - 1
     assert np.array_equal(keep[..., band], want[..., band])
     assert not keep[..., ~band].any()
@@ -103,8 +103,8 @@ def model_step_with_dropout(dev, dt, d, L, B, T, p, seed_base=0xD5, nthreads=Non
     pred, aux = m(None, xd, None)
     ((pred * wp.to(dev)).sum() + (aux * wa.to(dev)).sum()).backward()
     seed = m.last_seed
-    resident = _lib.lib().ss_relpos_attention_needs_transposed(_lib.dtype_code(dt), T, m.dp, m.max_rel) == 0
-    masks = dropout_ref.layer_masks(seed, L, B, T, d, 8, 3072, p, resident)
+    family = _lib.lib().ss_relpos_attention_family(_lib.dtype_code(dt), T, m.dp, m.max_rel) if getattr(m, 'f32_matmul', 'exact') == 'exact' else 0
+    masks = dropout_ref.layer_masks(seed, L, B, T, d, 8, 3072, p, family)
     ref = {k: v.clone() for k, v in sd.items()}
     for v in ref.values():
         if v.dtype == torch.float32:

@@ -51,7 +51,7 @@ def cfg2(cuda):
 
 def _oracle(cfg2, p, resident, seed, storage=False):
     from oracle import dropout_ref, loss_ref, model_ref
-    key = (p, bool(resident) if p > 0 else None, seed if p > 0 else None, storage)
+    key = (p, int(resident) if p > 0 else None, seed if p > 0 else None, storage)
     if key in cfg2['runs']:
         return cfg2['runs'][key]
     ref = {k: v.clone() for k, v in cfg2['sd'].items()}
@@ -140,7 +140,7 @@ def _full_step_check(cfg2, cuda, dt, p, tag, f32_matmul='exact'):
     the deviation of the oracle itself under bf16 storage (the yardstick; see tests/test_dropout_parity.py)."""
     f32 = dt == torch.float32
     m, pred, aux, loss = _step(cfg2, dt, cuda, p, f32_matmul)
-    resident = _lib.lib().ss_relpos_attention_needs_transposed(_lib.dtype_code(dt), 200, m.dp, m.max_rel) == 0
+    resident = _lib.lib().ss_relpos_attention_family(_lib.dtype_code(dt), 200, m.dp, m.max_rel)       # 0 per-tile, 1 resident 16 x 16, 2 transposed 32 x 32: selects the mask restatement
     ref = _oracle(cfg2, p, resident, m.last_seed)
     yard = None if f32 else _oracle(cfg2, p, resident, m.last_seed, storage=True)
     l1 = float((pred - ref['pred']).abs().mean())

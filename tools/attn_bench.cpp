@@ -36,10 +36,20 @@ int main(int argc, char** argv)
     void* pimg = nullptr; if (nsaved) CK(hipMalloc(&pimg, (size_t)nsaved));
     printf("saved probabilities: %.1f MB\n", nsaved / 1e6);
     hipStream_t st; CK(hipStreamCreate(&st));
+    // family 2 (transposed 32 x 32 score tiles): the embedding table E / scale in fragment order, from the f32 embeddings [H][2D-1][dp]
+    void* tab = nullptr;
+    const int family = ss_relpos_attention_family(SS_BF16, T, dp, D);
+    printf("kernel family %d (0 per-tile, 1 LDS-resident 16x16, 2 transposed 32x32)\n", family);
+    if (family == 2) {
+        std::vector<float> hf(nE); for (size_t i = 0; i < nE; ++i) { uint32_t u = (uint32_t)hE[i] << 16; memcpy(&hf[i], &u, 4); }
+        float* embf; CK(hipMalloc(&embf, nE * 4)); CK(hipMemcpy(embf, hf.data(), nE * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&tab, (size_t)ss_relpos_attention_table_bytes(H, dp, D)));
+        if (ss_relpos_attention_prepare_tables(embf, tab, H, D, dp, dp, 1.0f / sqrtf((float)dp), st)) { fprintf(stderr, "prepare_tables: %s\n", ss_last_error()); return 1; }
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const float scale = 1.0f / sqrtf((float)dp);
-    auto fwd = [&]() { return ss_relpos_attention_forward_p(SS_BF16, qkv, nullptr, E, out, lse, pimg, B, H, T, Tp, dp, D, scale, pdrop, 77, 3, st); };
-    auto bwd = [&]() { return ss_relpos_attention_backward_p(SS_BF16, qkv, nullptr, E, ET, out, lse, dO, nullptr, dsc, dqkv, pimg, B, H, T, Tp, dp, D, scale, pdrop, 77, 3, st); };
+    auto fwd = [&]() { return ss_relpos_attention_forward_p(SS_BF16, qkv, nullptr, E, tab, out, lse, pimg, B, H, T, Tp, dp, D, scale, pdrop, 77, 3, st); };
+    auto bwd = [&]() { return ss_relpos_attention_backward_p(SS_BF16, qkv, nullptr, E, ET, tab, out, lse, dO, nullptr, dsc, dqkv, pimg, B, H, T, Tp, dp, D, scale, pdrop, 77, 3, st); };
     for (int pass = 0; pass < 2; ++pass) {
         for (int i = 0; i < 3; ++i) if ((pass ? bwd() : fwd())) { fprintf(stderr, "launch failed: %s\n", ss_last_error()); return 1; }
         CK(hipStreamSynchronize(st));

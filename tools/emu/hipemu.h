@@ -308,6 +308,27 @@ inline v4f mfma_16x16x4_f32(float a, float b, v4f c) {
     sync_wave();
     return d;
 }
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i=l&31][k=(l>>5)*8+e], B[k=(l>>5)*8+e][j=l&31], e<8;
+//                           C/D: col j=l&31, row i=(reg&3)+8*(reg>>2)+4*(l>>5), reg<16  (cdna_hip_programming.md section 3).
+typedef float v16f __attribute__((ext_vector_type(16)));
+inline v16f mfma_32x32x16_bf16(v8s a, v8s b, v16f c) {
+    State& s = S();
+    int me = s.cur, lane = me & 63, base = me - lane;
+    for (int e = 0; e < 8; ++e) { s.big[me][e] = bf16_bits_to_f((unsigned short)a[e]); s.big[me][8 + e] = bf16_bits_to_f((unsigned short)b[e]); }
+    sync_wave();
+    v16f d = c;
+    int j = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int q = 0; q < 2; ++q)
+            for (int e = 0; e < 8; ++e)
+                acc = fmaf(s.big[base + i + 32 * q][e], s.big[base + j + 32 * q][8 + e], acc);
+        d[r] = acc;
+    }
+    sync_wave();
+    return d;
+}
 // global_load_lds_dwordx4: every lane copies 16 bytes from its own global address to  lds_base (wave-uniform) + lane*16
 inline void global_load_lds16(const void* gptr, void* lds_wave_base) {
     State& s = S();
