@@ -53,6 +53,7 @@ struct KP {
     const bf16_t* dO; const bf16_t* O; float* Dv; bf16_t* dqkv;
     int B, H, T, dp, D, nt;
     float c1, scale, oscale;            // scale * log2(e); scale; 1 / (1 - p)
+    unsigned long long* dbg;            // measurement only (SS_ATTN_T_STAMPS): phase time stamps of workgroup 0
     unsigned ts2, seedfold;             // packed signed 16-bit dropout thresholds (0x80008000 = keep everything); folded seed
     int drop;
 };
@@ -134,72 +135,233 @@ __device__ __forceinline__ void store_rows_t(unsigned char* tile, const f32x16 (
 }
 
 // =========================================================================== forward
+// phase time stamps (measurement only): wave w of workgroup 0 records s_memtime at phase k of its i-th pair
+__device__ __forceinline__ void stamp(const KP& p, int w, int it, int k) {
+#if !defined(SS_EMU)
+    if (p.dbg && blockIdx.x == 0 && it < 4 && (threadIdx.x & 63) == 0) p.dbg[(w * 4 + it) * 8 + k] = __builtin_amdgcn_s_memtime();
+#endif
+}
+__device__ __forceinline__ void stamp2(const KP& p, int w, int it, int k) {
+#if !defined(SS_EMU)
+    if (p.dbg && blockIdx.x == 0 && it == 1 && (threadIdx.x & 63) == 0) p.dbg[256 + w * 32 + k] = __builtin_amdgcn_s_memtime();
+#endif
+}
+// wave-uniform value of a quantity derived from the thread index (scalar register: uniform branches, scalar address arithmetic)
+__device__ __forceinline__ int uniform(int v) {
+#if defined(SS_EMU)
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+// one R-block's table fragments (KS x 16 bytes per lane, 1 KiB apart) requested from asm / waited for by hand (see the forward's logits loop)
+template <int KS>
+__device__ __forceinline__ void efrag_load(bf16x8 (&f)[KS], const bf16_t* ptr) {
+#if defined(SS_EMU)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) f[s] = *(const bf16x8*)(ptr + s * 512);
+#else
+    static_assert(KS <= 6, "global_load offset field: 13 bits signed");
+    const bf16_t* q = ptr + (KS > 4 ? 2048 : 0);              // offsets -4096 .. 1024
+    if (KS > 0) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(f[0]) : "v"(q), "n"(KS > 4 ? -4096 : 0) : "memory");
+    if (KS > 1) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(f[KS > 1 ? 1 : 0]) : "v"(q), "n"(KS > 4 ? -3072 : 1024) : "memory");
+    if (KS > 2) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(f[KS > 2 ? 2 : 0]) : "v"(q), "n"(KS > 4 ? -2048 : 2048) : "memory");
+    if (KS > 3) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(f[KS > 3 ? 3 : 0]) : "v"(q), "n"(KS > 4 ? -1024 : 3072) : "memory");
+    if (KS > 4) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(f[KS > 4 ? 4 : 0]) : "v"(q), "n"(0) : "memory");
+    if (KS > 5) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(f[KS > 5 ? 5 : 0]) : "v"(q), "n"(1024) : "memory");
+#endif
+}
+// at most N vector-memory operations requested after these fragments are still outstanding; ties every later use of the fragments to this point
+template <int KS, int N>
+__device__ __forceinline__ void efrag_wait(bf16x8 (&f)[KS]) {
+#if !defined(SS_EMU)
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(f[s]));
+#endif
+}
+__device__ __forceinline__ void sched_fence() {
+#if !defined(SS_EMU)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// table rows in flight: a thread's share of a T x dp table (16-byte chunks tid, tid + nthr, ...), loaded now, written to LDS later
+template <int DPK>
+__device__ __forceinline__ void table_load(u32x4 (&v)[2 * DPK], const bf16_t* src, long long ld, int T, int tid, int nthr) {
+    constexpr int CPR = DPK * 4;
+#pragma unroll
+    for (int u = 0; u < 2 * DPK; ++u) {
+        const int i = tid + u * nthr, r = i / CPR, ch = i - r * CPR;
+        if (i < T * CPR) v[u] = *(const u32x4*)(src + (long long)r * ld + ch * 8);
+    }
+}
+template <int DPK>
+__device__ __forceinline__ void table_store(unsigned char* dst, int pitch, const u32x4 (&v)[2 * DPK], int T, int tid, int nthr) {
+    constexpr int CPR = DPK * 4;
+#pragma unroll
+    for (int u = 0; u < 2 * DPK; ++u) {
+        const int i = tid + u * nthr, r = i / CPR, ch = i - r * CPR;
+        if (i < T * CPR) *(u32x4*)(dst + r * pitch + ch * 16) = v[u];
+    }
+}
+
+// A T x dp table (row stride ld elements in global memory) copied into LDS by ONE wave with global_load_lds_dwordx4: no registers, no
+// LDS store instructions, and the copy is in flight while the other waves compute.  An instruction deposits the 64 lanes' 16-byte
+// chunks back to back (1 KiB): chunk c of the image is (row c / CPR, 16-byte column c % CPR) with CPR = pitch / 16; a pad column
+// (pitch > dp*2) re-fetches the last real one.  The table occupies ceil(T * CPR / 64) KiB.
+template <int DPK>
+__device__ __forceinline__ void dma_table(unsigned char* dst, int pitch, const bf16_t* src, long long ld, int T, int lane) {
+    const int cpr = pitch >> 4, pieces = (T * cpr + 63) >> 6;
+    for (int i = 0; i < pieces; ++i) {
+        const int c = 64 * i + lane;
+        int r = c / cpr, col = c - r * cpr;
+        r = r < T ? r : T - 1; col = col < DPK * 4 ? col : DPK * 4 - 1;
+#if defined(ATTN_T_NO_DMA)
+        *(u32x4*)(dst + i * 1024 + lane * 16) = *(const u32x4*)(src + (long long)r * ld + col * 8);
+#else
+        glds16(src + (long long)r * ld + col * 8, dst + i * 1024);
+#endif
+    }
+}
+__host__ __device__ inline size_t dma_table_bytes(int T, int pitch) { return (size_t)(((size_t)T * (pitch >> 4) + 63) >> 6) * 1024; }
+
 // LDS: [K rows, pitch dp*2+16 | V rows, pitch dp*2 | per-wave skew buffers of SK_WORDS floats]
-template <int DPK, bool DROP>
-__global__ __launch_bounds__(NTM * 64) void attn_t_fwd_kernel(KP p)
+// One PERSISTENT workgroup per CU walks the (sequence, head) pairs blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of H: its head, and
+// with it the embedding table it streams, stays the same).  Waves 0 .. NT-1 compute: wave w owns the queries [32 w, 32 w + 32).  Wave NT
+// is the LOADER: it only copies tables into LDS (dma_table) and meets the others at the two barriers of a pair,
+//     compute:  logits(p) [K_p]            | barrier A |  softmax(p), image, P~V(p) [V_p], O             | barrier B
+//     loader :  V_p -> LDS, wait           | barrier A |  K_p+1 -> LDS, wait                               | barrier B
+// so no table load is ever waited for by a computing wave, and between the barriers the waves run at their own pace (one wave's
+// softmax -- VALU -- beside another's P~V -- MFMA).  R-blocks and key blocks wholly outside the +-(D-1) band are skipped.
+template <int DPK, int NT, bool DROP>
+__global__ __launch_bounds__((NT + 1) * 64) void attn_t_fwd_kernel(KP p)
 {
     constexpr int KS = 2 * DPK, KPB = DPK * 64 + KPAD, VPB = DPK * 64;
     SS_DYN_SMEM(lds);
-    const int T = p.T, D = p.D, nt = p.nt, H = p.H;
-    const int pair = blockIdx.x, b = pair / H, hd = pair - b * H;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, h = lane >> 5;
-    const long long ld = 3LL * H * p.dp;
+    const int T = p.T, D = p.D, H = p.H, npairs = p.B * H;
+    const int tid = threadIdx.x, w_ = uniform(tid >> 6);
+    const long long ld = 3LL * H * p.dp, ldo = (long long)H * p.dp;
     unsigned char* Ks = (unsigned char*)lds;
-    unsigned char* Vs = Ks + (size_t)T * KPB;
-    float* sk = (float*)(Vs + (((size_t)T * VPB + 15) & ~(size_t)15)) + (size_t)w * SK_WORDS;
-    const bf16_t* base = p.qkv + (long long)b * T * ld + hd * p.dp;
-    stage_table<DPK>(Ks, KPB, base + (long long)H * p.dp, ld, T, tid, blockDim.x);
-    stage_table<DPK>(Vs, VPB, base + 2LL * H * p.dp, ld, T, tid, blockDim.x);
+    unsigned char* Vs = Ks + dma_table_bytes(T, KPB);
+    float* sk0 = (float*)(Vs + dma_table_bytes(T, VPB));
+    int pair = blockIdx.x;
+    if (pair >= npairs) return;
 
-    // this lane's query row as B fragments (zero beyond the sequence)
-    const int i0 = 32 * w, qi = i0 + n;
-    bf16x8 qf[KS];
-    {
-        const bf16_t* qrow = base + (long long)(qi < T ? qi : T - 1) * ld + 8 * h;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) { const bf16x8 v = *(const bf16x8*)(qrow + 16 * s); qf[s] = qi < T ? v : zero8(); }
-    }
-    int jlo, nblk; tile_band(w, T, D, jlo, nblk);
-    const int dlo = jlo - w;
-    __syncthreads();
-
-    // ---- logits, transposed: acc[ub][r] = (Q.K + Q.E / scale) of key 32 (jlo + ub) + rho(r, h), query qi
-    f32x16 acc[NTM];
-    const bf16_t* tabF = p.tab + ((long long)hd * NU + (dlo + UOFF)) * (KS * 512) + lane * 8;
-    float* skw = sk + (SKP + 1) * n + 4 * h + 1;                 // + 32 ub + 8 (r >> 2) + (r & 3)
-    const float* skr = sk + SKP * n + 4 * h + 32;                // + 32 ub + 8 rg
-    const int krow = 32 * jlo + n;
-#pragma unroll
-    for (int ub = 0; ub <= NTM; ++ub) {
-        if (ub <= nblk) {
-            f32x16 rt = zero16();
-#pragma unroll
-            for (int s = 0; s < KS; ++s) rt = mfma32(*(const bf16x8*)(tabF + (ub * KS + s) * 512), qf[s], rt);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) skw[32 * ub + 8 * (r >> 2) + (r & 3)] = rt[r];
+    if (w_ == NT) {                                                 // ---- the loader wave
+        const int lane = tid & 63;
+        { const int b = pair / H, hd = pair - b * H; dma_table<DPK>(Ks, KPB, p.qkv + (long long)b * T * ld + hd * p.dp + (long long)H * p.dp, ld, T, lane); }
+        wait_vmcnt<0>();
+        __syncthreads();
+        for (; pair < npairs; pair += gridDim.x) {
+            const int b = pair / H, hd = pair - b * H;
+            dma_table<DPK>(Vs, VPB, p.qkv + (long long)b * T * ld + hd * p.dp + 2LL * H * p.dp, ld, T, lane);
+            wait_vmcnt<0>();
+            __syncthreads();                                         // A
+            const int nxt = pair + gridDim.x;
+            if (nxt < npairs) { const int b2 = nxt / H, h2 = nxt - b2 * H; dma_table<DPK>(Ks, KPB, p.qkv + (long long)b2 * T * ld + h2 * p.dp + (long long)H * p.dp, ld, T, lane); }
+            wait_vmcnt<0>();
+            __syncthreads();                                         // B
         }
-        if (ub >= 1 && ub <= nblk) {
-            const int kb = ub - 1;
-            wave_lds_sync();
-            f32x16 a;
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) { const f32x4 v = *(const f32x4*)(skr + 32 * kb + 8 * rg); a[4 * rg] = v[0]; a[4 * rg + 1] = v[1]; a[4 * rg + 2] = v[2]; a[4 * rg + 3] = v[3]; }
-            int row = krow + 32 * kb; row = row < T ? row : T - 1;
-            const unsigned char* kp = Ks + row * KPB + 16 * h;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) a = mfma32(*(const bf16x8*)(kp + 32 * s), qf[s], a);
-            acc[kb] = a;
-        }
+        return;
     }
-
-    // ---- band / sequence mask of the edge blocks, row maximum
-    float mx = -INFINITY;
+    __syncthreads();                                                 // K of the first pair
+    for (int it = 0; pair < npairs; pair += gridDim.x, ++it) {
+        const int b = pair / H, hd = pair - b * H;
+        const bf16_t* base = p.qkv + (long long)b * T * ld + hd * p.dp;
+        stamp(p, w_, it, 0);
+        // Opaque copies of the wave and lane numbers per pair: everything derived from them (band constants and compare masks of the 7 x 16
+        // logits, LDS addresses of the skew / K / V reads, image slots) is recomputed HERE.  Left to itself the compiler hoists ~250 scalar
+        // and ~90 vector registers of such loop invariants out of the pair loop and spills them around it.
+        int w = w_, lane = tid & 63;
+#if !defined(SS_EMU)
+        asm volatile("" : "+s"(w), "+v"(lane));
+#endif
+        const int n = lane & 31, h = lane >> 5;
+        float* sk = sk0 + (size_t)w * SK_WORDS;
+        const int i0 = 32 * w, qi = i0 + n;
+        float* skw = sk + (SKP + 1) * n + 4 * h + 1;                 // + 32 ub + 8 (r >> 2) + (r & 3)
+        const float* skr = sk + SKP * n + 4 * h + 32;                // + 32 kb + 8 rg
+        const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+        const int vlane = 4 * h + (i16 >> 2), vcol = (16 * g16 + 4 * (i16 & 3)) * 2;
+        int slot8[4];
 #pragma unroll
-    for (int kb = 0; kb < NTM; ++kb) {
-        if (kb < nblk) {
-            const int dj = 32 * (dlo + kb), j0 = 32 * (jlo + kb);
-            const bool edge = (dj < 0 ? -dj : dj) + 31 > D - 1 || j0 + 31 >= T;
-            if (edge) {
+        for (int rg = 0; rg < 4; ++rg) slot8[rg] = rg * 512 + pimg_slot(n, h, rg) * 8;
+        // this lane's query row as B fragments (zero beyond the sequence)
+        bf16x8 qf[KS];
+        {
+            const bf16_t* qrow = base + (long long)(qi < T ? qi : T - 1) * ld + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { const bf16x8 v = *(const bf16x8*)(qrow + 16 * s); qf[s] = qi < T ? v : zero8(); }
+        }
+        // ---- logits, transposed: acc[kb][r] = (Q.K + Q.E / scale) of key 32 kb + rho(r, h), query qi.  R-block ub = relative positions of key blocks ub - 1, ub
+        // R-block ub (u = ub - w) holds rel 32 u + D - 32 .. + 31: all-zero table rows outside [0, 2D - 2] -- only band-masked logits would read it
+#define RNEED(ub) (32 * ((ub) - w) + D - 1 >= 0 && 32 * ((ub) - w) + D - 32 <= 2 * D - 2)
+#define KOUT(kb) ((32 * ((kb) - w) < 0 ? -32 * ((kb) - w) : 32 * ((kb) - w)) - 31 > D - 1)
+        f32x16 acc[NT];
+        const bf16_t* tabF = p.tab + ((long long)hd * NU + (UOFF - w)) * (KS * 512) + lane * 8;
+        // Software pipeline over the R-blocks (R = E' Q^T of block ub: relative positions of key blocks ub - 1 and ub):
+        //     iteration ub:   skew-write R(ub)   |   MFMAs of R(ub + 1)   |   table fragments of R(ub + 2) requested   |   skew-read + Q.K of key block ub - 1
+        // so the MFMAs of the next R-block cover the LDS round trip of this one, and a table fragment has a whole iteration to arrive from L2.
+        // The fragment loads are asm (the compiler would sink them to just in front of their MFMAs to save registers, and wait for each there);
+        // their waits are counted by hand -- vmcnt counts in order, and only loads requested later than the ones needed are left outstanding.
+        // (The asm loads and their waits are UNCONDITIONAL: a fragment register defined by an asm load under a branch meets its other definition in
+        // a phi, and the copies the compiler places for it sit between the load and the wait -- they read registers the data has not reached yet.)
+        bf16x8 ef[KS];
+        f32x16 rt[2];
+        rt[0] = zero16();
+        efrag_load<KS>(ef, tabF);
+        efrag_wait<KS, 0>(ef);
+        if (RNEED(0)) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) rt[0] = mfma32(ef[s], qf[s], rt[0]);
+        }
+        efrag_load<KS>(ef, tabF + KS * 512);
+#pragma unroll
+        for (int ub = 0; ub <= NT; ++ub) {
+            stamp2(p, w_, it, 3 * ub);
+            if (RNEED(ub)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) skw[32 * ub + 8 * (r >> 2) + (r & 3)] = rt[ub & 1][r];
+            }
+            if (ub < NT) {
+                f32x16 t = zero16();
+                efrag_wait<KS, 0>(ef);
+                if (RNEED(ub + 1)) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) t = mfma32(ef[s], qf[s], t);
+                }
+                rt[(ub + 1) & 1] = t;
+                if (ub + 1 < NT) efrag_load<KS>(ef, tabF + (ub + 2) * KS * 512);
+            }
+            stamp2(p, w_, it, 3 * ub + 1);
+            if (ub >= 1) {
+                const int kb = ub - 1;
+                if (!KOUT(kb)) {
+                    wave_lds_sync();
+                    f32x16 a;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) { const f32x4 v = *(const f32x4*)(skr + 32 * kb + 8 * rg); a[4 * rg] = v[0]; a[4 * rg + 1] = v[1]; a[4 * rg + 2] = v[2]; a[4 * rg + 3] = v[3]; }
+                    int row = 32 * kb + n; row = row < T ? row : T - 1;
+                    const unsigned char* kp = Ks + row * KPB + 16 * h;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) a = mfma32(*(const bf16x8*)(kp + 32 * s), qf[s], a);
+                    acc[kb] = a;
+                }
+            }
+            stamp2(p, w_, it, 3 * ub + 2);
+            sched_fence();
+        }
+        stamp(p, w_, it, 1);
+        __syncthreads();                                             // A: V_p is in LDS; every wave is done with K_p
+        stamp(p, w_, it, 2);
+
+        // ---- band / sequence mask of the edge blocks, row maximum
+        float mx = -1e30f;                                           // (a row without a single key inside the sequence -- queries beyond T -- stays finite)
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb) {
+            const int dj = 32 * (kb - w), j0 = 32 * kb, adj = dj < 0 ? -dj : dj;
+            if (adj - 31 > D - 1) continue;                          // wholly outside the band
+            if (adj + 31 > D - 1 || j0 + 31 >= T) {
                 const int rel0 = dj + 4 * h - n + (D - 1), lim = 2 * (D - 1), jl = T - j0 - 4 * h;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -210,46 +372,41 @@ __global__ __launch_bounds__(NTM * 64) void attn_t_fwd_kernel(KP p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[kb][r]);
         }
-    }
-    mx = fmaxf(fmaxf(mx, xhalf(mx)), -1e30f);                     // a row without a single key inside the sequence (queries beyond T): no inf - inf
-    const float mc = mx * p.c1;
-    float sum = 0.f;
+        mx = fmaxf(mx, xhalf(mx));
+        const float mc = mx * p.c1;
+        float sum = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < NTM; ++kb)
-        if (kb < nblk) {
+        for (int kb = 0; kb < NT; ++kb) {
+            if (KOUT(kb)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float e = fast_exp2(acc[kb][r] * p.c1 - mc); acc[kb][r] = e; sum += e; }
         }
-    sum += xhalf(sum);
-    const float inv = qi < T ? fast_rcp(sum) : 0.f;              // rows beyond the sequence leave an all-zero image (the backward relies on it)
-    if (h == 0 && qi < T) p.lse[((long long)b * H + hd) * T + qi] = mc * LN2 + logf(sum);
+        sum += xhalf(sum);
+        const float inv = qi < T ? fast_rcp(sum) : 0.f;              // rows beyond the sequence leave an all-zero image (the backward relies on it)
+        if (h == 0 && qi < T) p.lse[((long long)b * H + hd) * T + qi] = mc * LN2 + logf(sum);
+        stamp(p, w_, it, 3);
 
-    // ---- probabilities -> bf16 (+ dropout decision in the sign bit) -> image, O^T += V^T P~^T
-    f32x16 o[DPK];
+        // ---- probabilities -> bf16 (+ dropout decision in the sign bit) -> image, and straight on as B operands: O^T += V^T P~^T
+        const unsigned dkey = DROP ? drop_key(p, pair, qi) : 0u;
+        unsigned char* img = p.pimg ? p.pimg + pimg_block(pair, NT, w, 0) : nullptr;
+        f32x16 o[DPK];
 #pragma unroll
-    for (int db = 0; db < DPK; ++db) o[db] = zero16();
-    const unsigned dkey = DROP ? drop_key(p, pair, qi) : 0u;
-    unsigned char* img = p.pimg ? p.pimg + pimg_block(pair, nt, w, jlo) : nullptr;
-    int slot8[4];
+        for (int db = 0; db < DPK; ++db) o[db] = zero16();
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) slot8[rg] = rg * 512 + pimg_slot(n, h, rg) * 8;
-    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-    const int vlane = 4 * h + (i16 >> 2), vcol = (16 * g16 + 4 * (i16 & 3)) * 2;
-#pragma unroll
-    for (int kb = 0; kb < NTM; ++kb) {
-        if (kb < nblk) {
+        for (int kb = 0; kb < NT; ++kb) {
+            if (KOUT(kb)) continue;
             unsigned pv[8];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 unsigned w0 = pack_bf16(acc[kb][4 * rg] * inv, acc[kb][4 * rg + 1] * inv), w1 = pack_bf16(acc[kb][4 * rg + 2] * inv, acc[kb][4 * rg + 3] * inv);
                 if (DROP) {
-                    unsigned s01, s23; drop_signs(dkey, 8 * (jlo + kb) + 2 * rg + h, p.ts2, s01, s23);
+                    unsigned s01, s23; drop_signs(dkey, 8 * kb + 2 * rg + h, p.ts2, s01, s23);
                     w0 |= s01 & 0x80008000u; w1 |= s23 & 0x80008000u;
                 }
                 if (img) { u32x2 v = {w0, w1}; *(u32x2*)(img + (long long)kb * 2048 + slot8[rg]) = v; }
                 pv[2 * rg] = DROP ? keep_pos(w0) : w0; pv[2 * rg + 1] = DROP ? keep_pos(w1) : w1;
             }
-            const int j0 = 32 * (jlo + kb);
+            const int j0 = 32 * kb;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pb = __builtin_bit_cast(bf16x8, (u32x4){pv[4 * s2], pv[4 * s2 + 1], pv[4 * s2 + 2], pv[4 * s2 + 3]});
@@ -264,10 +421,15 @@ __global__ __launch_bounds__(NTM * 64) void attn_t_fwd_kernel(KP p)
                 }
             }
         }
+        stamp(p, w_, it, 5);
+        store_rows_t<DPK>((unsigned char*)sk, o, p.oscale, p.out + ((long long)b * T + i0) * ldo + hd * p.dp, ldo, T - i0 < 32 ? T - i0 : 32, lane);
+        stamp(p, w_, it, 6);
+        __syncthreads();                                             // B: K_p+1 is in LDS; every wave is done with V_p
+        stamp(p, w_, it, 7);
+#undef RNEED
+#undef KOUT
     }
-    store_rows_t<DPK>((unsigned char*)sk, o, p.oscale, p.out + ((long long)b * T + i0) * ((long long)H * p.dp) + hd * p.dp, (long long)H * p.dp, T - i0 < 32 ? T - i0 : 32, lane);
 }
-
 
 // =========================================================================== backward helpers
 __device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c) {
@@ -294,17 +456,63 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* a0, const unsigne
     return f;
 }
 
+// =========================================================================== backward: loads in flight
+// Global loads of the backward kernels' streamed operands (image blocks, E'^T fragments) are requested from asm one block ahead of their
+// use and waited for by hand (vmcnt counts in order: only the loads requested LATER may stay outstanding) -- the compiler would place every
+// load right in front of its first use and wait for HBM there.  All of them are UNCONDITIONAL and live in statically indexed buffers: a
+// register defined by an asm load under a branch meets its other definition in a phi, whose copies read it before the data has arrived.
+// Address form: 64-bit scalar base (uniform) + 32-bit per-lane byte offset + immediate.
+__device__ __forceinline__ const void* uniform_ptr(const void* q) {
+#if defined(SS_EMU)
+    return q;
+#else
+    const unsigned long long v = (unsigned long long)q;
+    return (const void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+#endif
+}
+template <int IMM>
+__device__ __forceinline__ void aload8(u32x2& d, const void* base, unsigned off) {
+#if defined(SS_EMU) || defined(ATTN_T_PLAIN_LOADS)
+    d = *(const u32x2*)((const unsigned char*)base + off + IMM);
+#else
+    // s_nop 4: the scalar base may have been written by a VALU instruction (v_readfirstlane) just before; a vector-memory instruction that reads such an
+    // SGPR needs 5 wait states, and the compiler's hazard recogniser does not look inside asm (it pads nothing here)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(d) : "v"(off), "s"(base), "n"(IMM) : "memory");
+#endif
+}
+template <int IMM>
+__device__ __forceinline__ void aload16(u32x4& d, const void* base, unsigned off) {
+#if defined(SS_EMU) || defined(ATTN_T_PLAIN_LOADS)
+    d = *(const u32x4*)((const unsigned char*)base + off + IMM);
+#else
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(off), "s"(base), "n"(IMM) : "memory");
+#endif
+}
+template <int N> __device__ __forceinline__ void await_vm() {
+#if !defined(SS_EMU)
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+#endif
+}
+template <class V> __device__ __forceinline__ void apin(V& v) {
+#if !defined(SS_EMU)
+    asm volatile("" : "+v"(v));
+#endif
+}
+// band of tile w over the NT blocks of the other axis: first / last block with an entry inside |k - q| <= D - 1 (and inside the sequence)
+__device__ __forceinline__ bool blk_out(int kb, int w, int D) { const int dj = 32 * (kb - w); return (dj < 0 ? -dj : dj) - 31 > D - 1; }
+__device__ __forceinline__ bool rblk_need(int ub, int w, int D) { const int r0 = 32 * (ub - w) + D - 32; return r0 + 31 >= 0 && r0 <= 2 * D - 2; }
+
 // =========================================================================== backward, query-major: dQ (and D)
 // LDS: [K rows, pitch dp*2 (transposing reads) | V rows, pitch dp*2+16 (row fragments) | per-wave buffer: un-skew (bf16) / output staging]
 constexpr int BW_BUF = 6656 + 64;       // per-wave buffer bytes of both backward kernels (32 x (96*2+16) staging; >= 2 * SK_WORDS resp. 2048)
-template <int DPK>
-__global__ __launch_bounds__(NTM * 64) void attn_t_bwd_q_kernel(KP p)
+template <int DPK, int NT>
+__global__ __launch_bounds__(NT * 64) void attn_t_bwd_q_kernel(KP p)
 {
-    constexpr int KS = 2 * DPK, KPB = DPK * 64, VPB = DPK * 64 + KPAD;
+    constexpr int KS = 2 * DPK, KPB = DPK * 64, VPB = DPK * 64 + KPAD, NF = 2 * DPK;
     SS_DYN_SMEM(lds);
-    const int T = p.T, D = p.D, nt = p.nt, H = p.H;
+    const int T = p.T, D = p.D, H = p.H;
     const int pair = blockIdx.x, b = pair / H, hd = pair - b * H;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, w = uniform(tid >> 6), n = lane & 31, h = lane >> 5;
     const long long ld = 3LL * H * p.dp, ldo = (long long)H * p.dp;
     unsigned char* Ks = (unsigned char*)lds;
     unsigned char* Vs = Ks + (((size_t)T * KPB + 15) & ~(size_t)15);
@@ -313,6 +521,26 @@ __global__ __launch_bounds__(NTM * 64) void attn_t_bwd_q_kernel(KP p)
     const bf16_t* base = p.qkv + (long long)b * T * ld + hd * p.dp;
     stage_table<DPK>(Ks, KPB, base + (long long)H * p.dp, ld, T, tid, blockDim.x);
     stage_table<DPK>(Vs, VPB, base + 2LL * H * p.dp, ld, T, tid, blockDim.x);
+
+    // streamed operands of block 0: the image words of this lane (4 x 8 bytes) and the E'^T fragments of R-block 0
+    const unsigned char* img = (const unsigned char*)uniform_ptr(p.pimg + pimg_block(pair, NT, w, 0));
+    const unsigned char* tabB = (const unsigned char*)uniform_ptr(p.tab + (long long)H * NU * KS * 512 + ((long long)hd * NU + (UOFF - w)) * (NF * 512));
+    unsigned slot8[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) slot8[rg] = rg * 512 + pimg_slot(n, h, rg) * 8;
+    const unsigned lane16 = lane * 16;
+    u32x2 iw[2][4]; u32x4 tf[2][NF];
+    // key blocks outside the band were never written by the forward: their loads are pointed at the nearest block that was (the data is not used)
+    int lo = 0, hi = NT - 1;
+    while (lo < NT - 1 && blk_out(lo, w, D)) ++lo;
+    while (hi > 0 && blk_out(hi, w, D)) --hi;
+#define IMG_LOAD(BUF, KB) do { const unsigned char* ib_ = (const unsigned char*)uniform_ptr(img + (long long)((KB) < lo ? lo : (KB) > hi ? hi : (KB)) * 2048); \
+        aload8<0>(iw[BUF][0], ib_, slot8[0]); aload8<0>(iw[BUF][1], ib_, slot8[1]); aload8<0>(iw[BUF][2], ib_, slot8[2]); aload8<0>(iw[BUF][3], ib_, slot8[3]); } while (0)
+#define TAB_LOAD(BUF, UB) do { const unsigned char* tb_ = (const unsigned char*)uniform_ptr(tabB + (long long)(UB) * (NF * 1024)); \
+        aload16<0>(tf[BUF][0], tb_, lane16); aload16<1024>(tf[BUF][1], tb_, lane16); \
+        if (NF > 2) { aload16<2048>(tf[BUF][NF > 2 ? 2 : 0], tb_, lane16); aload16<3072>(tf[BUF][NF > 3 ? 3 : 0], tb_, lane16); } \
+        if (NF > 4) { const unsigned char* t2_ = (const unsigned char*)uniform_ptr(tb_ + 4096); aload16<0>(tf[BUF][NF > 4 ? 4 : 0], t2_, lane16); aload16<1024>(tf[BUF][NF > 5 ? 5 : 0], t2_, lane16); } } while (0)
+    IMG_LOAD(0, 0); TAB_LOAD(0, 0);
 
     const int i0 = 32 * w, qi = i0 + n;
     bf16x8 dof[KS];
@@ -330,44 +558,44 @@ __global__ __launch_bounds__(NTM * 64) void attn_t_bwd_q_kernel(KP p)
         Dp = qi < T ? Dp / p.oscale : 0.f;                        // D' = D / s
         if (h == 0 && qi < T) p.Dv[((long long)b * H + hd) * T + qi] = Dp;
     }
-    int jlo, nblk; tile_band(w, T, D, jlo, nblk);
-    const int dlo = jlo - w;
     f32x16 dq[DPK];
 #pragma unroll
     for (int db = 0; db < DPK; ++db) dq[db] = zero16();
-    const unsigned char* img = p.pimg + pimg_block(pair, nt, w, jlo);
-    int slot8[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) slot8[rg] = rg * 512 + pimg_slot(n, h, rg) * 8;
-    const bf16_t* tabB = p.tab + (long long)H * NU * KS * 512 + ((long long)hd * NU + (dlo + UOFF)) * (2 * DPK * 512) + lane * 8;
     const int i16 = lane & 15, g16 = (lane >> 4) & 1;
     const int klane = 4 * h + (i16 >> 2), kcol = (16 * g16 + 4 * (i16 & 3)) * 2;
     bf16_t* usw = us + SKP * n + 4 * h + 32;                     // + 32 kb + 8 rg      (aligned 8-byte pieces, row stride SKP)
     const bf16_t* usr = us + (SKP + 1) * n + 8 * h + 1;          // + 32 ub + 16 s2 + e (row stride SKP + 1: the un-skew)
     const u32x2 z2 = {0u, 0u};
+    // A key block outside the band that a needed R-block reads (at rel positions whose table rows are zero) must hold finite numbers: zeros,
+    // written just before that R-block is read -- not earlier: its words are those of the next row's key blocks kb - 2 / kb - 3 (see the layout).
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) *(u32x2*)(usw - 32 + 8 * rg) = z2;        // key block "-1" (before the band): read by R-block 0, never written
+    for (int rg = 0; rg < 4; ++rg) *(u32x2*)(usw - 32 + 8 * rg) = z2;        // key block "-1"
     __syncthreads();
 
 #pragma unroll
-    for (int kb = 0; kb < NTM; ++kb) {
-        if (kb < nblk) {
+    for (int kb = 0; kb <= NT; ++kb) {
+        const int cur = kb & 1;
+        if (kb < NT) { IMG_LOAD(cur ^ 1, kb + 1); TAB_LOAD(cur ^ 1, kb + 1 <= NT ? kb + 1 : NT); await_vm<4 + NF>(); } else await_vm<0>();
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) apin(iw[cur][rg]);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) apin(tf[cur][f]);
+        if (kb < NT && !blk_out(kb, w, D)) {
             // dP^T = V dO^T
             f32x16 dp_ = zero16();
-            int row = 32 * (jlo + kb) + n; row = row < T ? row : T - 1;
+            int row = 32 * kb + n; row = row < T ? row : T - 1;
             const unsigned char* vp = Vs + row * VPB + 16 * h;
 #pragma unroll
             for (int s = 0; s < KS; ++s) dp_ = mfma32(*(const bf16x8*)(vp + 32 * s), dof[s], dp_);
             unsigned ds[8];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const u32x2 iw = *(const u32x2*)(img + (long long)kb * 2048 + slot8[rg]);
-                ds_words(iw[0], iw[1], dp_[4 * rg], dp_[4 * rg + 1], dp_[4 * rg + 2], dp_[4 * rg + 3], Dp, Dp, Dp, Dp, ds[2 * rg], ds[2 * rg + 1]);
+                ds_words(iw[cur][rg][0], iw[cur][rg][1], dp_[4 * rg], dp_[4 * rg + 1], dp_[4 * rg + 2], dp_[4 * rg + 3], Dp, Dp, Dp, Dp, ds[2 * rg], ds[2 * rg + 1]);
                 const u32x2 v = {ds[2 * rg], ds[2 * rg + 1]};
                 *(u32x2*)(usw + 32 * kb + 8 * rg) = v;
             }
             // dQ^T += K^T dS'^T
-            const int j0 = 32 * (jlo + kb);
+            const int j0 = 32 * kb;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 sb = __builtin_bit_cast(bf16x8, (u32x4){ds[4 * s2], ds[4 * s2 + 1], ds[4 * s2 + 2], ds[4 * s2 + 3]});
@@ -377,54 +605,62 @@ __global__ __launch_bounds__(NTM * 64) void attn_t_bwd_q_kernel(KP p)
 #pragma unroll
                 for (int db = 0; db < DPK; ++db) dq[db] = mfma32(tr_frag(k0 + 64 * db, k1 + 64 * db), sb, dq[db]);
             }
+        } else if (rblk_need(kb, w, D) || (kb < NT && rblk_need(kb + 1, w, D))) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) *(u32x2*)(usw + 32 * kb + 8 * rg) = z2;
+        }
+        // dQ^T += E'^T dR'^T: R-block ub = kb is complete (key blocks kb - 1 and kb)
+        if (rblk_need(kb, w, D)) {
             wave_lds_sync();
-            // dQ^T += E'^T dR'^T: R-block ub = kb is complete (key blocks kb - 1 and kb), and so is ub = nblk after the last key block
 #pragma unroll
-            for (int last = 0; last < 2; ++last) {
-                if (last == 0 || kb == nblk - 1) {
-                    const int ub = kb + last;
-                    if (last) {         // key block "nblk" (past the band) is read by the last R-block and never written: zeros.  Only now -- its
-#pragma unroll                          // words are those of the NEXT row's key blocks nblk - 2 / nblk - 3, which R-block nblk - 1 has just read
-                        for (int rg = 0; rg < 4; ++rg) *(u32x2*)(usw + 32 * (kb + 1) + 8 * rg) = z2;
-                        wave_lds_sync();
-                    }
+            for (int s2 = 0; s2 < 2; ++s2) {
+                unsigned rw[4];
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        unsigned rw[4];
+                for (int e = 0; e < 4; ++e) rw[e] = (unsigned)usr[32 * kb + 16 * s2 + 2 * e] | ((unsigned)usr[32 * kb + 16 * s2 + 2 * e + 1] << 16);
+                const bf16x8 rb = __builtin_bit_cast(bf16x8, (u32x4){rw[0], rw[1], rw[2], rw[3]});
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) rw[e] = (unsigned)usr[32 * ub + 16 * s2 + 2 * e] | ((unsigned)usr[32 * ub + 16 * s2 + 2 * e + 1] << 16);
-                        const bf16x8 rb = __builtin_bit_cast(bf16x8, (u32x4){rw[0], rw[1], rw[2], rw[3]});
-#pragma unroll
-                        for (int db = 0; db < DPK; ++db) dq[db] = mfma32(*(const bf16x8*)(tabB + ((ub * 2 + s2) * DPK + db) * 512), rb, dq[db]);
-                    }
-                }
+                for (int db = 0; db < DPK; ++db) dq[db] = mfma32(__builtin_bit_cast(bf16x8, tf[cur][s2 * DPK + db]), rb, dq[db]);
             }
             wave_lds_sync();
         }
+        sched_fence();
     }
+#undef IMG_LOAD
+#undef TAB_LOAD
     store_rows_t<DPK>(buf, dq, p.scale * p.oscale, p.dqkv + ((long long)b * T + i0) * ld + hd * p.dp, ld, T - i0 < 32 ? T - i0 : 32, lane);
 }
 
 // =========================================================================== backward, key-major: dK, dV
 // The mirrored tile: wave w owns the 32 KEYS [32 w, 32 w + 32) (lane = key), its registers run over the queries of a block.
 // LDS: [Q rows, pitch dp*2 (transposing reads) | dO rows, pitch dp*2+16 (row fragments AND transposing reads) | D' | per-wave buffer: image block / output staging]
-template <int DPK>
-__global__ __launch_bounds__(NTM * 64) void attn_t_bwd_kv_kernel(KP p)
+template <int DPK, int NT>
+__global__ __launch_bounds__(NT * 64) void attn_t_bwd_kv_kernel(KP p)
 {
     constexpr int KS = 2 * DPK, QPB = DPK * 64, OPB = DPK * 64 + KPAD;
     SS_DYN_SMEM(lds);
-    const int T = p.T, D = p.D, nt = p.nt, H = p.H;
+    const int T = p.T, D = p.D, H = p.H;
     const int pair = blockIdx.x, b = pair / H, hd = pair - b * H;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, w = uniform(tid >> 6), n = lane & 31, h = lane >> 5;
     const long long ld = 3LL * H * p.dp, ldo = (long long)H * p.dp;
     unsigned char* Qs = (unsigned char*)lds;
     unsigned char* Os = Qs + (((size_t)T * QPB + 15) & ~(size_t)15);
     float* Ds = (float*)(Os + (size_t)T * OPB);
-    unsigned char* buf = (unsigned char*)(Ds + 32 * nt) + (size_t)w * BW_BUF;
+    unsigned char* buf = (unsigned char*)(Ds + 32 * NT) + (size_t)w * BW_BUF;
     const bf16_t* base = p.qkv + (long long)b * T * ld + hd * p.dp;
     stage_table<DPK>(Qs, QPB, base, ld, T, tid, blockDim.x);
     stage_table<DPK>(Os, OPB, p.dO + (long long)b * T * ldo + hd * p.dp, ldo, T, tid, blockDim.x);
-    for (int i = tid; i < 32 * nt; i += blockDim.x) Ds[i] = i < T ? p.Dv[((long long)b * H + hd) * T + i] : 0.f;
+    for (int i = tid; i < 32 * NT; i += blockDim.x) Ds[i] = i < T ? p.Dv[((long long)b * H + hd) * T + i] : 0.f;
+
+    // the image blocks (query tile ib, key block w), ib = 0 .. NT - 1: 2 KiB each, NT * 2 KiB apart; one block ahead, as they are
+    const unsigned char* img = (const unsigned char*)uniform_ptr(p.pimg + pimg_block(pair, NT, 0, w));
+    int lo = 0, hi = NT - 1;
+    while (lo < NT - 1 && blk_out(lo, w, D)) ++lo;
+    while (hi > 0 && blk_out(hi, w, D)) --hi;
+    const unsigned lane16 = lane * 16;
+    u32x4 ic[2][2];
+#define IMG_LOAD(BUF, IB) do { const unsigned char* ib_ = (const unsigned char*)uniform_ptr(img + (long long)((IB) < lo ? lo : (IB) > hi ? hi : (IB)) * (NT * 2048)); \
+        aload16<0>(ic[BUF][0], ib_, lane16); aload16<1024>(ic[BUF][1], ib_, lane16); } while (0)
+    IMG_LOAD(0, 0);
 
     const int j0 = 32 * w, kj = j0 + n;
     bf16x8 vf[KS];
@@ -433,7 +669,6 @@ __global__ __launch_bounds__(NTM * 64) void attn_t_bwd_kv_kernel(KP p)
 #pragma unroll
         for (int s = 0; s < KS; ++s) { const bf16x8 v = *(const bf16x8*)(vrow + 16 * s); vf[s] = kj < T ? v : zero8(); }
     }
-    int ilo, nblk; tile_band(w, T, D, ilo, nblk);
     f32x16 dk[DPK], dv[DPK];
 #pragma unroll
     for (int db = 0; db < DPK; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
@@ -446,19 +681,19 @@ __global__ __launch_bounds__(NTM * 64) void attn_t_bwd_kv_kernel(KP p)
     __syncthreads();
 
 #pragma unroll
-    for (int qb = 0; qb < NTM; ++qb) {
-        if (qb < nblk) {
-            const int ib = ilo + qb, q0 = 32 * ib;
-            // the image block of (query tile ib, key block w) -> LDS, as it is
-            const unsigned char* src = p.pimg + pimg_block(pair, nt, ib, w);
-            const u32x4 c0 = *(const u32x4*)(src + lane * 16), c1 = *(const u32x4*)(src + 1024 + lane * 16);
+    for (int qb = 0; qb < NT; ++qb) {
+        const int cur = qb & 1;
+        if (qb + 1 < NT) { IMG_LOAD(cur ^ 1, qb + 1); await_vm<2>(); } else await_vm<0>();
+        apin(ic[cur][0]); apin(ic[cur][1]);
+        if (!blk_out(qb, w, D)) {
+            const int q0 = 32 * qb;
             // dP = dO V^T (rows = queries)
             f32x16 dp_ = zero16();
             int row = q0 + n; row = row < T ? row : T - 1;
             const unsigned char* op = Os + row * OPB + 16 * h;
 #pragma unroll
             for (int s = 0; s < KS; ++s) dp_ = mfma32(*(const bf16x8*)(op + 32 * s), vf[s], dp_);
-            *(u32x4*)(buf + lane * 16) = c0; *(u32x4*)(buf + 1024 + lane * 16) = c1;
+            *(u32x4*)(buf + lane * 16) = ic[cur][0]; *(u32x4*)(buf + 1024 + lane * 16) = ic[cur][1];
             wave_lds_sync();
             unsigned pw[8], ds[8];
 #pragma unroll
@@ -483,7 +718,9 @@ __global__ __launch_bounds__(NTM * 64) void attn_t_bwd_kv_kernel(KP p)
                 }
             }
         }
+        sched_fence();
     }
+#undef IMG_LOAD
     const int nrows = T - j0 < 32 ? T - j0 : 32;
     bf16_t* drow = p.dqkv + ((long long)b * T + j0) * ld + hd * p.dp;
     store_rows_t<DPK>(buf, dk, p.scale * p.oscale, drow + (long long)H * p.dp, ld, nrows, lane);
@@ -511,7 +748,7 @@ __global__ void attn_t_tables_kernel(const float* __restrict__ emb, int H, int D
 }
 
 size_t bwd_smem(int T, int dp, int waves) { return (((size_t)T * dp * 2 + 15) & ~(size_t)15) + (size_t)T * (dp * 2 + KPAD) + (size_t)waves * (32 * 4 + BW_BUF) + 16; }
-size_t fwd_smem(int T, int dp, int waves) { return (size_t)T * (dp * 2 + KPAD) + (((size_t)T * dp * 2 + 15) & ~(size_t)15) + (size_t)waves * SK_WORDS * 4; }
+size_t fwd_smem(int T, int dp, int waves) { return dma_table_bytes(T, dp * 2 + KPAD) + dma_table_bytes(T, dp * 2) + (size_t)waves * SK_WORDS * 4; }
 const size_t LDS_MAX = 160 * 1024;
 
 void fill(KP& p, const AttnTArgs& a)
@@ -526,18 +763,21 @@ void fill(KP& p, const AttnTArgs& a)
     const unsigned ts = (t16 - 32768u) & 0xffffu;
     p.ts2 = ts | (ts << 16);
     p.oscale = p.drop ? 1.f / (1.f - a.dropout_p) : 1.f;
+    {
+        static unsigned long long* dbg = nullptr; static bool asked = false;
+#if !defined(SS_EMU)
+        if (!asked) { asked = true; const char* e = getenv("SS_ATTN_T_STAMPS"); if (e && e[0] == '1') { if (hipMalloc((void**)&dbg, 8 * 4 * 8 * 8 * 2) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 8 * 4 * 8 * 8 * 2); } }
+#endif
+        p.dbg = dbg;
+    }
     p.seedfold = (unsigned)a.seed ^ ((unsigned)(a.seed >> 32) * 0x9E3779B9u) ^ (a.stream_id * 0x85EBCA6Bu);
 }
 
 typedef void (*Kern)(KP);
-int launch(Kern k, int slot, int blocks, int waves, size_t smem, void* stream, const KP& p)
+int launch(Kern k, int blocks, int waves, size_t smem, void* stream, const KP& p)
 {
 #if !defined(SS_EMU)
-    static size_t granted[16] = {0};
-    if (granted[slot] < smem) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("attention (transposed): cannot reserve %zu bytes of LDS", smem); return 1; }
-        granted[slot] = smem;
-    }
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("attention (transposed): cannot reserve %zu bytes of LDS", smem); return 1; }
 #endif
     SS_LAUNCH(k, dim3(blocks), dim3(waves * 64), smem, stream, p);
     return 0;
@@ -560,22 +800,80 @@ int attn_t_prepare_tables(const float* emb, int H, int D, int dh, int dp, float 
     return 0;
 }
 
+template <int DPK, bool DROP> static Kern fwd_pick(int nt)
+{
+    switch (nt) {
+    case 1: return attn_t_fwd_kernel<DPK, 1, DROP>; case 2: return attn_t_fwd_kernel<DPK, 2, DROP>; case 3: return attn_t_fwd_kernel<DPK, 3, DROP>;
+    case 4: return attn_t_fwd_kernel<DPK, 4, DROP>; case 5: return attn_t_fwd_kernel<DPK, 5, DROP>; case 6: return attn_t_fwd_kernel<DPK, 6, DROP>;
+    default: return attn_t_fwd_kernel<DPK, 7, DROP>;
+    }
+}
+static int cu_count()
+{
+    static int cus = 0;
+    if (!cus) {
+#if defined(SS_EMU)
+        cus = 4;
+#else
+        int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+#endif
+    }
+    return cus;
+}
+// persistent grid: one workgroup per CU, a multiple of H (a workgroup keeps its head), never more than there are pairs
+static int persistent_blocks(int pairs, int H)
+{
+    int g = cu_count() / H * H;
+    if (g < H) g = H;
+    return g < pairs ? g : pairs;
+}
+
 int attn_t_forward(const AttnTArgs& a, void* stream)
 {
     KP p; fill(p, a);
     const int dpk = a.dp / 32, waves = p.nt;
-    static const Kern tab[2][3] = {{attn_t_fwd_kernel<1, false>, attn_t_fwd_kernel<2, false>, attn_t_fwd_kernel<3, false>},
-                                   {attn_t_fwd_kernel<1, true>, attn_t_fwd_kernel<2, true>, attn_t_fwd_kernel<3, true>}};
-    return launch(tab[p.drop][dpk - 1], p.drop * 3 + dpk - 1, a.B * a.H, waves, fwd_smem(a.T, a.dp, waves), stream, p);
+    Kern k = dpk == 1 ? (p.drop ? fwd_pick<1, true>(p.nt) : fwd_pick<1, false>(p.nt)) : dpk == 2 ? (p.drop ? fwd_pick<2, true>(p.nt) : fwd_pick<2, false>(p.nt))
+                                                                                      : (p.drop ? fwd_pick<3, true>(p.nt) : fwd_pick<3, false>(p.nt));
+    return launch(k, persistent_blocks(a.B * a.H, a.H), waves + 1, fwd_smem(a.T, a.dp, waves), stream, p);        // + 1: the loader wave
+}
+
+// measurement only: the stamps of the last forward launch (8 waves x 4 pairs x 8 phases), or 0 when SS_ATTN_T_STAMPS is not set
+extern "C" int ss_attn_t_debug_stamps(unsigned long long* out)
+{
+#if !defined(SS_EMU)
+    KP p; AttnTArgs a; memset(&a, 0, sizeof(a)); a.T = 32; a.dp = 32; a.D = 1; a.H = 1; a.scale = 1.f; fill(p, a);
+    if (!p.dbg) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) return 0;
+    return hipMemcpy(out, p.dbg, 8 * 4 * 8 * 8 * 2, hipMemcpyDeviceToHost) == hipSuccess ? 1 : 0;
+#else
+    (void)out; return 0;
+#endif
+}
+
+template <int DPK> static Kern bq_pick(int nt)
+{
+    switch (nt) {
+    case 1: return attn_t_bwd_q_kernel<DPK, 1>; case 2: return attn_t_bwd_q_kernel<DPK, 2>; case 3: return attn_t_bwd_q_kernel<DPK, 3>; case 4: return attn_t_bwd_q_kernel<DPK, 4>;
+    case 5: return attn_t_bwd_q_kernel<DPK, 5>; case 6: return attn_t_bwd_q_kernel<DPK, 6>; default: return attn_t_bwd_q_kernel<DPK, 7>;
+    }
+}
+template <int DPK> static Kern bkv_pick(int nt)
+{
+    switch (nt) {
+    case 1: return attn_t_bwd_kv_kernel<DPK, 1>; case 2: return attn_t_bwd_kv_kernel<DPK, 2>; case 3: return attn_t_bwd_kv_kernel<DPK, 3>; case 4: return attn_t_bwd_kv_kernel<DPK, 4>;
+    case 5: return attn_t_bwd_kv_kernel<DPK, 5>; case 6: return attn_t_bwd_kv_kernel<DPK, 6>; default: return attn_t_bwd_kv_kernel<DPK, 7>;
+    }
 }
 
 int attn_t_backward(const AttnTArgs& a, void* stream)
 {
     KP p; fill(p, a);
     const int dpk = a.dp / 32, waves = p.nt;
-    static const Kern bq[3] = {attn_t_bwd_q_kernel<1>, attn_t_bwd_q_kernel<2>, attn_t_bwd_q_kernel<3>};
-    static const Kern bkv[3] = {attn_t_bwd_kv_kernel<1>, attn_t_bwd_kv_kernel<2>, attn_t_bwd_kv_kernel<3>};
     const size_t smem = bwd_smem(a.T, a.dp, waves);
-    if (launch(bq[dpk - 1], 6 + dpk - 1, a.B * a.H, waves, smem, stream, p)) return 1;      // also writes D' for the key-major kernel
-    return launch(bkv[dpk - 1], 9 + dpk - 1, a.B * a.H, waves, smem, stream, p);
+    const Kern kq = dpk == 1 ? bq_pick<1>(p.nt) : dpk == 2 ? bq_pick<2>(p.nt) : bq_pick<3>(p.nt);
+    const Kern kkv = dpk == 1 ? bkv_pick<1>(p.nt) : dpk == 2 ? bkv_pick<2>(p.nt) : bkv_pick<3>(p.nt);
+    const char* dbg = getenv("SS_ATTN_T_SKIP");          // measurement / debugging only: 1 skips the query-major kernel, 2 the key-major one
+    if (!(dbg && dbg[0] == '1') && launch(kq, a.B * a.H, waves, smem, stream, p)) return 1;      // also writes D' for the key-major kernel
+    if (dbg && dbg[0] == '2') return 0;
+    return launch(kkv, a.B * a.H, waves, smem, stream, p);
 }

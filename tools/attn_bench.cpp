@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "silent_speech_hip.h"
+extern "C" int ss_attn_t_debug_stamps(unsigned long long* out);      // measurement hook of csrc/attention_t.hip (not part of the ABI header)
 
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static float frand(uint32_t& s) { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; }
@@ -62,6 +63,27 @@ int main(int argc, char** argv)
         double pairs = 0; for (int q = 0; q < T; ++q) for (int k = 0; k < T; ++k) if (abs(k - q) <= D - 1) pairs += 1;
         const double flops = pairs * 2.0 * dp * (pass ? 7.0 : 3.0) * B * H;
         printf("%s B=%d H=%d T=%d dp=%d D=%d p=%.2f : %.1f us  (%.1f TFLOP/s band-limited)\n", pass ? "backward" : "forward ", B, H, T, dp, D, pdrop, us, flops / us * 1e-6);
+    }
+    {   // SS_ATTN_T_STAMPS=1: phase time stamps of workgroup 0 of the last forward launch (s_memtime ticks = shader cycles)
+        if ((fwd())) return 1;
+        unsigned long long st8[8 * 4 * 8 * 2];
+        if (ss_attn_t_debug_stamps(st8)) {
+            const char* names[8] = {"top", "logits", "barrier A", "softmax", "-", "image+P~V", "O", "barrier B"};
+            for (int w = 0; w < 7; ++w) for (int it = 0; it < 4; ++it) {
+                const unsigned long long* r = st8 + (w * 4 + it) * 8;
+                if (!r[7]) continue;
+                printf("wave %d pair %d:", w, it);
+                for (int k = 1; k < 8; ++k) printf("  %s %llu", names[k], r[k] - r[k - 1]);
+                printf("  | total %llu\n", r[7] - r[0]);
+            }
+            for (int w = 0; w < 7; ++w) {
+                const unsigned long long* r = st8 + 256 + w * 32;
+                if (!r[0]) continue;
+                printf("wave %d pair 1 logits iterations (skew-write+R | skew-read+S):", w);
+                for (int ub = 0; ub < 8; ++ub) printf("  %llu|%llu", r[3 * ub + 1] - r[3 * ub], r[3 * ub + 2] - r[3 * ub + 1]);
+                printf("\n");
+            }
+        }
     }
     // checksum so two builds can be compared
     std::vector<uint16_t> ho(nO); CK(hipMemcpy(ho.data(), out, nO * 2, hipMemcpyDeviceToHost));
