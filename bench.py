@@ -735,7 +735,7 @@ def main():
             for k, v in prof.summary().items():
                 table[k] = v
             pmc, pmc_src, pmc_stale = {}, None, None
-            for fn in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            for fn in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
                 try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py)
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
                     pmc_src = 'profiles/' + fn
@@ -751,7 +751,7 @@ def main():
                 pmc = {}
             hints = {'gemm8_kc_kernel (288x256)': 'gemm8_kc_kernel<unsigned short, 9', 'gemm8_kc_kernel (256x256)': 'gemm8_kc_kernel<unsigned short, 8',
                      'gemm_dw_grouped': 'gemm8_dwk_kernel', 'gemm_smallk_kernel (K <= 32, first conv)': 'gemm_smallk_kernel', 'gemm_w2_kernel (128|144 x 128)': 'gemm_w2_kernel', 'gemm_glds_kernel (128x128)': 'gemm_glds_kernel',
-                     'attn_fwd': 'attn_fwd_res2_kernel', 'attn_bwd': ('attn_bwd_kv2_kernel', 'attn_bwd_q2_kernel', 'attn_dsum_kernel'), 'bn_stats': 'bn_partial_kernel', 'bn_apply': 'bn_apply_kernel',
+                     'attn_fwd': 'attn_t_fwd_kernel', 'attn_bwd': ('attn_t_bwd_kv_kernel', 'attn_t_bwd_q_kernel'), 'bn_stats': 'bn_partial_kernel', 'bn_apply': 'bn_apply_kernel',
                      'bn_bwd_sums': ('bn_bwd_partial_kernel', 'bn_bwd_finalize_kernel'), 'bn_bwd_apply': 'bn_bwd_apply_kernel', 'add_dropout_ln_fwd': 'add_dropout_ln_fwd_kernel',
                      'ln_bwd': ('ln_bwd2_kernel<', 'ln_bwd2_finalize_kernel'), 'adamw_kernel': 'adamw_kernel', 'dtw_kernel': 'dtw_kernel', 'silent_cost_skewed_kernel': 'silent_cost_skewed_kernel',
                      'colsum': 'colsum_partial_kernel', 'permute3d_batch (weight re-layout)': 'permute3d_batch_kernel', 'grad_unlayout': 'permute3d_batch_f32_kernel'}
@@ -786,9 +786,10 @@ def main():
                 if k['traffic']:        # the measured HBM bytes of a launch over its duration: what share of the 8 TB/s the kernel actually drew
                     k['traffic_frac_of_hbm_peak'] = k['traffic'] / (k['avg_launch_us'] * 1e-6) / 1e9 / PEAK_HBM_GBPS
                 if name in ('attn_fwd', 'attn_bwd'):
-                    k['note'] = ('counted as MFMA work (band-limited flops), but at T = 200 / d_head = 96 with the saved probability image the kernel moves '
-                                 '63 (forward) / 41 (backward) flops per HBM byte against a machine balance of 312: it is bound by HBM and LDS traffic; '
-                                 'traffic_frac_of_hbm_peak is the figure to read (DESIGN.md section 4)')
+                    k['note'] = ('counted as MFMA work (band-limited flops: 3 products forward, 5 backward); transposed-score kernels of round 5 '
+                                 '(csrc/attention_t.hip: S^T = K Q^T on 32x32x16 MFMAs, backward = query-major + key-major kernel on the saved probabilities, '
+                                 'D folded into the query-major one).  At T = 200 / d_head = 96 with the saved image the forward moves ~75 flops per HBM byte '
+                                 'against a machine balance of 312: traffic_frac_of_hbm_peak is the second figure to read (DESIGN.md section 4)')
             top = kernels[0]
             out['roofline'] = {'bound': top['bound'], 'achieved': top['achieved'], 'peak': top['peak'], 'unit': top['unit'], 'frac': top['frac'],
                                'traffic': top['traffic'], 'traffic_source': pmc_src if pmc and top['traffic'] is not None else None,
@@ -798,7 +799,7 @@ def main():
                                'serial_kernel_ms_per_step': total_s / psteps * 1e3,
                                'timing': 'HIP events around every kernel launch (inside the native plan: ss_plan_profile; Python-launched kernels: '
                                          'torch events on the launch stream) on every 5th (runs of <= 10 steps) / every (steps/2)-th timed step; those steps run without the side stream '
-                                         '(exclusive durations); rocprofv3 counterpart: profiles/r04_serial_kernel_stats.txt',
+                                         '(exclusive durations); rocprofv3 counterpart: profiles/r05_serial_kernel_stats.txt',
                                'kernels': kernels[:16]}
         if world == 1 and args.cpu_rows > 0:
             base, sub, ref_pred = cpu_baseline(batch_cpu, args.cpu_rows, args.cpu_warmup, args.cpu_steps, init_sd, dev)

@@ -180,9 +180,12 @@ __device__ __forceinline__ void efrag_wait(bf16x8 (&f)[KS]) {
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(f[s]));
 #endif
 }
+#ifndef ATTN_T_FENCE
+#define ATTN_T_FENCE 1
+#endif
 __device__ __forceinline__ void sched_fence() {
 #if !defined(SS_EMU)
-    __builtin_amdgcn_sched_barrier(0);
+    if (ATTN_T_FENCE) __builtin_amdgcn_sched_barrier(0);
 #endif
 }
 // table rows in flight: a thread's share of a T x dp table (16-byte chunks tid, tid + nthr, ...), loaded now, written to LDS later
