@@ -205,10 +205,11 @@ class Model(nn.Module):
         # ONE dispatcher op for the whole network (torch_ops.py): forward = the native plan; when gradients are wanted its registered
         # autograd formula runs silent_speech::model_backward, which accumulates straight into the flat .grad arena.
         track = self.training and torch.is_grad_enabled()
-        head = torch.ops.silent_speech.model_forward(xr, self._anchor if track else self._anchor.detach(), torch_ops.model_handle(self),
-                                                     bool(self.training), int(r), int(seed))
-        if xr is not x_raw and self.training and r > 0:
-            x_raw.copy_(xr)
+        head, shifted = torch.ops.silent_speech.model_forward(xr, self._anchor if track else self._anchor.detach(), torch_ops.model_handle(self),
+                                                              bool(self.training), int(r), int(seed))
+        if self.training and r > 0:
+            with torch.no_grad():
+                x_raw.copy_(shifted)                       # x[:, :-r] = x[:, r:]; x[:, -r:] = 0 on the caller's tensor (architecture.py:67-68)
         B, T = x_raw.shape[0], x_raw.shape[1] // 8
         n_out = self.num_outs
         pred = head[:, :n_out].view(B, T, n_out)

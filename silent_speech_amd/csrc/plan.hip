@@ -77,6 +77,7 @@ struct Plan {
     reduce_fn hook = 0; void* hook_user = 0;
     event_fn on_event = 0; void* event_user = 0;
     int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1, regate_on = 1, f32_x3 = 0;
+    int keep_input = 0;      // option 6: leave x_raw as it is (the shifted signal is only handed out in `shifted`; a functional caller copies it back itself)
     hipEvent_t ev_fork = 0, ev_join = 0;
     size_t esz() const { return D.dtype == SS_BF16 ? 2 : 4; }
 
@@ -267,10 +268,10 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
     if (!X.dry) {
         L_(timed(X, "emg_prepare", 0, (double)B * T0 * Cin0 * (4 + es), stream, [&] { return ss_emg_prepare(dt, x_raw, xin, (training && shift_r > 0) ? shifted : nullptr, B, T0, Cin0, training ? shift_r : 0, stream); }));
 #if !defined(SS_EMU)
-        if (training && shift_r > 0 && shifted)      // the reference mutates its input in place (architecture.py:67-68)
+        if (training && shift_r > 0 && shifted && !keep_input)      // the reference mutates its input in place (architecture.py:67-68)
             if (hipMemcpyAsync((void*)x_raw, shifted, (size_t)B * T0 * Cin0 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) { ss_set_error("forward: input write-back failed"); return 1; }
 #else
-        if (training && shift_r > 0 && shifted) memcpy((void*)x_raw, shifted, (size_t)B * T0 * Cin0 * 4);
+        if (training && shift_r > 0 && shifted && !keep_input) memcpy((void*)x_raw, shifted, (size_t)B * T0 * Cin0 * 4);
 #endif
     }
     // [9][2][C] per-channel sums of the nine BatchNorms, zeroed once: filled by the conv GEMM epilogues where the 8-wave kernel runs
@@ -558,6 +559,7 @@ extern "C" int ss_plan_set_option(ss_plan* h, int what, int value)
     else if (what == 3) { old = h->p->fuse_stats; h->p->fuse_stats = value; }
     else if (what == 4) { old = h->p->regate_on; h->p->regate_on = value; }
     else if (what == 5) { old = h->p->f32_x3; h->p->f32_x3 = value != 0; }
+    else if (what == 6) { old = h->p->keep_input; h->p->keep_input = value != 0; }
     return old;
 }
 extern "C" int ss_plan_set_reduce_hook(ss_plan* h, ss_reduce_hook fn, void* user) { SS_CHECK(h, "null plan"); h->p->hook = (reduce_fn)fn; h->p->hook_user = user; return 0; }

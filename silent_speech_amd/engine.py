@@ -409,7 +409,8 @@ class Ctx(object):
 
 
 def forward(model, x_raw, training, shift_r, seed):
-    """x_raw (B, 8T, 8) f32 on the GPU -> head [B*T][n_head_cols] f32 and the saved context (None in eval mode)."""
+    """x_raw (B, 8T, 8) f32 on the GPU -> head [B*T][n_head_cols] f32, the saved context (None in eval mode) and the time-shifted input
+    (None without a shift).  x_raw itself is NOT modified (plan option 6): the caller mirrors the reference's in-place shift."""
     pr = prepared(model)
     dev = x_raw.device
     B, T0, Cin0 = x_raw.shape
@@ -432,12 +433,13 @@ def forward(model, x_raw, training, shift_r, seed):
     buf = ctypes.create_string_buffer(pb.ctx_bytes)
     pb.ws = ws
     L.ss_plan_set_option(pb.handle, 5, int(model.f32_matmul == 'bf16x3'))
+    L.ss_plan_set_option(pb.handle, 6, 1)
     p_drop = model.dropout_p if training else 0.0
     rc = L.ss_plan_forward(pb.handle, _lib.ptr(x_raw), _lib.ptr(shifted), _lib.ptr(ws), nbytes, B, T0, int(training), int(shift_r if training else 0),
                            float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(head), buf, _lib.stream_of(x_raw))
     pb.raise_callback_error()
     _lib.check(rc, 'ss_plan_forward')
-    return head, (Ctx(buf, ws, B * (T0 // 8)) if training else None)
+    return head, (Ctx(buf, ws, B * (T0 // 8)) if training else None), shifted
 
 
 def backward(model, ctx, dhead):
@@ -458,6 +460,7 @@ def backward(model, ctx, dhead):
     L.ss_plan_set_option(pb.handle, 2, int(os.environ.get('SS_AMD_SIDE_BLOCKS', '2')))
     L.ss_plan_set_option(pb.handle, 4, int(os.environ.get('SS_AMD_BN_REGATE', '1') != '0'))
     L.ss_plan_set_option(pb.handle, 5, int(model.f32_matmul == 'bf16x3'))
+    L.ss_plan_set_option(pb.handle, 6, 1)
     rc = L.ss_plan_backward(pb.handle, ctx.buf, _lib.ptr(dhead), _lib.stream_of(dhead), ctypes.c_void_p(side.cuda_stream) if side is not None else None)
     pb.raise_callback_error()
     _lib.check(rc, 'ss_plan_backward')

@@ -49,26 +49,31 @@ def _model(handle):
 
 
 @torch.library.custom_op('silent_speech::model_forward', mutates_args=())
-def model_forward(x_raw: Tensor, anchor: Tensor, handle: int, training: bool, shift_r: int, seed: int) -> Tensor:
+def model_forward(x_raw: Tensor, anchor: Tensor, handle: int, training: bool, shift_r: int, seed: int) -> Tuple[Tensor, Tensor]:
     """x_raw (B, 8 T, 8) f32 -> head [B T][n_head_cols] f32 = [mel prediction | phoneme logits | pad] per frame.  `anchor` is a
     1-element tensor that requires grad: the parameters are updated in place by model_backward (their .grad live in the flat
-    arena), so autograd needs one differentiable input to call the backward formula at all."""
+    arena), so autograd needs one differentiable input to call the backward formula at all.  The op is FUNCTIONAL: x_raw is not touched; the
+    time-shifted signal of a training-mode forward is the second output (empty without a shift) and Model.forward copies it back into its
+    argument, mirroring the reference's in-place shift (architecture.py:67-68) outside the operator.  The forward context is kept for the
+    backward only when the anchor asks for a gradient (Model.forward hands over a detached anchor under no_grad / in eval mode): a forward
+    that will never be back-propagated does not pin its multi-GB workspace."""
     from . import engine
     m = _model(handle)
-    head, saved = engine.forward(m, x_raw, training, shift_r, seed)
-    if saved is not None:
+    head, saved, shifted = engine.forward(m, x_raw, training, shift_r, seed)
+    if saved is not None and anchor.requires_grad:
         ctxs = m._saved_ctx
         while len(ctxs) >= _KEEP:                      # a training-mode forward that is never back-propagated must not pin its 5 GB workspace
             ctxs.pop(next(iter(ctxs)))
         ctxs[int(seed)] = saved
-    return head
+    return head, (shifted if shifted is not None else x_raw.new_empty(0))
 
 
 @model_forward.register_fake
 def _(x_raw, anchor, handle, training, shift_r, seed):
     from . import engine
     m = _model(handle)
-    return x_raw.new_empty((x_raw.shape[0] * (x_raw.shape[1] // 8), engine.prepared(m).n_head_cols), dtype=torch.float32)
+    return (x_raw.new_empty((x_raw.shape[0] * (x_raw.shape[1] // 8), engine.prepared(m).n_head_cols), dtype=torch.float32),
+            torch.empty_like(x_raw) if (training and shift_r > 0) else x_raw.new_empty(0))
 
 
 @torch.library.custom_op('silent_speech::model_backward', mutates_args=())
@@ -91,7 +96,7 @@ def _model_setup(ctx, inputs, output):
     ctx.handle, ctx.seed, ctx.training = inputs[2], inputs[5], inputs[3]
 
 
-def _model_bwd(ctx, dhead):
+def _model_bwd(ctx, dhead, g_shifted):
     if not ctx.training:
         raise RuntimeError('backward through a forward pass that ran in eval mode')
     torch.ops.silent_speech.model_backward(dhead.contiguous(), ctx.handle, ctx.seed)
@@ -145,11 +150,11 @@ def _(head, Y, phones, idx, desc, n_mel, n_ph, lam, inv_total, n_voiced, n_silen
 
 
 def _dtw_setup(ctx, inputs, output):
-    ctx.dhead = output[2]
+    ctx.save_for_backward(output[2])           # (an op output kept as a plain attribute would form a tensor -> grad_fn -> ctx -> tensor cycle)
 
 
 def _dtw_bwd(ctx, g_loss, g_correct, g_dhead, g_results, g_amax):
-    return (ctx.dhead * g_loss,) + (None,) * 17
+    return (ctx.saved_tensors[0] * g_loss,) + (None,) * 17
 
 
 dtw_loss.register_autograd(_dtw_bwd, setup_context=_dtw_setup)
@@ -199,11 +204,11 @@ def _(logits, desc, targets, n, max_s, ws_floats, V, blank):
 
 
 def _ctc_setup(ctx, inputs, output):
-    ctx.dlogits = output[1]
+    ctx.save_for_backward(output[1])
 
 
 def _ctc_bwd(ctx, g_loss, g_dl, g_nll, g_amax):
-    return (ctx.dlogits * g_loss,) + (None,) * 7
+    return (ctx.saved_tensors[0] * g_loss,) + (None,) * 7
 
 
 ctc_loss.register_autograd(_ctc_bwd, setup_context=_ctc_setup)

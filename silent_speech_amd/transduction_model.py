@@ -70,6 +70,7 @@ class _LossPlan(object):
         self.lengths, self.silent, self.t2 = lengths, silent, t2
         self.pred_off, self.tgt_off = pred_off, tgt_off
         self.results = self.argmax = None
+        self.signature = None
 
     def host_tables(self):
         return [self.utt_host, self.desc_host]
@@ -93,6 +94,9 @@ def _target_jobs(example, device):
     jobs over device tensors or, for a batch that arrives in host memory, as ONE pinned host concatenation + upload each."""
     audio, phones = example['audio_features'], example['phonemes']
     on_device = audio[0].is_cuda or _lib.is_emulator()
+    if on_device and not _lib.is_emulator():          # a mixed batch (some targets still on the host): the gather kernel only takes device pointers
+        audio = [a if a.is_cuda else a.to(device) for a in audio]
+        phones = [q if q.is_cuda else q.to(device) for q in phones]
     if on_device:
         audio = [a if a.dtype == torch.float32 else a.float() for a in audio]
         phones = [q if q.dtype == torch.int64 else q.long() for q in phones]
@@ -121,10 +125,18 @@ class _Prepared(object):
     rows = 0
 
 
+def _target_signature(example):
+    """What the prepared loss plan snapshotted of a batch: address and version counter of every target tensor, and the silent flags (about 90
+    cheap attribute reads for a reference-size batch).  A caller that edits or replaces targets between prepare_batch and dtw_loss gets a
+    fresh plan instead of stale targets."""
+    return (tuple((t.data_ptr(), t._version) for t in example['audio_features']), tuple((t.data_ptr(), t._version) for t in example['phonemes']),
+            tuple(bool(x) for x in example['silent']))
+
+
 def _loss_plan(example, rows_total, device):
     if _Prepared.example is example and _Prepared.plan is not None and _Prepared.rows == rows_total:
         plan, _Prepared.example, _Prepared.plan = _Prepared.plan, None, None
-        if plan.lengths == [int(n) for n in example['lengths']] and plan.Y.device == device:
+        if plan.lengths == [int(n) for n in example['lengths']] and plan.Y.device == device and plan.signature == _target_signature(example):
             return plan
     return _build_loss_plan(example, rows_total, device)
 
@@ -299,6 +311,7 @@ def prepare_batch(batch, device, seq_len=200, loss_plan=True):
         k = len(jobs)
         if ja is not None:
             Y, ph = ja.launch(up[k + 2]), jp.launch(up[k + 3])
+        plan.signature = _target_signature(batch)
         _Prepared.example, _Prepared.plan, _Prepared.rows = batch, plan.bind(up[k], up[k + 1], Y, ph), rows_total
     return tuple(packed)
 

@@ -155,6 +155,14 @@ def test_prepare_batch_then_dtw_loss_equals_standalone(dev):
     cpu = dict(ex, audio_features=[a.cpu() for a in ex['audio_features']], phonemes=[p.cpu() for p in ex['phonemes']])
     want, _ = loss_ref.dtw_loss_ref(pred.cpu(), aux.cpu(), cpu, lam=0.5)
     assert abs(float(l3) - float(want)) < 2e-5 * abs(float(want)) and abs(float(l3) - float(l1)) > 1e-4 * abs(float(l1))
+    # targets edited BETWEEN prepare_batch and dtw_loss (same dict, same lengths): the prepared plan snapshotted the old values; the
+    # (address, version) signature of the targets sends this call to a fresh plan instead of silently using them
+    tm.prepare_batch(ex, dev, seq_len=row)
+    ex['audio_features'][1].mul_(0.5)
+    l4, _ = tm.dtw_loss(pred, aux, ex, True, None, phoneme_loss_weight=0.5)
+    cpu = dict(ex, audio_features=[a.cpu() for a in ex['audio_features']], phonemes=[p.cpu() for p in ex['phonemes']])
+    want4, _ = loss_ref.dtw_loss_ref(pred.cpu(), aux.cpu(), cpu, lam=0.5)
+    assert abs(float(l4) - float(want4)) < 2e-5 * abs(float(want4)) and abs(float(l4) - float(l3)) > 1e-4 * abs(float(l3))
 
 
 def test_dtw_loss_all_silent_and_degenerate_utterances(dev):
