@@ -507,130 +507,173 @@ __device__ __forceinline__ bool rblk_need(int ub, int w, int D) { const int r0 =
 
 // =========================================================================== backward, query-major: dQ (and D)
 // LDS: [K rows, pitch dp*2 (transposing reads) | V rows, pitch dp*2+16 (row fragments) | per-wave buffer: un-skew (bf16) / output staging]
+// PERSISTENT like the forward (one workgroup per CU walks the pairs blockIdx.x, + gridDim.x, ...; waves 0 .. NT-1 compute, wave NT is the
+// loader), in TWO passes per pair so that each table is needed in one pass only and the other's time hides its copy:
+//     compute:  pass 1 [V_p]: dP = dO V^T, dS' (kept: 8 words per key block), un-skew, dQ += E'^T dR'   | barrier A |  pass 2 [K_p]: dQ += K^T dS'^T, dQ out   | barrier B
+//     loader :  K_p -> LDS, wait                                                                            | barrier A |  V_p+1 -> LDS, wait                          | barrier B
 constexpr int BW_BUF = 6656 + 64;       // per-wave buffer bytes of both backward kernels (32 x (96*2+16) staging; >= 2 * SK_WORDS resp. 2048)
 template <int DPK, int NT>
-__global__ __launch_bounds__(NT * 64) void attn_t_bwd_q_kernel(KP p)
+__global__ __launch_bounds__((NT + 1) * 64) void attn_t_bwd_q_kernel(KP p)
 {
     constexpr int KS = 2 * DPK, KPB = DPK * 64, VPB = DPK * 64 + KPAD, NF = 2 * DPK;
     SS_DYN_SMEM(lds);
-    const int T = p.T, D = p.D, H = p.H;
-    const int pair = blockIdx.x, b = pair / H, hd = pair - b * H;
-    const int tid = threadIdx.x, lane = tid & 63, w = uniform(tid >> 6), n = lane & 31, h = lane >> 5;
+    const int T = p.T, D = p.D, H = p.H, npairs = p.B * H;
+    const int tid = threadIdx.x, w_ = uniform(tid >> 6);
     const long long ld = 3LL * H * p.dp, ldo = (long long)H * p.dp;
     unsigned char* Ks = (unsigned char*)lds;
-    unsigned char* Vs = Ks + (((size_t)T * KPB + 15) & ~(size_t)15);
-    unsigned char* buf = Vs + (size_t)T * VPB + (size_t)w * BW_BUF;
-    bf16_t* us = (bf16_t*)buf;
-    const bf16_t* base = p.qkv + (long long)b * T * ld + hd * p.dp;
-    stage_table<DPK>(Ks, KPB, base + (long long)H * p.dp, ld, T, tid, blockDim.x);
-    stage_table<DPK>(Vs, VPB, base + 2LL * H * p.dp, ld, T, tid, blockDim.x);
+    unsigned char* Vs = Ks + dma_table_bytes(T, KPB);
+    unsigned char* buf0 = Vs + dma_table_bytes(T, VPB);
+    int pair = blockIdx.x;
+    if (pair >= npairs) return;
 
-    // streamed operands of block 0: the image words of this lane (4 x 8 bytes) and the E'^T fragments of R-block 0
-    const unsigned char* img = (const unsigned char*)uniform_ptr(p.pimg + pimg_block(pair, NT, w, 0));
-    const unsigned char* tabB = (const unsigned char*)uniform_ptr(p.tab + (long long)H * NU * KS * 512 + ((long long)hd * NU + (UOFF - w)) * (NF * 512));
-    unsigned slot8[4];
+    if (w_ == NT) {                                                 // ---- the loader wave
+        const int lane = tid & 63;
+        { const int b = pair / H, hd = pair - b * H; dma_table<DPK>(Vs, VPB, p.qkv + (long long)b * T * ld + hd * p.dp + 2LL * H * p.dp, ld, T, lane); }
+        wait_vmcnt<0>();
+        __syncthreads();
+        for (; pair < npairs; pair += gridDim.x) {
+            const int b = pair / H, hd = pair - b * H;
+            dma_table<DPK>(Ks, KPB, p.qkv + (long long)b * T * ld + hd * p.dp + (long long)H * p.dp, ld, T, lane);
+            wait_vmcnt<0>();
+            __syncthreads();                                         // A
+            const int nxt = pair + gridDim.x;
+            if (nxt < npairs) { const int b2 = nxt / H, h2 = nxt - b2 * H; dma_table<DPK>(Vs, VPB, p.qkv + (long long)b2 * T * ld + h2 * p.dp + 2LL * H * p.dp, ld, T, lane); }
+            wait_vmcnt<0>();
+            __syncthreads();                                         // B
+        }
+        return;
+    }
+    __syncthreads();                                                 // V of the first pair
+    for (; pair < npairs; pair += gridDim.x) {
+        const int b = pair / H, hd = pair - b * H;
+        int w = w_, lane = tid & 63;                                 // opaque per pair (see the forward): nothing derived from them is hoisted out of the loop and spilled
+#if !defined(SS_EMU)
+        asm volatile("" : "+s"(w), "+v"(lane));
+#endif
+        const int n = lane & 31, h = lane >> 5;
+        unsigned char* buf = buf0 + (size_t)w * BW_BUF;
+        bf16_t* us = (bf16_t*)buf;
+        // streamed operands of block 0: the image words of this lane (4 x 8 bytes) and the E'^T fragments of R-block 0
+        const unsigned char* img = (const unsigned char*)uniform_ptr(p.pimg + pimg_block(pair, NT, w, 0));
+        const unsigned char* tabB = (const unsigned char*)uniform_ptr(p.tab + (long long)H * NU * KS * 512 + ((long long)hd * NU + (UOFF - w)) * (NF * 512));
+        unsigned slot8[4];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) slot8[rg] = rg * 512 + pimg_slot(n, h, rg) * 8;
-    const unsigned lane16 = lane * 16;
-    u32x2 iw[2][4]; u32x4 tf[2][NF];
-    // key blocks outside the band were never written by the forward: their loads are pointed at the nearest block that was (the data is not used)
-    int lo = 0, hi = NT - 1;
-    while (lo < NT - 1 && blk_out(lo, w, D)) ++lo;
-    while (hi > 0 && blk_out(hi, w, D)) --hi;
+        for (int rg = 0; rg < 4; ++rg) slot8[rg] = rg * 512 + pimg_slot(n, h, rg) * 8;
+        const unsigned lane16 = lane * 16;
+        u32x2 iw[2][4]; u32x4 tf[2][NF];
+        // key blocks outside the band were never written by the forward: their loads are pointed at the nearest block that was (the data is not used)
+        int lo = 0, hi = NT - 1;
+        while (lo < NT - 1 && blk_out(lo, w, D)) ++lo;
+        while (hi > 0 && blk_out(hi, w, D)) --hi;
 #define IMG_LOAD(BUF, KB) do { const unsigned char* ib_ = (const unsigned char*)uniform_ptr(img + (long long)((KB) < lo ? lo : (KB) > hi ? hi : (KB)) * 2048); \
         aload8<0>(iw[BUF][0], ib_, slot8[0]); aload8<0>(iw[BUF][1], ib_, slot8[1]); aload8<0>(iw[BUF][2], ib_, slot8[2]); aload8<0>(iw[BUF][3], ib_, slot8[3]); } while (0)
 #define TAB_LOAD(BUF, UB) do { const unsigned char* tb_ = (const unsigned char*)uniform_ptr(tabB + (long long)(UB) * (NF * 1024)); \
         aload16<0>(tf[BUF][0], tb_, lane16); aload16<1024>(tf[BUF][1], tb_, lane16); \
         if (NF > 2) { aload16<2048>(tf[BUF][NF > 2 ? 2 : 0], tb_, lane16); aload16<3072>(tf[BUF][NF > 3 ? 3 : 0], tb_, lane16); } \
         if (NF > 4) { const unsigned char* t2_ = (const unsigned char*)uniform_ptr(tb_ + 4096); aload16<0>(tf[BUF][NF > 4 ? 4 : 0], t2_, lane16); aload16<1024>(tf[BUF][NF > 5 ? 5 : 0], t2_, lane16); } } while (0)
-    IMG_LOAD(0, 0); TAB_LOAD(0, 0);
+        IMG_LOAD(0, 0); TAB_LOAD(0, 0);
 
-    const int i0 = 32 * w, qi = i0 + n;
-    bf16x8 dof[KS];
-    float Dp = 0.f;
-    {
-        const long long ro = ((long long)b * T + (qi < T ? qi : T - 1)) * ldo + hd * p.dp + 8 * h;
+        const int i0 = 32 * w, qi = i0 + n;
+        bf16x8 dof[KS];
+        float Dp = 0.f;
+        {
+            const long long ro = ((long long)b * T + (qi < T ? qi : T - 1)) * ldo + hd * p.dp + 8 * h;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const u32x4 a = *(const u32x4*)(p.dO + ro + 16 * s), o = *(const u32x4*)(p.O + ro + 16 * s);
-            dof[s] = qi < T ? __builtin_bit_cast(bf16x8, a) : zero8();
+            for (int s = 0; s < KS; ++s) {
+                const u32x4 a = *(const u32x4*)(p.dO + ro + 16 * s), o = *(const u32x4*)(p.O + ro + 16 * s);
+                dof[s] = qi < T ? __builtin_bit_cast(bf16x8, a) : zero8();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Dp = dot2_bf16(a[e], o[e], Dp);
-        }
-        Dp += xhalf(Dp);
-        Dp = qi < T ? Dp / p.oscale : 0.f;                        // D' = D / s
-        if (h == 0 && qi < T) p.Dv[((long long)b * H + hd) * T + qi] = Dp;
-    }
-    f32x16 dq[DPK];
-#pragma unroll
-    for (int db = 0; db < DPK; ++db) dq[db] = zero16();
-    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-    const int klane = 4 * h + (i16 >> 2), kcol = (16 * g16 + 4 * (i16 & 3)) * 2;
-    bf16_t* usw = us + SKP * n + 4 * h + 32;                     // + 32 kb + 8 rg      (aligned 8-byte pieces, row stride SKP)
-    const bf16_t* usr = us + (SKP + 1) * n + 8 * h + 1;          // + 32 ub + 16 s2 + e (row stride SKP + 1: the un-skew)
-    const u32x2 z2 = {0u, 0u};
-    // A key block outside the band that a needed R-block reads (at rel positions whose table rows are zero) must hold finite numbers: zeros,
-    // written just before that R-block is read -- not earlier: its words are those of the next row's key blocks kb - 2 / kb - 3 (see the layout).
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) *(u32x2*)(usw - 32 + 8 * rg) = z2;        // key block "-1"
-    __syncthreads();
-
-#pragma unroll
-    for (int kb = 0; kb <= NT; ++kb) {
-        const int cur = kb & 1;
-        if (kb < NT) { IMG_LOAD(cur ^ 1, kb + 1); TAB_LOAD(cur ^ 1, kb + 1 <= NT ? kb + 1 : NT); await_vm<4 + NF>(); } else await_vm<0>();
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) apin(iw[cur][rg]);
-#pragma unroll
-        for (int f = 0; f < NF; ++f) apin(tf[cur][f]);
-        if (kb < NT && !blk_out(kb, w, D)) {
-            // dP^T = V dO^T
-            f32x16 dp_ = zero16();
-            int row = 32 * kb + n; row = row < T ? row : T - 1;
-            const unsigned char* vp = Vs + row * VPB + 16 * h;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) dp_ = mfma32(*(const bf16x8*)(vp + 32 * s), dof[s], dp_);
-            unsigned ds[8];
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                ds_words(iw[cur][rg][0], iw[cur][rg][1], dp_[4 * rg], dp_[4 * rg + 1], dp_[4 * rg + 2], dp_[4 * rg + 3], Dp, Dp, Dp, Dp, ds[2 * rg], ds[2 * rg + 1]);
-                const u32x2 v = {ds[2 * rg], ds[2 * rg + 1]};
-                *(u32x2*)(usw + 32 * kb + 8 * rg) = v;
+                for (int e = 0; e < 4; ++e) Dp = dot2_bf16(a[e], o[e], Dp);
             }
-            // dQ^T += K^T dS'^T
+            Dp += xhalf(Dp);
+            Dp = qi < T ? Dp / p.oscale : 0.f;                        // D' = D / s
+            if (h == 0 && qi < T) p.Dv[((long long)b * H + hd) * T + qi] = Dp;
+        }
+        f32x16 dq[DPK];
+#pragma unroll
+        for (int db = 0; db < DPK; ++db) dq[db] = zero16();
+        bf16_t* usw = us + SKP * n + 4 * h + 32;                     // + 32 kb + 8 rg      (aligned 8-byte pieces, row stride SKP)
+        const bf16_t* usr = us + (SKP + 1) * n + 8 * h + 1;          // + 32 ub + 16 s2 + e (row stride SKP + 1: the un-skew)
+        const u32x2 z2 = {0u, 0u};
+        // A key block outside the band that a needed R-block reads (at rel positions whose table rows are zero) must hold finite numbers: zeros,
+        // written just before that R-block is read -- not earlier: its words are those of the next row's key blocks kb - 2 / kb - 3 (see the layout).
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) *(u32x2*)(usw - 32 + 8 * rg) = z2;        // key block "-1"
+        unsigned dsall[NT][8];
+
+        // ---- pass 1 (V resident): dS' of every key block, the positional half of dQ
+#pragma unroll
+        for (int kb = 0; kb <= NT; ++kb) {
+            const int cur = kb & 1;
+            if (kb < NT) { IMG_LOAD(cur ^ 1, kb + 1); TAB_LOAD(cur ^ 1, kb + 1 <= NT ? kb + 1 : NT); await_vm<4 + NF>(); } else await_vm<0>();
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) apin(iw[cur][rg]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) apin(tf[cur][f]);
+            if (kb < NT && !blk_out(kb, w, D)) {
+                f32x16 dp_ = zero16();
+                int row = 32 * kb + n; row = row < T ? row : T - 1;
+                const unsigned char* vp = Vs + row * VPB + 16 * h;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) dp_ = mfma32(*(const bf16x8*)(vp + 32 * s), dof[s], dp_);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    unsigned d0, d1;
+                    ds_words(iw[cur][rg][0], iw[cur][rg][1], dp_[4 * rg], dp_[4 * rg + 1], dp_[4 * rg + 2], dp_[4 * rg + 3], Dp, Dp, Dp, Dp, d0, d1);
+                    const u32x2 v = {d0, d1};
+                    *(u32x2*)(usw + 32 * kb + 8 * rg) = v;
+                    dsall[kb < NT ? kb : 0][2 * rg] = d0; dsall[kb < NT ? kb : 0][2 * rg + 1] = d1;
+                }
+            } else {
+                if (kb < NT) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dsall[kb < NT ? kb : 0][e] = 0u;
+                }
+                if (rblk_need(kb, w, D) || (kb < NT && rblk_need(kb + 1, w, D))) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) *(u32x2*)(usw + 32 * kb + 8 * rg) = z2;
+                }
+            }
+            // dQ^T += E'^T dR'^T: R-block ub = kb is complete (key blocks kb - 1 and kb)
+            if (rblk_need(kb, w, D)) {
+                wave_lds_sync();
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    unsigned rw[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rw[e] = (unsigned)usr[32 * kb + 16 * s2 + 2 * e] | ((unsigned)usr[32 * kb + 16 * s2 + 2 * e + 1] << 16);
+                    const bf16x8 rb = __builtin_bit_cast(bf16x8, (u32x4){rw[0], rw[1], rw[2], rw[3]});
+#pragma unroll
+                    for (int db = 0; db < DPK; ++db) dq[db] = mfma32(__builtin_bit_cast(bf16x8, tf[cur][s2 * DPK + db]), rb, dq[db]);
+                }
+                wave_lds_sync();
+            }
+            sched_fence();
+        }
+#undef IMG_LOAD
+#undef TAB_LOAD
+        __syncthreads();                                             // A: K_p is in LDS; every wave is done with V_p
+
+        // ---- pass 2 (K resident): dQ^T += K^T dS'^T
+        const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+        const int klane = 4 * h + (i16 >> 2), kcol = (16 * g16 + 4 * (i16 & 3)) * 2;
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb) {
+            if (blk_out(kb, w, D)) continue;
             const int j0 = 32 * kb;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 sb = __builtin_bit_cast(bf16x8, (u32x4){ds[4 * s2], ds[4 * s2 + 1], ds[4 * s2 + 2], ds[4 * s2 + 3]});
+                const bf16x8 sb = __builtin_bit_cast(bf16x8, (u32x4){dsall[kb][4 * s2], dsall[kb][4 * s2 + 1], dsall[kb][4 * s2 + 2], dsall[kb][4 * s2 + 3]});
                 int r0 = j0 + 16 * s2 + klane, r1 = r0 + 8;
                 r0 = r0 < T ? r0 : T - 1; r1 = r1 < T ? r1 : T - 1;
                 const unsigned char* k0 = Ks + r0 * KPB + kcol; const unsigned char* k1 = Ks + r1 * KPB + kcol;
 #pragma unroll
                 for (int db = 0; db < DPK; ++db) dq[db] = mfma32(tr_frag(k0 + 64 * db, k1 + 64 * db), sb, dq[db]);
             }
-        } else if (rblk_need(kb, w, D) || (kb < NT && rblk_need(kb + 1, w, D))) {
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) *(u32x2*)(usw + 32 * kb + 8 * rg) = z2;
         }
-        // dQ^T += E'^T dR'^T: R-block ub = kb is complete (key blocks kb - 1 and kb)
-        if (rblk_need(kb, w, D)) {
-            wave_lds_sync();
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                unsigned rw[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rw[e] = (unsigned)usr[32 * kb + 16 * s2 + 2 * e] | ((unsigned)usr[32 * kb + 16 * s2 + 2 * e + 1] << 16);
-                const bf16x8 rb = __builtin_bit_cast(bf16x8, (u32x4){rw[0], rw[1], rw[2], rw[3]});
-#pragma unroll
-                for (int db = 0; db < DPK; ++db) dq[db] = mfma32(__builtin_bit_cast(bf16x8, tf[cur][s2 * DPK + db]), rb, dq[db]);
-            }
-            wave_lds_sync();
-        }
-        sched_fence();
+        store_rows_t<DPK>(buf, dq, p.scale * p.oscale, p.dqkv + ((long long)b * T + i0) * ld + hd * p.dp, ld, T - i0 < 32 ? T - i0 : 32, lane);
+        __syncthreads();                                             // B: V_p+1 is in LDS; every wave is done with K_p
     }
-#undef IMG_LOAD
-#undef TAB_LOAD
-    store_rows_t<DPK>(buf, dq, p.scale * p.oscale, p.dqkv + ((long long)b * T + i0) * ld + hd * p.dp, ld, T - i0 < 32 ? T - i0 : 32, lane);
 }
 
 // =========================================================================== backward, key-major: dK, dV
@@ -750,6 +793,7 @@ __global__ void attn_t_tables_kernel(const float* __restrict__ emb, int H, int D
     }
 }
 
+size_t bwdq_smem(int T, int dp, int waves) { return dma_table_bytes(T, dp * 2) + dma_table_bytes(T, dp * 2 + KPAD) + (size_t)waves * BW_BUF + 16; }
 size_t bwd_smem(int T, int dp, int waves) { return (((size_t)T * dp * 2 + 15) & ~(size_t)15) + (size_t)T * (dp * 2 + KPAD) + (size_t)waves * (32 * 4 + BW_BUF) + 16; }
 size_t fwd_smem(int T, int dp, int waves) { return dma_table_bytes(T, dp * 2 + KPAD) + dma_table_bytes(T, dp * 2) + (size_t)waves * SK_WORDS * 4; }
 const size_t LDS_MAX = 160 * 1024;
@@ -790,7 +834,7 @@ int launch(Kern k, int blocks, int waves, size_t smem, void* stream, const KP& p
 bool attn_t_supported(int T, int dp, int D)
 {
     if (T < 1 || T > 32 * NTM || dp % 32 != 0 || dp < 32 || dp > 96 || D < 1 || D > 100) return false;
-    return fwd_smem(T, dp, (T + 31) / 32) <= LDS_MAX && bwd_smem(T, dp, (T + 31) / 32) <= LDS_MAX;
+    return fwd_smem(T, dp, (T + 31) / 32) <= LDS_MAX && bwd_smem(T, dp, (T + 31) / 32) <= LDS_MAX && bwdq_smem(T, dp, (T + 31) / 32) <= LDS_MAX;
 }
 int64_t attn_t_saved_bytes(int B, int H, int T) { const int64_t nt = (T + 31) / 32; return (int64_t)B * H * nt * nt * 2048; }
 int64_t attn_t_table_bytes(int H, int dp) { return 2LL * H * NU * (dp / 16) * 512 * 2; }
@@ -876,7 +920,7 @@ int attn_t_backward(const AttnTArgs& a, void* stream)
     const Kern kq = dpk == 1 ? bq_pick<1>(p.nt) : dpk == 2 ? bq_pick<2>(p.nt) : bq_pick<3>(p.nt);
     const Kern kkv = dpk == 1 ? bkv_pick<1>(p.nt) : dpk == 2 ? bkv_pick<2>(p.nt) : bkv_pick<3>(p.nt);
     const char* dbg = getenv("SS_ATTN_T_SKIP");          // measurement / debugging only: 1 skips the query-major kernel, 2 the key-major one
-    if (!(dbg && dbg[0] == '1') && launch(kq, a.B * a.H, waves, smem, stream, p)) return 1;      // also writes D' for the key-major kernel
+    if (!(dbg && dbg[0] == '1') && launch(kq, persistent_blocks(a.B * a.H, a.H), waves + 1, bwdq_smem(a.T, a.dp, waves), stream, p)) return 1;      // also writes D' for the key-major kernel
     if (dbg && dbg[0] == '2') return 0;
     return launch(kkv, a.B * a.H, waves, smem, stream, p);
 }
