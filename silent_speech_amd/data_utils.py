@@ -145,17 +145,24 @@ def mel_spectrogram_batch(signals, n_fft=1024, num_mels=80, sampling_rate=22050,
     """load_audio's `np.clip` + `mel_spectrogram(..., center=False)` (data_utils.py:76-78) for EVERY utterance of a batch in one
     launch sequence: one ragged clip + reflect-pad kernel, ONE hop-strided DFT GEMM over all frames of all utterances (rows of the
     padded buffer = utterances, RowMap batch stride), magnitude, one mel GEMM with the log-clamp epilogue.
-    signals: list of 1-D f32 device tensors at `sampling_rate`.  Returns (buf [B][F_max][num_mels] f32, frames per utterance):
+    signals: list of 1-D f32 device tensors at `sampling_rate`, or the pair (flat f32 device tensor holding them back to back, lengths) -- what
+    a loader that uploaded the whole batch in one copy has.  Returns (buf [B][F_max][num_mels] f32, frames per utterance):
     utterance b's `pytorch_mspec.squeeze(0).T` is buf[b, :frames[b]] -- a contiguous view, no per-utterance copy."""
     if hop_size % 4 or n_fft % 4:
         raise ValueError('hop_size and n_fft must be multiples of 4 (16-byte f32 rows)')
-    B = len(signals)
-    lens = [int(t.shape[0]) for t in signals]
+    packed = isinstance(signals, tuple)
+    lens = [int(n) for n in signals[1]] if packed else [int(t.shape[0]) for t in signals]
+    B = len(lens)
     pad = int((n_fft - hop_size) / 2)
     if min(lens) + 2 * pad < n_fft or min(lens) <= pad:
         raise ValueError('signal too short for one frame')
     dev = signals[0].device
-    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in signals]) if B > 1 else signals[0].reshape(-1).to(torch.float32).contiguous()
+    if packed:
+        flat = signals[0].reshape(-1)
+        if flat.dtype != torch.float32 or int(flat.shape[0]) != sum(lens):
+            raise ValueError('packed signals: a flat float32 tensor of sum(lengths) samples')
+    else:
+        flat = torch.cat([t.reshape(-1).to(torch.float32) for t in signals]) if B > 1 else signals[0].reshape(-1).to(torch.float32).contiguous()
     offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
     frames = [1 + (L + 2 * pad - n_fft) // hop_size for L in lens]
     F = max(frames)

@@ -15,7 +15,7 @@ import random
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, staging
 from .data_utils import mel_spectrogram
 
 _L = _lib.lib
@@ -153,6 +153,14 @@ class ShardedSizeAwareSampler(torch.utils.data.Sampler):
 
 
 # ------------------------------------------------------------------ the per-batch device loader (N3 composed with N4)
+class _NullCtx(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def _feature_frames(n_1k):
     """Frames of get_emg_features (data_utils.py:100: librosa.util.frame(frame_length=16, hop_length=6)) on the 516.79 Hz resample
     (read_emg.py:71) of a recording of n_1k raw 1 kHz samples -- the count load_utterance truncates everything to (:82-88)."""
@@ -189,18 +197,29 @@ class DeviceBatchBuilder(object):
         self.device, self.mfcc_norm, self.emg_norm, self.limit_length, self.sil_index = torch.device(device), mfcc_norm, emg_norm, limit_length, sil_index
         self.remove_channels = tuple(int(c) for c in remove_channels)
 
+    # ---- host arrays of a batch in ONE pinned copy (round 5: the leg was host-bound -- 123 small uploads and ~100 glue launches per batch)
+    @staticmethod
+    def _host(x, dtype):
+        """x as a contiguous numpy array of `dtype`, or None when it lives on the device already (then the per-recording path is taken)."""
+        if torch.is_tensor(x):
+            if x.is_cuda:
+                return None
+            x = x.detach().numpy()
+        return np.ascontiguousarray(np.asarray(x), dtype=dtype)
+
     # ---- EMG: every recording of the batch through ONE filter / resample launch sequence
-    def _filtered_689(self, recordings):
+    def _filtered_689(self, recordings, packed=None):
         from .read_emg import butter_highpass_coeffs, filtfilt_cascade_batch, iirnotch_coeffs, subsample_batch
         dev = self.device
         sigs, cuts = [], []
         for rec in recordings:
             parts = [rec.get('raw_emg_before'), rec['raw_emg'], rec.get('raw_emg_after')]
-            ts = [torch.as_tensor(np.asarray(p) if not torch.is_tensor(p) else p).to(device=dev, dtype=torch.float64) for p in parts if p is not None and len(p)]
             cuts.append((0 if parts[0] is None else len(parts[0]), 0 if parts[2] is None else len(parts[2])))
-            sigs.append(torch.cat(ts, 0) if len(ts) > 1 else ts[0])                        # read_emg.py:66
+            if packed is None:
+                ts = [torch.as_tensor(np.asarray(p) if not torch.is_tensor(p) else p).to(device=dev, dtype=torch.float64) for p in parts if p is not None and len(p)]
+                sigs.append(torch.cat(ts, 0) if len(ts) > 1 else ts[0])                    # read_emg.py:66
         filters = [iirnotch_coeffs(60 * h, 30, 1000) for h in range(1, 8)] + [butter_highpass_coeffs(3, 2, 1000)]
-        ys = filtfilt_cascade_batch(filters, sigs)                                         # :67-68
+        ys = filtfilt_cascade_batch(filters, sigs if packed is None else packed)           # :67-68
         ys = [y[nb:y.shape[0] - na] for y, (nb, na) in zip(ys, cuts)]                      # :69
         return subsample_batch(ys, 689.06, 1000)                                           # :70
 
@@ -214,14 +233,40 @@ class DeviceBatchBuilder(object):
         # audio of every recording whose mel frames are needed: own audio (lengths; targets when voiced) and the voiced twins
         twins = [r['parallel'] if r['silent'] else None for r in recordings]
         audio_src = list(recordings) + [t for t in twins if t is not None]
-        sig = [torch.as_tensor(np.asarray(r['audio']) if not torch.is_tensor(r['audio']) else r['audio']).to(device=dev, dtype=torch.float32) for r in audio_src]
-        mel, mframes = mel_spectrogram_batch(sig)
-        if self.mfcc_norm is not None:
-            mean, std = _normalizer_tensors(self.mfcc_norm, mel.shape[-1], dev)
-            _soft_clip(mel, mel, mel.shape[-1], mean, std, 1.0, 0.0)                       # FeatureNormalizer.normalize (read_emg.py:231), in place
+        # everything that arrives in host memory -- audio, raw EMG with its filter context -- crosses PCIe in ONE pinned copy (staging.upload)
+        a_host = [self._host(r['audio'], np.float32) for r in audio_src]
+        e_host = [[self._host(p, np.float64) for p in (r.get('raw_emg_before'), r['raw_emg'], r.get('raw_emg_after')) if p is not None and len(p)] for r in recordings]
+        emg_packed = None
+        if all(a is not None for a in a_host) and all(p is not None for ps in e_host for p in ps):
+            e_rows = [sum(int(p.shape[0]) for p in ps) for ps in e_host]
+            up = staging.upload([[a.reshape(-1) for a in a_host], [p.reshape(p.shape[0], -1) for ps in e_host for p in ps]], dev)
+            sig = (up[0], [int(a.shape[0]) for a in a_host])
+            emg_packed = (up[1], e_rows)
+        else:
+            sig = [torch.as_tensor(np.asarray(r['audio']) if not torch.is_tensor(r['audio']) else r['audio']).to(device=dev, dtype=torch.float32) for r in audio_src]
+        # the audio half (clip, reflect pad, DFT / mel GEMMs, normalise) runs on a SIDE stream under the EMG half (a chain of ~50 short,
+        # latency-bound filter launches that leave most of the chip idle): the two are independent until the batch dict is assembled
+        side = None
+        if dev.type == 'cuda' and not _lib.is_emulator():
+            side = getattr(self, '_side', None)
+            if side is None:
+                side = self._side = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)                                                          # the upload above
+            for t in ([sig[0]] if isinstance(sig, tuple) else sig):
+                t.record_stream(side)
+        with (torch.cuda.stream(side) if side is not None else _NullCtx()):
+            mel, mframes = mel_spectrogram_batch(sig)
+            if self.mfcc_norm is not None:
+                mean, std = _normalizer_tensors(self.mfcc_norm, mel.shape[-1], dev)
+                _soft_clip(mel, mel, mel.shape[-1], mean, std, 1.0, 0.0)                   # FeatureNormalizer.normalize (read_emg.py:231), in place
+        if side is not None:
+            mel_done = torch.cuda.Event()
+            mel_done.record(side)
+            mel.record_stream(main)
         n_own = [self._frames(r, mframes[i], self.limit_length) for i, r in enumerate(recordings)]
         # raw EMG: filter every recording, gather rows 8 .. 8 + 8 n into ONE buffer, soft-clip it in one launch
-        e689 = self._filtered_689(recordings)
+        e689 = self._filtered_689(recordings, emg_packed)
         # a resampled signal that ends before row 8 + 8 n: the reference's slice raw_emg[8:8+8n] (read_emg.py:90) silently comes out shorter;
         # here the frame count of that recording follows the samples that exist (whole frames), so every downstream length stays consistent
         n_own = [min(n, max(0, (int(e.shape[0]) - 8) // 8)) for e, n in zip(e689, n_own)]
@@ -237,9 +282,14 @@ class DeviceBatchBuilder(object):
         for ch in self.remove_channels:                                                     # read_emg.py:73-75 (on the model-rate signal; zero stays zero through the clip)
             raw[:, ch].zero_()
         _soft_clip(raw, raw, 8, None, None, 20.0, 50.0)                                     # read_emg.py:227-228
+        if side is not None:
+            main.wait_event(mel_done)                                                        # the mel targets join the batch here
         out = {k: [] for k in ('audio_features', 'audio_feature_lengths', 'emg', 'raw_emg', 'parallel_voiced_emg', 'phonemes', 'session_ids',
                                'lengths', 'silent', 'text_int', 'text_int_lengths')}
+        # pass 1 (host): target lengths and phoneme labels; the labels and session ids of the whole batch then travel in one copy, and the
+        # (unused, zero) hand-crafted feature tensors are views of ONE zero buffer -- instead of three small launches per utterance
         ti = len(recordings)
+        meta, ph_host, sess_host = [], [], []
         for i, (r, n) in enumerate(zip(recordings, n_own)):
             if r['silent']:
                 t = r['parallel']
@@ -249,12 +299,20 @@ class DeviceBatchBuilder(object):
             else:
                 nt, feats, ph_src = n, mel[i, :n], r
             ph = ph_src.get('phonemes')
-            ph = torch.full((nt,), self.sil_index, dtype=torch.int64) if ph is None else torch.as_tensor(ph, dtype=torch.int64)[:nt]
+            ph = np.full((nt,), self.sil_index, dtype=np.int64) if ph is None else (ph.detach().cpu().numpy() if torch.is_tensor(ph) else np.asarray(ph)).astype(np.int64)[:nt]
             if ph.shape[0] != nt:
                 raise ValueError('phoneme labels shorter than the %d target frames' % nt)
+            meta.append((nt, feats))
+            ph_host.append(ph)
+            sess_host.append(np.full((n,), int(r.get('session_index', 0)), dtype=np.int64))
+        ph_all, sess_all = staging.upload([ph_host, sess_host], dev)
+        zeros = torch.zeros(sum(n_own), 112, dtype=torch.float32, device=dev)
+        po = so = 0
+        for i, (r, n) in enumerate(zip(recordings, n_own)):
+            nt, feats = meta[i]
             ef = r.get('emg_features')
             if ef is None:
-                emg = torch.zeros(n, 112, dtype=torch.float32, device=dev)
+                emg = zeros[so:so + n]
             else:
                 emg = torch.as_tensor(ef, dtype=torch.float32)[:n].to(dev)
                 emg = normalize_features(emg, self.emg_norm, 8.0) if self.emg_norm is not None else emg
@@ -268,7 +326,8 @@ class DeviceBatchBuilder(object):
                 pv = torch.as_tensor(r['parallel']['emg_features'], dtype=torch.float32).to(dev)
                 pv = normalize_features(pv, self.emg_norm, 8.0) if self.emg_norm is not None else pv
             out['parallel_voiced_emg'].append(pv)
-            out['phonemes'].append(ph.to(dev)); out['session_ids'].append(torch.full((n,), int(r.get('session_index', 0)), dtype=torch.int64, device=dev))
+            out['phonemes'].append(ph_all[po:po + nt]); out['session_ids'].append(sess_all[so:so + n])
+            po += nt; so += n
             out['lengths'].append(n); out['silent'].append(bool(r['silent']))
             out['text_int'].append(text); out['text_int_lengths'].append(int(text.shape[0]))
         return out

@@ -131,11 +131,19 @@ def filtfilt_cascade(filters, signal):
 def filtfilt_cascade_batch(filters, signals):
     """filtfilt_cascade for a RAGGED BATCH: `signals` = list of (T_u, C) f64 device tensors of different lengths -> list of filtered
     tensors (views of one packed buffer).  One launch sequence for all recordings (8 launches per filter + 1), instead of one per
-    recording: the recurrences are serial in time, so the parallelism is (chunks x channels) and a batch supplies many more of them."""
-    dev = signals[0].device
-    C = int(signals[0].shape[1])
-    lens = np.asarray([int(t.shape[0]) for t in signals], dtype=np.int32)
-    x = torch.cat([t.to(torch.float64) for t in signals], 0).contiguous() if len(signals) > 1 else signals[0].to(torch.float64).contiguous()
+    recording: the recurrences are serial in time, so the parallelism is (chunks x channels) and a batch supplies many more of them.
+    `signals` may also be the pair (packed (sum T, C) f64 device tensor, lengths): the recordings back to back, as one upload left them."""
+    if isinstance(signals, tuple):
+        x, lens = signals[0], np.asarray([int(n) for n in signals[1]], dtype=np.int32)
+        if x.dtype != torch.float64 or x.dim() != 2 or int(x.shape[0]) != int(lens.sum()) or not x.is_contiguous():
+            raise ValueError('packed signals: a contiguous (sum(lengths), C) float64 tensor')
+        signals = [None] * len(lens)
+        dev, C = x.device, int(x.shape[1])
+    else:
+        dev = signals[0].device
+        C = int(signals[0].shape[1])
+        lens = np.asarray([int(t.shape[0]) for t in signals], dtype=np.int32)
+        x = torch.cat([t.to(torch.float64) for t in signals], 0).contiguous() if len(signals) > 1 else signals[0].to(torch.float64).contiguous()
     coef = _pack_filters(filters)
     maxpad = int(coef[:, 12].max())
     if int(lens.min()) <= maxpad:

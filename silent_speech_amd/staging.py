@@ -48,8 +48,11 @@ class _Ring(object):
 
 def upload(arrays, device):
     """arrays: list of numpy arrays.  Returns one device tensor per array (same dtype and shape), all living in ONE device
-    buffer filled by ONE host-to-device copy on the current stream.  Emulator backend (tests): plain CPU tensors."""
-    arrays = [np.ascontiguousarray(a) for a in arrays]
+    buffer filled by ONE host-to-device copy on the current stream.  Emulator backend (tests): plain CPU tensors.
+    An entry may also be a LIST of arrays to be concatenated along axis 0 (same dtype and trailing shape): the pieces are copied
+    straight into the pinned buffer, without a host-side np.concatenate first (the device loader's 10 MB of raw recordings)."""
+    parts = [[np.ascontiguousarray(p) for p in a] if isinstance(a, (list, tuple)) else None for a in arrays]
+    arrays = [_Joined(ps) if ps is not None else np.ascontiguousarray(a) for a, ps in zip(arrays, parts)]
     offs, total = [], 0
     for a in arrays:
         offs.append(total)
@@ -59,7 +62,7 @@ def upload(arrays, device):
     if device.type != 'cuda':
         if not _lib.is_emulator():
             raise RuntimeError('silent_speech_amd: staging to %s; the HIP kernels need an AMD GPU (no CPU fallback exists)' % device)
-        return [torch.from_numpy(a.copy()) for a in arrays]
+        return [torch.from_numpy(np.concatenate(a.parts, 0) if isinstance(a, _Joined) else a.copy()) for a in arrays]
     if device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
     ring = _rings.get(device)
@@ -68,7 +71,12 @@ def upload(arrays, device):
     host, ev = ring.slot(total)
     hv = host.numpy()
     for a, o in zip(arrays, offs):
-        if a.nbytes:
+        if isinstance(a, _Joined):
+            for q in a.parts:
+                if q.nbytes:
+                    hv[o:o + q.nbytes] = q.view(np.uint8).reshape(-1)
+                    o += q.nbytes
+        elif a.nbytes:
             hv[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
     dev = torch.empty(total, dtype=torch.uint8, device=device)
     dev.copy_(host[:total], non_blocking=True)
@@ -78,6 +86,17 @@ def upload(arrays, device):
         t = dev[o:o + a.nbytes].view(_TORCH_DTYPE[a.dtype.type])
         out.append(t.view(a.shape) if a.ndim != 1 else t)
     return out
+
+
+class _Joined(object):
+    """Several arrays that become one along axis 0 in the staging buffer: what upload needs to know of the result."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        self.dtype = parts[0].dtype
+        self.shape = (sum(int(q.shape[0]) for q in parts),) + tuple(parts[0].shape[1:])
+        self.ndim = len(self.shape)
+        self.nbytes = sum(q.nbytes for q in parts)
 
 
 _TORCH_DTYPE = {np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8, np.float32: torch.float32, np.float64: torch.float64}
