@@ -180,6 +180,10 @@ __device__ __forceinline__ void efrag_wait(bf16x8 (&f)[KS]) {
     for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(f[s]));
 #endif
 }
+// Build-time debugging switches of this file (none is set by the Makefile): -DATTN_T_FENCE=0 drops the scheduling fences between pipeline stages,
+// -DATTN_T_NO_DMA makes the loader wave copy through registers instead of global_load_lds, -DATTN_T_PLAIN_LOADS turns the asm loads of the
+// backward into compiler-visible ones -- the three variants that told a scheduling problem from a hazard from a race when the hardware and
+// the emulator disagreed.
 #ifndef ATTN_T_FENCE
 #define ATTN_T_FENCE 1
 #endif

@@ -1,3 +1,5 @@
+"""Developer tool (GPU): the transposed-score attention forward against the closed form over a list of shapes, with the rows / tiles / (batch, head)
+pairs that are off -- how the narrow-band and partial-tile failures of round 5 (asm loads under branches) were localised."""
 import math, sys, torch
 sys.path.insert(0, '.')
 from oracle import model_ref
