@@ -389,7 +389,7 @@ def eval_leg(dev):
     torch.cuda.synchronize()
     t_long = time.perf_counter() - t0
     return {'test': {'utterances': len(ds), 'frames': frames, 'ms': t_test * 1e3, 'frames_per_s': frames / t_test, 'loss': float(loss), 'phoneme_acc': float(acc),
-                     'note': 'eval-mode forward on batches of 32 utterances packed into 200-frame rows + dtw_loss(eval) incl. one DTW per silent utterance and the host-side confusion matrix'},
+                     'note': 'eval-mode forward on batches of 32 utterances packed into 200-frame rows + dtw_loss(eval) incl. one DTW per silent utterance and the phoneme confusion matrix accumulated on the device (one read-back per test())'},
             'whole_utterance': {'utterances': len(long_ds), 'frames': lframes, 'ms': t_long * 1e3, 'frames_per_s': lframes / t_long, 'finite': bool(torch.isfinite(out).all()),
                                 'note': 'predict_utterance: B = 1, T = 600..1000 (un-chunked): per-tile banded attention kernels (cost linear in T)'}}
 
@@ -427,7 +427,7 @@ def pipeline_leg(dev, n_utt=24):
         mel_ref.mel_spectrogram_ref(r['audio'][None])
     t_cpu = (time.perf_counter() - t0) * n_utt / k
     return {'workload': '%d recordings (%d frames): 8-filter zero-phase IIR cascade + resample + soft clip, batched STFT / mel / normalise -> batch dict' % (n_utt, frames),
-            'hip_ms': t_dev * 1e3, 'frames_per_s': frames / t_dev, 'includes': 'H2D of the raw recordings and audio (host arrays in); ONE ragged filter / resample launch sequence and one DFT GEMM for the whole batch',
+            'hip_ms': t_dev * 1e3, 'frames_per_s': frames / t_dev, 'includes': 'H2D of the raw recordings and audio (host arrays in, one pinned upload per kind); ONE ragged filter / resample launch sequence and one DFT GEMM for the whole batch, the audio half on a side stream; median of 5 builds after 4 warm ones',
             'cpu_frames_per_s': frames / t_cpu, 'cpu_kind': 'oracle/filter_ref.py + oracle/mel_ref.py (numpy, 1 process; %d of %d recordings timed, scaled)' % (k, n_utt)}
 
 

@@ -18,6 +18,15 @@
 //       atomics.  Tiles are copied untransposed ([64 k][256 m], pitch 544 B) and transposed by ds_read_b64_tr_b16.
 #include "gemm8_common.h"
 
+#if defined(G8_STAMPS)       // measurement builds only (tools/g8_stamps.sh): wall-clock stamps of every workgroup's tiles
+__device__ unsigned long long g8_stamp_buf[256 * 8 * 8];
+extern "C" int ss_gemm8_debug_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g8_stamp_buf), sizeof(g8_stamp_buf)) == hipSuccess ? 1 : 0; }
+#define G8_STAMP(item, k) do { if (tid == 0 && blockIdx.x < 256 && (item) < 8) { g8_stamp_buf[(blockIdx.x * 8 + (item)) * 8 + (k)] = wall_clock64(); \
+        if ((k) == 1 || (k) == 2) g8_stamp_buf[(blockIdx.x * 8 + (item)) * 8 + 4 + (k)] = clock64(); } } while (0)      /* slots 5, 6: shader cycles around the K loop */
+#else
+#define G8_STAMP(item, k) do { } while (0)
+#endif
+
 namespace g8 {
 
 __device__ __forceinline__ int fsw(int row) { return (row & 7) ^ (((row >> 3) & 3) << 1); }
@@ -29,6 +38,8 @@ struct Stage {
     unsigned off[NP];                 // byte offset of this lane's source chunk (row clamped, chunk pre-swizzled), K offset excluded
     // When PIECES is not a multiple of 8 the waves beyond the last piece repeat their previous one (same bytes to the same LDS
     // address): a branch around one copy would split the K loop's basic block and cost the counted LDS waits more than 1 KiB does.
+    // LEAN: one offset at a time (called from inside the K loop, where ~250 registers are live: interleaved, the temporaries of the NP row maps spill)
+    template <bool LEAN = false>
     __device__ __forceinline__ void init(const RowMap& map, int outer0, int outer_size, int wave, int lane) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -37,6 +48,7 @@ struct Stage {
             int o = outer0 + r; o = o < outer_size ? o : outer_size - 1;
             const int chunk = (lane & 7) ^ fsw(r);
             off[i] = (unsigned)((rowmap_off(map, o) + chunk * 8) * 2);
+            if constexpr (LEAN) sched_fence();
         }
     }
     __device__ __forceinline__ void issue(const unsigned char* base_k, unsigned char* tile, int wave) {
@@ -94,6 +106,20 @@ __device__ __forceinline__ void barrier_all() {
 #endif
 }
 
+// The first barrier of an item whose predecessor left through direct_store8<INTERIOR>: this item's first K tile was requested BEFORE those
+// NST stores (from the last K step of the predecessor), and vector-memory operations retire in issue order -- "at most NST outstanding"
+// means the K tile has landed, while the stores drain under the first K step instead of in front of it (2.2 -> 0.5 us per tile).
+template <int NST>
+__device__ __forceinline__ void barrier_after_stores() {
+#if defined(SS_EMU)
+    __syncthreads();
+#else
+    static_assert(NST >= 0 && NST < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt(((NST >> 4) << 14) | (7 << 4) | (NST & 15));      // vmcnt(NST) lgkmcnt(0), expcnt untouched (gfx9 encoding)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
+}
 
 // ---- epilogue.  Everything the epilogue reads from memory is requested EARLY and all at once: the bias of the wave's four column groups
 // before the tile's first pass, and the per-element side input of a flush pass (the gate = saved activation of the ReLU / dropout backward, or
@@ -127,6 +153,124 @@ __device__ __forceinline__ void stage8_sw(const f32x4& a, TO* __restrict__ ct, i
     for (int e = 0; e < 4; ++e) x[e] = fmaxf(a[e] * epi.alpha + bias[e], lo);
     if constexpr (sizeof(TO) == 2) { u32x2 w; w[0] = pack_bf16(x[0], x[1]); w[1] = pack_bf16(x[2], x[3]); *(u32x2*)(ct + lrow * ldc + lcol0) = w; }
     else { f32x4 w = {x[0], x[1], x[2], x[3]}; *(f32x4*)(ct + lrow * ldc + lcol0) = w; }
+}
+
+// ---- the plain epilogue of the transposed accumulator layout WITHOUT the LDS C piece (bf16 out; no side input, no column statistics).
+// Lane (r, q) holds row r and columns 4 q .. 4 q + 3 of each of the wave's four 16-column tiles j: 8 bytes per tile, 32 bytes apart.  One
+// v_permlane16_swap per dword exchanges, between the lanes q and q ^ 1 of a row, the piece of tile 2 jp + 1 (from q even) against the piece
+// of tile 2 jp (from q odd): afterwards lane (r, q) holds columns 8 (q >> 1) .. + 7 of tile 2 jp + (q & 1), 16 contiguous bytes, and the 16
+// rows of a store instruction each receive one 64-byte run.  The C piece cost 3 x (12 ds_write_b64, barrier, 6 ds_read_b128 + address
+// arithmetic per thread, barrier) = 4.6 us per 288 x 256 tile with no MFMA running (tools/g8_stamps); this form has no barrier at all.
+__device__ __forceinline__ void lane16_swap(unsigned& x, unsigned& y) {
+#if defined(SS_EMU)
+    const int lane = (int)(threadIdx.x & 63), q = lane >> 4;
+    const unsigned xo = __shfl(y, (lane - 16) & 63), yo = __shfl(x, (lane + 16) & 63);      // every lane takes part in both exchanges
+    if (q & 1) x = xo; else y = yo;
+#else
+    const auto v = __builtin_amdgcn_permlane16_swap(x, y, false, false);     // rows 1, 3 of x <-> rows 0, 2 of y (a row = 16 lanes)
+    x = v[0]; y = v[1];
+#endif
+}
+// INTERIOR: the tile lies inside the matrix -- no per-lane predicate, so every wave issues at least 2 NI vector-memory operations behind
+// the next item's first K tile (the next item's first barrier counts on that number: barrier_after_stores).
+// Side inputs (addressed like C, 16 bytes per lane and store): the gate (saved activation of a ReLU / dropout backward) and / or the old C of
+// "C += v".  One of them travels two row tiles ahead in registers (the fragment registers of the K loop are free here); when both
+// are present the old C is read in place.  Arithmetic and rounding are those of the C-piece epilogue: bf16(alpha acc + bias), then the gate
+// and the sum on that rounded value in f32, rounded once more.
+// STATS = 2: per-column sums of the stored (rounded) values: 16 accumulators per lane, folded over the 16 rows of a DPP row at the end,
+// one atomic per column, wave and tile.
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+template <int NI, bool INTERIOR, int STATS>
+__device__ __forceinline__ void direct_store8(const f32x4 (&acc)[NI][4], bf16_t* __restrict__ C, const GemmEpi& epi, int m0, int n0, int M, int N, int wm, int wn, int r, int q,
+                                              const f32x4 (&b16)[4])
+{
+    constexpr int AHEAD = 2, SLOTS = AHEAD + 1;                // the side input of row tile i + AHEAD is requested when row tile i is worked on
+    const float lo = epi.relu ? 0.f : -INFINITY;
+    const float alpha = epi.alpha, gs = epi.gate_scale;
+    const bf16_t* gate = (const bf16_t*)epi.gate;
+    const bool acc_c = epi.mode == 1;
+    const bf16_t* side = gate ? gate : (acc_c ? (const bf16_t*)C : nullptr);       // the prefetched input
+    const int colb = n0 + wn * 64 + (q & 1) * 16 + (q >> 1) * 8;
+    const bool cok0 = INTERIOR || colb < N, cok1 = INTERIOR || colb + 32 < N;
+    float cs[2][8];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[jp][e] = 0.f;
+    u32x4 pre[SLOTS][2];
+    auto row_of = [&](int i) { return m0 + (wm * NI + i) * 16 + r; };
+    auto fetch = [&](auto ic) {
+        constexpr int i = ic;
+        const int row = row_of(i);
+        const long long ro = rowmap_off(epi.cmap, INTERIOR || row < M ? row : M - 1);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        pre[i % SLOTS][0] = (INTERIOR || (row < M && cok0)) ? *(const u32x4*)(side + ro + colb) : z;
+        pre[i % SLOTS][1] = (INTERIOR || (row < M && cok1)) ? *(const u32x4*)(side + ro + colb + 32) : z;
+    };
+    if (side) static_for<0, (AHEAD < NI ? AHEAD : NI)>([&](auto ic) { fetch(ic); });
+    static_for<0, NI>([&](auto ic) {
+        constexpr int i = ic;
+        if constexpr (i + AHEAD < NI) { if (side) fetch(std::integral_constant<int, i + AHEAD>{}); }
+        const int row = row_of(i);
+        const bool rok = INTERIOR || row < M;
+        const long long ro = rowmap_off(epi.cmap, rok ? row : M - 1);
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+            unsigned w[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = fmaxf(acc[i][2 * jp + t][e] * alpha + b16[2 * jp + t][e], lo);
+                w[t][0] = pack_bf16(x[0], x[1]); w[t][1] = pack_bf16(x[2], x[3]);
+            }
+            lane16_swap(w[0][0], w[1][0]);
+            lane16_swap(w[0][1], w[1][1]);
+            unsigned v[4] = {w[0][0], w[0][1], w[1][0], w[1][1]};
+            const int col = colb + jp * 32;
+            const bool ok = INTERIOR || (rok && (jp ? cok1 : cok0));
+            if (side) {
+                u32x4 old = {0u, 0u, 0u, 0u};
+                if (gate && acc_c && ok) old = *(const u32x4*)(C + ro + col);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    float x0 = bf_lo(v[d]), x1 = bf_hi(v[d]);
+                    const unsigned sd = pre[i % SLOTS][jp][d];
+                    if (gate) {
+                        x0 = bf_lo(sd) > 0.f ? x0 * gs : 0.f; x1 = bf_hi(sd) > 0.f ? x1 * gs : 0.f;
+                        if (acc_c) { x0 += bf_lo(old[d]); x1 += bf_hi(old[d]); }
+                    } else { x0 += bf_lo(sd); x1 += bf_hi(sd); }
+                    v[d] = pack_bf16(x0, x1);
+                }
+            }
+            if (ok) {
+                const u32x4 o = {v[0], v[1], v[2], v[3]};
+                *(u32x4*)(C + ro + col) = o;
+                if constexpr (STATS == 2) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { cs[jp][2 * d] += bf_lo(v[d]); cs[jp][2 * d + 1] += bf_hi(v[d]); }
+                }
+            }
+        }
+        sched_fence();
+    });
+    if constexpr (STATS == 2) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = cs[jp][e];
+                t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+                cs[jp][e] = t;
+            }
+        if (r == 0) {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int col = colb + jp * 32 + e; if (INTERIOR || col < N) atomicAdd(epi.col_sum + col, cs[jp][e]); }
+        }
+    }
 }
 
 // chunk `it` of thread `tid` in flush pass `pass`: LDS row / column chunk, output row / column, validity
@@ -303,7 +447,16 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
     constexpr bool SPR = (PIN & 1) != 0, SPD = (PIN & 2) != 0;              // spread the fragment reads / the DMA pieces between the MFMA groups
     constexpr int NCH = SPD ? NPH / 2 : 1, CS = (NPW + NCH - 1) / NCH;     // the copy of a K tile is issued in NCH chunks of CS pieces
 
-    for (;;) {
+    int item = 0;
+    bool stores_behind_tile0 = false;
+    for (;; ++item) {
+        G8_STAMP(item, 0);
+        // The next item's first K tile is one more tile of the same ring: with >= 2 K steps its copies leave from the slots in which a tile
+        // nsteps of THIS item would be requested (last phase of step nsteps-2, early phases of step nsteps-1), under the MFMAs of the last
+        // K step.  (Requested in one burst after the loop, the 9 copies per wave cost 2.1 us per tile: tools/g8_stamps, "drain".)
+        const int cm0 = m0, cn0 = n0;
+        const bool has_next = it + G < nitems;
+        const bool ring_next = has_next && nsteps >= 2 && !(ABL & 2);
         f32x4 acc[NI][4];
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -352,12 +505,28 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             constexpr bool last = ph + 1 == NPH, STEADY = steady_c;
             constexpr int chunk = last ? 0 : ph + 1;
             bool rd = true, dm = false; unsigned rst = S, dst = 0; long long kb = 0;
+            if constexpr (!STEADY && ph == NCH - 1) {
+                // this item's last copy has left (chunk NCH-1 of K tile nsteps-1, one phase ago): the offsets become the next item's
+                if (ring_next && s + 2 == nsteps) {
+                    it += G;
+                    tile_coord(it, G, nitems, tiles_n, mt, nt);
+                    m0 = mt * BMT; n0 = nt * TBN;
+                    sched_fence();
+                    sa.template init<true>(amap, m0, M, wave, lane); sb.template init<true>(bmap, n0, N, wave, lane);
+                }
+            }
             if constexpr (last) {
                 if (STEADY || s + 1 < nsteps) {
                     barrier_all();               // every wave holds its last fragments of stage S; K tile s+1 has landed in O
-                    rst = O; dm = (STEADY || s + 2 < nsteps) && !(ABL & 2); kb = (long long)(s + 2) * BK8 * 2; dst = S;
+                    rst = O; dst = S;
+                    if constexpr (STEADY) { dm = !(ABL & 2); kb = (long long)(s + 2) * BK8 * 2; }
+                    else { const bool mine = s + 2 < nsteps; dm = (mine && !(ABL & 2)) || ring_next; kb = mine ? (long long)(s + 2) * BK8 * 2 : 0; }      // s + 2 == nsteps: K tile 0 of the next item
                 } else rd = false;
-            } else if constexpr (chunk < NCH) { dm = (STEADY || s + 1 < nsteps) && !(ABL & 2); kb = (long long)(s + 1) * BK8 * 2; dst = O; }
+            } else if constexpr (chunk < NCH) {
+                dst = O;
+                if constexpr (STEADY) { dm = !(ABL & 2); kb = (long long)(s + 1) * BK8 * 2; }
+                else { const bool mine = s + 1 < nsteps; dm = (mine && !(ABL & 2)) || ring_next; kb = mine ? (long long)(s + 1) * BK8 * 2 : 0; }
+            }
             if (ABL & 4) rd = false;
             static_for<0, HR>([&](auto xc) {
                 constexpr int x = xc;
@@ -377,7 +546,9 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             if (rd) wait_frags(std::integral_constant<int, nx>{});
             sched_fence();
         };
-        barrier_all();                                       // K tile 0 of this item has landed in stage `cur`; stage cur^1 is free
+        if (stores_behind_tile0) barrier_after_stores<2 * NI>(); else barrier_all();       // K tile 0 of this item has landed in stage `cur`; stage cur^1 is free
+        stores_behind_tile0 = false;
+        G8_STAMP(item, 1);
         // chunk 0 of K tile 1 (its other chunks follow from the phases of step 0, like those of every later tile)
         if (nsteps > 1 && !(ABL & 2)) static_for<0, (NCH > 1 ? CS : NPW)>([&](auto k) { dma(k, (long long)BK8 * 2, (unsigned)((cur ^ 1) * STAGE)); });
         static_for<0, HR>([&](auto x) { read_a(std::integral_constant<int, 0>{}, x, (unsigned)(cur * STAGE)); });
@@ -391,9 +562,16 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
         }
         // `cur` names the stage the last K tile did NOT use (free since the previous mid-step barrier): the next item's first
         // K tile goes there while this item's C tile leaves through the other stage
-        const int cm0 = m0, cn0 = n0;
-        const bool has_next = it + G < nitems;
-        if (has_next) {
+        G8_STAMP(item, 2);
+        // The epilogue's per-thread constants (flush rows, LDS offsets: ~20 values derived from the thread number) must not be hoisted out of
+        // the item loop: live across the K loop they are spilled, and every reload inside the epilogue is a scratch load behind the tile's
+        // global stores (vmcnt counts in order: s_waitcnt vmcnt(0) per reload = the store pipe drained ~30 times per tile, epilogue 4.6 -> 8.5 us)
+        int tid_e = tid;
+#if !defined(SS_EMU)
+        asm volatile("" : "+v"(tid_e));
+#endif
+        const int lane_e = tid_e & 63, r_e = lane_e & 15, q_e = lane_e >> 4;
+        if (has_next && !ring_next) {
             it += G;
             tile_coord(it, G, nitems, tiles_n, mt, nt);
             m0 = mt * BMT; n0 = nt * TBN;
@@ -408,63 +586,85 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (SWAP) { const int col = cn0 + wn * 64 + j * 16 + q * 4; bias4[j] = 0.f; b16[j] = (epi.bias && col < N) ? *(const f32x4*)(epi.bias + col) : z; }      // N % 8 == 0 (epi.fast)
-            else { const int col = cn0 + wn * 64 + j * 16 + r; bias4[j] = (epi.bias && col < N) ? epi.bias[col] : 0.f; b16[j] = z; }
+            if constexpr (SWAP) { const int col = cn0 + wn * 64 + j * 16 + q_e * 4; bias4[j] = 0.f; b16[j] = (epi.bias && col < N) ? *(const f32x4*)(epi.bias + col) : z; }      // N % 8 == 0 (epi.fast)
+            else { const int col = cn0 + wn * 64 + j * 16 + r_e; bias4[j] = (epi.bias && col < N) ? epi.bias[col] : 0.f; b16[j] = z; }
         }
         // (not in the full column-statistics instantiation: its three per-column register arrays leave no room for the side-input buffers --
         // with them the gate + column-sum epilogue of the FFN input gradient spilled and ran 219 instead of 185 us; the sums-only form has room)
         const int pf = STATS == 1 ? 0 : (epi.gate ? 1 : (epi.mode == 1 ? 2 : 0));
         const TO* pf_src = pf == 1 ? (const TO*)epi.gate : C;
-        u32x4 pa[Flush8<TO, NI, IPP>::NIT / 2], pb[Flush8<TO, NI, IPP>::NIT / 2];
-        if (pf) flush8_prefetch<TO, NI, IPP, 0>(pf_src, epi, cm0, cn0, 0, M, N, tid, pa);
-        barrier_keep_vm();                                   // every wave is done reading stage cur^1 -> it becomes the C piece
-        TO* ct = (TO*)(lds + (cur ^ 1) * STAGE);
-        constexpr int LDC = TBN + 16 / (int)sizeof(TO);
-        static_assert((size_t)2 * IPP * 16 * LDC * sizeof(TO) <= (size_t)STAGE, "C piece does not fit the free stage");
-        constexpr int EV = OutVec<TO>::N, CPR = TBN / EV;
-        float cs[EV], cq[EV], sh[EV];
-#pragma unroll
-        for (int e = 0; e < EV; ++e) { cs[e] = 0.f; cq[e] = 0.f; sh[e] = 0.f; }
-        if constexpr (STATS) {
-            // column statistics of the stored tile: registers (per thread: one 16-byte column chunk, all its rows) -> per-wave LDS bins
-            // (plain stores: every wave covers all 256 columns) -> 512 threads add the 8 waves' bins -> one global atomic per column and
-            // tile.  The bins sit behind the C piece in the free stage.
-            constexpr int BINS_OFF = NI % 3 == 0 ? 51200 : 40960;
-            float* bins = (float*)(lds + (cur ^ 1) * STAGE + BINS_OFF);
-            static_assert((size_t)2 * IPP * 16 * LDC * sizeof(TO) <= BINS_OFF && BINS_OFF + 8 * 2 * TBN * 4 <= STAGE, "column-statistics bins overlap the C piece");
-            const int ch = tid % CPR;
-            if (STATS == 1 && epi.col_shift) {
-#pragma unroll
-                for (int e = 0; e < EV; ++e) { const int col = cn0 + ch * EV + e; sh[e] = col < N ? epi.col_shift[col] : 0.f; }
-            }
-            if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
-            else Passes8<TO, 0, NI, IPP, 0, NPASS, STATS, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
-            if (CPR == 32) {                  // bf16 out: lanes l and l + 32 of a wave hold the same column chunk
-#pragma unroll
-                for (int e = 0; e < EV; ++e) { cs[e] += __shfl_xor(cs[e], 32); if (STATS == 1) cq[e] += __shfl_xor(cq[e], 32); }
-            }
-            if (CPR == 64 || lane < 32) {
-                float* wb = bins + wave * 2 * TBN;
-#pragma unroll
-                for (int e = 0; e < EV; ++e) { wb[ch * EV + e] = cs[e]; if (STATS == 1) wb[TBN + ch * EV + e] = cq[e]; }
-            }
-            barrier_keep_vm();
-            {
-                float t = 0.f;
-                if (STATS == 1 || tid < TBN) {
-#pragma unroll
-                    for (int w8 = 0; w8 < 8; ++w8) t += bins[w8 * 2 * TBN + tid];
-                }
-                const int col = cn0 + (tid & (TBN - 1));
-                if (col < N) {
-                    if (tid < TBN) atomicAdd(epi.col_sum + col, t);
-                    else if (STATS == 1 && epi.col_sumsq) atomicAdd(epi.col_sumsq + col, t);
-                }
-            }
+        // bf16 results of the transposed accumulator layout leave straight from the registers (direct_store8: alpha / bias / ReLU, gate, C += v,
+        // column sums); the C piece in LDS remains for the dropout kernels (untransposed layout), the BatchNorm statistics and f32 output
+        constexpr bool DIRECT = SWAP && sizeof(TO) == 2 && STATS == 0;
+        if constexpr (DIRECT) {
+            G8_STAMP(item, 3);
+            if (cm0 + BMT <= M && cn0 + TBN <= N) {
+                direct_store8<NI, true, STATS>(acc, (bf16_t*)C, epi, cm0, cn0, M, N, wm, wn, r_e, q_e, b16);
+                stores_behind_tile0 = ring_next;
+            } else direct_store8<NI, false, STATS>(acc, (bf16_t*)C, epi, cm0, cn0, M, N, wm, wn, r_e, q_e, b16);
         } else {
-            if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
-            else Passes8<TO, 0, NI, IPP, 0, NPASS, 0, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+            // ("some value", fixed per item: left plainly undefined on the paths without a side input, the 24 registers became a value carried
+            // around the item loop -- spilled before the K loop and reloaded, behind the global stores, in the epilogue; zeroed, they are live
+            // registers of every epilogue)
+            u32x4 pa[Flush8<TO, NI, IPP>::NIT / 2], pb[Flush8<TO, NI, IPP>::NIT / 2];
+#if !defined(SS_EMU)
+#pragma unroll
+            for (int i = 0; i < Flush8<TO, NI, IPP>::NIT / 2; ++i) { pa[i] = __builtin_nondeterministic_value(pa[i]); pb[i] = __builtin_nondeterministic_value(pb[i]); }
+#else
+            for (int i = 0; i < Flush8<TO, NI, IPP>::NIT / 2; ++i) { const u32x4 z = {0u, 0u, 0u, 0u}; pa[i] = z; pb[i] = z; }
+#endif
+            if (pf) flush8_prefetch<TO, NI, IPP, 0>(pf_src, epi, cm0, cn0, 0, M, N, tid_e, pa);
+            barrier_keep_vm();                                   // every wave is done reading stage cur^1 -> it becomes the C piece
+            G8_STAMP(item, 3);
+            TO* ct = (TO*)(lds + (cur ^ 1) * STAGE);
+            constexpr int LDC = TBN + 16 / (int)sizeof(TO);
+            static_assert((size_t)2 * IPP * 16 * LDC * sizeof(TO) <= (size_t)STAGE, "C piece does not fit the free stage");
+            constexpr int EV = OutVec<TO>::N, CPR = TBN / EV;
+            float cs[EV], cq[EV], sh[EV];
+#pragma unroll
+            for (int e = 0; e < EV; ++e) { cs[e] = 0.f; cq[e] = 0.f; sh[e] = 0.f; }
+            if constexpr (STATS) {
+                // column statistics of the stored tile: registers (per thread: one 16-byte column chunk, all its rows) -> per-wave LDS bins
+                // (plain stores: every wave covers all 256 columns) -> 512 threads add the 8 waves' bins -> one global atomic per column and
+                // tile.  The bins sit behind the C piece in the free stage.
+                constexpr int BINS_OFF = NI % 3 == 0 ? 51200 : 40960;
+                float* bins = (float*)(lds + (cur ^ 1) * STAGE + BINS_OFF);
+                static_assert((size_t)2 * IPP * 16 * LDC * sizeof(TO) <= BINS_OFF && BINS_OFF + 8 * 2 * TBN * 4 <= STAGE, "column-statistics bins overlap the C piece");
+                const int ch = tid_e % CPR;
+                if (STATS == 1 && epi.col_shift) {
+#pragma unroll
+                    for (int e = 0; e < EV; ++e) { const int col = cn0 + ch * EV + e; sh[e] = col < N ? epi.col_shift[col] : 0.f; }
+                }
+                if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+                else Passes8<TO, 0, NI, IPP, 0, NPASS, STATS, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+                if (CPR == 32) {                  // bf16 out: lanes l and l + 32 of a wave hold the same column chunk
+#pragma unroll
+                    for (int e = 0; e < EV; ++e) { cs[e] += __shfl_xor(cs[e], 32); if (STATS == 1) cq[e] += __shfl_xor(cq[e], 32); }
+                }
+                if (CPR == 64 || lane_e < 32) {
+                    float* wb = bins + wave * 2 * TBN;
+#pragma unroll
+                    for (int e = 0; e < EV; ++e) { wb[ch * EV + e] = cs[e]; if (STATS == 1) wb[TBN + ch * EV + e] = cq[e]; }
+                }
+                barrier_keep_vm();
+                {
+                    float t = 0.f;
+                    if (STATS == 1 || tid_e < TBN) {
+#pragma unroll
+                        for (int w8 = 0; w8 < 8; ++w8) t += bins[w8 * 2 * TBN + tid_e];
+                    }
+                    const int col = cn0 + (tid_e & (TBN - 1));
+                    if (col < N) {
+                        if (tid_e < TBN) atomicAdd(epi.col_sum + col, t);
+                        else if (STATS == 1 && epi.col_sumsq) atomicAdd(epi.col_sumsq + col, t);
+                    }
+                }
+            } else {
+                if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+                else Passes8<TO, 0, NI, IPP, 0, NPASS, 0, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+            }
         }
+        G8_STAMP(item, 4);
         if (!has_next) break;
     }
 }
