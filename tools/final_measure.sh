@@ -31,4 +31,11 @@ SS_AMD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats -d $O/kx -o kx
 python tools/rocprof_summary.py $(find $O/kx -name "*.db" | head -1) 4 > $O/x3_kernel_stats.txt; rm -rf $O/kx
 PYTHONPATH=. timeout 300 python tools/x3_gemm_probe.py > $O/x3_gemm_probe.txt 2>&1
 (./tools/bin/dtw_bench 64 1000 10; ./tools/bin/dtw_bench 256 1000 10; SS_DTW_DEBUG=8 ./tools/bin/dtw_bench 64 1000 10; SS_DTW_DEBUG=8 ./tools/bin/dtw_bench 256 1000 10; ./tools/bin/ta_probe) > $O/dtw_bench.txt 2>&1
+# the 8-wave GEMM tile by tile (measurement build with stamps: tools/g8_stamps.sh, built here beforehand), against the previous build where present
+if [ -x tools/bin/g8_stamps ]; then
+  (for s in "22000 2304 768" "22000 768 768" "22000 768 2304" "22000 3072 768"; do tools/bin/g8_stamps $s; done
+   if [ -x tools/bin/g8_stamps_old ]; then for s in "22000 2304 768" "22000 768 768" "22000 768 2304" "22000 3072 768"; do echo "== $s, 12 rotating output / A buffers: this build | the build before the ring / direct epilogue"; tools/bin/g8_stamps $s 12 | head -1; tools/bin/g8_stamps_old $s 12 | head -1; done; fi) > $O/g8_stamps.txt 2>&1
+fi
+if [ -f tools/bin/ablib/libsilent_speech_hip.so ]; then bash tools/ab_seq.sh tools/bin/ablib gemm8_kc 66 2>&1 | grep -v "^W2026" > $O/g8_ab_in_step.txt; fi
+timeout 300 python tools/pipeline_profile.py > $O/pipeline_profile.txt 2>&1
 cat $O/pytest_gpu.log; cat $O/side_stream_ab.txt; cat $O/mfma_peak.txt; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/gpu_idle_rotated.txt; cat $O/attention_bench.txt; cat $O/dtw_bench.txt
