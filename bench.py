@@ -409,8 +409,8 @@ def pipeline_leg(dev, n_utt=24):
         recs.append({'raw_emg': x[200:200 + n], 'raw_emg_before': x[:200], 'raw_emg_after': x[200 + n:], 'silent': False,
                      'audio': np.clip(0.1 * rng.standard_normal(256 * (T + 2)), -1, 1).astype(np.float32), 'text_int': np.zeros(3, dtype=np.int64)})
     builder = DeviceBatchBuilder(dev)
-    for _ in range(4):                                     # steady state: the pinned staging ring (8 slots) has grown to the batch's size
-        b = builder.build(recs)
+    for _ in range(10):                                    # steady state: EVERY slot of the pinned staging ring (8 slots, visited in turn by the batch's
+        b = builder.build(recs)                            # three uploads) has grown to the size of the large one -- a pinned allocation of 32 MB costs 1-2 ms
     torch.cuda.synchronize()
     ts = []
     for _ in range(5):
@@ -427,7 +427,7 @@ def pipeline_leg(dev, n_utt=24):
         mel_ref.mel_spectrogram_ref(r['audio'][None])
     t_cpu = (time.perf_counter() - t0) * n_utt / k
     return {'workload': '%d recordings (%d frames): 8-filter zero-phase IIR cascade + resample + soft clip, batched STFT / mel / normalise -> batch dict' % (n_utt, frames),
-            'hip_ms': t_dev * 1e3, 'frames_per_s': frames / t_dev, 'includes': 'H2D of the raw recordings and audio (host arrays in, one pinned upload per kind); ONE ragged filter / resample launch sequence and one DFT GEMM for the whole batch, the audio half on a side stream; median of 5 builds after 4 warm ones',
+            'hip_ms': t_dev * 1e3, 'frames_per_s': frames / t_dev, 'includes': 'H2D of the raw recordings and audio (host arrays in, one pinned upload per kind); ONE ragged filter / resample launch sequence and one DFT GEMM for the whole batch, the audio half on a side stream; median of 5 builds after 10 warm ones (the 8-slot pinned ring at its final size)',
             'cpu_frames_per_s': frames / t_cpu, 'cpu_kind': 'oracle/filter_ref.py + oracle/mel_ref.py (numpy, 1 process; %d of %d recordings timed, scaled)' % (k, n_utt)}
 
 

@@ -218,7 +218,9 @@ class DeviceBatchBuilder(object):
             if packed is None:
                 ts = [torch.as_tensor(np.asarray(p) if not torch.is_tensor(p) else p).to(device=dev, dtype=torch.float64) for p in parts if p is not None and len(p)]
                 sigs.append(torch.cat(ts, 0) if len(ts) > 1 else ts[0])                    # read_emg.py:66
-        filters = [iirnotch_coeffs(60 * h, 30, 1000) for h in range(1, 8)] + [butter_highpass_coeffs(3, 2, 1000)]
+        filters = getattr(DeviceBatchBuilder, '_filters', None)
+        if filters is None:                                                                 # the same eight sections for every batch
+            filters = DeviceBatchBuilder._filters = [iirnotch_coeffs(60 * h, 30, 1000) for h in range(1, 8)] + [butter_highpass_coeffs(3, 2, 1000)]
         ys = filtfilt_cascade_batch(filters, sigs if packed is None else packed)           # :67-68
         ys = [y[nb:y.shape[0] - na] for y, (nb, na) in zip(ys, cuts)]                      # :69
         return subsample_batch(ys, 689.06, 1000)                                           # :70

@@ -70,14 +70,16 @@ def upload(arrays, device):
         ring = _rings[device] = _Ring(device)
     host, ev = ring.slot(total)
     hv = host.numpy()
+    jobs = []                                                  # (offset in the pinned buffer, source bytes)
     for a, o in zip(arrays, offs):
         if isinstance(a, _Joined):
             for q in a.parts:
                 if q.nbytes:
-                    hv[o:o + q.nbytes] = q.view(np.uint8).reshape(-1)
+                    jobs.append((o, q.view(np.uint8).reshape(-1)))
                     o += q.nbytes
         elif a.nbytes:
-            hv[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
+            jobs.append((o, a.view(np.uint8).reshape(-1)))
+    _fill(hv, jobs, total)
     dev = torch.empty(total, dtype=torch.uint8, device=device)
     dev.copy_(host[:total], non_blocking=True)
     ev.record(torch.cuda.current_stream(device))
@@ -86,6 +88,43 @@ def upload(arrays, device):
         t = dev[o:o + a.nbytes].view(_TORCH_DTYPE[a.dtype.type])
         out.append(t.view(a.shape) if a.ndim != 1 else t)
     return out
+
+
+_POOL = [None]
+_PAR_BYTES = 4 << 20          # below this one thread is as fast as the hand-over to a pool
+_PAR_THREADS = max(1, int(__import__('os').environ.get('SS_STAGING_THREADS', '4')))
+
+
+def _fill(hv, jobs, total):
+    """The memcpys into the pinned buffer.  A device-loader batch is ~27 MB of raw recordings and audio: one thread copies that in ~1 ms,
+    a quarter of the loader's host time per batch; numpy releases the GIL inside a large copy, so four threads share the jobs by bytes."""
+    if total < _PAR_BYTES or len(jobs) < 2 or _PAR_THREADS < 2:
+        for o, q in jobs:
+            hv[o:o + q.nbytes] = q
+        return
+    if _POOL[0] is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL[0] = ThreadPoolExecutor(max_workers=_PAR_THREADS, thread_name_prefix='ss-staging')
+    shares, acc, cur = [], 0, []
+    per = (sum(q.nbytes for _, q in jobs) + _PAR_THREADS - 1) // _PAR_THREADS
+    for o, q in jobs:                                          # contiguous runs of jobs of about `per` bytes; a large job is cut at that size
+        at = 0
+        while at < q.nbytes:
+            n = min(q.nbytes - at, per - acc)
+            cur.append((o + at, q[at:at + n]))
+            at += n; acc += n
+            if acc >= per:
+                shares.append(cur); cur, acc = [], 0
+    if cur:
+        shares.append(cur)
+
+    def run(share):
+        for o, q in share:
+            hv[o:o + q.nbytes] = q
+    futs = [_POOL[0].submit(run, sh) for sh in shares[1:]]
+    run(shares[0])
+    for f in futs:
+        f.result()
 
 
 class _Joined(object):

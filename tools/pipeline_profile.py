@@ -38,3 +38,10 @@ for _ in range(3):
     t0 = _t.perf_counter(); b = bb.build(recs); t1 = _t.perf_counter(); torch.cuda.synchronize(); print("steady build: host %.2f ms total %.2f ms" % ((t1 - t0) * 1e3, (_t.perf_counter() - t0) * 1e3))
 pr = cProfile.Profile(); pr.enable(); b = bb.build(recs); pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(5):
+    b = DeviceBatchBuilder(dev).build(recs)
+pr.disable(); torch.cuda.synchronize()
+print('host profile of 5 builds:')
+pstats.Stats(pr).sort_stats('tottime').print_stats(28)
