@@ -235,29 +235,32 @@ class DeviceBatchBuilder(object):
         # audio of every recording whose mel frames are needed: own audio (lengths; targets when voiced) and the voiced twins
         twins = [r['parallel'] if r['silent'] else None for r in recordings]
         audio_src = list(recordings) + [t for t in twins if t is not None]
-        # everything that arrives in host memory -- audio, raw EMG with its filter context -- crosses PCIe in ONE pinned copy (staging.upload)
+        # everything that arrives in host memory crosses PCIe in one pinned copy per kind (staging.upload).  The raw EMG goes first, on the main
+        # stream, with its filter chain right behind it (~50 short, latency-bound launches: the critical path of a build); the audio is then
+        # copied into its pinned buffer WHILE that chain runs, uploaded on a SIDE stream, and its half (clip, reflect pad, DFT / mel GEMMs,
+        # normalise) runs there under the EMG half: the two are independent until the batch dict is assembled
         a_host = [self._host(r['audio'], np.float32) for r in audio_src]
         e_host = [[self._host(p, np.float64) for p in (r.get('raw_emg_before'), r['raw_emg'], r.get('raw_emg_after')) if p is not None and len(p)] for r in recordings]
         emg_packed = None
-        if all(a is not None for a in a_host) and all(p is not None for ps in e_host for p in ps):
+        if all(p is not None for ps in e_host for p in ps):
             e_rows = [sum(int(p.shape[0]) for p in ps) for ps in e_host]
-            up = staging.upload([[a.reshape(-1) for a in a_host], [p.reshape(p.shape[0], -1) for ps in e_host for p in ps]], dev)
-            sig = (up[0], [int(a.shape[0]) for a in a_host])
-            emg_packed = (up[1], e_rows)
-        else:
-            sig = [torch.as_tensor(np.asarray(r['audio']) if not torch.is_tensor(r['audio']) else r['audio']).to(device=dev, dtype=torch.float32) for r in audio_src]
-        # the audio half (clip, reflect pad, DFT / mel GEMMs, normalise) runs on a SIDE stream under the EMG half (a chain of ~50 short,
-        # latency-bound filter launches that leave most of the chip idle): the two are independent until the batch dict is assembled
+            emg_packed = (staging.upload([[p.reshape(p.shape[0], -1) for ps in e_host for p in ps]], dev)[0], e_rows)
+        e689 = self._filtered_689(recordings, emg_packed)
         side = None
         if dev.type == 'cuda' and not _lib.is_emulator():
             side = getattr(self, '_side', None)
             if side is None:
                 side = self._side = torch.cuda.Stream(device=dev)
             main = torch.cuda.current_stream(dev)
-            side.wait_stream(main)                                                          # the upload above
-            for t in ([sig[0]] if isinstance(sig, tuple) else sig):
-                t.record_stream(side)
         with (torch.cuda.stream(side) if side is not None else _NullCtx()):
+            if all(a is not None for a in a_host):
+                sig = (staging.upload([[a.reshape(-1) for a in a_host]], dev)[0], [int(a.shape[0]) for a in a_host])
+            else:
+                sig = [torch.as_tensor(np.asarray(r['audio']) if not torch.is_tensor(r['audio']) else r['audio']).to(device=dev, dtype=torch.float32) for r in audio_src]
+                if side is not None:
+                    side.wait_stream(main)                                                  # device tensors handed in: produced on the caller's stream
+                    for t in sig:
+                        t.record_stream(side)
             mel, mframes = mel_spectrogram_batch(sig)
             if self.mfcc_norm is not None:
                 mean, std = _normalizer_tensors(self.mfcc_norm, mel.shape[-1], dev)
@@ -267,8 +270,7 @@ class DeviceBatchBuilder(object):
             mel_done.record(side)
             mel.record_stream(main)
         n_own = [self._frames(r, mframes[i], self.limit_length) for i, r in enumerate(recordings)]
-        # raw EMG: filter every recording, gather rows 8 .. 8 + 8 n into ONE buffer, soft-clip it in one launch
-        e689 = self._filtered_689(recordings, emg_packed)
+        # raw EMG (filtered above): rows 8 .. 8 + 8 n of every recording gathered into ONE buffer, soft-clipped in one launch
         # a resampled signal that ends before row 8 + 8 n: the reference's slice raw_emg[8:8+8n] (read_emg.py:90) silently comes out shorter;
         # here the frame count of that recording follows the samples that exist (whole frames), so every downstream length stays consistent
         n_own = [min(n, max(0, (int(e.shape[0]) - 8) // 8)) for e, n in zip(e689, n_own)]
