@@ -14,7 +14,7 @@ reference-size batch per GPU (256 000 raw-sample budget => ~40 utterances, ~22 k
 Prints ONE JSON line on rank 0:
   value / ms_per_step   the K timed steps (barrier + synchronize on both sides, max over ranks)
   roofline              the kernel with the largest share of the step + a `kernels` list (MFMA- and HBM-bound ones):
-                        HIP events around every launch on every 5th timed step (those steps run serially: no side stream)
+                        HIP events around every launch on every 10th timed step (those steps run serially: no side stream)
   cpu_baseline          the oracle (CPU restatement of the reference step) on >= 16 packed rows of the same batch, this node's cores
   parity                mel-L1 of the HIP model (bf16 and exact-f32 kernels) against the oracle on those rows, same weights
   dtw / mel             BASELINE configs[2] (64 and 256 x 1000^2 DTW, HIP vs the oracle's C twin on 1 core and on all cores) and the
@@ -615,13 +615,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host_enqueue = ring_wait = 0.0
-    pstride = max(5, args.steps // 2)              # per-launch events on two steps of the timed region (every 5th for short runs): they run serially (no side stream)
+    pstride = max(10, args.steps // 2)             # per-launch events on one step in ten of the timed region (two steps of a long run): they run serially (no side stream)
     timed_frames = 0
     for i in range(args.steps):
         timed_frames += frames_of[it[0] % len(batches)]
         profiled = prof is not None and i % pstride == 0
         if prof is not None:
-            # every 5th timed step carries the per-launch HIP events (roofline numerator); those steps run serially (no side stream):
+            # every 10th timed step carries the per-launch HIP events (roofline numerator); those steps run serially (no side stream):
             # a duration taken while a second stream shares the CUs is not a per-kernel quantity
             prof.enabled = profiled
             L.ss_plan_profile(plan.handle, int(profiled))
@@ -803,7 +803,7 @@ def main():
                                'algorithmic_per_launch': top['algorithmic_per_launch'], 'event_timed_steps': psteps,
                                'serial_kernel_ms_per_step': total_s / psteps * 1e3,
                                'timing': 'HIP events around every kernel launch (inside the native plan: ss_plan_profile; Python-launched kernels: '
-                                         'torch events on the launch stream) on every 5th (runs of <= 10 steps) / every (steps/2)-th timed step; those steps run without the side stream '
+                                         'torch events on the launch stream) on every 10th (runs of <= 20 steps) / every (steps/2)-th timed step; those steps run without the side stream '
                                          '(exclusive durations); rocprofv3 counterpart: profiles/r05_serial_kernel_stats.txt',
                                'kernels': kernels[:16]}
         if world == 1 and args.cpu_rows > 0:

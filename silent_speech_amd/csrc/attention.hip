@@ -658,11 +658,7 @@ __device__ __forceinline__ int res_tile_of(int i, int nb) { const int mid = nb >
 __device__ __forceinline__ int res_split_index(int i, int half) { return half < 0 ? i : 2 * i + half; }
 __device__ __forceinline__ int res_next(int* ctr, int lane) {
     int i = 0; if (lane == 0) i = atomicAdd(ctr, 1);
-#if defined(SS_EMU)
-    return __shfl(i, 0);
-#else
-    return __builtin_amdgcn_readfirstlane(i);        // scalar: the tile index drives uniform branches and LDS base addresses
-#endif
+    return wave_first(i);                            // scalar: the tile index drives uniform branches and LDS base addresses
 }
 }  // namespace
 
@@ -830,11 +826,7 @@ template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
 }
-__device__ __forceinline__ void afence() {
-#if !defined(SS_EMU)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
+__device__ __forceinline__ void afence() { sched_fence(); }
 template <int OFF, class V16>
 __device__ __forceinline__ void ard128(V16& d, const unsigned char* lds, unsigned a) {
     static_assert(sizeof(V16) == 16, "128-bit destination");
@@ -896,11 +888,7 @@ template <int N> __device__ __forceinline__ void await_but() {
 #endif
 }
 // ties later uses of x to this point of the asm stream (registers written by the asm reads above are not read before the wait)
-template <class T> __device__ __forceinline__ void apin(T& x) {
-#if !defined(SS_EMU)
-    asm volatile("" : "+v"(x));
-#endif
-}
+template <class T> __device__ __forceinline__ void apin(T& x) { pin_vgpr(x); }
 __device__ __forceinline__ bf16x8 join8(const s16x4& lo, const s16x4& hi) { bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; return f; }
 
 #if defined(SS_EMU)
@@ -938,12 +926,7 @@ __device__ __forceinline__ void res2_block(const AttnP& p, int& pair, int& half)
 // to spare: 48-62 scalars spilled to VGPR lanes and 26 more VGPRs to scratch, + 4 / + 17 us per launch.  An s_load per field and item costs nothing.
 // an opaque copy of a per-thread value: what is computed from it inside a loop stays inside (staging addresses hoisted out of the item loop
 // would live through the tile loop, which has no registers to spare)
-__device__ __forceinline__ int opaque_v(int x) {
-#if !defined(SS_EMU)
-    asm volatile("" : "+v"(x));
-#endif
-    return x;
-}
+__device__ __forceinline__ int opaque_v(int x) { pin_vgpr(x); return x; }
 #if defined(SS_EMU)
 typedef const AttnP* AttnArgs;
 __device__ __forceinline__ AttnArgs fresh_args(const AttnP& p) { return &p; }
@@ -1152,11 +1135,7 @@ __global__ __launch_bounds__(RES_W_FWD * 64) void attn_fwd_res2_kernel(AttnP p)
     const unsigned VS = 0, KS = VS + Tr * PK, ES = KS + Tr * PK, PT = ES + NE * PK, CT = PT + (unsigned)p.tail;      // tail: chunk buffers, and room for reads past the E table
     int* ctr = (int*)(lds + CT);
     const long long ldq = 3LL * H * dp;
-#if defined(SS_EMU)
-    const unsigned lbase = 0;
-#else
-    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
-#endif
+    const unsigned lbase = lds_byte_address(lds);
     int pair, half;
     for (int item = 0;; ++item) {                                           // one (sequence, head) pair, or the sequences of this workgroup's head (res2_item)
     const AttnArgs a = fresh_args(p);
@@ -1355,11 +1334,7 @@ __global__ __launch_bounds__(RES_W_BQ * 64) void attn_bwd_q2_kernel(AttnP p)
     const unsigned KS = 0, VS = KS + Tr * PK, ES = VS + Tr * PK, PT = ES + NE * PK, CT = PT + (unsigned)p.tail;
     int* ctr = (int*)(lds + CT);
     const long long ldq = 3LL * H * dp;
-#if defined(SS_EMU)
-    const unsigned lbase = 0;
-#else
-    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
-#endif
+    const unsigned lbase = lds_byte_address(lds);
     const float sdrop = p.drop_scale, inv_s = 1.f / sdrop;
     int pair, half;
     for (int item = 0;; ++item) {                                           // one (sequence, head) pair, or the sequences of this workgroup's head (res2_item)
@@ -1557,11 +1532,7 @@ __global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv2_kernel(AttnP p)
     for (int i = tid; i < Tn; i += RES_W_BKV * 64) ((float*)(lds + DV))[i] = p.Dv[((long long)b * H + h) * Tn + i] * inv_s;
     if (tid == 0) *ctr = 0;
     __syncthreads();
-#if defined(SS_EMU)
-    const unsigned lbase = 0;
-#else
-    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
-#endif
+    const unsigned lbase = lds_byte_address(lds);
     const unsigned tpa = lbase + TP + w * 4 * KV_TILE + (c * RT_LD + g * 4) * 2;
     int it = res_split_index(res_next(ctr, lane), half);
     bf16x8 vf[DPK], vn[DPK];
@@ -1928,14 +1899,7 @@ static bool fwd2_enabled() {
 typedef void (*ResKernel)(AttnP);
 static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, void* stream, AttnP p, bool stagger = false, bool per_head = false) {
     // one workgroup per CU at a time: pairs beyond the last full round of #CU are split in two halves when that shortens it
-    static int cus = 0;
-    if (!cus) {
-#if defined(SS_EMU)
-        cus = 4;
-#else
-        int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-#endif
-    }
+    const int cus = ss_cu_count(4);
     const int rem = pairs % cus;
     const bool split = pairs > cus && rem > 0 && 2 * rem <= cus;
     p.gx = split ? pairs - rem : pairs;
@@ -1946,13 +1910,11 @@ static int res_launch(ResKernel k, int slot, int pairs, int waves, size_t smem, 
         if (!(e && e[0] == '0')) { p.persist = cus / p.H; blocks = cus; }
     }
     if (stagger && split && !p.persist) { const char* e = getenv("SS_ATTN_STAGGER"); if (!(e && e[0] == '0')) { p.h1 = 2 * rem < cus / 2 ? 2 * rem : (cus / 2) & ~1; } }
-#if !defined(SS_EMU)
     static size_t granted[48] = {0};
     if (granted[slot] < smem) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("attention: cannot reserve %zu bytes of LDS", smem); return 1; }
+        if (!ss_grant_lds((const void*)k, smem)) { ss_set_error("attention: cannot reserve %zu bytes of LDS", smem); return 1; }
         granted[slot] = smem;
     }
-#endif
     SS_LAUNCH(k, dim3(blocks), dim3(waves * 64), smem, stream, p);
     return 0;
 }

@@ -147,13 +147,7 @@ __device__ __forceinline__ void stamp2(const KP& p, int w, int it, int k) {
 #endif
 }
 // wave-uniform value of a quantity derived from the thread index (scalar register: uniform branches, scalar address arithmetic)
-__device__ __forceinline__ int uniform(int v) {
-#if defined(SS_EMU)
-    return v;
-#else
-    return __builtin_amdgcn_readfirstlane(v);
-#endif
-}
+__device__ __forceinline__ int uniform(int v) { return wave_uniform(v); }
 // one R-block's table fragments (KS x 16 bytes per lane, 1 KiB apart) requested from asm / waited for by hand (see the forward's logits loop)
 template <int KS>
 __device__ __forceinline__ void efrag_load(bf16x8 (&f)[KS], const bf16_t* ptr) {
@@ -174,11 +168,9 @@ __device__ __forceinline__ void efrag_load(bf16x8 (&f)[KS], const bf16_t* ptr) {
 // at most N vector-memory operations requested after these fragments are still outstanding; ties every later use of the fragments to this point
 template <int KS, int N>
 __device__ __forceinline__ void efrag_wait(bf16x8 (&f)[KS]) {
-#if !defined(SS_EMU)
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+    wait_vmcnt<N>();
 #pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(f[s]));
-#endif
+    for (int s = 0; s < KS; ++s) pin_vgpr(f[s]);
 }
 // Build-time debugging switches of this file (none is set by the Makefile): -DATTN_T_FENCE=0 drops the scheduling fences between pipeline stages,
 // -DATTN_T_NO_DMA makes the loader wave copy through registers instead of global_load_lds, -DATTN_T_PLAIN_LOADS turns the asm loads of the
@@ -187,11 +179,7 @@ __device__ __forceinline__ void efrag_wait(bf16x8 (&f)[KS]) {
 #ifndef ATTN_T_FENCE
 #define ATTN_T_FENCE 1
 #endif
-__device__ __forceinline__ void sched_fence() {
-#if !defined(SS_EMU)
-    if (ATTN_T_FENCE) __builtin_amdgcn_sched_barrier(0);
-#endif
-}
+__device__ __forceinline__ void stage_fence() { if (ATTN_T_FENCE) ::sched_fence(); }
 // table rows in flight: a thread's share of a T x dp table (16-byte chunks tid, tid + nthr, ...), loaded now, written to LDS later
 template <int DPK>
 __device__ __forceinline__ void table_load(u32x4 (&v)[2 * DPK], const bf16_t* src, long long ld, int T, int tid, int nthr) {
@@ -280,9 +268,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void attn_t_fwd_kernel(KP p)
         // logits, LDS addresses of the skew / K / V reads, image slots) is recomputed HERE.  Left to itself the compiler hoists ~250 scalar
         // and ~90 vector registers of such loop invariants out of the pair loop and spills them around it.
         int w = w_, lane = tid & 63;
-#if !defined(SS_EMU)
-        asm volatile("" : "+s"(w), "+v"(lane));
-#endif
+        pin_sgpr(w); pin_vgpr(lane);
         const int n = lane & 31, h = lane >> 5;
         float* sk = sk0 + (size_t)w * SK_WORDS;
         const int i0 = 32 * w, qi = i0 + n;
@@ -356,7 +342,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void attn_t_fwd_kernel(KP p)
                 }
             }
             stamp2(p, w_, it, 3 * ub + 2);
-            sched_fence();
+            stage_fence();
         }
         stamp(p, w_, it, 1);
         __syncthreads();                                             // A: V_p is in LDS; every wave is done with K_p
@@ -495,16 +481,8 @@ __device__ __forceinline__ void aload16(u32x4& d, const void* base, unsigned off
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(off), "s"(base), "n"(IMM) : "memory");
 #endif
 }
-template <int N> __device__ __forceinline__ void await_vm() {
-#if !defined(SS_EMU)
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
-#endif
-}
-template <class V> __device__ __forceinline__ void apin(V& v) {
-#if !defined(SS_EMU)
-    asm volatile("" : "+v"(v));
-#endif
-}
+template <int N> __device__ __forceinline__ void await_vm() { wait_vmcnt<N>(); }
+template <class V> __device__ __forceinline__ void apin(V& v) { pin_vgpr(v); }
 // band of tile w over the NT blocks of the other axis: first / last block with an entry inside |k - q| <= D - 1 (and inside the sequence)
 __device__ __forceinline__ bool blk_out(int kb, int w, int D) { const int dj = 32 * (kb - w); return (dj < 0 ? -dj : dj) - 31 > D - 1; }
 __device__ __forceinline__ bool rblk_need(int ub, int w, int D) { const int r0 = 32 * (ub - w) + D - 32; return r0 + 31 >= 0 && r0 <= 2 * D - 2; }
@@ -551,9 +529,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void attn_t_bwd_q_kernel(KP p)
     for (; pair < npairs; pair += gridDim.x) {
         const int b = pair / H, hd = pair - b * H;
         int w = w_, lane = tid & 63;                                 // opaque per pair (see the forward): nothing derived from them is hoisted out of the loop and spilled
-#if !defined(SS_EMU)
-        asm volatile("" : "+s"(w), "+v"(lane));
-#endif
+        pin_sgpr(w); pin_vgpr(lane);
         const int n = lane & 31, h = lane >> 5;
         unsigned char* buf = buf0 + (size_t)w * BW_BUF;
         bf16_t* us = (bf16_t*)buf;
@@ -652,7 +628,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void attn_t_bwd_q_kernel(KP p)
                 }
                 wave_lds_sync();
             }
-            sched_fence();
+            stage_fence();
         }
 #undef IMG_LOAD
 #undef TAB_LOAD
@@ -768,7 +744,7 @@ __global__ __launch_bounds__(NT * 64) void attn_t_bwd_kv_kernel(KP p)
                 }
             }
         }
-        sched_fence();
+        stage_fence();
     }
 #undef IMG_LOAD
     const int nrows = T - j0 < 32 ? T - j0 : 32;
@@ -827,9 +803,7 @@ void fill(KP& p, const AttnTArgs& a)
 typedef void (*Kern)(KP);
 int launch(Kern k, int blocks, int waves, size_t smem, void* stream, const KP& p)
 {
-#if !defined(SS_EMU)
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("attention (transposed): cannot reserve %zu bytes of LDS", smem); return 1; }
-#endif
+    if (!ss_grant_lds((const void*)k, smem)) { ss_set_error("attention (transposed): cannot reserve %zu bytes of LDS", smem); return 1; }
     SS_LAUNCH(k, dim3(blocks), dim3(waves * 64), smem, stream, p);
     return 0;
 }
@@ -859,18 +833,7 @@ template <int DPK, bool DROP> static Kern fwd_pick(int nt)
     default: return attn_t_fwd_kernel<DPK, 7, DROP>;
     }
 }
-static int cu_count()
-{
-    static int cus = 0;
-    if (!cus) {
-#if defined(SS_EMU)
-        cus = 4;
-#else
-        int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-#endif
-    }
-    return cus;
-}
+static int cu_count() { return ss_cu_count(4); }
 // persistent grid: one workgroup per CU, a multiple of H (a workgroup keeps its head), never more than there are pairs
 static int persistent_blocks(int pairs, int H)
 {

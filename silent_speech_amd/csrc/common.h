@@ -217,6 +217,99 @@ __device__ __forceinline__ void wait_vmcnt() {
 #endif
 }
 
+// ---- host side of the same seam
+// compute units of the current device (the emulator pretends `emu_cus`, so that persistent kernels walk several items per workgroup in tests)
+static inline int ss_cu_count(int emu_cus) {
+#if defined(SS_EMU)
+    return emu_cus;
+#else
+    static int cus = 0;
+    if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+    return cus;
+#endif
+}
+// a kernel that wants more than 64 KiB of dynamic LDS has to be granted it once; false = refused
+static inline bool ss_grant_lds(const void* kernel, size_t bytes) {
+#if defined(SS_EMU)
+    (void)kernel; (void)bytes;
+    return true;
+#else
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+#endif
+}
+static inline bool ss_memset_async(void* p, int value, size_t bytes, void* stream) {
+#if defined(SS_EMU)
+    (void)stream; memset(p, value, bytes);
+    return true;
+#else
+    return hipMemsetAsync(p, value, bytes, (hipStream_t)stream) == hipSuccess;
+#endif
+}
+static inline bool ss_copy_d2d_async(void* dst, const void* src, size_t bytes, void* stream) {
+#if defined(SS_EMU)
+    (void)stream; memcpy(dst, src, bytes);
+    return true;
+#else
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess;
+#endif
+}
+
+// ---- the backend seam of the hand-scheduled kernels: every sequence that exists twice (gfx950 / the host emulator of tests/) lives in ONE
+// named helper here; the kernels call the helper and carry no #if of their own for it.
+// a wave-uniform value as a scalar (v_readfirstlane): drives uniform branches, M0 / LDS base addresses
+__device__ __forceinline__ int wave_uniform(int v) {
+#if defined(SS_EMU)
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+// the value of the first lane in every lane (v_readfirstlane again; the emulator has to exchange it: every live lane of the wave calls this)
+__device__ __forceinline__ int wave_first(int v) {
+#if defined(SS_EMU)
+    return __shfl(v, 0);
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+// "this value is opaque here": the compiler can neither hoist what is derived from it out of the enclosing loop nor move a consumer above
+// this point (used after hand-counted waits to pin the registers an asm load has written)
+template <class T> __device__ __forceinline__ void pin_vgpr(T& x) {
+#if !defined(SS_EMU)
+    asm volatile("" : "+v"(x));
+#else
+    (void)x;
+#endif
+}
+template <class T> __device__ __forceinline__ void pin_sgpr(T& x) {
+#if !defined(SS_EMU)
+    asm volatile("" : "+s"(x));
+#else
+    (void)x;
+#endif
+}
+// compiler-level memory fence (no instruction)
+__device__ __forceinline__ void compiler_fence() {
+#if !defined(SS_EMU)
+    asm volatile("" ::: "memory");
+#endif
+}
+// byte address of an LDS pointer inside the workgroup's segment (what ds_* / M0 take); the emulator addresses LDS through the pointer itself
+__device__ __forceinline__ unsigned lds_byte_address(const void* lds_ptr) {
+#if defined(SS_EMU)
+    (void)lds_ptr;
+    return 0u;
+#else
+    return (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds_ptr);
+#endif
+}
+// nothing crosses this point in the instruction schedule
+__device__ __forceinline__ void sched_fence() {
+#if !defined(SS_EMU)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // LDS transpose read (ds_read_b64_tr_b16): see tools/emu/hipemu.h for the lane map (verified on gfx950)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s16x4 lds_read_tr16(const void* lds_ptr) {

@@ -256,10 +256,8 @@ __device__ __forceinline__ void issue_group(f32x4 (&buf)[8], const float* p) {
     gload128<0>(buf[4], p); gload128<1024>(buf[5], p); gload128<2048>(buf[6], p); gload128<3072>(buf[7], p);
 }
 __device__ __forceinline__ void pin_group(f32x4 (&buf)[8]) {
-#if !defined(SS_EMU)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(buf[e]));
-#endif
+    for (int e = 0; e < 8; ++e) pin_vgpr(buf[e]);
 }
 template <int N> __device__ __forceinline__ void wait_vm() {       // s_waitcnt vmcnt(N), expcnt / lgkmcnt untouched
 #if !defined(SS_EMU)
@@ -269,13 +267,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {       // s_waitcnt 
 template <int I, int N, class F> __device__ __forceinline__ void dfor(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); dfor<I + 1, N>(f); }
 }
-__device__ __forceinline__ int dtw_uniform(int v) {
-#if defined(SS_EMU)
-    return v;
-#else
-    return __builtin_amdgcn_readfirstlane(v);
-#endif
-}
+__device__ __forceinline__ int dtw_uniform(int v) { return wave_uniform(v); }
 __device__ __forceinline__ unsigned dtw_readlane(unsigned v, int l) {      // l wave-uniform
 #if defined(SS_EMU)
     return __shfl(v, l);
@@ -324,13 +316,9 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
 #pragma unroll
         for (int r = 0; r < DR; ++r) if (o0 + r <= Np - 1) last4[r] = cmat[(long long)(Mp - 1) * ld + o0 + r];
     }
-#if defined(SS_EMU)
-    const unsigned lbase = 0;
-#else
-    __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0) HERE: left to the compiler the wait lands in front of the first patched step of every
-    asm volatile("" : "+v"(last4));                      // clamped super-step, where it also drains the cost fetches just issued
-    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)chunk);      // LDS byte address of the dynamic segment
-#endif
+    wait_vm<0>();                                        // vmcnt(0) HERE: left to the compiler the wait lands in front of the first patched step of every
+    pin_vgpr(last4);                                     // clamped super-step, where it also drains the cost fetches just issued
+    const unsigned lbase = lds_byte_address(chunk);      // LDS byte address of the dynamic segment
     unsigned char* const ring_emu = chunk;               // (emulator: ring addresses are offsets into the dynamic segment)
     const unsigned ring_w = lbase + CR_PAD + (unsigned)w * CR_WAVE;           // this wave's cost ring (aliases the backtrace window: the phases do not overlap)
     const unsigned rd1 = ring_w + lane * 16 - sub * 1024;                     // read base: slot (tau - sub) for tau >= sub ..
@@ -419,10 +407,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
         };
         auto settle = [&](int par) {
             wait_lds();
-#if !defined(SS_EMU)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { if (par) asm volatile("" : "+v"(rb[1][e])); else asm volatile("" : "+v"(rb[0][e])); }
-#endif
+            for (int e = 0; e < 8; ++e) { if (par) pin_vgpr(rb[1][e]); else pin_vgpr(rb[0][e]); }
         };
         if (source) {
             dfor<0, 32>([&](auto cc) { constexpr int c = cc; fetch(std::true_type{}, 0, std::integral_constant<int, c - 7>{}); });     // groups -1 .. 2
@@ -468,11 +454,9 @@ __global__ __launch_bounds__(256) void dtw_kernel(const long long* __restrict__ 
                 // also drains the cost loads issued just before -- one memory round trip per super-step)
                 auto top_lds = [&]() {
                     const float v = w == 0 ? INFINITY : lds_bnd[w][ring_slot(t0 + 1 + lane)];
-#if !defined(SS_EMU)
                     // settle the LDS read NOW: left pending, the compiler re-waits lgkmcnt(0) at EVERY step, which also
                     // drains that step's ring write (an LDS round trip on the serial chain of each of the 64 steps)
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-#endif
+                    wait_lds();
                     return v;
                 };
                 if (source) {
@@ -648,14 +632,11 @@ static int dtw_launch(const long long* desc_dev, int n, int max_n, int max_m, vo
         SS_LAUNCH_CHECK("ss_dtw_align(skew)");
     }
     const size_t smem = (size_t)DCH * 64 + CR_PAD;        // backtrace window; during the sweep of in-place sources: pad + 4 cost rings
-#if !defined(SS_EMU)
     static bool granted = false;
     if (!granted) {
-        if (hipFuncSetAttribute((const void*)dtw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-            hipFuncSetAttribute((const void*)dtw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("ss_dtw_align: cannot reserve %zu bytes of LDS", smem); return 1; }
+        if (!ss_grant_lds((const void*)dtw_kernel<false>, smem) || !ss_grant_lds((const void*)dtw_kernel<true>, smem)) { ss_set_error("ss_dtw_align: cannot reserve %zu bytes of LDS", smem); return 1; }
         granted = true;
     }
-#endif
     if (costs) SS_LAUNCH(SS_KERNEL(dtw_kernel<true>), dim3(n), dim3(256), smem, stream, desc_dev, (unsigned char*)ws, results, dbg, costs);
     else SS_LAUNCH(SS_KERNEL(dtw_kernel<false>), dim3(n), dim3(256), smem, stream, desc_dev, (unsigned char*)ws, results, dbg, costs);
     SS_LAUNCH_CHECK("ss_dtw_align");

@@ -181,9 +181,7 @@ struct TileMmaTR {
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[kk][j] = tr_frag(Bs, wn * 4 + j, kk, c, q);
         }
-#if !defined(SS_EMU)
-        __builtin_amdgcn_sched_barrier(0);                 // the 32 transposing reads go out together, ahead of the MFMAs
-#endif
+        sched_fence();                                     // the 32 transposing reads go out together, ahead of the MFMAs
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll

@@ -414,11 +414,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
     SS_DYN_SMEM(lds_raw);
     unsigned char* lds = (unsigned char*)lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
-#if defined(SS_EMU)
-    const int wave = tid >> 6;
-#else
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
+    const int wave = wave_uniform(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int G = gridDim.x, nsteps = K / BK8;
     Stage<BMT> sa; Stage<TBN> sb;
@@ -431,11 +427,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
         boff[0] = BMT * RB + (wn * 64 + r) * RB + (cq << 4);
         boff[1] = BMT * RB + (wn * 64 + r) * RB + ((cq ^ 4) << 4);
     }
-#if defined(SS_EMU)
-    const unsigned lbase = 0;
-#else
-    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);      // LDS byte address of the dynamic segment
-#endif
+    const unsigned lbase = lds_byte_address(lds);                                  // LDS byte address of the dynamic segment
     const unsigned wslot = (unsigned)wave * 1024u;                                 // this wave's 1 KiB slot inside an 8-piece group of a stage
     int it = blockIdx.x, mt, nt, cur = 0;
     tile_coord(it, G, nitems, tiles_n, mt, nt);
@@ -567,9 +559,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
         // the item loop: live across the K loop they are spilled, and every reload inside the epilogue is a scratch load behind the tile's
         // global stores (vmcnt counts in order: s_waitcnt vmcnt(0) per reload = the store pipe drained ~30 times per tile, epilogue 4.6 -> 8.5 us)
         int tid_e = tid;
-#if !defined(SS_EMU)
-        asm volatile("" : "+v"(tid_e));
-#endif
+        pin_vgpr(tid_e);
         const int lane_e = tid_e & 63, r_e = lane_e & 15, q_e = lane_e >> 4;
         if (has_next && !ring_next) {
             it += G;

@@ -7,11 +7,7 @@
 
 namespace g8 {
 constexpr int TBN = 256, RB = 128, BK8 = 64;
-__device__ __forceinline__ void sched_fence() {
-#if !defined(SS_EMU)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
+using ::sched_fence;
 // ---- fragment reads whose completion the KERNEL counts, not the compiler.  hipcc either waits lgkmcnt(0) right after the
 // reads of the next phase (fenced order) or re-serialises "one ds_read -> wait -> 4 MFMAs" (its own order): in both cases the
 // LDS latency sits in front of the MFMAs.  The reads are therefore issued from inline asm (invisible to the compiler's wait
@@ -44,19 +40,9 @@ __device__ __forceinline__ void lds_wait_pin(bf16x8 (&f)[N]) {
 
 }  // namespace g8
 
-static inline int g8_cus() {
-#if defined(SS_EMU)
-    return 3;
-#else
-    static int cus = 0;
-    if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
-    return cus;
-#endif
-}
+static inline int g8_cus() { return ss_cu_count(3); }
 static inline int g8_grant(const void* fn, size_t smem) {
-#if !defined(SS_EMU)
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { ss_set_error("gemm8: cannot reserve %zu bytes of LDS", smem); return 1; }
-#endif
+    if (!ss_grant_lds(fn, smem)) { ss_set_error("gemm8: cannot reserve %zu bytes of LDS", smem); return 1; }
     return 0;
 }
 

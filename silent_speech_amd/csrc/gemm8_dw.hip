@@ -104,11 +104,7 @@ __global__ __launch_bounds__(NW * 64) void gemm8_dw_kernel(DwJobs jobs, int nite
     SS_DYN_SMEM(lds_raw);
     unsigned char* lds = (unsigned char*)lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
-#if defined(SS_EMU)
-    const int wave = tid >> 6;
-#else
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
+    const int wave = wave_uniform(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN, G = gridDim.x;
     StageTR8<NR> st;
     u32x4 ra[NR], rb[NR];
@@ -336,13 +332,8 @@ __global__ __launch_bounds__(512) void gemm8_dwk_kernel(DwJobs jobs, int nitems,
     SS_DYN_SMEM(lds_raw);
     unsigned char* lds = (unsigned char*)lds_raw;
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
-#if defined(SS_EMU)
-    const int wave = tid >> 6;
-    const unsigned lbase = 0;
-#else
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lbase = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)lds);
-#endif
+    const int wave = wave_uniform(tid >> 6);
+    const unsigned lbase = lds_byte_address(lds);
     const int wm = wave >> 2, wn = wave & 3, opsel = wave >> 2, G = gridDim.x;
     // fragment of MFMA tile i: outer columns 16 i + c (c = lane & 15) = group mm = c & 7, row 2 i + (c >> 3) (+ 16 wm | 8 wn): tile i adds 2 rows
     const unsigned aoff = (unsigned)(((c & 7) * KS + (c >> 3) + 16 * wm) * KP + q * 16), boff = (unsigned)((KROWS + (c & 7) * KS + (c >> 3) + 8 * wn) * KP + q * 16);

@@ -267,21 +267,13 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
     void* xin = X.alloc((size_t)B * (T0 + 2) * Cin0 * es);
     if (!X.dry) {
         L_(timed(X, "emg_prepare", 0, (double)B * T0 * Cin0 * (4 + es), stream, [&] { return ss_emg_prepare(dt, x_raw, xin, (training && shift_r > 0) ? shifted : nullptr, B, T0, Cin0, training ? shift_r : 0, stream); }));
-#if !defined(SS_EMU)
         if (training && shift_r > 0 && shifted && !keep_input)      // the reference mutates its input in place (architecture.py:67-68)
-            if (hipMemcpyAsync((void*)x_raw, shifted, (size_t)B * T0 * Cin0 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) { ss_set_error("forward: input write-back failed"); return 1; }
-#else
-        if (training && shift_r > 0 && shifted && !keep_input) memcpy((void*)x_raw, shifted, (size_t)B * T0 * Cin0 * 4);
-#endif
+            if (!ss_copy_d2d_async((void*)x_raw, shifted, (size_t)B * T0 * Cin0 * 4, stream)) { ss_set_error("forward: input write-back failed"); return 1; }
     }
     // [9][2][C] per-channel sums of the nine BatchNorms, zeroed once: filled by the conv GEMM epilogues where the 8-wave kernel runs
     float* bnsums = training ? (float*)X.alloc((size_t)9 * 2 * d * 4) : nullptr;
     if (bnsums && !X.dry) {
-#if !defined(SS_EMU)
-        if (hipMemsetAsync(bnsums, 0, (size_t)9 * 2 * d * 4, (hipStream_t)stream) != hipSuccess) { ss_set_error("forward: memset failed"); return 1; }
-#else
-        memset(bnsums, 0, (size_t)9 * 2 * d * 4);
-#endif
+        if (!ss_memset_async(bnsums, 0, (size_t)9 * 2 * d * 4, stream)) { ss_set_error("forward: memset failed"); return 1; }
     }
     int Tin = T0, Cin = Cin0;
     for (int i = 0; i < 3; ++i) {
@@ -385,11 +377,7 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
     const void* dh_t = dhead;
     if (dt != SS_F32) { void* t = X.alloc((size_t)M * nh * es); if (!X.dry) L_(timed(X, "cast", 0, (double)M * nh * (4 + es), stream, [&] { return ss_cast_f32(dhead, t, dt, (long long)M * nh, stream); })); dh_t = t; }
     if (!X.dry && stage_arena && stage_arena_bytes > 0) {        // staging buffers of the re-laid-out weight gradients (one memset, main stream)
-#if !defined(SS_EMU)
-        if (hipMemsetAsync(stage_arena, 0, (size_t)stage_arena_bytes, (hipStream_t)stream) != hipSuccess) { ss_set_error("backward: memset failed"); return 1; }
-#else
-        memset(stage_arena, 0, (size_t)stage_arena_bytes);
-#endif
+        if (!ss_memset_async(stage_arena, 0, (size_t)stage_arena_bytes, stream)) { ss_set_error("backward: memset failed"); return 1; }
     }
     const int old_blocks = ss_gemm_set_blocks_per_cu(overlapped ? side_blocks : 2);
     struct Restore { int v; ~Restore() { ss_gemm_set_blocks_per_cu(v); } } restore{old_blocks};
