@@ -32,7 +32,7 @@ python tools/rocprof_summary.py $(find $O/kx -name "*.db" | head -1) 4 > $O/x3_k
 PYTHONPATH=. timeout 300 python tools/x3_gemm_probe.py > $O/x3_gemm_probe.txt 2>&1
 (./tools/bin/dtw_bench 64 1000 10; ./tools/bin/dtw_bench 256 1000 10; SS_DTW_DEBUG=8 ./tools/bin/dtw_bench 64 1000 10; SS_DTW_DEBUG=8 ./tools/bin/dtw_bench 256 1000 10; ./tools/bin/ta_probe) > $O/dtw_bench.txt 2>&1
 # the 8-wave GEMM tile by tile (measurement build with stamps: tools/g8_stamps.sh, built here beforehand), against the previous build where present
-if [ -x tools/bin/g8_stamps ]; then
+if [ -x tools/bin/g8_stamps ] && [ -f tools/bin/stamplib/libsilent_speech_hip.so ]; then
   (for s in "22000 2304 768" "22000 768 768" "22000 768 2304" "22000 3072 768"; do tools/bin/g8_stamps $s; done
    if [ -x tools/bin/g8_stamps_old ]; then for s in "22000 2304 768" "22000 768 768" "22000 768 2304" "22000 3072 768"; do echo "== $s, 12 rotating output / A buffers: this build | the build before the ring / direct epilogue"; tools/bin/g8_stamps $s 12 | head -1; tools/bin/g8_stamps_old $s 12 | head -1; done; fi) > $O/g8_stamps.txt 2>&1
 fi
