@@ -720,7 +720,7 @@ def main():
                        'unprofiled': None if n_same == 0 else {
                            'steps': n_same, 'ms_per_step_rotated': rot_ms, 'frames_per_s_rotated': rot_frames / rot_ms * 1e3,
                            'ms_per_step_same_batch': same_ms, 'frames_per_s_same_batch': frames / same_ms * 1e3,
-                           'note': 'after the timed loop, no per-launch events (the timed loop runs two of its steps serially for the roofline table): '
+                           'note': 'after the timed loop, no per-launch events (the timed loop runs one step in ten serially for the roofline table): '
                                    'the rotating loop again, and batch 0 on every step (what rounds 1-3 timed)'},
                        'host_enqueue_ms_per_step': (host_enqueue - ring_wait) / max(n_plain, 1) * 1e3,
                        'host_ring_wait_ms_per_step': ring_wait / max(n_plain, 1) * 1e3,

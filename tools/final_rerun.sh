@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=gpurun_out/final2; rm -rf $O; mkdir -p $O
-cp profiles/r05_pmc_traffic.json $O/ 2>/dev/null
+
 python bench.py > $O/bench.json.log 2>$O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --steps 8 --warmup 4 --cpu-rows 0 --no-legs --no-profile --no-same > $O/kt_bench.log 2>&1
 python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -1) 12 > $O/kernel_stats.txt
