@@ -354,6 +354,43 @@ def test_gemm8_gate_is_a_sign_test_of_the_saved_activation(dev, gemm_opts, colsu
         assert_close_robust(cs.cpu() - 2.0, stored.sum(0), 2e-5, name='col_sum', max_outlier_frac=0)
 
 
+@pytest.mark.parametrize('ni', [8, 9])
+@pytest.mark.parametrize('side', ['accumulate', 'gate', 'gate+accumulate'])
+def test_gemm8_side_inputs_on_a_halo_output_map(dev, gemm_opts, ni, side):
+    """The register epilogue of the 8-wave kernel (direct_store8: results leave straight from the accumulators, the gate / the old C are read at
+    the store addresses two row tiles ahead) on what the training step gives it: C += v and the ReLU gate into the (B, T + 2, C) buffer of a
+    convolution -- rows mapped through a division, zero halo rows that must stay untouched -- with ragged last row / column tiles, several items
+    per persistent workgroup and 1 / 3 K tiles (the next item's first K tile rides the ring only from 2 K steps on)."""
+    from silent_speech_amd import _lib
+    gemm_opts(ops.GEMM_OPT_G8, 2); gemm_opts(ops.GEMM_OPT_G8_NI, ni)
+    big = not is_emu(dev)
+    g = torch.Generator().manual_seed(300 + ni)
+    for K in (64, 192):
+        Bn, T, N = (5, 700, 520) if big else (3, 130, 264)
+        M = Bn * T
+        a = torch.randn(M, K, generator=g).to(torch.bfloat16); b = (torch.randn(N, K, generator=g) * 0.2).to(torch.bfloat16)
+        base = torch.randn(Bn, T + 2, N, generator=g).to(torch.bfloat16)
+        base[:, 0] = 0; base[:, -1] = 0
+        gate = torch.randn(Bn, T + 2, N, generator=g).to(torch.bfloat16)
+        C = base.clone().to(dev)
+        cmap = ops.rowmap(N, T, (T + 2) * N, base=N)
+        kw = {}
+        if 'gate' in side:
+            kw.update(gate=gate.to(dev), gate_scale=1.25)
+        if 'accumulate' in side:
+            kw.update(mode=1)
+        ops.gemm(a.to(dev), b.to(dev), C, M, N, K, ops.rowmap(K), ops.rowmap(K), cmap, **kw)
+        assert _lib.lib().ss_gemm_last_kernel() == (4 if ni == 9 else 3)
+        v = (a.float() @ b.float().t()).view(Bn, T, N).to(torch.bfloat16).float()          # the epilogue rounds the product to bf16 first
+        if 'gate' in side:
+            v = v * 1.25 * (gate[:, 1:-1].float() > 0).float()
+        if 'accumulate' in side:
+            v = v + base[:, 1:-1].float()
+        got = C.float().cpu()
+        assert_close_robust(got[:, 1:-1], v, 1.2e-2, name='gemm8 %s K=%d' % (side, K), max_outlier_frac=0)
+        assert float(got[:, 0].abs().max()) == 0.0 and float(got[:, -1].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------ K <= 32: the LDS-free kernel of the first convolution (csrc/gemm_smallk.hip)
 @pytest.mark.parametrize('ktaps', [3, 1])
 @pytest.mark.parametrize('stats', [False, True])
