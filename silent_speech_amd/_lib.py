@@ -188,6 +188,17 @@ def is_emulator():
     return _is_emulator
 
 
+def kernels_can_read(t):
+    """True when the loaded library's kernels can dereference this tensor's memory: a GPU tensor for the product library (the only case outside
+    tests/), a CPU tensor for the host-emulator build that tests/backend.py loads.  The one place where the package asks which of the two it has."""
+    return bool(t.is_cuda) != is_emulator()
+
+
+def kernel_device_for(t):
+    """The device a host-side input has to be moved to before a kernel reads it: where it is, if the kernels can read it there; else the GPU."""
+    return t.device if kernels_can_read(t) else torch.device('cuda')
+
+
 def check(rc, what=''):
     if rc != 0:
         raise RuntimeError('%s failed: %s' % (what or 'silent_speech_hip call', lib().ss_last_error().decode()))
@@ -207,11 +218,11 @@ def ptr(t):
     """Device pointer of a tensor, enforcing that the product library only ever sees GPU memory."""
     if t is None:
         return None
-    if not is_emulator() and not t.is_cuda:
+    if not kernels_can_read(t):
+        if is_emulator():
+            raise RuntimeError('emulator backend (tests only) needs CPU tensors')
         raise RuntimeError('silent_speech_amd: tensor is on %s; the HIP kernels need an AMD GPU tensor '
                            '(no CPU fallback exists)' % t.device)
-    if is_emulator() and t.is_cuda:
-        raise RuntimeError('emulator backend (tests only) needs CPU tensors')
     return ctypes.c_void_p(t.data_ptr())
 
 

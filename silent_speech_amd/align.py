@@ -73,7 +73,7 @@ def _as_device_matrix(x, device):
     if t.shape[0] < 1 or t.shape[1] < 1:
         raise IndexError('empty cost matrix')                         # the reference raises at shape[0]-1 indexing too
     if device is None:
-        device = t.device if (t.is_cuda or _lib.is_emulator()) else torch.device('cuda')
+        device = _lib.kernel_device_for(t)
     if t.dtype not in (torch.float32, torch.float64):
         t = t.to(torch.float32)
     return t.to(device)

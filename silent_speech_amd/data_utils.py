@@ -254,7 +254,7 @@ def combine_fixed_length(tensor_list, length):
     `ss_concat_pad`; the table is rebuilt for every call -- a training loop hands over new tensors every step -- and uploaded
     from pinned memory).  Host tensors (staging code, tests) are packed with a host concatenation."""
     first = tensor_list[0]
-    on_device = first.is_cuda or _lib.is_emulator()          # emulator (tests): CPU tensors run the same kernel source
+    on_device = _lib.kernels_can_read(first)
     if not on_device:
         return _host_pack(tensor_list, length)
     from . import staging

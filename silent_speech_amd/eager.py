@@ -31,7 +31,7 @@ def _round_up(x, m):
 def _check(x):
     if x.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError('float32 or bfloat16 input expected, got %s' % x.dtype)
-    if not (x.is_cuda or _lib.is_emulator()):
+    if not _lib.kernels_can_read(x):
         raise RuntimeError('silent_speech_amd: tensor is on %s; the HIP kernels need an AMD GPU tensor (no CPU fallback exists)' % x.device)
 
 

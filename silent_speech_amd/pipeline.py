@@ -247,7 +247,7 @@ class DeviceBatchBuilder(object):
             emg_packed = (staging.upload([[p.reshape(p.shape[0], -1) for ps in e_host for p in ps]], dev)[0], e_rows)
         e689 = self._filtered_689(recordings, emg_packed)
         side = None
-        if dev.type == 'cuda' and not _lib.is_emulator():
+        if dev.type == 'cuda':
             side = getattr(self, '_side', None)
             if side is None:
                 side = self._side = torch.cuda.Stream(device=dev)

@@ -117,7 +117,7 @@ def _to_device_2d(signal):
         t = t.unsqueeze(1)
     if t.dim() != 2:
         raise ValueError('signal must be (T,) or (T, channels)')
-    dev = t.device if (t.is_cuda or _lib.is_emulator()) else torch.device('cuda')
+    dev = _lib.kernel_device_for(t)
     t = t.to(dev).contiguous()
 
     def restore(y):

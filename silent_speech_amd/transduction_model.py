@@ -93,8 +93,8 @@ def _target_jobs(example, device):
     """The two concatenations of dtw_loss's targets (all utterances' audio features / phoneme labels back to back) either as gather
     jobs over device tensors or, for a batch that arrives in host memory, as ONE pinned host concatenation + upload each."""
     audio, phones = example['audio_features'], example['phonemes']
-    on_device = audio[0].is_cuda or _lib.is_emulator()
-    if on_device and not _lib.is_emulator():          # a mixed batch (some targets still on the host): the gather kernel only takes device pointers
+    on_device = _lib.kernels_can_read(audio[0])
+    if on_device and audio[0].is_cuda:                # a mixed batch (some targets still on the host): the gather kernel only takes device pointers
         audio = [a if a.is_cuda else a.to(device) for a in audio]
         phones = [q if q.is_cuda else q.to(device) for q in phones]
     if on_device:
@@ -289,7 +289,7 @@ def prepare_batch(batch, device, seq_len=200, loss_plan=True):
     fields = ('emg', 'raw_emg', 'session_ids')
     lens = (seq_len, seq_len * 8, seq_len)
     first = batch['raw_emg'][0]
-    on_device = first.is_cuda or _lib.is_emulator()
+    on_device = _lib.kernels_can_read(first)
     jobs, packed = [], []
     if on_device:
         jobs = [PackJob(batch[f], n) for f, n in zip(fields, lens)]
