@@ -34,6 +34,24 @@ def test_dtw_align_op_matches_oracle_and_has_a_fake(dev):
         assert tuple(m.shape) == (3, 80, 1 + (4096 + 768 - 1024) // 256)
 
 
+def test_functional_ops_pass_opcheck(dev):
+    """torch.library.opcheck on the ops that declare no mutation (schema vs behaviour, fake implementation vs real shapes / dtypes, AOT dispatch):
+    what torch.compile / functionalization rely on.  silent_speech::model_forward is functional since round 5 (the shifted input comes back as an
+    output; Model.forward writes it into x_raw like architecture.py:67-68)."""
+    rng = np.random.default_rng(9)
+    c = torch.from_numpy(rng.random((23, 31), dtype=np.float32)).to(dev)
+    torch.library.opcheck(torch.ops.silent_speech.dtw_align.default, (c,), test_utils=('test_schema', 'test_faketensor'))
+    y = torch.from_numpy(rng.standard_normal((2, 2048)).astype(np.float32) * 0.1).to(dev)
+    torch.library.opcheck(torch.ops.silent_speech.stft_logmel.default, (y, 1024, 80, 22050, 256, 1024, 0, 8000, False), test_utils=('test_schema', 'test_faketensor'))
+    torch.manual_seed(0)
+    model = Model(112, 80, 48, model_size=16, num_layers=1, dropout=0.0, compute_dtype=torch.float32).to(dev).eval()
+    x = torch.randn(2, 8 * 16, 8).to(dev)
+    before = x.clone()
+    args = (x, model.w_out.weight, torch_ops.model_handle(model), False, 0, 1)
+    torch.library.opcheck(torch.ops.silent_speech.model_forward.default, args, test_utils=('test_schema', 'test_faketensor'))
+    assert torch.equal(x, before)
+
+
 def test_model_forward_is_a_dispatcher_op_with_autograd(dev):
     torch.manual_seed(0)
     model = Model(112, 80, 48, model_size=16, num_layers=1, dropout=0.0, compute_dtype=torch.float32).to(dev).train()
