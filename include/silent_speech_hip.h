@@ -30,9 +30,9 @@ extern "C" {
 const char* ss_last_error(void);
 /* Library/ABI version and the GPU architecture the kernels were compiled for ("gfx950"). */
 /* Bumped whenever a struct layout or an entry-point signature changes (3: ss_gemm_epilogue column-statistics fields, the plan /
- * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative; 4: ss_loss_index_tables; 5: gate recomputation arguments of ss_bn_backward_sums / ss_bn_backward_apply).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
+ * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative; 4: ss_loss_index_tables; 5: gate recomputation arguments of ss_bn_backward_sums / ss_bn_backward_apply; 7: ss_split_planes / ss_gemm_planes, ss_dw_job.flags, up to 24 jobs per grouped launch).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
  * library paired with newer headers would otherwise read garbage struct fields instead of failing. */
-#define SS_ABI_VERSION 6
+#define SS_ABI_VERSION 7
 int ss_abi_version(void);
 const char* ss_target_arch(void);
 
@@ -93,6 +93,21 @@ int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, 
             int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap,
             const ss_gemm_epilogue* epilogue, int split_k, void* stream);
 
+/* f32 operands as two bf16 planes (round 6: the parity-grade arithmetic of SS_F32X3 on the 8-wave bf16 kernel).
+ * ss_split_planes: hi[i] = bf16(x[i]), lo[i] = bf16(x[i] - hi[i])  (x = hi + lo to 2^-17 relative); an elementwise pass, 16-byte aligned buffers.
+ * ss_gemm_planes:  C[m][n] = epilogue(sum_k A(m,k) B(n,k)) with A = A_hi + A_lo, B = B_hi + B_lo, both operands K-contiguous and both planes
+ *   of an operand addressed by the SAME row map, computed as ONE bf16 contraction of length 3 K,  [A_lo | A_hi | A_hi] . [B_hi | B_lo | B_hi]^T
+ *   (three bf16 MFMAs per product, f32 accumulate; the a_lo.b_lo term, 2^-18 of the product, is dropped -- the arithmetic of SS_F32X3).
+ *   f32 output only; runs on the 8-wave kernel or not at all: ss_gemm_planes_supported() answers 1 when it does (K % 64 == 0, 16-byte
+ *   rows, no transposed second output, no log-clamp), and the call fails otherwise (the caller keeps ss_gemm(SS_F32X3) for such shapes).
+ * Replaces, in the f32-storage plan: the f32 matmuls of architecture.py:18-24,51,55,59 and transformer.py:32,34,96-98,111 and their
+ * input gradients.  Weight gradients of that mode: ss_gemm_dw_grouped with three jobs per gradient (hi.hi, hi.lo, lo.hi; flags bit 0). */
+int ss_split_planes(const float* x, void* hi, void* lo, int64_t n, void* stream);
+int ss_gemm_planes(int dtype_out, const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, int M, int N, int K,
+                   const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap, const ss_gemm_epilogue* epilogue, void* stream);
+int ss_gemm_planes_supported(int dtype_out, const void* C, int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap,
+                             const ss_gemm_epilogue* epilogue); /* [host] */
+
 /* Persistent-grid size of ss_gemm for the calling thread: 2 (default) or 1 workgroup per CU.  The weight-gradient GEMMs that
  * run on a side stream use 1 so that the dependent chain on the main stream can co-reside on every CU.  Returns the old value. */
 int ss_gemm_set_blocks_per_cu(int n); /* [host] */
@@ -114,7 +129,7 @@ int ss_gemm_set_option(int what, int value); /* [host] */
 /* Grouped weight-gradient GEMMs: for every job  C[m][n] += sum_k A(k, m) * B(k, n)  (bf16 operands, f32 C, reduction over the
  * K = B*T frame rows; both operands outer-contiguous: element (k, m) of A at A[amap(k) + m]).  Replaces the autograd backward
  * of nn.Linear / nn.Conv1d / the per-head einsum projections w.r.t. their weights (transduction_model.py:209 through
- * architecture.py:18-24,51 and transformer.py:32,34,96-98,111): dW = dY^T X.  ONE persistent launch covers up to 8 jobs (e.g.
+ * architecture.py:18-24,51 and transformer.py:32,34,96-98,111): dW = dY^T X.  ONE persistent launch covers up to 24 jobs (e.g.
  * the four weight gradients of an encoder layer), so the K split that fills the 256 CUs -- and with it the number of f32
  * atomic accumulations -- is chosen for the group, not per GEMM.  M, N multiples of 8; amap / bmap must cut the rows into
  * batches of equal length (rows_per_batch). */
@@ -125,7 +140,7 @@ typedef struct ss_dw_job {
     ss_rowmap amap, bmap;
     int64_t ldc;
     int32_t M, N, K;
-    int32_t reserved;
+    int32_t flags;          /* bit 0: other jobs of this launch accumulate into the same C (always atomic updates) */
 } ss_dw_job;
 int ss_gemm_dw_grouped(int n_jobs, const ss_dw_job* jobs /* [host] */, void* stream);
 /* Tuning knobs of ss_gemm_dw_grouped for the calling thread: what = 0 K split override (0 = automatic), 1 scheduling fences,

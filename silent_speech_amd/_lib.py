@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('SS_AMD_LIBRARY') or os.path.join(_HERE, 'lib', 'libsilent_speech_hip.so')      # override: A/B runs of two builds on one box
 
 SS_F32, SS_BF16, SS_F64, SS_F32X3 = 0, 1, 2, 3
-ABI_VERSION = 6          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
+ABI_VERSION = 7          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
 OP_KC, OP_OC = 0, 1
 
 
@@ -34,7 +34,7 @@ class GemmEpilogue(ctypes.Structure):
 
 class DwJob(ctypes.Structure):
     _fields_ = [('A', ctypes.c_void_p), ('B', ctypes.c_void_p), ('C', ctypes.c_void_p), ('amap', RowMap), ('bmap', RowMap),
-                ('ldc', ctypes.c_int64), ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('ldc', ctypes.c_int64), ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('flags', ctypes.c_int32)]
 
 
 class ProfileRow(ctypes.Structure):
@@ -57,6 +57,8 @@ SIGNATURES = {
     'ss_gemm': [_I, _I, _I, _I, _P, _P, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap),
                 ctypes.POINTER(RowMap), ctypes.POINTER(GemmEpilogue), _I, _P],
     'ss_gemm_dw_grouped': [_I, ctypes.POINTER(DwJob), _P],
+    'ss_split_planes': [_P, _P, _P, _L, _P],
+    'ss_gemm_planes': [_I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), ctypes.POINTER(GemmEpilogue), _P],
     'ss_permute3d': [_P, _I, _P, _I, _I, _I, _I, _L, _L, _L, _I, _I, _F, _I, _P],
     'ss_permute3d_batch': [_P, _P, _I, _I, _P],
     'ss_dtw_align': [_P, _P, _I, _I, _I, _P, _P, _P],
@@ -110,6 +112,7 @@ _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int6
                'ss_gemm_set_option': ([_I, _I], ctypes.c_int),
                'ss_gemm_fuses_column_stats': ([_I, _I, _I, _I, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), ctypes.POINTER(RowMap),
                                                ctypes.POINTER(GemmEpilogue), _I], ctypes.c_int),
+               'ss_gemm_planes_supported': ([_I, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), ctypes.POINTER(GemmEpilogue)], ctypes.c_int),
                'ss_gemm_dw_set_option': ([_I, _I], ctypes.c_int),
                'ss_plan_create': ([_P], _P), 'ss_plan_destroy': ([_P], None), 'ss_plan_slot_count': ([_P], ctypes.c_int),
                'ss_plan_slot_name': ([_P, _I], ctypes.c_char_p), 'ss_plan_bind': ([_P, _I, _P], ctypes.c_int),

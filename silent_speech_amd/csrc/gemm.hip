@@ -752,7 +752,8 @@ static int gemm_slots() {
 // (tools/gemm_bench.cpp, 22 000 .. 88 000 rows, us): a tile costs 13 + 0.0245 K (256 rows) or 13 + 0.0295 K (288 rows) while the whole chip
 // streams; a last round of `rem` tiles runs faster (0.55 + 0.45 rem / CUs of a tile).  The 128-wide kernels sustain ~560 TFLOP/s at
 // K <= 1024 and ~680 beyond, plus ~6 us.
-static bool pick_gemm8(bool bf16_in, int a_mode, int b_mode, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, int split_k, int* ni_out, int* pin_out)
+// kmul = 3: the hi / lo plane form (ss_gemm_planes) -- the contraction the K loop walks is 3 K long, and there is no 128-wide alternative to compare with
+static bool pick_gemm8(bool bf16_in, int a_mode, int b_mode, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, int split_k, int* ni_out, int* pin_out, int kmul = 1)
 {
     if (!(bf16_in && gemm_opt(OPT_G8) && a_mode == OP_KC && b_mode == OP_KC && epi.fast && !epi.c2 && split_k == 1 && K % 64 == 0 && K > 0)) return false;
     if (epi.general == 1 && epi.col_sum) return false;       // column statistics of a dropout epilogue: not instantiated (nothing asks for it)
@@ -772,13 +773,13 @@ static bool pick_gemm8(bool bf16_in, int a_mode, int b_mode, int M, int N, int K
         if (ni_force && cand != ni_force) continue;
         const int bmt = 32 * cand;
         const long long t = (long long)((M + bmt - 1) / bmt) * ((N + 255) / 256);
-        const double tile = 13.0 + (cand == 9 ? 0.0295 : 0.0245) * K;
+        const double tile = 13.0 + (cand == 9 ? 0.0295 : 0.0245) * K * kmul;
         const long long full = t / cus, rem = t % cus;
         const double cost = 5.0 + full * tile + (rem ? tile * (0.55 + 0.45 * (double)rem / cus) : 0.0);
         if (!ni || cost < best8) { best8 = cost; ni = cand; }
     }
     const double cost_old = 6.0 + 2.0 * M * N * K / ((K <= 1024 ? 560.0 : 680.0) * 1e6);
-    if (!ni || !(gemm_opt(OPT_G8) == 2 || best8 < cost_old)) return false;
+    if (!ni || !(gemm_opt(OPT_G8) == 2 || kmul > 1 || best8 < cost_old)) return false;
     // Spreading the fragment reads / DMA pieces between the MFMA groups (PIN = 3) is the default for both tile heights: since the
     // steady K steps are one straight-line block with scalar-base copies (gemm8.hip) the 288-row variant no longer spills in the loop and
     // beats the burst schedule by 0..16 % depending on the shape and the box (tools/gemm_bench.cpp: 22 000 x 768 x 3072 96 vs 113 us).
@@ -947,6 +948,36 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
     if (dtype_in == SS_BF16 && dtype_out == SS_F32) return launch_gemm<bf16_t, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
     if (dtype_in == SS_F32X3) return launch_gemm<float, float, 1>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
     return launch_gemm<float, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
+}
+
+// ---- f32 operands as hi / lo bf16 planes (the parity-grade mode of the training plan on the 8-wave kernel)
+static int planes_setup(int dtype_out, const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, const void* C, int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap,
+                        const ss_rowmap* cmap, const ss_gemm_epilogue* e, GemmEpi& epi, int* ni, int* pin)
+{
+    if (!amap || !bmap || !cmap || dtype_out != SS_F32 || M <= 0 || N <= 0 || K <= 0 || K % 64) return 0;
+    if (amap->base % 8 || amap->batch_stride % 8 || amap->row_stride % 8 || bmap->base % 8 || bmap->batch_stride % 8 || bmap->row_stride % 8) return 0;
+    if (((uintptr_t)A_hi | (uintptr_t)A_lo | (uintptr_t)B_hi | (uintptr_t)B_lo) % 16) return 0;
+    if (build_epi(epi, dtype_out, C, M, N, cmap, e, 1)) return 0;
+    return pick_gemm8(true, OP_KC, OP_KC, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, 1, ni, pin, 3) ? 1 : 0;
+}
+extern "C" int ss_gemm_planes_supported(int dtype_out, const void* C, int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap, const ss_gemm_epilogue* e)
+{
+    GemmEpi epi; int ni = 0, pin = 0;
+    return planes_setup(dtype_out, (const void*)16, (const void*)16, (const void*)16, (const void*)16, C, M, N, K, amap, bmap, cmap, e, epi, &ni, &pin);
+}
+extern "C" int ss_gemm_planes(int dtype_out, const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, int M, int N, int K,
+                              const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap, const ss_gemm_epilogue* e, void* stream)
+{
+    SS_CHECK(A_hi && A_lo && B_hi && B_lo && C && amap && bmap && cmap, "ss_gemm_planes: null pointer");
+    SS_CHECK(M >= 0 && N >= 0 && K >= 0, "ss_gemm_planes: negative size");
+    if (M == 0 || N == 0) return 0;
+    GemmEpi epi; int ni = 0, pin = 0;
+    SS_CHECK(planes_setup(dtype_out, A_hi, A_lo, B_hi, B_lo, C, M, N, K, amap, bmap, cmap, e, epi, &ni, &pin),
+             "ss_gemm_planes: M=%d N=%d K=%d with this epilogue does not run on the 8-wave kernel (ask ss_gemm_planes_supported; K %% 64 == 0, f32 out, 16-byte rows, no transposed second output)", M, N, K);
+    if (gemm8_launch_kc<float>(ni, pin, A_hi, B_hi, C, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, stream, true,
+                               (long long)((const char*)A_lo - (const char*)A_hi), (long long)((const char*)B_lo - (const char*)B_hi))) return 1;
+    g_last_kernel = ni == 9 ? 4 : 3;
+    return 0;
 }
 
 extern "C" int ss_gemm_fuses_column_stats(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* C, int M, int N, int K, const ss_rowmap* amap,

@@ -400,9 +400,14 @@ struct Passes8<TO, GEN, NI, IPP, NPASS, NPASS, STATS, SW> {
 // (a bias gradient: a third of the registers, which leaves room for the side-input buffers of a gated epilogue) (separate instantiations: the extra live
 // registers of that path would otherwise spill in the main loop of every launch).
 // ABL: compile-time ablation mask for tuning (results are wrong): 1 no MFMA, 2 no in-loop global->LDS copies, 4 no in-loop fragment reads.
-template <class TO, int NI, int PIN, int ABL, int STATS, int GENSEL>
+// PL ("planes", the parity-grade f32 x3 mode on this kernel): A and B are the HI planes of f32 operands split into hi = bf16(x), lo = bf16(x - hi);
+// the LO planes sit a_lo / b_lo bytes behind them with the same row maps.  The K loop then runs over a THREE times longer contraction
+//     C = [A_lo | A_hi | A_hi] . [B_hi | B_lo | B_hi]^T        (small terms first; the a_lo.b_lo term, 2^-18 of the product, is dropped)
+// -- the same arithmetic as TileMmaX3 of gemm.hip (three bf16 MFMAs per product, f32 accumulate), but on bf16 LDS tiles and this kernel's
+// schedule: a K tile index t of the ring maps to (segment t / (K/64), K offset t % (K/64)), i.e. only the scalar base of a copy changes.
+template <class TO, int NI, int PIN, int ABL, int STATS, int GENSEL, bool PL = false>
 __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
-                                                       int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi, int tiles_n, int nitems)
+                                                       int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi, int tiles_n, int nitems, long long a_lo, long long b_lo)
 {
     using namespace g8;
     constexpr bool SWAP = GENSEL == 0;                       // kernels that can never run the dropout epilogue: transposed accumulator tiles (see stage8_sw)
@@ -416,7 +421,15 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int wave = wave_uniform(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int G = gridDim.x, nsteps = K / BK8;
+    const int G = gridDim.x, n1 = K / BK8, nsteps = PL ? 3 * n1 : n1;
+    // byte offsets (from the operand bases) of K tile t of the ring; tile 0 of an item: (ka0, 0)
+    const long long ka0 = PL ? a_lo : 0;
+    auto koff = [&](int t, long long& ka, long long& kbb) {
+        if constexpr (PL) {
+            const int seg = (t >= n1 ? 1 : 0) + (t >= 2 * n1 ? 1 : 0), kk = t - seg * n1;
+            ka = (long long)kk * (BK8 * 2) + (seg == 0 ? a_lo : 0); kbb = (long long)kk * (BK8 * 2) + (seg == 1 ? b_lo : 0);
+        } else { ka = (long long)t * (BK8 * 2); kbb = ka; }
+    };
     Stage<BMT> sa; Stage<TBN> sb;
     // per-lane fragment read offsets: entry x serves (kk ^ i) & 1 == x (A) / (kk ^ j) & 1 == x (B)
     int aoff[2], boff[2];
@@ -433,7 +446,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
     tile_coord(it, G, nitems, tiles_n, mt, nt);
     int m0 = mt * BMT, n0 = nt * TBN;
     sa.init(amap, m0, M, wave, lane); sb.init(bmap, n0, N, wave, lane);
-    sa.issue((const unsigned char*)A, lds, wave); sb.issue((const unsigned char*)B, lds + BMT * RB, wave);
+    sa.issue((const unsigned char*)A + ka0, lds, wave); sb.issue((const unsigned char*)B, lds + BMT * RB, wave);
 
     constexpr int SA_NP = Stage<BMT>::NP, NPW = SA_NP + Stage<TBN>::NP;     // global->LDS pieces per wave and K tile
     constexpr bool SPR = (PIN & 1) != 0, SPD = (PIN & 2) != 0;              // spread the fragment reads / the DMA pieces between the MFMA groups
@@ -469,10 +482,10 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             lds_wait_pin(fa[ph & 1]);
             if constexpr (ph % NPK == 0) lds_wait_pin(fb[ph / NPK]);
         };
-        auto dma = [&](auto kc, long long kbyte, unsigned st) {      // piece k of the K tile at byte offset kbyte -> stage at st
+        auto dma = [&](auto kc, long long kbyte, long long kbyte_b, unsigned st) {      // piece k of the K tile at byte offsets kbyte (A) / kbyte_b (B) -> stage at st
             constexpr int k = kc;
             if constexpr (k < SA_NP) sa.template issue_one_s<k>((const unsigned char*)A + kbyte, lds + st, wave, lbase + st + wslot, lbase + st + Stage<BMT>::last_piece_off(wave));
-            else if constexpr (k < NPW) sb.template issue_one_s<k - SA_NP>((const unsigned char*)B + kbyte, lds + st + BMT * RB, wave, lbase + st + BMT * RB + wslot,
+            else if constexpr (k < NPW) sb.template issue_one_s<k - SA_NP>((const unsigned char*)B + kbyte_b, lds + st + BMT * RB, wave, lbase + st + BMT * RB + wslot,
                                                                             lbase + st + BMT * RB + Stage<TBN>::last_piece_off(wave));
         };
         auto mfma_row = [&](auto phc, auto xc) {
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             constexpr int ph = phc, nx = ph + 1 < NPH ? ph + 1 : 0;
             constexpr bool last = ph + 1 == NPH, STEADY = steady_c;
             constexpr int chunk = last ? 0 : ph + 1;
-            bool rd = true, dm = false; unsigned rst = S, dst = 0; long long kb = 0;
+            bool rd = true, dm = false; unsigned rst = S, dst = 0; long long kb = 0, kb2 = 0;
             if constexpr (!STEADY && ph == NCH - 1) {
                 // this item's last copy has left (chunk NCH-1 of K tile nsteps-1, one phase ago): the offsets become the next item's
                 if (ring_next && s + 2 == nsteps) {
@@ -511,13 +524,13 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
                 if (STEADY || s + 1 < nsteps) {
                     barrier_all();               // every wave holds its last fragments of stage S; K tile s+1 has landed in O
                     rst = O; dst = S;
-                    if constexpr (STEADY) { dm = !(ABL & 2); kb = (long long)(s + 2) * BK8 * 2; }
-                    else { const bool mine = s + 2 < nsteps; dm = (mine && !(ABL & 2)) || ring_next; kb = mine ? (long long)(s + 2) * BK8 * 2 : 0; }      // s + 2 == nsteps: K tile 0 of the next item
+                    if constexpr (STEADY) { dm = !(ABL & 2); koff(s + 2, kb, kb2); }
+                    else { const bool mine = s + 2 < nsteps; dm = (mine && !(ABL & 2)) || ring_next; if (mine) koff(s + 2, kb, kb2); else { kb = ka0; kb2 = 0; } }      // s + 2 == nsteps: K tile 0 of the next item
                 } else rd = false;
             } else if constexpr (chunk < NCH) {
                 dst = O;
-                if constexpr (STEADY) { dm = !(ABL & 2); kb = (long long)(s + 1) * BK8 * 2; }
-                else { const bool mine = s + 1 < nsteps; dm = (mine && !(ABL & 2)) || ring_next; kb = mine ? (long long)(s + 1) * BK8 * 2 : 0; }
+                if constexpr (STEADY) { dm = !(ABL & 2); koff(s + 1, kb, kb2); }
+                else { const bool mine = s + 1 < nsteps; dm = (mine && !(ABL & 2)) || ring_next; if (mine) koff(s + 1, kb, kb2); else { kb = ka0; kb2 = 0; } }
             }
             if (ABL & 4) rd = false;
             static_for<0, HR>([&](auto xc) {
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
                     if constexpr (nx % NPK == 0) static_for<x0 * 4 / HR, x1 * 4 / HR>([&](auto j) { read_b(std::integral_constant<int, nx>{}, j, rst); });
                 }
                 if constexpr (chunk < NCH) {
-                    if (dm) static_for<chunk * CS + y0 * CS / HR, chunk * CS + y1 * CS / HR>([&](auto k) { dma(k, kb, dst); });
+                    if (dm) static_for<chunk * CS + y0 * CS / HR, chunk * CS + y1 * CS / HR>([&](auto k) { dma(k, kb, kb2, dst); });
                 }
                 sched_fence();
                 if (!(ABL & 1)) mfma_row(phc, xc);
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
         stores_behind_tile0 = false;
         G8_STAMP(item, 1);
         // chunk 0 of K tile 1 (its other chunks follow from the phases of step 0, like those of every later tile)
-        if (nsteps > 1 && !(ABL & 2)) static_for<0, (NCH > 1 ? CS : NPW)>([&](auto k) { dma(k, (long long)BK8 * 2, (unsigned)((cur ^ 1) * STAGE)); });
+        if (nsteps > 1 && !(ABL & 2)) { long long k1a, k1b; koff(1, k1a, k1b); static_for<0, (NCH > 1 ? CS : NPW)>([&](auto k) { dma(k, k1a, k1b, (unsigned)((cur ^ 1) * STAGE)); }); }
         static_for<0, HR>([&](auto x) { read_a(std::integral_constant<int, 0>{}, x, (unsigned)(cur * STAGE)); });
         static_for<0, 4>([&](auto j) { read_b(std::integral_constant<int, 0>{}, j, (unsigned)(cur * STAGE)); });
         wait_frags(std::integral_constant<int, 0>{});
@@ -566,7 +579,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             tile_coord(it, G, nitems, tiles_n, mt, nt);
             m0 = mt * BMT; n0 = nt * TBN;
             sa.init(amap, m0, M, wave, lane); sb.init(bmap, n0, N, wave, lane);
-            sa.issue((const unsigned char*)A, lds + cur * STAGE, wave); sb.issue((const unsigned char*)B, lds + cur * STAGE + BMT * RB, wave);
+            sa.issue((const unsigned char*)A + ka0, lds + cur * STAGE, wave); sb.issue((const unsigned char*)B, lds + cur * STAGE + BMT * RB, wave);
         }
         // side inputs of the epilogue (after the next item's copies: a wait for these must not have to drain younger copies first)
         constexpr int IPP = sizeof(TO) == 2 ? (NI % 3 == 0 ? 3 : 2) : 1;
@@ -661,8 +674,10 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
 
 // ---------------------------------------------------------------- host side
 // which == NI (8 or 9).  Legality (bf16 in, K % 64 == 0, 32-bit operand offsets, no transposed second output) is the caller's job.
+// planes: A / B are the hi planes of split f32 operands, the lo planes a_lo / b_lo BYTES behind them (gemm8_kc_kernel<..., PL = true>; f32 out, default schedule only)
 template <class TO>
-int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, void* stream)
+int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, void* stream,
+                    bool planes, long long a_lo, long long b_lo)
 {
     const int bmt = 2 * ni * 16, tiles_m = (M + bmt - 1) / bmt, tiles_n = (N + 255) / 256, nitems = tiles_m * tiles_n;
     const size_t smem = (size_t)2 * (bmt + 256) * 128;
@@ -673,8 +688,24 @@ int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int 
     do {                                                                                                                      \
         static bool granted = false;                                                                                          \
         if (!granted) { if (g8_grant((const void*)gemm8_kc_kernel<TO, NI_, PIN_, ABL_, ST_, GS_>, smem)) return 1; granted = true; } \
-        SS_LAUNCH(SS_KERNEL(gemm8_kc_kernel<TO, NI_, PIN_, ABL_, ST_, GS_>), grid, block, smem, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, tiles_n, nitems); \
+        SS_LAUNCH(SS_KERNEL(gemm8_kc_kernel<TO, NI_, PIN_, ABL_, ST_, GS_>), grid, block, smem, stream, (const bf16_t*)A, (const bf16_t*)B, (TO*)C, M, N, K, am, bm, epi, tiles_n, nitems, 0LL, 0LL); \
     } while (0)
+#define G8_PLANES(NI_, ST_, GS_)                                                                                               \
+    do {                                                                                                                      \
+        static bool granted = false;                                                                                          \
+        if (!granted) { if (g8_grant((const void*)gemm8_kc_kernel<float, NI_, 3, 0, ST_, GS_, true>, smem)) return 1; granted = true; } \
+        SS_LAUNCH(SS_KERNEL(gemm8_kc_kernel<float, NI_, 3, 0, ST_, GS_, true>), grid, block, smem, stream, (const bf16_t*)A, (const bf16_t*)B, (float*)C, M, N, K, am, bm, epi, tiles_n, nitems, a_lo, b_lo); \
+    } while (0)
+    if (planes) {
+        if constexpr (sizeof(TO) == 4) {
+            const int st = epi.col_sum ? ((!epi.col_sumsq && !epi.col_shift) ? 2 : 1) : 0, gs = epi.general == 1 ? 1 : 0;
+            if (st && gs) { ss_set_error("gemm8 (planes): column statistics of a dropout epilogue are not instantiated"); return 1; }
+            if (ni == 9) { if (st == 2) G8_PLANES(9, 2, 0); else if (st == 1) G8_PLANES(9, 1, 0); else if (gs) G8_PLANES(9, 0, 1); else G8_PLANES(9, 0, 0); }
+            else { if (st == 2) G8_PLANES(8, 2, 0); else if (st == 1) G8_PLANES(8, 1, 0); else if (gs) G8_PLANES(8, 0, 1); else G8_PLANES(8, 0, 0); }
+            SS_LAUNCH_CHECK("ss_gemm_planes(gemm8)");
+            return 0;
+        } else { ss_set_error("gemm8 (planes): f32 output only"); return 1; }
+    }
     const int abl = (epi.debug >> 4) & 7;
 #if defined(G8_FAST_BUILD)        // tuning builds: three bf16-out main-loop variants only (a full build of this file takes minutes)
     if constexpr (sizeof(TO) == 2) {
@@ -706,6 +737,7 @@ int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int 
 #endif
 #undef G8_CASE
 #undef G8_CASE6
+#undef G8_PLANES
 }
-template int gemm8_launch_kc<bf16_t>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*);
-template int gemm8_launch_kc<float>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*);
+template int gemm8_launch_kc<bf16_t>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*, bool, long long, long long);
+template int gemm8_launch_kc<float>(int, int, const void*, const void*, void*, int, int, int, const RowMap&, const RowMap&, const GemmEpi&, void*, bool, long long, long long);

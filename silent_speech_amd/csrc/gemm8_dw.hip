@@ -19,7 +19,7 @@ struct DwJob {
     int M, N, K;                        // C is M x N, reduction over K frames
     int tiles_n, ntiles, split, k_chunk, item0, nitem, atomic;
 };
-constexpr int DW_MAX_JOBS = 8;
+constexpr int DW_MAX_JOBS = 24;      // (3.3 KB of kernel arguments; the hi / lo plane form of the parity-grade mode hands in three jobs per weight gradient)
 struct DwJobs { DwJob job[DW_MAX_JOBS]; int n; };
 
 namespace g8 {
@@ -494,8 +494,10 @@ extern "C" int ss_gemm_dw_grouped(int n_jobs, const ss_dw_job* jobs, void* strea
     DwJobs J; memset(&J, 0, sizeof(J));
     J.n = n_jobs;
     long long tiles_total = 0; int kmax = 0;
+    int s_flags[DW_MAX_JOBS];
     for (int i = 0; i < n_jobs; ++i) {
         const ss_dw_job& s = jobs[i];
+        s_flags[i] = s.flags;
         SS_CHECK(s.A && s.B && s.C, "ss_gemm_dw_grouped: null pointer in job %d", i);
         SS_CHECK(s.M > 0 && s.N > 0 && s.K > 0 && s.M % 8 == 0 && s.N % 8 == 0, "ss_gemm_dw_grouped: job %d: M=%d, N=%d must be positive multiples of 8 (16-byte rows), K=%d > 0", i, s.M, s.N, s.K);
         SS_CHECK(((uintptr_t)s.A) % 16 == 0 && ((uintptr_t)s.B) % 16 == 0, "ss_gemm_dw_grouped: job %d: operands must be 16-byte aligned", i);
@@ -513,6 +515,17 @@ extern "C" int ss_gemm_dw_grouped(int n_jobs, const ss_dw_job* jobs, void* strea
     // one K split for the whole group: the largest that keeps (tiles x split) inside ONE round of the CUs
     const int cus = g8_cus();
     int split = (int)(cus / (tiles_total > 0 ? tiles_total : 1)); split = split < 1 ? 1 : split;
+    if (tiles_total > cus) {
+        // more tiles than CUs (the plane form: three jobs per gradient): the split that minimises rounds x (K tiles per item + ~12 K tiles' worth of
+        // atomic epilogue) -- 324 tiles of 344 K tiles: split 1 = 2 rounds x 356, split 3 = 4 rounds x 127
+        const int ks = (kmax + 63) / 64;
+        double best = 0;
+        for (int cand = 1; cand <= 8; ++cand) {
+            const long long items = tiles_total * cand, rounds = (items + cus - 1) / cus;
+            const double cost = (double)rounds * ((ks + cand - 1) / cand + 12);
+            if (cand == 1 || cost < best) { best = cost; split = cand; }
+        }
+    }
     if (g_dw_split_override > 0) split = g_dw_split_override;
     int item0 = 0;
     for (int i = 0; i < n_jobs; ++i) {
@@ -521,7 +534,7 @@ extern "C" int ss_gemm_dw_grouped(int n_jobs, const ss_dw_job* jobs, void* strea
         int sp = split; if (sp > ksteps / 4) sp = ksteps / 4 > 0 ? ksteps / 4 : 1;          // at least 4 K tiles per item
         const int per = (ksteps + sp - 1) / sp;
         d.k_chunk = per * 64; d.split = (ksteps + per - 1) / per;
-        d.atomic = d.split > 1 ? 1 : 0;                     // one item per tile: a plain read-modify-write of C suffices
+        d.atomic = (d.split > 1 || (s_flags[i] & 1)) ? 1 : 0;   // one item per tile of a C nobody else updates: a plain read-modify-write suffices
         d.item0 = item0; d.nitem = d.ntiles * d.split; item0 += d.nitem;
     }
     const int nitems = item0;

@@ -156,7 +156,8 @@ __device__ __forceinline__ void epilogue_flush(const TO* __restrict__ ct, int ld
 
 // 8-wave 256-column-tile kernels (gemm8.hip); ni = 8 or 9 (256 / 288 tile rows), pin = scheduling fences on/off
 template <class TO>
-int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, void* stream);
+int gemm8_launch_kc(int ni, int pin, const void* A, const void* B, void* C, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, void* stream,
+                    bool planes = false, long long a_lo = 0, long long b_lo = 0);
 
 // gemm_smallk.hip: K <= 32 (first convolution and its residual projection), no LDS
 bool gemm_smallk_ok(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, const void* B, const void* C, int M, int N, int K,

@@ -42,12 +42,17 @@ struct LayerP {
 struct BlockCtx { void *xin, *c1, *cr, *h1, *c2, *y; float *m1, *i1, *m2, *i2, *mr, *ir, *scratch; int Tin, Cin, Tout, O, pad_y; };
 struct LayerCtx { void *x, *qkv, *qkvT, *o, *z1, *y1, *hid, *z2, *pimg; float *lse, *mean1, *rstd1, *mean2, *rstd2; };
 constexpr int MAX_LAYERS = 16;
+// hi / lo bf16 planes of f32 buffers (parity-grade mode on the 8-wave kernels): every GEMM operand is split ONCE per step, on first use, into
+// [2][elems] bf16 carved from the workspace (hi plane, then lo); forward activations keep theirs for the weight-gradient GEMMs of the backward.
+constexpr int MAX_PLANES = 384;
+struct PlaneCache { int n; const void* key[MAX_PLANES]; void* hi[MAX_PLANES]; long long elems[MAX_PLANES]; };
 struct Ctx {
     int B, T0, T, M, Tp, need_T, n_layers;
     float p_drop, scale; unsigned long long seed;
     BlockCtx blk[3];
     LayerCtx layer[MAX_LAYERS];
     void *conv_out, *x_final;
+    PlaneCache planes;
     unsigned long long ws_used;
     char* ws; unsigned long long ws_bytes;
 };
@@ -77,6 +82,9 @@ struct Plan {
     reduce_fn hook = 0; void* hook_user = 0;
     event_fn on_event = 0; void* event_user = 0;
     int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1, regate_on = 1, f32_x3 = 0;
+    int x3_planes = 1;       // option 7: an f32_x3 plan runs every GEMM the 8-wave kernel can take on hi / lo bf16 planes (off = operands split in registers on the 128 x 128 kernels, round 4)
+    Ctx* cur = nullptr;      // the context of the call in flight (plane cache)
+    bool use_planes() const { return D.dtype == SS_F32 && f32_x3 && x3_planes; }
     int keep_input = 0;      // option 6: leave x_raw as it is (the shifted signal is only handed out in `shifted`; a functional caller copies it back itself)
     hipEvent_t ev_fork = 0, ev_join = 0;
     size_t esz() const { return D.dtype == SS_BF16 ? 2 : 4; }
@@ -150,10 +158,39 @@ struct Plan {
     }
 
     // ---------------------------------------------------------------- small launch helpers (all return non-zero on error)
+    // elements an operand's row map spans (rows x row_len window)
+    static long long extent(const ss_rowmap& m, int rows, int row_len) {
+        const long long nb = m.rows_per_batch > 0 ? (rows - 1) / m.rows_per_batch : 0, rr = m.rows_per_batch > 0 ? (rows < m.rows_per_batch ? rows : m.rows_per_batch) - 1 : rows - 1;
+        return m.base + nb * m.batch_stride + rr * m.row_stride + row_len;
+    }
+    // hi plane of the f32 buffer [src, src + n) (lo plane n elements behind it); split on first use, on the MAIN stream (every consumer -- side-stream
+    // launches included -- is ordered behind it by the fork that precedes them).  key: what identifies the buffer (its address; a weight: its slot)
+    struct Pl { void* hi; void* lo; };
+    Pl planes(Exec& X, const void* key, const void* src, long long n) {
+        PlaneCache& pc = cur->planes;
+        // (a null key is never reused: in the sizing pass the first workspace buffer and the caller's dhead both have address 0)
+        if (key) for (int i = 0; i < pc.n; ++i) if (pc.key[i] == key && pc.elems[i] >= n) return Pl{pc.hi[i], (char*)pc.hi[i] + pc.elems[i] * 2};
+        n = (n + 7) & ~7LL;
+        void* hi = X.alloc((size_t)n * 4);
+        if (key && pc.n < MAX_PLANES) { pc.key[pc.n] = key; pc.hi[pc.n] = hi; pc.elems[pc.n] = n; ++pc.n; }
+        if (!X.dry) {
+            if (timed(X, "split_planes", 0, (double)n * 8, X.stream, [&] { return ss_split_planes((const float*)src, hi, (char*)hi + n * 2, n, X.stream); })) return Pl{nullptr, nullptr};
+        }
+        return Pl{hi, (char*)hi + n * 2};
+    }
+
     int gemm(Exec& X, int dt_out, const void* A, const void* B, void* C, int M, int N, int K, ss_rowmap am, ss_rowmap bm, ss_rowmap cm, const ss_gemm_epilogue* e = 0,
-             int a_mode = SS_OP_KC, int b_mode = SS_OP_KC, int split = 1, void* stream = 0) {
-        if (X.dry) return 0;
+             int a_mode = SS_OP_KC, int b_mode = SS_OP_KC, int split = 1, void* stream = 0, const void* wkey = nullptr) {
         void* st = stream ? stream : X.stream;
+        if (use_planes() && st == X.stream && a_mode == SS_OP_KC && b_mode == SS_OP_KC && dt_out == SS_F32 && split == 1 &&
+            ss_gemm_planes_supported(SS_F32, C, M, N, K, &am, &bm, &cm, e)) {
+            const Pl a = planes(X, A, A, extent(am, M, K)), b = planes(X, wkey ? wkey : B, B, extent(bm, N, K));
+            if (X.dry) return 0;
+            if (!a.hi || !b.hi) return 1;
+            return timed(X, "gemm", 2.0 * M * N * K, ((double)M * K + (double)N * K) * 4 + (double)M * N * 4.0, st,
+                         [&] { return ss_gemm_planes(SS_F32, a.hi, a.lo, b.hi, b.lo, C, M, N, K, &am, &bm, &cm, e, st); }, true);
+        }
+        if (X.dry) return 0;
         const double ob = dt_out == SS_BF16 ? 2.0 : 4.0;
         return timed(X, a_mode == SS_OP_OC && b_mode == SS_OP_OC ? "gemm_dw" : "gemm", 2.0 * M * N * K, ((double)M * K + (double)N * K) * esz() + (double)M * N * ob, st,
                      [&] { return ss_gemm(D.dtype == SS_F32 && f32_x3 ? SS_F32X3 : D.dtype, dt_out, a_mode, b_mode, A, B, C, M, N, K, &am, &bm, &cm, e, split, st); }, true);
@@ -215,8 +252,21 @@ struct Plan {
     }
 
     struct DwGroup {
-        Plan* P; Exec* X; bool grouped; int n = 0; ss_dw_job jobs[8];
+        Plan* P; Exec* X; bool grouped; int n = 0; ss_dw_job jobs[24];
         int add(const void* dy, const void* x, float* grad, int N, int K, int rows, ss_rowmap am, ss_rowmap bm, void* stream) {
+            if (grouped && P->use_planes()) {
+                // hi / lo planes of both operands: dW = dY_lo^T X_hi + dY_hi^T X_lo + dY_hi^T X_hi as three jobs that accumulate into the same gradient
+                if (n + 3 > 24 && launch(stream)) return 1;
+                const Pl a = P->planes(*X, dy, dy, extent(am, rows, N)), b = P->planes(*X, x, x, extent(bm, rows, K));
+                if (X->dry) return 0;
+                if (!a.hi || !b.hi) return 1;
+                const void* as[3] = {a.lo, a.hi, a.hi}; const void* bs[3] = {b.hi, b.lo, b.hi};
+                for (int t = 0; t < 3; ++t) {
+                    ss_dw_job& j = jobs[n++]; memset(&j, 0, sizeof(j));
+                    j.A = as[t]; j.B = bs[t]; j.C = grad; j.amap = am; j.bmap = bm; j.ldc = K; j.M = N; j.N = K; j.K = rows; j.flags = 1;
+                }
+                return 0;
+            }
             if (grouped) {
                 if (n == 8 && launch(stream)) return 1;
                 ss_dw_job& j = jobs[n++]; memset(&j, 0, sizeof(j));
@@ -237,7 +287,8 @@ struct Plan {
             int rc = 0;
             if (n && !X->dry) {
                 double fl = 0, by = 0;
-                for (int i = 0; i < n; ++i) { fl += 2.0 * jobs[i].M * jobs[i].N * jobs[i].K; by += ((double)jobs[i].M + jobs[i].N) * jobs[i].K * 2.0 + (double)jobs[i].M * jobs[i].N * 4.0; }
+                const double pl = P->use_planes() ? 3.0 : 1.0;      // plane form: three jobs per gradient -> useful flops = a third
+                for (int i = 0; i < n; ++i) { fl += 2.0 * jobs[i].M * jobs[i].N * jobs[i].K / pl; by += ((double)jobs[i].M + jobs[i].N) * jobs[i].K * 2.0 + (double)jobs[i].M * jobs[i].N * 4.0 / pl; }
                 rc = P->timed(*X, "gemm_dw_grouped", fl, by, stream, [&] { return ss_gemm_dw_grouped(n, jobs, stream); });
             }
             n = 0; return rc;
@@ -261,6 +312,7 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
     SS_CHECK(T0 % 8 == 0, "raw EMG length %d must be a multiple of 8 (three stride-2 convolutions)", T0);
     SS_CHECK(D.n_layers <= MAX_LAYERS, "at most %d encoder layers", MAX_LAYERS);
     void* stream = X.stream;
+    cur = c; c->planes.n = 0;
     if (!training) p_drop = 0.f;
     c->B = B; c->T0 = T0; c->p_drop = p_drop; c->seed = seed; c->n_layers = D.n_layers;
 
@@ -370,8 +422,10 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
     void* stream = X.stream;
     void* side = (side_enabled && X.side) ? X.side : X.stream;
     const bool overlapped = side != stream;
-    Exec XS = X; XS.side = side;        // the DwGroup's view: knows whether a second stream is in use
-    const bool grouped = dt == SS_BF16 && dw_grouped;
+    X.side = side;                      // (side stream switched off: nothing forks, the DwGroups see one stream)
+    Exec& XS = X;                       // the DwGroups allocate (operand planes) from the same bump allocator
+    const bool grouped = (dt == SS_BF16 || use_planes()) && dw_grouped;
+    cur = c;
 
     // ---- heads (architecture.py:82)
     const void* dh_t = dhead;
@@ -548,6 +602,7 @@ extern "C" int ss_plan_set_option(ss_plan* h, int what, int value)
     else if (what == 4) { old = h->p->regate_on; h->p->regate_on = value; }
     else if (what == 5) { old = h->p->f32_x3; h->p->f32_x3 = value != 0; }
     else if (what == 6) { old = h->p->keep_input; h->p->keep_input = value != 0; }
+    else if (what == 7) { old = h->p->x3_planes; h->p->x3_planes = value != 0; }
     return old;
 }
 extern "C" int ss_plan_set_reduce_hook(ss_plan* h, ss_reduce_hook fn, void* user) { SS_CHECK(h, "null plan"); h->p->hook = (reduce_fn)fn; h->p->hook_user = user; return 0; }

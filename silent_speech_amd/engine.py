@@ -424,6 +424,8 @@ def forward(model, x_raw, training, shift_r, seed):
     pb.ensure_bound(model, pr, gu, dev)
     pb.set_reduce_hook(model._bn_reduce_fn if training else None)
     L = pb.lib
+    L.ss_plan_set_option(pb.handle, 5, int(model.f32_matmul == 'bf16x3'))         # (before the sizing pass: the plane form of that mode allocates operand planes)
+    L.ss_plan_set_option(pb.handle, 7, int(os.environ.get('SS_AMD_X3_PLANES', '1') != '0'))
     nbytes = int(L.ss_plan_workspace_bytes(pb.handle, B, T0, int(training)))
     if nbytes < 0:
         raise RuntimeError('ss_plan_workspace_bytes failed: %s' % L.ss_last_error().decode())
@@ -432,7 +434,6 @@ def forward(model, x_raw, training, shift_r, seed):
     shifted = torch.empty_like(x_raw) if (training and shift_r > 0) else None
     buf = ctypes.create_string_buffer(pb.ctx_bytes)
     pb.ws = ws
-    L.ss_plan_set_option(pb.handle, 5, int(model.f32_matmul == 'bf16x3'))
     L.ss_plan_set_option(pb.handle, 6, 1)
     p_drop = model.dropout_p if training else 0.0
     rc = L.ss_plan_forward(pb.handle, _lib.ptr(x_raw), _lib.ptr(shifted), _lib.ptr(ws), nbytes, B, T0, int(training), int(shift_r if training else 0),

@@ -153,15 +153,57 @@ def gemm_set_option(what, value):
 
 def gemm_dw_grouped(jobs):
     """jobs: list of (dY, X, dW, M, N, K, amap, bmap, ldc): dW[m][n] += sum_k dY(k, m) X(k, n) for every job, ONE launch
-    (include/silent_speech_hip.h: ss_gemm_dw_grouped).  Groups of more than 8 jobs are cut into several launches."""
-    for g0 in range(0, len(jobs), 8):
-        grp = jobs[g0:g0 + 8]
+    (include/silent_speech_hip.h: ss_gemm_dw_grouped).  Groups of more than 8 jobs are cut into several launches.
+    bf16 operands, or -- the parity-grade f32 form -- (hi, lo) plane pairs from split_planes(): three jobs per gradient
+    (lo.hi, hi.lo, hi.hi) that accumulate into the same dW."""
+    flat = []
+    for (dy, x, dw, M, N, K, amap, bmap, ldc) in jobs:
+        if isinstance(dy, tuple):
+            (dh, dl), (xh, xl) = dy, x
+            flat += [(dl, xh, dw, M, N, K, amap, bmap, ldc, 1), (dh, xl, dw, M, N, K, amap, bmap, ldc, 1), (dh, xh, dw, M, N, K, amap, bmap, ldc, 1)]
+        else:
+            flat.append((dy, x, dw, M, N, K, amap, bmap, ldc, 0))
+    cap = 24 if any(f[9] for f in flat) else 8
+    for g0 in range(0, len(flat), cap):
+        grp = flat[g0:g0 + cap]
         arr = (_lib.DwJob * len(grp))()
-        for j, (dy, x, dw, M, N, K, amap, bmap, ldc) in zip(arr, grp):
+        for j, (dy, x, dw, M, N, K, amap, bmap, ldc, flags) in zip(arr, grp):
             assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
             j.A, j.B, j.C = _p(dy).value, _p(x).value, _p(dw).value
-            j.amap, j.bmap, j.ldc, j.M, j.N, j.K = amap, bmap, int(ldc), int(M), int(N), int(K)
+            j.amap, j.bmap, j.ldc, j.M, j.N, j.K, j.flags = amap, bmap, int(ldc), int(M), int(N), int(K), flags
         _lib.check(_L().ss_gemm_dw_grouped(len(grp), arr, _s(grp[0][2])), 'ss_gemm_dw_grouped')
+
+
+def split_planes(x):
+    """f32 tensor -> (hi, lo) bf16 tensors of the same shape: hi = bf16(x), lo = bf16(x - hi) (ss_split_planes)."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_L().ss_split_planes(_p(x), _p(hi), _p(lo), x.numel(), _s(x)), 'ss_split_planes')
+    return hi, lo
+
+
+def gemm_planes_supported(C, M, N, K, amap, bmap, cmap, epi=None):
+    return bool(_L().ss_gemm_planes_supported(_lib.SS_F32, _p(C), M, N, K, ctypes.byref(amap), ctypes.byref(bmap), ctypes.byref(cmap), ctypes.byref(epi) if epi is not None else None))
+
+
+def gemm_planes(A, B, C, M, N, K, amap, bmap, cmap, bias=None, relu=False, gate=None, gate_scale=1.0, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0,
+                mode=0, col_stats=None):
+    """C = epilogue(A . B^T) with A = (A_hi, A_lo), B = (B_hi, B_lo) plane pairs (split_planes), f32 C: the bf16 x 3 arithmetic of
+    gemm(f32_math='bf16x3') as ONE bf16 contraction of length 3 K on the 8-wave kernel (ss_gemm_planes)."""
+    epi = GemmEpilogue()
+    if col_stats is not None:
+        cs, cq, sh = col_stats
+        epi.col_sum, epi.col_sumsq, epi.col_shift = _p(cs).value, (_p(cq).value if cq is not None else None), (_p(sh).value if sh is not None else None)
+    epi.bias = _p(bias).value if bias is not None else None
+    epi.gate = _p(gate).value if gate is not None else None
+    epi.gate_scale, epi.alpha, epi.relu, epi.dropout_p = gate_scale, alpha, int(bool(relu)), float(dropout_p)
+    epi.seed, epi.rng_stream, epi.mode = int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_stream), int(mode)
+    assert C.dtype == torch.float32 and all(t.dtype == torch.bfloat16 for t in (A[0], A[1], B[0], B[1]))
+    rc = _L().ss_gemm_planes(_lib.SS_F32, _p(A[0]), _p(A[1]), _p(B[0]), _p(B[1]), _p(C), M, N, K, ctypes.byref(amap), ctypes.byref(bmap), ctypes.byref(cmap),
+                             ctypes.byref(epi), _s(C))
+    _lib.check(rc, 'ss_gemm_planes')
+    return C
 
 
 # ------------------------------------------------------------------ BatchNorm / LayerNorm / misc

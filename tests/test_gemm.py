@@ -427,3 +427,121 @@ def test_gemm_smallk_first_conv(dev, gemm_opts, ktaps, stats):
             assert_close_robust(cq, 3.0 + (v * v).sum(0), 1e-4, name='col_sumsq', max_outlier_frac=0)
     if 0 in res:
         assert torch.equal(res[1], res[0])                              # same products, same f32 accumulation order inside one MFMA
+
+
+# ------------------------------------------------------------------ hi / lo bf16 planes (round 6: the parity-grade arithmetic on the 8-wave kernels)
+def test_split_planes(dev):
+    """hi = bf16(x), lo = bf16(x - hi), bit for bit against torch's round-to-nearest-even; x = hi + lo to 2^-16 relative; ragged length."""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(3001, generator=g) * torch.exp(3 * torch.randn(3001, generator=g)))
+    x[:4] = torch.tensor([0.0, -0.0, 1.0, -3.0e-30])
+    hi, lo = ops.split_planes(x.to(dev))
+    want_hi = x.bfloat16()
+    want_lo = (x - want_hi.float()).bfloat16()
+    assert torch.equal(hi.cpu().view(torch.int16), want_hi.view(torch.int16))
+    assert torch.equal(lo.cpu().view(torch.int16), want_lo.view(torch.int16))
+    rel = ((hi.cpu().float() + lo.cpu().float() - x).abs() / x.abs().clamp_min(1e-30)).max()
+    assert float(rel) < 2.0 ** -16
+
+
+def _x3_err(C, want, scale):
+    return float(((C.cpu().double() - want).abs() / scale).max())
+
+
+@pytest.mark.parametrize('ni', [8, 9])
+def test_gemm_planes_kc(dev, gemm_opts, ni):
+    """ss_gemm_planes on gemm8_kc_kernel<float, ..., PL>: the three-segment K ring (lo.hi | hi.lo | hi.hi), several items per persistent
+    workgroup (the next item's first tile is a LO-plane tile), 1 / 2 / 5 K tiles per segment, ragged M / N, bias + ReLU; the error against
+    the f64 product must be that of the bf16 x 3 arithmetic (< 2^-16 of sum |a||b|, far below plain bf16)."""
+    from silent_speech_amd import _lib
+    big = not is_emu(dev)
+    gemm_opts(ops.GEMM_OPT_G8_NI, ni)
+    g = torch.Generator().manual_seed(300 + ni)
+    for (M, N, K) in ([(3000, 776, 768), (1000, 264, 64), (70000, 264, 128)] if big else [(600, 264, 128), (330, 520, 64), (40, 72, 320)]):
+        a = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g)); b = torch.randn(N, K, generator=g); bias = torch.randn(N, generator=g)
+        want = torch.relu(a.double() @ b.double().t() + bias.double())
+        scale = a.abs().double() @ b.abs().double().t() + bias.abs().double()
+        C = torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+        assert ops.gemm_planes_supported(C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N))
+        ops.gemm_planes(ops.split_planes(a.to(dev)), ops.split_planes(b.to(dev)), C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), bias=bias.to(dev), relu=True)
+        assert _lib.lib().ss_gemm_last_kernel() == (4 if ni == 9 else 3)
+        err = _x3_err(C, want, scale)
+        bf = _x3_err(torch.relu(a.bfloat16().double() @ b.bfloat16().double().t() + bias.double()), want, scale)
+        assert err < 2.0 ** -16 and err < bf / 30, (M, N, K, err, bf)
+
+
+def test_gemm_planes_epilogues_and_conv(dev, gemm_opts):
+    """gate + C += v, dropout (the same mask as the bf16 kernels draw), column statistics, and a k = 3 stride-2 convolution over a zero-padded
+    (B, T+2, C) buffer whose planes keep the buffer's geometry (overlapping rows, row-mapped output)."""
+    big = not is_emu(dev)
+    g = torch.Generator().manual_seed(17)
+    M, N, K = (1000, 328, 256) if big else (300, 136, 128)
+    a = torch.randn(M, K, generator=g); b = torch.randn(N, K, generator=g)
+    A, B = ops.split_planes(a.to(dev)), ops.split_planes(b.to(dev))
+    prod = a.double() @ b.double().t()
+    scale = a.abs().double() @ b.abs().double().t() + 1.0
+    gate = (torch.randn(M, N, generator=g) > 0).float(); base = torch.randn(M, N, generator=g)
+    C = base.clone().to(dev)
+    ops.gemm_planes(A, B, C, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), gate=gate.to(dev), gate_scale=1.25, mode=1)
+    assert _x3_err(C, base.double() + prod * gate.double() * 1.25, scale) < 2.0 ** -16
+    # dropout: identical keep decisions to the bf16 kernel with the same (seed, stream)
+    Cd = torch.zeros(M, N, dtype=torch.float32, device=dev)
+    ops.gemm_planes(A, B, Cd, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), relu=True, dropout_p=0.2, seed=99, rng_stream=6)
+    Cb = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    gemm_opts(ops.GEMM_OPT_G8, 2)
+    ops.gemm(a.bfloat16().to(dev), b.bfloat16().to(dev), Cb, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), relu=True, dropout_p=0.2, seed=99, rng_stream=6)
+    pos = torch.relu(prod) > 1e-2 * scale
+    assert torch.equal((Cd.cpu() != 0) & pos, (Cb.cpu().float() != 0) & pos)
+    assert _x3_err(torch.where(Cd.cpu() != 0, Cd.cpu().double(), torch.relu(prod) / 0.8), torch.relu(prod) / 0.8, scale) < 2.0 ** -15
+    # column statistics of the stored result
+    cs = torch.zeros(N, device=dev); cq = torch.zeros(N, device=dev); sh = torch.randn(N, generator=g).to(dev)
+    Cs = torch.zeros(M, N, dtype=torch.float32, device=dev)
+    ops.gemm_planes(A, B, Cs, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N), col_stats=(cs, cq, sh))
+    d = Cs.cpu().double() - sh.cpu().double()
+    assert_close_robust(cs, d.sum(0).float(), 1e-4, name='planes col_sum', max_outlier_frac=0)
+    assert_close_robust(cq, (d * d).sum(0).float(), 1e-4, name='planes col_sumsq', max_outlier_frac=0)
+    # convolution
+    Bn, T, Ci, Co = (3, 400, 64, 264) if big else (2, 40, 64, 48)
+    x = torch.randn(Bn, T, Ci, generator=g); w = torch.randn(Co, Ci, 3, generator=g) * 0.2
+    want = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), None, stride=2, padding=1).transpose(1, 2)
+    To = want.shape[1]
+    xpad = torch.zeros(Bn, T + 2, Ci); xpad[:, 1:-1] = x
+    wg = w.permute(0, 2, 1).reshape(Co, 3 * Ci).contiguous()
+    y = torch.zeros(Bn, 2 * To, Co, dtype=torch.float32, device=dev)
+    ops.gemm_planes(ops.split_planes(xpad.to(dev)), ops.split_planes(wg.to(dev)), y, Bn * To, Co, 3 * Ci,
+                    ops.rowmap(2 * Ci, rows_per_batch=To, batch_stride=(T + 2) * Ci), ops.rowmap(3 * Ci), ops.rowmap(2 * Co, To, 2 * To * Co, base=Co))
+    sc = torch.nn.functional.conv1d(x.abs().double().transpose(1, 2), w.abs().double(), None, stride=2, padding=1).transpose(1, 2)
+    assert _x3_err(y[:, 1::2], want, sc) < 2.0 ** -16
+    assert float(y[:, 0::2].abs().max()) == 0.0
+
+
+def test_gemm_planes_refuses_what_the_8_wave_kernel_cannot_run(dev):
+    C = torch.zeros(64, 64, dtype=torch.float32, device=dev)
+    assert not ops.gemm_planes_supported(C, 64, 64, 96, ops.rowmap(96), ops.rowmap(96), ops.rowmap(64))      # K % 64
+    a = ops.split_planes(torch.zeros(64, 96).to(dev))
+    with pytest.raises(RuntimeError):
+        ops.gemm_planes(a, a, C, 64, 64, 96, ops.rowmap(96), ops.rowmap(96), ops.rowmap(64))
+
+
+@pytest.mark.parametrize('split', [0, 2])
+def test_gemm_dw_grouped_planes(dev, split):
+    """Weight gradients of the parity-grade mode: (hi, lo) plane pairs -> three jobs per gradient accumulating into the same dW (atomics even
+    at split 1); more tiles than the (emulator's / chip's) workgroup slots exercises the rounds-based K split."""
+    from silent_speech_amd import _lib
+    big = not is_emu(dev)
+    g = torch.Generator().manual_seed(78)
+    jobs, wants, outs, scales = [], [], [], []
+    R = 4000 if big else 200
+    for (N, K) in ([(520, 264), (256, 768), (768, 3072)] if big else [(264, 40), (24, 264)]):
+        dy = torch.randn(R, N, generator=g) * torch.exp(torch.randn(1, N, generator=g)); x = torch.randn(R, K, generator=g)
+        base = torch.randn(N, K, generator=g)
+        dW = base.clone().to(dev)
+        jobs.append((ops.split_planes(dy.to(dev)), ops.split_planes(x.to(dev)), dW, N, K, R, ops.rowmap(N), ops.rowmap(K), K))
+        wants.append(base.double() + dy.double().t() @ x.double()); outs.append(dW); scales.append(dy.abs().double().t() @ x.abs().double() + base.abs().double())
+    old = _lib.lib().ss_gemm_dw_set_option(0, split)
+    try:
+        ops.gemm_dw_grouped(jobs)
+    finally:
+        _lib.lib().ss_gemm_dw_set_option(0, old)
+    for i, (o, w, sc) in enumerate(zip(outs, wants, scales)):
+        assert _x3_err(o, w, sc) < 2.0 ** -16, i

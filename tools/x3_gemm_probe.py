@@ -40,4 +40,12 @@ for (M, N, K) in ((22000, 3072, 768), (22000, 768, 3072), (22000, 2304, 768), (2
     row.append('dW exact %.0f us' % us)
     us = timeit(lambda: ops.gemm(c32, a32, dw, N, K, M, ops.rowmap(N), ops.rowmap(K), ops.rowmap(K), a_mode=OP_OC, b_mode=OP_OC, mode=2, split_k=8, f32_math='bf16x3'))
     row.append('dW x3 %.0f us (%.0f TF)' % (us, fl / us / 1e6))
+    # round 6: the same arithmetic on hi / lo bf16 planes through the 8-wave kernels (ss_gemm_planes, three dW jobs per gradient)
+    ap, bp, cp = ops.split_planes(a32), ops.split_planes(b32), ops.split_planes(c32)
+    us = timeit(lambda: ops.gemm_planes(ap, bp, c32, M, N, K, ops.rowmap(K), ops.rowmap(K), ops.rowmap(N)))
+    row.append('x3 planes %.0f us (%.0f TF)' % (us, fl / us / 1e6))
+    us = timeit(lambda: ops.split_planes(a32))
+    row.append('split A %.0f us (%.2f TB/s)' % (us, a32.numel() * 8 / us / 1e6))
+    us = timeit(lambda: ops.gemm_dw_grouped([(cp, ap, dw, N, K, M, ops.rowmap(N), ops.rowmap(K), K)]))
+    row.append('dW x3 planes %.0f us (%.0f TF)' % (us, fl / us / 1e6))
     print('%d x %d x %d: %s' % (M, N, K, ' | '.join(row)))
