@@ -102,7 +102,7 @@ def attention_mask_resident(seed, stream, B, H, T, p):
 def attention_mask_transposed(seed, stream, B, H, T, p):
     """Transposed-score attention kernels (bf16 rows of <= 224 frames; csrc/attention_t.hip `drop_key` / `drop_signs`): the 4 consecutive
     keys 4g..4g+3 of query q draw 16 bits each from ONE 32 x 32 -> 64-bit product of x = key(pair, q) + g * 0x632BE5AB with 0x9E3779B1
-    (keys 4g, 4g+1: the halves of lo ^ hi; 4g+2, 4g+3: the halves of hi); an entry is dropped iff its draw, read as a SIGNED 16-bit
+    (keys 4g, 4g+1: the halves of lo ^ hi; 4g+2, 4g+3: the halves of hi * 0x85EBCA6B + lo); an entry is dropped iff its draw, read as a SIGNED 16-bit
     number, is below t16 - 32768 (saturating subtract, sign bit), t16 = threshold >> 16.  -> bool (B, H, T, T)."""
     with np.errstate(over='ignore'):
         Tk = (T + 3) // 4 * 4
@@ -114,7 +114,8 @@ def attention_mask_transposed(seed, stream, B, H, T, p):
         prod = x * np.uint64(0x9E3779B1)
         lo, hi = (prod & np.uint64(_M32)).astype(U32), (prod >> np.uint64(32)).astype(U32)
         a = lo ^ hi
-        draws = np.stack([a & U32(0xffff), a >> U32(16), hi & U32(0xffff), hi >> U32(16)], -1).astype(np.uint16).view(np.int16).astype(np.int32)   # (BH, T, Tk/4, 4)
+        c = hi * U32(0x85EBCA6B) + lo
+        draws = np.stack([a & U32(0xffff), a >> U32(16), c & U32(0xffff), c >> U32(16)], -1).astype(np.uint16).view(np.int16).astype(np.int32)   # (BH, T, Tk/4, 4)
         ts = int(dropout_threshold(p) >> 16) - 32768
         keep = draws >= ts
         return keep.reshape(B, H, T, Tk)[..., :T]

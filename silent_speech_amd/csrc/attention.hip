@@ -525,6 +525,10 @@ __global__ __launch_bounds__(256, DPK <= 3 ? 2 : 1) void attn_bwd_kv_kernel(Attn
     }
 }
 
+// The LDS-resident 16 x 16 family of rounds 1-4 below is compiled only into A/B builds (-DSS_ATTN_RES16: tools/measure_lib.sh): every shape it
+// ran (bf16, T <= 208, d_head <= 96) runs the transposed-score kernels of attention_t.hip since round 5, so the product library carries no
+// kernel that only an environment switch (SS_ATTN_T=0) could reach.
+#if defined(SS_ATTN_RES16)
 // =========================================================================== resident (whole sequence in LDS) kernels, bf16
 // The training rows are T = 200 frames: the K/V (or Q/dO) rows of one (sequence, head) and the head's 2D-1 embedding rows
 // fit in the 160 KB LDS of a CU.  The per-tile kernels above re-fetch those operands from L2 for every 16-row tile
@@ -1813,6 +1817,8 @@ __global__ __launch_bounds__(RES_W_BKV * 64) void attn_bwd_kv_res_kernel(AttnP p
     }
 }
 
+#endif  // SS_ATTN_RES16
+
 // =========================================================================== host side
 static int attn_check(const char* what, int dtype, int B, int H, int T, int Tp, int dp, int D, float dropout_p)
 {
@@ -1856,6 +1862,7 @@ static void attn_fill(AttnP& p, int B, int H, int T, int Tp, int dp, int D, floa
         }                                                                                                       \
     } while (0)
 
+#if defined(SS_ATTN_RES16)
 // ---- resident-path dispatch
 #include <stdlib.h>
 static const size_t RES_LDS_MAX = 160 * 1024;
@@ -1937,13 +1944,17 @@ static ResKernel res_pick(int which, int dpk, bool drop = false) {
     return dpk >= 1 && dpk <= 3 ? tab[which][dpk - 1] : (ResKernel)0;
 }
 
+#endif  // SS_ATTN_RES16
+
 // Which kernels a problem runs: 0 = per-tile (any T, f32 / bf16 x 3; read the transposed copies qkvT / dOT), 1 = LDS-resident 16 x 16 tiles
 // (rounds 1-4, attention.hip), 2 = transposed 32 x 32 score tiles (attention_t.hip; need the prepared embedding tables).
 static bool family_t(int dtype, int T, int dp, int D) {
     if (dtype != SS_BF16 || !attn_t_supported(T, dp, D)) return false;
-    const char* e = getenv("SS_ATTN_T");                  // "0": keep the 16 x 16 resident kernels (A/B measurements, tests of both)
+#if defined(SS_ATTN_RES16)
+    const char* e = getenv("SS_ATTN_T");                  // A/B builds: "0" keeps the 16 x 16 resident kernels
     if (e && e[0] == '0') return false;
-    const char* r = getenv("SS_ATTN_RESIDENT");
+#endif
+    const char* r = getenv("SS_ATTN_RESIDENT");           // "0": the per-tile kernels (tests of both paths)
     return !(r && r[0] == '0');
 }
 extern "C" int ss_relpos_attention_family(int dtype, int T, int dp, int D)
@@ -1969,10 +1980,14 @@ extern "C" int ss_relpos_attention_prepare_tables(const float* emb, void* tab, i
 extern "C" int ss_relpos_attention_needs_transposed(int dtype, int T, int dp, int D)
 {
     if (family_t(dtype, T, dp, D)) return 0;
+#if defined(SS_ATTN_RES16)
     const int dpk = dp / 32;
     const bool resident = res_enabled(dtype, T) && dp % 32 == 0 && dpk >= 1 && dpk <= 3 && res_smem(0, T, dp, D) <= RES_LDS_MAX && res_smem(1, T, dp, D) <= RES_LDS_MAX &&
                           res_smem(2, T, dp, D) <= RES_LDS_MAX;
     return resident ? 0 : 1;
+#else
+    return 1;
+#endif
 }
 
 // bytes of the P image (see above) the forward can leave for the backward, 0 if this shape does not run the kernels that use one
@@ -1980,12 +1995,16 @@ extern "C" int64_t ss_relpos_attention_saved_bytes(int dtype, int B, int H, int 
 {
     if (B <= 0 || H <= 0 || T <= 0 || dp % 32 != 0 || dp < 32 || dp > 96 || D < 1 || D > 100) return 0;
     if (family_t(dtype, T, dp, D)) return attn_t_saved_bytes(B, H, T);
+#if !defined(SS_ATTN_RES16)
+    return 0;
+#else
     if (ss_relpos_attention_needs_transposed(dtype, T, dp, D) || !fwd2_enabled()) return 0;
     if (res_smem(3, T, dp, D) > RES_LDS_MAX || res_smem(4, T, dp, D) > RES_LDS_MAX || res_smem(5, T, dp, D) > RES_LDS_MAX) return 0;
     const char* e = getenv("SS_ATTN_SAVE_P");             // "0": backward recomputes the probabilities (A/B measurements, tests of both paths)
     if (e && e[0] == '0') return 0;
     const int64_t nb = (T + 15) / 16;
     return (int64_t)B * H * nb * pimg_slots((int)nb) * 512;
+#endif
 }
 
 static void attn_t_args(AttnTArgs& a, const void* qkv, const void* tab, int B, int H, int T, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream)
@@ -2012,6 +2031,7 @@ extern "C" int ss_relpos_attention_forward_p(int dtype, const void* qkv, const v
     p.qkv = qkv; p.qkvT = qkvT; p.E = E; p.out = out; p.lse = lse;
     SS_CHECK(!pimg || ss_relpos_attention_saved_bytes(dtype, B, H, T, dp, D) > 0, "ss_relpos_attention_forward_p: this shape does not save probabilities (ss_relpos_attention_saved_bytes is 0)");
     p.pimg = pimg;
+#if defined(SS_ATTN_RES16)
     if (!ss_relpos_attention_needs_transposed(dtype, T, dp, D)) {
         if (fwd2_enabled() && res_smem(3, T, dp, D) <= RES_LDS_MAX) {
             p.tail = (int)res2_tail(3, T, dp, D);
@@ -2020,6 +2040,7 @@ extern "C" int ss_relpos_attention_forward_p(int dtype, const void* qkv, const v
         SS_LAUNCH_CHECK("ss_relpos_attention_forward");
         return 0;
     }
+#endif
     p.gx = ((T + 15) / 16 + 3) / 4;
     dim3 grid(p.gx * H * B);
     SS_ATTN_DISPATCH(attn_fwd_kernel, grid, 256, 0);
@@ -2059,6 +2080,7 @@ extern "C" int ss_relpos_attention_backward_p(int dtype, const void* qkv, const 
         if (dtype == SS_BF16) SS_LAUNCH(attn_dsum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dO, (const bf16_t*)out, Dscratch, B, H, T, dp);
         else SS_LAUNCH(attn_dsum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)dO, (const float*)out, Dscratch, B, H, T, dp);
     }
+#if defined(SS_ATTN_RES16)
     if (pimg) {
         SS_CHECK(ss_relpos_attention_saved_bytes(dtype, B, H, T, dp, D) > 0, "ss_relpos_attention_backward_p: this shape has no saved probabilities");
         p.pimg = (void*)pimg;
@@ -2075,6 +2097,9 @@ extern "C" int ss_relpos_attention_backward_p(int dtype, const void* qkv, const 
         SS_LAUNCH_CHECK("ss_relpos_attention_backward");
         return 0;
     }
+#else
+    SS_CHECK(!pimg, "ss_relpos_attention_backward_p: this shape has no saved probabilities");
+#endif
     const size_t esz = dtype == SS_BF16 ? 2 : 4;
     const int nwq = dtype == SS_BF16 ? 4 : 2;                         // keep the dynamic LDS request under 64 KiB
     const size_t smem_q = (size_t)nwq * 16 * (size_t)(PT_LD + p.MPt + 8) * esz;

@@ -59,8 +59,11 @@ struct KP {
 };
 
 // ---- dropout of this kernel family: the 4 consecutive keys 4g..4g+3 of query q draw 16 bits each from ONE 32x32 -> 64-bit product
-// (lo ^ hi | hi); an entry is dropped iff its draw, read as a signed 16-bit number, is below ts = t16 - 32768.  oracle/dropout_ref.py
-// (attention_mask_transposed) restates it.
+// (keys 4g, 4g+1: the halves of lo ^ hi; keys 4g+2, 4g+3: the halves of hi * 0x85EBCA6B + lo); an entry is dropped iff its draw, read as a
+// signed 16-bit number, is below ts = t16 - 32768.  oracle/dropout_ref.py (attention_mask_transposed) restates it.
+// (Round 5 took the second pair straight from hi: hi < 0x9E3779B1, so its upper half only covered [0, 0x9E37] and every fourth key was dropped
+// at 0.19 instead of 0.2, far off at other p -- the parity tests could not see it, the oracle restated the same formula.  Both words now mix the
+// uniformly distributed lo in; tests/test_dropout_parity.py checks the drop rate per key position mod 4 against p.)
 __device__ __forceinline__ unsigned drop_key(const KP& p, int bh, int q) {
     return mix32(((unsigned)bh * (unsigned)p.T + (unsigned)q) * 0x9E3779B1u ^ p.seedfold) + p.seedfold;
 }
@@ -69,7 +72,7 @@ __device__ __forceinline__ void drop_signs(unsigned key, int g, unsigned ts2, un
     const unsigned lo = x * 0x9E3779B1u, hi = __umulhi(x, 0x9E3779B1u);
     const s16x2 t = __builtin_bit_cast(s16x2, ts2);
     s01 = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, lo ^ hi), t));     // bit 15 of a half set <=> dropped
-    s23 = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, hi), t));
+    s23 = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, hi * 0x85EBCA6Bu + lo), t));
 }
 __device__ __forceinline__ unsigned keep_pos(unsigned img) {        // signed bf16 pair -> the kept probabilities (negative = dropped -> 0)
     const s16x2 z = {0, 0};
@@ -136,13 +139,14 @@ __device__ __forceinline__ void store_rows_t(unsigned char* tile, const f32x16 (
 
 // =========================================================================== forward
 // phase time stamps (measurement only): wave w of workgroup 0 records s_memtime at phase k of its i-th pair
+// (compiled only into measurement builds, -DATTN_T_MEASURE: tools/Makefile `stamplib`; the product library has no hook, no allocation and no environment switch here)
 __device__ __forceinline__ void stamp(const KP& p, int w, int it, int k) {
-#if !defined(SS_EMU)
+#if !defined(SS_EMU) && defined(ATTN_T_MEASURE)
     if (p.dbg && blockIdx.x == 0 && it < 4 && (threadIdx.x & 63) == 0) p.dbg[(w * 4 + it) * 8 + k] = __builtin_amdgcn_s_memtime();
 #endif
 }
 __device__ __forceinline__ void stamp2(const KP& p, int w, int it, int k) {
-#if !defined(SS_EMU)
+#if !defined(SS_EMU) && defined(ATTN_T_MEASURE)
     if (p.dbg && blockIdx.x == 0 && it == 1 && (threadIdx.x & 63) == 0) p.dbg[256 + w * 32 + k] = __builtin_amdgcn_s_memtime();
 #endif
 }
@@ -790,13 +794,13 @@ void fill(KP& p, const AttnTArgs& a)
     const unsigned ts = (t16 - 32768u) & 0xffffu;
     p.ts2 = ts | (ts << 16);
     p.oscale = p.drop ? 1.f / (1.f - a.dropout_p) : 1.f;
+#if !defined(SS_EMU) && defined(ATTN_T_MEASURE)
     {
         static unsigned long long* dbg = nullptr; static bool asked = false;
-#if !defined(SS_EMU)
         if (!asked) { asked = true; const char* e = getenv("SS_ATTN_T_STAMPS"); if (e && e[0] == '1') { if (hipMalloc((void**)&dbg, 8 * 4 * 8 * 8 * 2) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 8 * 4 * 8 * 8 * 2); } }
-#endif
         p.dbg = dbg;
     }
+#endif
     p.seedfold = (unsigned)a.seed ^ ((unsigned)(a.seed >> 32) * 0x9E3779B9u) ^ (a.stream_id * 0x85EBCA6Bu);
 }
 
@@ -851,7 +855,8 @@ int attn_t_forward(const AttnTArgs& a, void* stream)
     return launch(k, persistent_blocks(a.B * a.H, a.H), waves + 1, fwd_smem(a.T, a.dp, waves), stream, p);        // + 1: the loader wave
 }
 
-// measurement only: the stamps of the last forward launch (8 waves x 4 pairs x 8 phases), or 0 when SS_ATTN_T_STAMPS is not set
+// measurement builds only (-DATTN_T_MEASURE): the stamps of the last forward launch (8 waves x 4 pairs x 8 phases), or 0 when SS_ATTN_T_STAMPS is not set
+#if defined(ATTN_T_MEASURE)
 extern "C" int ss_attn_t_debug_stamps(unsigned long long* out)
 {
 #if !defined(SS_EMU)
@@ -863,6 +868,7 @@ extern "C" int ss_attn_t_debug_stamps(unsigned long long* out)
     (void)out; return 0;
 #endif
 }
+#endif
 
 template <int DPK> static Kern bq_pick(int nt)
 {
@@ -886,7 +892,11 @@ int attn_t_backward(const AttnTArgs& a, void* stream)
     const size_t smem = bwd_smem(a.T, a.dp, waves);
     const Kern kq = dpk == 1 ? bq_pick<1>(p.nt) : dpk == 2 ? bq_pick<2>(p.nt) : bq_pick<3>(p.nt);
     const Kern kkv = dpk == 1 ? bkv_pick<1>(p.nt) : dpk == 2 ? bkv_pick<2>(p.nt) : bkv_pick<3>(p.nt);
-    const char* dbg = getenv("SS_ATTN_T_SKIP");          // measurement / debugging only: 1 skips the query-major kernel, 2 the key-major one
+#if defined(ATTN_T_MEASURE)
+    const char* dbg = getenv("SS_ATTN_T_SKIP");          // measurement builds only (timing one kernel of the pair; gradients are then garbage): 1 skips the query-major kernel, 2 the key-major one
+#else
+    const char* dbg = nullptr;
+#endif
     if (!(dbg && dbg[0] == '1') && launch(kq, persistent_blocks(a.B * a.H, a.H), waves + 1, bwdq_smem(a.T, a.dp, waves), stream, p)) return 1;      // also writes D' for the key-major kernel
     if (dbg && dbg[0] == '2') return 0;
     return launch(kkv, a.B * a.H, waves, smem, stream, p);

@@ -117,10 +117,19 @@ def test_attention_transposed_score_kernels(dev, case, p):
     _run(dev, torch.bfloat16, B=2, H=2 if is_emu(dev) else 8, T=T, dh=dh, D=D, seed=T + D, tol_f=2e-2, tol_b=3e-2, p=p)
 
 
+def _need_res16(monkeypatch, T, dp, D):
+    """The LDS-resident 16 x 16 family (rounds 1-4) lives only in A/B builds of the library (-DSS_ATTN_RES16, tools/measure_lib.sh) since round 6."""
+    monkeypatch.setenv('SS_ATTN_T', '0')
+    if ops.relpos_attention_family(torch.bfloat16, T, dp, D) != 1:
+        pytest.skip('the 16 x 16 resident attention kernels are compiled only into A/B builds (-DSS_ATTN_RES16)')
+
+
+
 @pytest.mark.parametrize('dt_old', [torch.bfloat16])
 def test_attention_resident_16x16_kernels_still_agree(dev, monkeypatch, dt_old):
     """SS_ATTN_T=0 keeps the LDS-resident 16 x 16 kernels of rounds 1-4 reachable (A/B measurements): same function."""
-    monkeypatch.setenv('SS_ATTN_T', '0')
+    dev_T, dev_dp, dev_D = (37, 32, 9) if is_emu(dev) else (200, 96, 100)
+    _need_res16(monkeypatch, dev_T, dev_dp, dev_D)
     if is_emu(dev):
         _run(dev, dt_old, B=1, H=2, T=37, dh=8, D=9, seed=1, tol_f=2e-2, tol_b=3e-2, p=0.25)
     else:
@@ -212,9 +221,9 @@ def test_resident_forward_generations_agree(dev, monkeypatch, T, D, dh, p):
     same log-sum-exp, same dropped set, outputs equal up to the bf16 rounding of the probabilities (normalised before vs after P~V)."""
     if is_emu(dev) and T > 100:
         pytest.skip('full-size rows: gpu tier')
-    monkeypatch.setenv('SS_ATTN_T', '0')                 # the 16 x 16 resident kernels (rounds 1-4), kept behind this switch
     B, H, dt = 2, 2, torch.bfloat16
     dp, Tp = (dh + 31) // 32 * 32, (T + 7) // 8 * 8
+    _need_res16(monkeypatch, T, dp, D)                   # the 16 x 16 resident kernels (rounds 1-4), kept behind this switch in A/B builds
     g = torch.Generator().manual_seed(7)
     qkv = (torch.randn(B * T, 3 * H * dp, generator=g) * 0.7).to(dt)
     E = (torch.randn(H, 2 * D - 1, dp, generator=g) * dh ** -0.5).to(dt)
@@ -237,9 +246,9 @@ def test_persistent_per_head_schedule_equals_one_workgroup_per_pair(dev, monkeyp
     # two of them without a half; (7, 1): 3 left over of 4 -> not split (a second whole round for three workgroups).  GPU: the benchmarked launch.
     if not is_emu(dev) and BH != (5, 2):
         pytest.skip('emulator-size schedules')
-    monkeypatch.setenv('SS_ATTN_T', '0')                 # a schedule of the 16 x 16 resident kernels
     B, H, T, dh, D = (BH[0], BH[1], 40, 32, 9) if is_emu(dev) else (110, 8, 200, 96, 100)
     dt, dp, Tp = torch.bfloat16, (dh + 31) // 32 * 32, (T + 7) // 8 * 8
+    _need_res16(monkeypatch, T, dp, D)                   # a schedule of the 16 x 16 resident kernels
     g = torch.Generator().manual_seed(17)
     qkv = (torch.randn(B * T, 3 * H * dp, generator=g) * 0.7).to(dt).to(dev)
     E = (torch.randn(H, 2 * D - 1, dp, generator=g) * dh ** -0.5).to(dt)

@@ -74,6 +74,24 @@ def test_attention_mask(dev, dt):
     assert not keep[..., ~band].any()
 
 
+@pytest.mark.parametrize('p', [0.05, 0.1, 0.2, 0.25, 0.5])
+def test_attention_mask_transposed_drop_rate_per_key_position(p):
+    """The four keys 4g .. 4g+3 of a query share one 64-bit product; every one of the four 16-bit draws must be uniform, i.e. the drop rate per key
+    position mod 4 equals p (round 5 drew keys 4g+2, 4g+3 from the upper product word alone: 0.191 instead of 0.2 on every fourth key, 0.081 instead
+    of 0.05).  The oracle function is what the kernel's masks are compared with bit for bit (test_attention_mask), so its statistics are the kernel's.
+    480 000 draws per position: 5 sigma of a binomial plus the 2^-16 granularity of the threshold."""
+    keep = dropout_ref.attention_mask_transposed(1234, 7, 6, 8, 200, p)
+    n = keep[..., 0::4].size
+    tol = 5.0 * math.sqrt(p * (1 - p) / n) + 2.0 ** -15
+    for r in range(4):
+        rate = 1.0 - keep[..., r::4].mean()
+        assert abs(rate - p) < tol, (r, rate, p)
+    # neighbouring keys of one product are not copies of each other
+    a, b = keep[..., 2::4].ravel(), keep[..., 3::4].ravel()
+    both = float((~a & ~b).mean())
+    assert abs(both - p * p) < 5.0 * math.sqrt(p * p / a.size) + 1e-3, both
+
+
 # ------------------------------------------------------------------ (2) a whole training step at p > 0
 class _FixedShift(object):
     @staticmethod

@@ -8,7 +8,13 @@
 #include <string.h>
 #include <vector>
 #include "silent_speech_hip.h"
-extern "C" int ss_attn_t_debug_stamps(unsigned long long* out);      // measurement hook of csrc/attention_t.hip (not part of the ABI header)
+#include <dlfcn.h>
+// measurement hook of csrc/attention_t.hip: exists only in a -DATTN_T_MEASURE build of the library (tools/Makefile: stamplib), looked up at run time
+static int ss_attn_t_debug_stamps(unsigned long long* out) {
+    typedef int (*fn_t)(unsigned long long*);
+    static fn_t fn = (fn_t)dlsym(RTLD_DEFAULT, "ss_attn_t_debug_stamps");
+    return fn ? fn(out) : 0;
+}
 
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static float frand(uint32_t& s) { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; }
