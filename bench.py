@@ -131,7 +131,7 @@ def parity_entry(sub, ref_pred, model_sd, dev, dropout_p=0.2):
                 pred, _ = m(None, X_raw, None)
             want = ref_pred
             if p > 0:
-                resident = _lib.lib().ss_relpos_attention_family(_lib.dtype_code(dt), 200, m.dp, m.max_rel)
+                resident = m.attention_mask_family(200)
                 B = int(X_raw.shape[0])
                 masks = dropout_ref.layer_masks(m.last_seed, 6, B, 200, 768, 8, 3072, p, resident)
                 with torch.no_grad():

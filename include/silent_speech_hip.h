@@ -381,6 +381,23 @@ int ss_relpos_attention_backward_p(int dtype, const void* qkv, const void* qkvT,
                                    int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed,
                                    uint32_t rng_stream, void* stream);
 
+/* The parity-grade mode of the attention (round 6): f32 operands as hi / lo bf16 planes (ss_split_planes), every product of the kernels above
+ * on three bf16 MFMAs (a_lo.b_hi + a_hi.b_lo + a_hi.b_hi, f32 accumulate) -- the transposed-score kernels' formulation, so bf16 rows of up to
+ * 224 frames, d_head <= 96 (ss_relpos_attention_x3_supported; other shapes keep SS_F32X3 of the entry points above).  qkv / dO arrive as
+ * plane pairs, out / dqkv LEAVE as plane pairs (their consumers are ss_gemm_planes / the grouped weight-gradient jobs); the table holds E / scale
+ * as [hi | lo] (ss_relpos_attention_x3_prepare_tables, ss_relpos_attention_x3_table_bytes), the saved probabilities two images [hi | lo]
+ * (ss_relpos_attention_x3_saved_bytes; required by the backward).  Dropout masks are those of kernel family 2.
+ * Replaces the f32 arithmetic of transformer.py:87-112, :229-297 and its autograd backward. */
+int ss_relpos_attention_x3_supported(int T, int dp, int D);                               /* [host] */
+int64_t ss_relpos_attention_x3_saved_bytes(int B, int H, int T, int dp, int D);           /* [host] */
+int64_t ss_relpos_attention_x3_table_bytes(int H, int dp, int D);                         /* [host] */
+int ss_relpos_attention_x3_prepare_tables(const float* emb, void* tab, int H, int D, int dh, int dp, float scale, void* stream);
+int ss_relpos_attention_x3_forward(const void* qkv_hi, const void* qkv_lo, const void* tab, void* out_hi, void* out_lo, float* lse, void* pimg,
+                                   int B, int H, int T, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream);
+int ss_relpos_attention_x3_backward(const void* qkv_hi, const void* qkv_lo, const void* tab, const void* out_hi, const void* out_lo, const void* dO_hi, const void* dO_lo,
+                                    float* Dscratch, void* dqkv_hi, void* dqkv_lo, const void* pimg,
+                                    int B, int H, int T, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Offline EMG conditioning ("next" row N4): the zero-phase IIR cascade of read_emg.py:27-38 (7 x filtfilt(iirnotch(60 h, 30)) then
  * filtfilt(butter(3, 2 Hz, 'highpass')), scipy.signal.filtfilt defaults: odd extension of 3 max(len a, len b) samples, lfilter_zi
@@ -428,7 +445,7 @@ void ss_plan_destroy(ss_plan* plan);                                /* [host] */
 int ss_plan_slot_count(const ss_plan* plan);                        /* [host] */
 const char* ss_plan_slot_name(const ss_plan* plan, int slot);       /* [host] */
 int ss_plan_bind(ss_plan* plan, int slot, void* device_ptr_or_value); /* [host] slots named *.total / *.all_f32 / *.bytes take integers */
-int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off, 4 BatchNorm backward recomputes the ReLU gate (on) or reads the saved output (off), 5 an SS_F32 plan runs its GEMMs as SS_F32X3 (bf16 x 3 MFMA on f32 operands) on/off (default off = exact f32), 6 the training-mode forward leaves x_raw untouched and only hands the shifted signal out in shifted_scratch (default off = written back in place like architecture.py:67-68) */
+int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off, 4 BatchNorm backward recomputes the ReLU gate (on) or reads the saved output (off), 5 an SS_F32 plan runs its GEMMs as SS_F32X3 (bf16 x 3 MFMA on f32 operands) on/off (default off = exact f32), 6 the training-mode forward leaves x_raw untouched and only hands the shifted signal out in shifted_scratch (default off = written back in place like architecture.py:67-68), 7 an SS_F32X3 plan runs every GEMM the 8-wave kernel can take on hi / lo bf16 planes (ss_split_planes / ss_gemm_planes; default on), 8 the bound EF tables are the [hi | lo] tables of ss_relpos_attention_x3_prepare_tables: such a plan also runs its attention on planes (default off) */
 int ss_plan_set_reduce_hook(ss_plan* plan, ss_reduce_hook fn, void* user); /* [host] */
 int ss_plan_set_event_hook(ss_plan* plan, ss_event_hook fn, void* user);   /* [host] */
 int64_t ss_plan_ctx_bytes(void);                                    /* [host] */

@@ -71,6 +71,9 @@ SIGNATURES = {
     'ss_relpos_attention_forward_p': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_relpos_attention_backward_p': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_relpos_attention_prepare_tables': [_P, _P, _I, _I, _I, _I, _F, _P],
+    'ss_relpos_attention_x3_prepare_tables': [_P, _P, _I, _I, _I, _I, _F, _P],
+    'ss_relpos_attention_x3_forward': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_relpos_attention_x3_backward': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_bn_stats_sums': [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     'ss_bn_finalize': [_P, ctypes.c_double, _I, _P, _P, _P, _P, _F, _F, _I, _P],
     'ss_bn_finalize_shift': [_P, _P, ctypes.c_double, _I, _P, _P, _P, _P, _F, _F, _I, _P],
@@ -126,6 +129,9 @@ _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int6
                'ss_relpos_attention_needs_transposed': ([_I, _I, _I, _I], ctypes.c_int),
                'ss_relpos_attention_family': ([_I, _I, _I, _I], ctypes.c_int),
                'ss_relpos_attention_table_bytes': ([_I, _I, _I], ctypes.c_int64),
+               'ss_relpos_attention_x3_supported': ([_I, _I, _I], ctypes.c_int),
+               'ss_relpos_attention_x3_saved_bytes': ([_I, _I, _I, _I, _I], ctypes.c_int64),
+               'ss_relpos_attention_x3_table_bytes': ([_I, _I, _I], ctypes.c_int64),
                'ss_relpos_attention_saved_bytes': ([_I, _I, _I, _I, _I, _I], ctypes.c_int64),
                'ss_layernorm_backward_scratch_floats': ([_I, _I], ctypes.c_int64)}
 _RESTYPES = {'ss_last_error': ctypes.c_char_p, 'ss_target_arch': ctypes.c_char_p, 'ss_abi_version': ctypes.c_int}

@@ -182,6 +182,18 @@ class Model(nn.Module):
         self._weights_version += 1
         return r
 
+    def attention_mask_family(self, T):
+        """Which dropout-mask function the attention of a training forward on rows of T frames draws from (oracle/dropout_ref.attention_mask):
+        0 per-tile kernels, 1 LDS-resident 16 x 16 (A/B builds), 2 transposed-score kernels -- bf16 plans ask the library; an f32 plan runs the
+        per-tile kernels unless it is the parity-grade mode on hi / lo planes (f32_matmul='bf16x3'), whose attention is the transposed-score one."""
+        import os
+        from . import _lib
+        L = _lib.lib()
+        if self.compute_dtype == torch.bfloat16:
+            return int(L.ss_relpos_attention_family(_lib.dtype_code(self.compute_dtype), T, self.dp, self.max_rel))
+        planes = self.f32_matmul == 'bf16x3' and all(os.environ.get(k, '1') != '0' for k in ('SS_AMD_X3_PLANES', 'SS_AMD_X3_ATTENTION', 'SS_AMD_DW_GROUPED'))
+        return 2 if planes and L.ss_relpos_attention_x3_supported(T, self.dp, self.max_rel) else 0
+
     def set_seed(self, seed):
         self._seed_base = int(seed)
 

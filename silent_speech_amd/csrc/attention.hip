@@ -2048,6 +2048,51 @@ extern "C" int ss_relpos_attention_forward_p(int dtype, const void* qkv, const v
     return 0;
 }
 
+// ---- the parity-grade mode on the transposed-score kernels: f32 operands as hi / lo bf16 planes (attention_t.hip, "x3")
+extern "C" int ss_relpos_attention_x3_supported(int T, int dp, int D) { return attn_t_x3_supported(T, dp, D) ? 1 : 0; }
+extern "C" int64_t ss_relpos_attention_x3_saved_bytes(int B, int H, int T, int dp, int D)
+{
+    return (B > 0 && H > 0 && attn_t_x3_supported(T, dp, D)) ? 2 * attn_t_saved_bytes(B, H, T) : 0;
+}
+extern "C" int64_t ss_relpos_attention_x3_table_bytes(int H, int dp, int D)
+{
+    (void)D;
+    return (H > 0 && dp % 32 == 0 && dp >= 32 && dp <= 96) ? 2 * attn_t_table_bytes(H, dp) : 0;
+}
+extern "C" int ss_relpos_attention_x3_prepare_tables(const float* emb, void* tab, int H, int D, int dh, int dp, float scale, void* stream)
+{
+    SS_CHECK(emb && tab, "ss_relpos_attention_x3_prepare_tables: null pointer");
+    SS_CHECK(H > 0 && D >= 1 && D <= 100 && dh >= 1 && dh <= dp && dp % 32 == 0 && dp <= 96 && scale > 0.f, "ss_relpos_attention_x3_prepare_tables: bad shape");
+    if (attn_t_prepare_tables_x3(emb, H, D, dh, dp, scale, tab, stream)) return 1;
+    SS_LAUNCH_CHECK("ss_relpos_attention_x3_prepare_tables");
+    return 0;
+}
+extern "C" int ss_relpos_attention_x3_forward(const void* qkv_hi, const void* qkv_lo, const void* tab, void* out_hi, void* out_lo, float* lse, void* pimg,
+                                              int B, int H, int T, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
+{
+    if (attn_check("ss_relpos_attention_x3_forward", SS_BF16, B, H, T, (T + 7) / 8 * 8, dp, D, dropout_p)) return 1;
+    SS_CHECK(attn_t_x3_supported(T, dp, D), "ss_relpos_attention_x3_forward: T=%d dp=%d D=%d does not run the plane kernels (ss_relpos_attention_x3_supported)", T, dp, D);
+    SS_CHECK(qkv_hi && qkv_lo && tab && out_hi && out_lo && lse, "ss_relpos_attention_x3_forward: null pointer");
+    AttnTArgs a; attn_t_args(a, qkv_hi, tab, B, H, T, dp, D, scale, dropout_p, seed, rng_stream);
+    a.qkv_lo = qkv_lo; a.out = out_hi; a.out_lo = out_lo; a.lse = lse; a.pimg = pimg;
+    if (attn_t_forward_x3(a, stream)) return 1;
+    SS_LAUNCH_CHECK("ss_relpos_attention_x3_forward");
+    return 0;
+}
+extern "C" int ss_relpos_attention_x3_backward(const void* qkv_hi, const void* qkv_lo, const void* tab, const void* out_hi, const void* out_lo, const void* dO_hi, const void* dO_lo,
+                                               float* Dscratch, void* dqkv_hi, void* dqkv_lo, const void* pimg,
+                                               int B, int H, int T, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
+{
+    if (attn_check("ss_relpos_attention_x3_backward", SS_BF16, B, H, T, (T + 7) / 8 * 8, dp, D, dropout_p)) return 1;
+    SS_CHECK(attn_t_x3_supported(T, dp, D), "ss_relpos_attention_x3_backward: T=%d dp=%d D=%d does not run the plane kernels (ss_relpos_attention_x3_supported)", T, dp, D);
+    SS_CHECK(qkv_hi && qkv_lo && tab && out_hi && out_lo && dO_hi && dO_lo && Dscratch && dqkv_hi && dqkv_lo && pimg, "ss_relpos_attention_x3_backward: null pointer");
+    AttnTArgs a; attn_t_args(a, qkv_hi, tab, B, H, T, dp, D, scale, dropout_p, seed, rng_stream);
+    a.qkv_lo = qkv_lo; a.O = out_hi; a.O_lo = out_lo; a.dO = dO_hi; a.dO_lo = dO_lo; a.Dv = Dscratch; a.dqkv = dqkv_hi; a.dqkv_lo = dqkv_lo; a.pimg = (void*)pimg;
+    if (attn_t_backward_x3(a, stream)) return 1;
+    SS_LAUNCH_CHECK("ss_relpos_attention_x3_backward");
+    return 0;
+}
+
 extern "C" int ss_relpos_attention_forward(int dtype, const void* qkv, const void* qkvT, const void* E, const void* tab, void* out, float* lse,
                                            int B, int H, int T, int Tp, int dp, int D, float scale, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {

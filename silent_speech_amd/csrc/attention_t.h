@@ -17,6 +17,8 @@ struct AttnTArgs {
     float scale, dropout_p;
     uint64_t seed;
     uint32_t stream_id;
+    // x3 (f32 operands as hi / lo bf16 planes): the lo planes of qkv / out / dO / O / dqkv; the table then holds [hi | lo], the image [hi | lo]
+    const void* qkv_lo; void* out_lo; const void* dO_lo; const void* O_lo; void* dqkv_lo;
 };
 
 bool attn_t_supported(int T, int dp, int D);                    // shape limits and LDS budget of all three kernels
@@ -25,3 +27,8 @@ int64_t attn_t_table_bytes(int H, int dp);
 int attn_t_prepare_tables(const float* emb, int H, int D, int dh, int dp, float scale, void* tab, void* stream);
 int attn_t_forward(const AttnTArgs& a, void* stream);
 int attn_t_backward(const AttnTArgs& a, void* stream);
+// x3: the same kernels' formulation on hi / lo planes (three bf16 MFMAs per product); tables = 2 x attn_t_table_bytes, image = 2 x attn_t_saved_bytes
+bool attn_t_x3_supported(int T, int dp, int D);
+int attn_t_prepare_tables_x3(const float* emb, int H, int D, int dh, int dp, float scale, void* tab, void* stream);
+int attn_t_forward_x3(const AttnTArgs& a, void* stream);
+int attn_t_backward_x3(const AttnTArgs& a, void* stream);

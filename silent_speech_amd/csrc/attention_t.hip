@@ -56,6 +56,8 @@ struct KP {
     unsigned long long* dbg;            // measurement only (SS_ATTN_T_STAMPS): phase time stamps of workgroup 0
     unsigned ts2, seedfold;             // packed signed 16-bit dropout thresholds (0x80008000 = keep everything); folded seed
     int drop;
+    // x3 kernels (f32 operands as hi / lo bf16 planes): ELEMENT offsets from the hi plane to the lo plane of qkv / tab / out / dO / O / dqkv, BYTES for the image
+    long long lo_qkv, lo_tab, lo_out, lo_dO, lo_O, lo_dqkv, lo_pimg;
 };
 
 // ---- dropout of this kernel family: the 4 consecutive keys 4g..4g+3 of query q draw 16 bits each from ONE 32x32 -> 64-bit product
@@ -115,7 +117,14 @@ __device__ __forceinline__ void stage_table(unsigned char* dst, int pitch, const
 
 // 32 x dp f32 accumulator tile held TRANSPOSED (lane = row n, registers = columns) -> rows of `ld` elements in global memory,
 // through a per-wave LDS tile (8-byte pieces in, whole 16-byte chunks of a row out)
-template <int DPK>
+// PLANE = 1: the LO plane of the scaled values, bf16(x - bf16(x)) (x3 kernels: outputs leave as hi / lo planes)
+__device__ __forceinline__ float bfw_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfw_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_plane(float a, float b, int plane) {
+    const unsigned hw = pack_bf16(a, b);
+    return plane ? pack_bf16(a - bfw_lo(hw), b - bfw_hi(hw)) : hw;
+}
+template <int DPK, int PLANE = 0>
 __device__ __forceinline__ void store_rows_t(unsigned char* tile, const f32x16 (&acc)[DPK], float sc, bf16_t* dst, long long ld, int nrows, int lane) {
     constexpr int TP = DPK * 64 + 16;
     const int n = lane & 31, h = lane >> 5;
@@ -124,7 +133,7 @@ __device__ __forceinline__ void store_rows_t(unsigned char* tile, const f32x16 (
     for (int db = 0; db < DPK; ++db)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            u32x2 v = {pack_bf16(acc[db][4 * rg] * sc, acc[db][4 * rg + 1] * sc), pack_bf16(acc[db][4 * rg + 2] * sc, acc[db][4 * rg + 3] * sc)};
+            u32x2 v = {pack_plane(acc[db][4 * rg] * sc, acc[db][4 * rg + 1] * sc, PLANE), pack_plane(acc[db][4 * rg + 2] * sc, acc[db][4 * rg + 3] * sc, PLANE)};
             *(u32x2*)(tile + n * TP + (32 * db + 8 * rg + 4 * h) * 2) = v;
         }
     wave_lds_sync();
@@ -627,6 +636,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void attn_t_bwd_q_kernel(KP p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rw[e] = (unsigned)usr[32 * kb + 16 * s2 + 2 * e] | ((unsigned)usr[32 * kb + 16 * s2 + 2 * e + 1] << 16);
                     const bf16x8 rb = __builtin_bit_cast(bf16x8, (u32x4){rw[0], rw[1], rw[2], rw[3]});
+
 #pragma unroll
                     for (int db = 0; db < DPK; ++db) dq[db] = mfma32(__builtin_bit_cast(bf16x8, tf[cur][s2 * DPK + db]), rb, dq[db]);
                 }
@@ -757,11 +767,662 @@ __global__ __launch_bounds__(NT * 64) void attn_t_bwd_kv_kernel(KP p)
     store_rows_t<DPK>(buf, dv, p.oscale, drow + 2LL * H * p.dp, ld, nrows, lane);
 }
 
+// =========================================================================== x3: f32 operands as hi / lo bf16 planes (round 6)
+// The parity-grade mode (f32 storage between the kernels, every product on three bf16 MFMAs: a.b ~ a_lo.b_hi + a_hi.b_lo + a_hi.b_hi, f32
+// accumulate) used to run the per-tile kernels of attention.hip -- 9 x the time of these kernels (every tile re-fetches its operands from L2
+// as f32 and splits them in registers).  Here the operands arrive SPLIT (qkv / dO as two bf16 planes written by ss_split_planes, the embedding
+// table as two prepared tables), the outputs leave as planes (O, dqkv: their consumers are plane GEMMs), and the saved probabilities are TWO
+// images (hi carries the dropout decision in its sign bit as before, lo = bf16(P - hi)).  The formulation is the bf16 family's; what changes:
+//   * every contraction runs three times over plane combinations.  The logits do it as three PASSES of the bf16 loop (lo.hi, hi.lo, hi.hi --
+//     small terms first) that accumulate in the same registers: one plane of Q (24 registers) is live at a time, which is what lets 7 x 16
+//     logits + the pipeline state fit 256 registers; the skew runs once per pass.
+//   * four tables (K, V as hi / lo) do not fit next to the skew buffers: V shares the bytes of the SKEW BUFFERS (dead between the logits and the
+//     next pair), so the loader wave brings V in under the softmax (barrier A .. A2) and the next pair's K under P~V (A2 .. B).
+//   * the backward kernels first form dP = dO V^T for ALL blocks (the same three-pass trick on a 7 x 16 register array), then overwrite it
+//     block by block with dS' as hi / lo words (same registers), so that neither both planes of dO nor of V have to be live with them.
+// Reference arithmetic: f32 throughout, transformer.py:87-112, :229-297.
+template <int DPK, int NT, bool DROP>
+__global__ __launch_bounds__((NT + 1) * 64) void attn_t_fwd_x3_kernel(KP p)
+{
+    constexpr int KS = 2 * DPK, KPB = DPK * 64 + KPAD, VPB = DPK * 64;
+    SS_DYN_SMEM(lds);
+    const int T = p.T, D = p.D, H = p.H, npairs = p.B * H;
+    const int tid = threadIdx.x, w_ = uniform(tid >> 6);
+    const long long ld = 3LL * H * p.dp, ldo = (long long)H * p.dp;
+    const size_t kbytes = dma_table_bytes(T, KPB), vbytes = dma_table_bytes(T, VPB);
+    unsigned char* Kh = (unsigned char*)lds;
+    unsigned char* Kl = Kh + kbytes;
+    unsigned char* Vh = Kl + kbytes;                                 // region 2: the per-wave skew buffers during the logits, the V planes during P~V
+    unsigned char* Vl = Vh + vbytes;
+    float* sk0 = (float*)Vh;
+    int pair = blockIdx.x;
+    if (pair >= npairs) return;
+
+    if (w_ == NT) {                                                 // ---- the loader wave
+        const int lane = tid & 63;
+        {
+            const int b = pair / H, hd = pair - b * H;
+            const bf16_t* kq = p.qkv + (long long)b * T * ld + hd * p.dp + (long long)H * p.dp;
+            dma_table<DPK>(Kh, KPB, kq, ld, T, lane); dma_table<DPK>(Kl, KPB, kq + p.lo_qkv, ld, T, lane);
+        }
+        wait_vmcnt<0>();
+        __syncthreads();                                             // K of the first pair
+        for (; pair < npairs; pair += gridDim.x) {
+            const int b = pair / H, hd = pair - b * H;
+            __syncthreads();                                         // A: every wave is done with the logits (K, skew buffers)
+            const bf16_t* vq = p.qkv + (long long)b * T * ld + hd * p.dp + 2LL * H * p.dp;
+            dma_table<DPK>(Vh, VPB, vq, ld, T, lane); dma_table<DPK>(Vl, VPB, vq + p.lo_qkv, ld, T, lane);
+            wait_vmcnt<0>();
+            __syncthreads();                                         // A2: V_p is in LDS
+            const int nxt = pair + gridDim.x;
+            if (nxt < npairs) {
+                const int b2 = nxt / H, h2 = nxt - b2 * H;
+                const bf16_t* kq = p.qkv + (long long)b2 * T * ld + h2 * p.dp + (long long)H * p.dp;
+                dma_table<DPK>(Kh, KPB, kq, ld, T, lane); dma_table<DPK>(Kl, KPB, kq + p.lo_qkv, ld, T, lane);
+            }
+            wait_vmcnt<0>();
+            __syncthreads();                                         // B: every wave is done with V_p; K_p+1 is in LDS
+        }
+        return;
+    }
+    __syncthreads();                                                 // K of the first pair
+    for (; pair < npairs; pair += gridDim.x) {
+        const int b = pair / H, hd = pair - b * H;
+        const bf16_t* base = p.qkv + (long long)b * T * ld + hd * p.dp;
+        int w = w_, lane = tid & 63;                                 // opaque per pair (see the bf16 forward)
+        pin_sgpr(w); pin_vgpr(lane);
+        const int n = lane & 31, h = lane >> 5;
+        float* sk = sk0 + (size_t)w * SK_WORDS;
+        const int i0 = 32 * w, qi = i0 + n;
+        float* skw = sk + (SKP + 1) * n + 4 * h + 1;
+        const float* skr = sk + SKP * n + 4 * h + 32;
+        const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+        const int vlane = 4 * h + (i16 >> 2), vcol = (16 * g16 + 4 * (i16 & 3)) * 2;
+        int slot8[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) slot8[rg] = rg * 512 + pimg_slot(n, h, rg) * 8;
+#define RNEED(ub) (32 * ((ub) - w) + D - 1 >= 0 && 32 * ((ub) - w) + D - 32 <= 2 * D - 2)
+#define KOUT(kb) ((32 * ((kb) - w) < 0 ? -32 * ((kb) - w) : 32 * ((kb) - w)) - 31 > D - 1)
+        f32x16 acc[NT];
+        const bf16_t* tabF = p.tab + ((long long)hd * NU + (UOFF - w)) * (KS * 512) + lane * 8;
+        // ---- one pass of the bf16 forward's logits loop over ONE plane combination: the Q plane at qplane, the table at tab_, the K plane at Kt;
+        // FIRST: acc = result, else acc += result (the skewed R' plus Q.K start from the value the earlier passes left)
+        auto logits_pass = [&](auto first_c, const bf16_t* qplane, const bf16_t* tab_, const unsigned char* Kt) {
+            constexpr bool FIRST = first_c;
+            bf16x8 qf[KS];
+            {
+                const bf16_t* qrow = qplane + (long long)(qi < T ? qi : T - 1) * ld + 8 * h;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) { const bf16x8 v = *(const bf16x8*)(qrow + 16 * s); qf[s] = qi < T ? v : zero8(); }
+            }
+            bf16x8 ef[KS];
+            f32x16 rt[2];
+            rt[0] = zero16();
+            efrag_load<KS>(ef, tab_);
+            efrag_wait<KS, 0>(ef);
+            if (RNEED(0)) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) rt[0] = mfma32(ef[s], qf[s], rt[0]);
+            }
+            efrag_load<KS>(ef, tab_ + KS * 512);
+#pragma unroll
+            for (int ub = 0; ub <= NT; ++ub) {
+                if (RNEED(ub)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) skw[32 * ub + 8 * (r >> 2) + (r & 3)] = rt[ub & 1][r];
+                }
+                if (ub < NT) {
+                    f32x16 t = zero16();
+                    efrag_wait<KS, 0>(ef);
+                    if (RNEED(ub + 1)) {
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) t = mfma32(ef[s], qf[s], t);
+                    }
+                    rt[(ub + 1) & 1] = t;
+                    if (ub + 1 < NT) efrag_load<KS>(ef, tab_ + (ub + 2) * KS * 512);
+                }
+                if (ub >= 1) {
+                    const int kb = ub - 1;
+                    if (!KOUT(kb)) {
+                        wave_lds_sync();
+                        f32x16 a;
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) { const f32x4 v = *(const f32x4*)(skr + 32 * kb + 8 * rg); a[4 * rg] = v[0]; a[4 * rg + 1] = v[1]; a[4 * rg + 2] = v[2]; a[4 * rg + 3] = v[3]; }
+                        if constexpr (!FIRST) a += acc[kb];
+                        int row = 32 * kb + n; row = row < T ? row : T - 1;
+                        const unsigned char* kp = Kt + row * KPB + 16 * h;
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) a = mfma32(*(const bf16x8*)(kp + 32 * s), qf[s], a);
+                        acc[kb] = a;
+                    }
+                }
+                stage_fence();
+            }
+            wave_lds_sync();                                         // the next pass rewrites the skew buffer
+        };
+        logits_pass(std::true_type{}, base, tabF + p.lo_tab, Kl);                    // Q_hi . (E'_lo | K_lo)
+        logits_pass(std::false_type{}, base + p.lo_qkv, tabF, Kh);                   // Q_lo . (E'_hi | K_hi)
+        logits_pass(std::false_type{}, base, tabF, Kh);                              // Q_hi . (E'_hi | K_hi)
+        __syncthreads();                                             // A: the loader may overwrite the skew buffers with V_p
+
+        // ---- band / sequence mask of the edge blocks, row maximum, exp, row sum (registers only: V arrives meanwhile)
+        float mx = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb) {
+            const int dj = 32 * (kb - w), j0 = 32 * kb, adj = dj < 0 ? -dj : dj;
+            if (adj - 31 > D - 1) continue;
+            if (adj + 31 > D - 1 || j0 + 31 >= T) {
+                const int rel0 = dj + 4 * h - n + (D - 1), lim = 2 * (D - 1), jl = T - j0 - 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = 8 * (r >> 2) + (r & 3);
+                    if ((unsigned)(rel0 + e) > (unsigned)lim || e >= jl) acc[kb][r] = -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[kb][r]);
+        }
+        mx = fmaxf(mx, xhalf(mx));
+        const float mc = mx * p.c1;
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb) {
+            if (KOUT(kb)) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = fast_exp2(acc[kb][r] * p.c1 - mc); acc[kb][r] = e; sum += e; }
+        }
+        sum += xhalf(sum);
+        const float inv = qi < T ? 1.0f / sum : 0.f;
+        if (h == 0 && qi < T) p.lse[((long long)b * H + hd) * T + qi] = mc * LN2 + logf(sum);
+        __syncthreads();                                             // A2: V_p is in LDS
+
+        // ---- probabilities -> hi / lo bf16 (+ the dropout decision in the sign bit of hi) -> the two images, and straight on as B operands
+        const unsigned dkey = DROP ? drop_key(p, pair, qi) : 0u;
+        unsigned char* img = p.pimg ? p.pimg + pimg_block(pair, NT, w, 0) : nullptr;
+        f32x16 o[DPK];
+#pragma unroll
+        for (int db = 0; db < DPK; ++db) o[db] = zero16();
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb) {
+            if (KOUT(kb)) continue;
+            unsigned pv[8], pl[8];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float p0 = acc[kb][4 * rg] * inv, p1 = acc[kb][4 * rg + 1] * inv, p2 = acc[kb][4 * rg + 2] * inv, p3 = acc[kb][4 * rg + 3] * inv;
+                unsigned w0 = pack_bf16(p0, p1), w1 = pack_bf16(p2, p3);
+                unsigned l0 = pack_bf16(p0 - bfw_lo(w0), p1 - bfw_hi(w0)), l1 = pack_bf16(p2 - bfw_lo(w1), p3 - bfw_hi(w1));
+                unsigned k0 = l0, k1 = l1;                           // lo words of the KEPT probabilities
+                if (DROP) {
+                    unsigned s01, s23; drop_signs(dkey, 8 * kb + 2 * rg + h, p.ts2, s01, s23);
+                    w0 |= s01 & 0x80008000u; w1 |= s23 & 0x80008000u;
+                    const s16x2 sh = {15, 15};
+                    k0 &= ~__builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, s01) >> sh);
+                    k1 &= ~__builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, s23) >> sh);
+                }
+                if (img) {
+                    u32x2 v = {w0, w1}; *(u32x2*)(img + (long long)kb * 2048 + slot8[rg]) = v;
+                    u32x2 u = {l0, l1}; *(u32x2*)(img + p.lo_pimg + (long long)kb * 2048 + slot8[rg]) = u;
+                }
+                pv[2 * rg] = DROP ? keep_pos(w0) : w0; pv[2 * rg + 1] = DROP ? keep_pos(w1) : w1;
+                pl[2 * rg] = k0; pl[2 * rg + 1] = k1;
+            }
+            const int j0 = 32 * kb;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pbh = __builtin_bit_cast(bf16x8, (u32x4){pv[4 * s2], pv[4 * s2 + 1], pv[4 * s2 + 2], pv[4 * s2 + 3]});
+                const bf16x8 pbl = __builtin_bit_cast(bf16x8, (u32x4){pl[4 * s2], pl[4 * s2 + 1], pl[4 * s2 + 2], pl[4 * s2 + 3]});
+                int r0 = j0 + 16 * s2 + vlane, r1 = r0 + 8;
+                r0 = r0 < T ? r0 : T - 1; r1 = r1 < T ? r1 : T - 1;
+                const int o0 = r0 * VPB + vcol, o1 = r1 * VPB + vcol;
+#pragma unroll
+                for (int db = 0; db < DPK; ++db) {
+                    const bf16x8 vah = tr_frag(Vh + o0 + 64 * db, Vh + o1 + 64 * db), val = tr_frag(Vl + o0 + 64 * db, Vl + o1 + 64 * db);
+                    o[db] = mfma32(val, pbh, o[db]);
+                    o[db] = mfma32(vah, pbl, o[db]);
+                    o[db] = mfma32(vah, pbh, o[db]);
+                }
+            }
+        }
+        __syncthreads();                                             // B: every wave is done with V_p (the skew buffers are this wave's again); K_p+1 is in LDS
+        bf16_t* orow = p.out + ((long long)b * T + i0) * ldo + hd * p.dp;
+        const int nrows = T - i0 < 32 ? T - i0 : 32;
+        store_rows_t<DPK, 0>((unsigned char*)sk, o, p.oscale, orow, ldo, nrows, lane);
+        store_rows_t<DPK, 1>((unsigned char*)sk, o, p.oscale, orow + p.lo_out, ldo, nrows, lane);
+#undef RNEED
+#undef KOUT
+    }
+}
+
+// ---- x3 backward helpers
+// probability of an entry from its two image halves: |hi| + lo (the sign bit of hi is the dropout decision)
+__device__ __forceinline__ float px3(float hi, float lo) { return fabsf(hi) + lo; }
+// dS' = (kept ? P dP : 0) - P D'  for the 4 entries of two hi words / two lo words  ->  hi and lo words of dS'
+__device__ __forceinline__ void ds_words_x3(unsigned w0, unsigned w1, unsigned l0, unsigned l1, float dp0, float dp1, float dp2, float dp3, float d0, float d1, float d2, float d3,
+                                            unsigned& h0, unsigned& h1, unsigned& o0, unsigned& o1) {
+    const float q0 = px3(bfw_lo(w0), bfw_lo(l0)), q1 = px3(bfw_hi(w0), bfw_hi(l0)), q2 = px3(bfw_lo(w1), bfw_lo(l1)), q3 = px3(bfw_hi(w1), bfw_hi(l1));
+    const float s0 = ((w0 & 0x8000u) ? 0.f : q0 * dp0) - q0 * d0, s1 = ((w0 & 0x80000000u) ? 0.f : q1 * dp1) - q1 * d1;
+    const float s2 = ((w1 & 0x8000u) ? 0.f : q2 * dp2) - q2 * d2, s3 = ((w1 & 0x80000000u) ? 0.f : q3 * dp3) - q3 * d3;
+    h0 = pack_bf16(s0, s1); h1 = pack_bf16(s2, s3);
+    o0 = pack_bf16(s0 - bfw_lo(h0), s1 - bfw_hi(h0)); o1 = pack_bf16(s2 - bfw_lo(h1), s3 - bfw_hi(h1));
+}
+// lo words of the KEPT probabilities: zero where the hi word carries the dropped mark
+__device__ __forceinline__ unsigned keep_lo(unsigned hiw, unsigned low) {
+    const s16x2 sh = {15, 15};
+    return low & ~__builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, hiw) >> sh);
+}
+
+// =========================================================================== x3 backward, query-major: dQ (and D)
+// LDS: [region 1: the V planes (pitch dp*2+16: row fragments), later the K planes (pitch dp*2: transposing reads) | per-wave buffer: two un-skew planes / output staging]
+//     compute:  A [V_p]: D', dP of every key block (three plane products)      | 1 |  B: dS' words, un-skew, dQ += E'^T dR' (three products)  | 2 |  C [K_p]: dQ += K^T dS'^T  | 3 |  D: dQ out
+//     loader :                                                                  | 1 |  K_p -> region 1, wait                                      | 2 |                             | 3 |  V_p+1 -> region 1, wait
+// (the top of the next pair is the barrier "V landed").  Phase B needs no table: it hides the copy of K completely.
+constexpr int BWX_BUF = 2 * SK_WORDS * 2 + 64;      // per-wave bytes: two un-skew planes of bf16 (>= the 6656 bytes of the output staging tile)
+template <int DPK, int NT>
+__global__ __launch_bounds__((NT + 1) * 64) void attn_t_bwd_q_x3_kernel(KP p)
+{
+    constexpr int KS = 2 * DPK, KPB = DPK * 64, VPB = DPK * 64 + KPAD, NF = 2 * DPK;
+    SS_DYN_SMEM(lds);
+    const int T = p.T, D = p.D, H = p.H, npairs = p.B * H;
+    const int tid = threadIdx.x, w_ = uniform(tid >> 6);
+    const long long ld = 3LL * H * p.dp, ldo = (long long)H * p.dp;
+    const size_t kbytes = dma_table_bytes(T, KPB), vbytes = dma_table_bytes(T, VPB);
+    unsigned char* R1 = (unsigned char*)lds;
+    unsigned char* buf0 = R1 + 2 * (kbytes > vbytes ? kbytes : vbytes);
+    int pair = blockIdx.x;
+    if (pair >= npairs) return;
+
+    if (w_ == NT) {                                                 // ---- the loader wave
+        const int lane = tid & 63;
+        {
+            const int b = pair / H, hd = pair - b * H;
+            const bf16_t* vq = p.qkv + (long long)b * T * ld + hd * p.dp + 2LL * H * p.dp;
+            dma_table<DPK>(R1, VPB, vq, ld, T, lane); dma_table<DPK>(R1 + vbytes, VPB, vq + p.lo_qkv, ld, T, lane);
+        }
+        wait_vmcnt<0>();
+        for (; pair < npairs; pair += gridDim.x) {
+            const int b = pair / H, hd = pair - b * H;
+            __syncthreads();                                         // V_p is in LDS
+            __syncthreads();                                         // 1: every wave is done with V_p
+            const bf16_t* kq = p.qkv + (long long)b * T * ld + hd * p.dp + (long long)H * p.dp;
+            dma_table<DPK>(R1, KPB, kq, ld, T, lane); dma_table<DPK>(R1 + kbytes, KPB, kq + p.lo_qkv, ld, T, lane);
+            wait_vmcnt<0>();
+            __syncthreads();                                         // 2: K_p is in LDS
+            __syncthreads();                                         // 3: every wave is done with K_p
+            const int nxt = pair + gridDim.x;
+            if (nxt < npairs) {
+                const int b2 = nxt / H, h2 = nxt - b2 * H;
+                const bf16_t* vq = p.qkv + (long long)b2 * T * ld + h2 * p.dp + 2LL * H * p.dp;
+                dma_table<DPK>(R1, VPB, vq, ld, T, lane); dma_table<DPK>(R1 + vbytes, VPB, vq + p.lo_qkv, ld, T, lane);
+            }
+            wait_vmcnt<0>();
+        }
+        return;
+    }
+    for (; pair < npairs; pair += gridDim.x) {
+        const int b = pair / H, hd = pair - b * H;
+        int w = w_, lane = tid & 63;                                 // opaque per pair
+        pin_sgpr(w); pin_vgpr(lane);
+        const int n = lane & 31, h = lane >> 5;
+        unsigned char* buf = buf0 + (size_t)w * BWX_BUF;
+        const int i0 = 32 * w, qi = i0 + n;
+        const long long ro = ((long long)b * T + (qi < T ? qi : T - 1)) * ldo + hd * p.dp + 8 * h;
+        // ---- D' = rowsum(dO * O) / s from the four planes (every product of two bf16 is exact in f32)
+        float Dp = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const u32x4 ah = *(const u32x4*)(p.dO + ro + 16 * s), al = *(const u32x4*)(p.dO + p.lo_dO + ro + 16 * s);
+            const u32x4 oh = *(const u32x4*)(p.O + ro + 16 * s), ol = *(const u32x4*)(p.O + p.lo_O + ro + 16 * s);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { Dp = dot2_bf16(al[e], ol[e], Dp); Dp = dot2_bf16(al[e], oh[e], Dp); Dp = dot2_bf16(ah[e], ol[e], Dp); Dp = dot2_bf16(ah[e], oh[e], Dp); }
+        }
+        Dp += xhalf(Dp);
+        Dp = qi < T ? Dp / p.oscale : 0.f;
+        if (h == 0 && qi < T) p.Dv[((long long)b * H + hd) * T + qi] = Dp;
+
+        __syncthreads();                                             // V_p is in LDS
+        // ---- phase A: dP^T = V dO^T of every key block in the band, three plane products accumulated in dpds[kb]
+        f32x16 dpds[NT];
+        {
+            const unsigned char* Vh = R1; const unsigned char* Vl = R1 + vbytes;
+            bf16x8 dof[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { const bf16x8 v = *(const bf16x8*)(p.dO + p.lo_dO + ro + 16 * s); dof[s] = qi < T ? v : zero8(); }
+#pragma unroll
+            for (int kb = 0; kb < NT; ++kb) {
+                if (blk_out(kb, w, D)) continue;
+                f32x16 a = zero16();
+                int row = 32 * kb + n; row = row < T ? row : T - 1;
+                const unsigned char* vp = Vh + row * VPB + 16 * h;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) a = mfma32(*(const bf16x8*)(vp + 32 * s), dof[s], a);       // V_hi . dO_lo
+                dpds[kb] = a;
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { const bf16x8 v = *(const bf16x8*)(p.dO + ro + 16 * s); dof[s] = qi < T ? v : zero8(); }
+#pragma unroll
+            for (int kb = 0; kb < NT; ++kb) {
+                if (blk_out(kb, w, D)) continue;
+                f32x16 a = dpds[kb];
+                int row = 32 * kb + n; row = row < T ? row : T - 1;
+                const unsigned char* vl = Vl + row * VPB + 16 * h; const unsigned char* vh = Vh + row * VPB + 16 * h;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) a = mfma32(*(const bf16x8*)(vl + 32 * s), dof[s], a);       // V_lo . dO_hi
+#pragma unroll
+                for (int s = 0; s < KS; ++s) a = mfma32(*(const bf16x8*)(vh + 32 * s), dof[s], a);       // V_hi . dO_hi
+                dpds[kb] = a;
+            }
+        }
+        __syncthreads();                                             // 1: the loader may overwrite V_p with K_p
+
+        // ---- phase B.1: dS' of every key block as hi / lo words, in the registers that held its dP (elements 0..7: hi words 2 rg + t, 8..15: lo words)
+        const unsigned char* img = (const unsigned char*)uniform_ptr(p.pimg + pimg_block(pair, NT, w, 0));
+        unsigned slot8[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) slot8[rg] = rg * 512 + pimg_slot(n, h, rg) * 8;
+        int lo = 0, hi = NT - 1;
+        while (lo < NT - 1 && blk_out(lo, w, D)) ++lo;
+        while (hi > 0 && blk_out(hi, w, D)) --hi;
+        {
+            u32x2 iw[2][8];                                          // [buffer][rg: hi image | 4 + rg: lo image]
+#define IMG_LOAD(BUF, KB) do { const unsigned char* ib_ = (const unsigned char*)uniform_ptr(img + (long long)((KB) < lo ? lo : (KB) > hi ? hi : (KB)) * 2048); \
+        const unsigned char* il_ = (const unsigned char*)uniform_ptr(ib_ + p.lo_pimg); \
+        aload8<0>(iw[BUF][0], ib_, slot8[0]); aload8<0>(iw[BUF][1], ib_, slot8[1]); aload8<0>(iw[BUF][2], ib_, slot8[2]); aload8<0>(iw[BUF][3], ib_, slot8[3]); \
+        aload8<0>(iw[BUF][4], il_, slot8[0]); aload8<0>(iw[BUF][5], il_, slot8[1]); aload8<0>(iw[BUF][6], il_, slot8[2]); aload8<0>(iw[BUF][7], il_, slot8[3]); } while (0)
+            IMG_LOAD(0, 0);
+#pragma unroll
+            for (int kb = 0; kb < NT; ++kb) {
+                const int cur = kb & 1;
+                if (kb + 1 < NT) { IMG_LOAD(cur ^ 1, kb + 1); await_vm<8>(); } else await_vm<0>();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) apin(iw[cur][i]);
+                if (!blk_out(kb, w, D)) {
+                    unsigned hw[8], lw[8];
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        ds_words_x3(iw[cur][rg][0], iw[cur][rg][1], iw[cur][4 + rg][0], iw[cur][4 + rg][1], dpds[kb][4 * rg], dpds[kb][4 * rg + 1], dpds[kb][4 * rg + 2], dpds[kb][4 * rg + 3],
+                                    Dp, Dp, Dp, Dp, hw[2 * rg], hw[2 * rg + 1], lw[2 * rg], lw[2 * rg + 1]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { dpds[kb][e] = __uint_as_float(hw[e]); dpds[kb][8 + e] = __uint_as_float(lw[e]); }
+                } else dpds[kb] = zero16();
+                stage_fence();
+            }
+#undef IMG_LOAD
+        }
+        // ---- phase B.2: dQ^T += E'^T dR'^T -- the bf16 kernel's un-skew loop, once on (E'_lo, dS'_hi), once on E'_hi with BOTH planes of dS'
+        f32x16 dq[DPK];
+#pragma unroll
+        for (int db = 0; db < DPK; ++db) dq[db] = zero16();
+        const unsigned char* tabB = (const unsigned char*)uniform_ptr(p.tab + (long long)H * NU * KS * 512 + ((long long)hd * NU + (UOFF - w)) * (NF * 512));
+        const unsigned lane16 = lane * 16;
+        auto unskew_pass = [&](auto both_c, const unsigned char* tb0) {
+            constexpr bool BOTH = both_c;                            // BOTH: planes hi and lo of dS' (two buffers), else the hi plane only
+            bf16_t* us = (bf16_t*)buf;
+            bf16_t* usw = us + SKP * n + 4 * h + 32;
+            const bf16_t* usr = us + (SKP + 1) * n + 8 * h + 1;
+            constexpr int P2 = SK_WORDS;                              // element offset of the second plane's buffer
+            const u32x2 z2 = {0u, 0u};
+            u32x4 tf[2][NF];
+#define TAB_LOAD(BUF, UB) do { const unsigned char* tb_ = (const unsigned char*)uniform_ptr(tb0 + (long long)(UB) * (NF * 1024)); \
+        aload16<0>(tf[BUF][0], tb_, lane16); aload16<1024>(tf[BUF][1], tb_, lane16); \
+        if (NF > 2) { aload16<2048>(tf[BUF][NF > 2 ? 2 : 0], tb_, lane16); aload16<3072>(tf[BUF][NF > 3 ? 3 : 0], tb_, lane16); } \
+        if (NF > 4) { const unsigned char* t2_ = (const unsigned char*)uniform_ptr(tb_ + 4096); aload16<0>(tf[BUF][NF > 4 ? 4 : 0], t2_, lane16); aload16<1024>(tf[BUF][NF > 5 ? 5 : 0], t2_, lane16); } } while (0)
+            TAB_LOAD(0, 0);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) { *(u32x2*)(usw - 32 + 8 * rg) = z2; if (BOTH) *(u32x2*)(usw + P2 - 32 + 8 * rg) = z2; }        // key block "-1"
+#pragma unroll
+            for (int kb = 0; kb <= NT; ++kb) {
+                const int cur = kb & 1;
+                // the rows of the buffer overlay each other (row n + 1's block u - 2 sits on row n's block u): the order of the LANES' writes matters.  Lock-step on the
+                // hardware; the host emulator runs a lane until its next rendezvous, and in this loop (unlike the bf16 kernel's, whose dP MFMAs sit in front of the
+                // writes) nothing else would make the lanes meet between the blocks
+                wave_lds_sync();
+                if (kb < NT) { TAB_LOAD(cur ^ 1, kb + 1 <= NT ? kb + 1 : NT); await_vm<NF>(); } else await_vm<0>();
+#pragma unroll
+                for (int f = 0; f < NF; ++f) apin(tf[cur][f]);
+                if (kb < NT && !blk_out(kb, w, D)) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const u32x2 v = {__float_as_uint(dpds[kb < NT ? kb : 0][2 * rg]), __float_as_uint(dpds[kb < NT ? kb : 0][2 * rg + 1])};
+                        *(u32x2*)(usw + 32 * kb + 8 * rg) = v;
+                        if (BOTH) { const u32x2 u = {__float_as_uint(dpds[kb < NT ? kb : 0][8 + 2 * rg]), __float_as_uint(dpds[kb < NT ? kb : 0][8 + 2 * rg + 1])}; *(u32x2*)(usw + P2 + 32 * kb + 8 * rg) = u; }
+                    }
+                } else if (rblk_need(kb, w, D) || (kb < NT && rblk_need(kb + 1, w, D))) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) { *(u32x2*)(usw + 32 * kb + 8 * rg) = z2; if (BOTH) *(u32x2*)(usw + P2 + 32 * kb + 8 * rg) = z2; }
+                }
+                if (rblk_need(kb, w, D)) {
+                    wave_lds_sync();
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        unsigned rw[4], rl[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            rw[e] = (unsigned)usr[32 * kb + 16 * s2 + 2 * e] | ((unsigned)usr[32 * kb + 16 * s2 + 2 * e + 1] << 16);
+                            if (BOTH) rl[e] = (unsigned)usr[P2 + 32 * kb + 16 * s2 + 2 * e] | ((unsigned)usr[P2 + 32 * kb + 16 * s2 + 2 * e + 1] << 16); else rl[e] = 0u;
+                        }
+                        const bf16x8 rb = __builtin_bit_cast(bf16x8, (u32x4){rw[0], rw[1], rw[2], rw[3]});
+                        const bf16x8 rbl = __builtin_bit_cast(bf16x8, (u32x4){rl[0], rl[1], rl[2], rl[3]});
+
+#pragma unroll
+                        for (int db = 0; db < DPK; ++db) {
+                            if (BOTH) dq[db] = mfma32(__builtin_bit_cast(bf16x8, tf[cur][s2 * DPK + db]), rbl, dq[db]);
+                            dq[db] = mfma32(__builtin_bit_cast(bf16x8, tf[cur][s2 * DPK + db]), rb, dq[db]);
+                        }
+                    }
+                    wave_lds_sync();
+                }
+                stage_fence();
+            }
+#undef TAB_LOAD
+        };
+        unskew_pass(std::false_type{}, tabB + p.lo_tab * 2);        // E'_lo^T . dR'_hi
+        unskew_pass(std::true_type{}, tabB);                         // E'_hi^T . (dR'_lo + dR'_hi)
+        __syncthreads();                                             // 2: K_p is in LDS
+
+        // ---- phase C (K planes resident): dQ^T += K^T dS'^T, three plane products
+        {
+            const unsigned char* Kh = R1; const unsigned char* Kl = R1 + kbytes;
+            const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+            const int klane = 4 * h + (i16 >> 2), kcol = (16 * g16 + 4 * (i16 & 3)) * 2;
+#pragma unroll
+            for (int kb = 0; kb < NT; ++kb) {
+                if (blk_out(kb, w, D)) continue;
+                const int j0 = 32 * kb;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 sbh = __builtin_bit_cast(bf16x8, (f32x4){dpds[kb][4 * s2], dpds[kb][4 * s2 + 1], dpds[kb][4 * s2 + 2], dpds[kb][4 * s2 + 3]});
+                    const bf16x8 sbl = __builtin_bit_cast(bf16x8, (f32x4){dpds[kb][8 + 4 * s2], dpds[kb][8 + 4 * s2 + 1], dpds[kb][8 + 4 * s2 + 2], dpds[kb][8 + 4 * s2 + 3]});
+                    int r0 = j0 + 16 * s2 + klane, r1 = r0 + 8;
+                    r0 = r0 < T ? r0 : T - 1; r1 = r1 < T ? r1 : T - 1;
+                    const int o0 = r0 * KPB + kcol, o1 = r1 * KPB + kcol;
+#pragma unroll
+                    for (int db = 0; db < DPK; ++db) {
+                        const bf16x8 kh = tr_frag(Kh + o0 + 64 * db, Kh + o1 + 64 * db), kl = tr_frag(Kl + o0 + 64 * db, Kl + o1 + 64 * db);
+                        dq[db] = mfma32(kl, sbh, dq[db]);
+                        dq[db] = mfma32(kh, sbl, dq[db]);
+                        dq[db] = mfma32(kh, sbh, dq[db]);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                             // 3: the loader may overwrite K_p with V_p+1
+        bf16_t* drow = p.dqkv + ((long long)b * T + i0) * ld + hd * p.dp;
+        const int nrows = T - i0 < 32 ? T - i0 : 32;
+        store_rows_t<DPK, 0>(buf, dq, p.scale * p.oscale, drow, ld, nrows, lane);
+        store_rows_t<DPK, 1>(buf, dq, p.scale * p.oscale, drow + p.lo_dqkv, ld, nrows, lane);
+    }
+}
+
+// =========================================================================== x3 backward, key-major: dK, dV
+// The mirrored tile (lane = key).  LDS: [region 1: the dO planes (pitch dp*2+16: row fragments AND transposing reads), later the Q planes (pitch dp*2) | D' |
+// per-wave buffer: image block hi + lo (4 KiB) / output staging].  One workgroup per pair:
+//     dO planes -> LDS | dP of every query block (three plane products, V fragments of one plane live at a time) | per query block: image -> dS' words (kept in the
+//     registers of its dP) and dV^T += dO^T P~ (three products) | barrier | Q planes -> LDS | dK^T += Q^T dS' (three products) | dK, dV out as planes
+template <int DPK, int NT>
+__global__ __launch_bounds__(NT * 64) void attn_t_bwd_kv_x3_kernel(KP p)
+{
+    constexpr int KS = 2 * DPK, QPB = DPK * 64, OPB = DPK * 64 + KPAD;
+    SS_DYN_SMEM(lds);
+    const int T = p.T, D = p.D, H = p.H;
+    const int pair = blockIdx.x, b = pair / H, hd = pair - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, w = uniform(tid >> 6), n = lane & 31, h = lane >> 5;
+    const long long ld = 3LL * H * p.dp, ldo = (long long)H * p.dp;
+    const size_t qbytes = ((size_t)T * QPB + 15) & ~(size_t)15, obytes = (size_t)T * OPB;
+    unsigned char* R1 = (unsigned char*)lds;
+    float* Ds = (float*)(R1 + 2 * (qbytes > obytes ? qbytes : obytes));
+    unsigned char* buf = (unsigned char*)(Ds + 32 * NT) + (size_t)w * BWX_BUF;
+    const bf16_t* base = p.qkv + (long long)b * T * ld + hd * p.dp;
+    unsigned char* Oh = R1; unsigned char* Ol = R1 + obytes;
+    stage_table<DPK>(Oh, OPB, p.dO + (long long)b * T * ldo + hd * p.dp, ldo, T, tid, blockDim.x);
+    stage_table<DPK>(Ol, OPB, p.dO + p.lo_dO + (long long)b * T * ldo + hd * p.dp, ldo, T, tid, blockDim.x);
+    for (int i = tid; i < 32 * NT; i += blockDim.x) Ds[i] = i < T ? p.Dv[((long long)b * H + hd) * T + i] : 0.f;
+
+    const unsigned char* img = (const unsigned char*)uniform_ptr(p.pimg + pimg_block(pair, NT, 0, w));
+    int lo = 0, hi = NT - 1;
+    while (lo < NT - 1 && blk_out(lo, w, D)) ++lo;
+    while (hi > 0 && blk_out(hi, w, D)) --hi;
+    const unsigned lane16 = lane * 16;
+    u32x4 ic[4];                                                     // one image block in flight: hi (2 KiB) and lo (2 KiB), 16 bytes per lane each
+#define IMG_LOAD(IB) do { const unsigned char* ib_ = (const unsigned char*)uniform_ptr(img + (long long)((IB) < lo ? lo : (IB) > hi ? hi : (IB)) * (NT * 2048)); \
+        const unsigned char* il_ = (const unsigned char*)uniform_ptr(ib_ + p.lo_pimg); \
+        aload16<0>(ic[0], ib_, lane16); aload16<1024>(ic[1], ib_, lane16); aload16<0>(ic[2], il_, lane16); aload16<1024>(ic[3], il_, lane16); } while (0)
+    IMG_LOAD(0);
+
+    const int j0 = 32 * w, kj = j0 + n;
+    const bf16_t* vrow = base + 2LL * H * p.dp + (long long)(kj < T ? kj : T - 1) * ld + 8 * h;
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int qlane = 4 * h + (i16 >> 2), qcol = (16 * g16 + 4 * (i16 & 3)) * 2;
+    int ioff[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) { const int nq = 8 * rg + 4 * h + (i16 >> 2), kg = 4 * g16 + (i16 & 3); ioff[rg] = (kg >> 1) * 512 + pimg_slot(nq, kg & 1, kg >> 1) * 8; }
+    __syncthreads();
+
+    // ---- dP = dO V^T of every query block in the band (rows = queries, lane = key): three plane products in dpds[qb]
+    f32x16 dpds[NT];
+    {
+        bf16x8 vf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { const bf16x8 v = *(const bf16x8*)(vrow + p.lo_qkv + 16 * s); vf[s] = kj < T ? v : zero8(); }
+#pragma unroll
+        for (int qb = 0; qb < NT; ++qb) {
+            if (blk_out(qb, w, D)) continue;
+            f32x16 a = zero16();
+            int row = 32 * qb + n; row = row < T ? row : T - 1;
+            const unsigned char* op = Oh + row * OPB + 16 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a = mfma32(*(const bf16x8*)(op + 32 * s), vf[s], a);               // dO_hi . V_lo
+            dpds[qb] = a;
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { const bf16x8 v = *(const bf16x8*)(vrow + 16 * s); vf[s] = kj < T ? v : zero8(); }
+#pragma unroll
+        for (int qb = 0; qb < NT; ++qb) {
+            if (blk_out(qb, w, D)) continue;
+            f32x16 a = dpds[qb];
+            int row = 32 * qb + n; row = row < T ? row : T - 1;
+            const unsigned char* ol = Ol + row * OPB + 16 * h; const unsigned char* oh = Oh + row * OPB + 16 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a = mfma32(*(const bf16x8*)(ol + 32 * s), vf[s], a);               // dO_lo . V_hi
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a = mfma32(*(const bf16x8*)(oh + 32 * s), vf[s], a);               // dO_hi . V_hi
+            dpds[qb] = a;
+        }
+    }
+    // ---- per query block: the image block (hi, lo) through LDS (transposing reads) -> dS' words and dV^T += dO^T P~
+    f32x16 dv[DPK];
+#pragma unroll
+    for (int db = 0; db < DPK; ++db) dv[db] = zero16();
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb) {
+        await_vm<0>();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) apin(ic[i]);
+        const bool in_band = !blk_out(qb, w, D);
+        if (in_band) {
+            *(u32x4*)(buf + lane * 16) = ic[0]; *(u32x4*)(buf + 1024 + lane * 16) = ic[1];
+            *(u32x4*)(buf + 2048 + lane * 16) = ic[2]; *(u32x4*)(buf + 3072 + lane * 16) = ic[3];
+        }
+        stage_fence();
+        if (qb + 1 < NT) IMG_LOAD(qb + 1);                           // (its registers were just stored: a whole block of work hides the load)
+        if (in_band) {
+            const int q0 = 32 * qb;
+            wave_lds_sync();
+            unsigned pwh[8], pwl[8], hw[8], lw[8];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const u32x2 iwh = __builtin_bit_cast(u32x2, lds_read_tr16(buf + ioff[rg]));
+                const u32x2 iwl = __builtin_bit_cast(u32x2, lds_read_tr16(buf + 2048 + ioff[rg]));
+                const f32x4 dd = *(const f32x4*)(Ds + q0 + 8 * rg + 4 * h);
+                ds_words_x3(iwh[0], iwh[1], iwl[0], iwl[1], dpds[qb][4 * rg], dpds[qb][4 * rg + 1], dpds[qb][4 * rg + 2], dpds[qb][4 * rg + 3], dd[0], dd[1], dd[2], dd[3],
+                            hw[2 * rg], hw[2 * rg + 1], lw[2 * rg], lw[2 * rg + 1]);
+                pwh[2 * rg] = keep_pos(iwh[0]); pwh[2 * rg + 1] = keep_pos(iwh[1]);
+                pwl[2 * rg] = keep_lo(iwh[0], iwl[0]); pwl[2 * rg + 1] = keep_lo(iwh[1], iwl[1]);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dpds[qb][e] = __uint_as_float(hw[e]); dpds[qb][8 + e] = __uint_as_float(lw[e]); }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pbh = __builtin_bit_cast(bf16x8, (u32x4){pwh[4 * s2], pwh[4 * s2 + 1], pwh[4 * s2 + 2], pwh[4 * s2 + 3]});
+                const bf16x8 pbl = __builtin_bit_cast(bf16x8, (u32x4){pwl[4 * s2], pwl[4 * s2 + 1], pwl[4 * s2 + 2], pwl[4 * s2 + 3]});
+                int r0 = q0 + 16 * s2 + qlane, r1 = r0 + 8;
+                r0 = r0 < T ? r0 : T - 1; r1 = r1 < T ? r1 : T - 1;
+                const int o0 = r0 * OPB + qcol, o1 = r1 * OPB + qcol;
+#pragma unroll
+                for (int db = 0; db < DPK; ++db) {
+                    const bf16x8 dh_ = tr_frag(Oh + o0 + 64 * db, Oh + o1 + 64 * db), dl_ = tr_frag(Ol + o0 + 64 * db, Ol + o1 + 64 * db);
+                    dv[db] = mfma32(dl_, pbh, dv[db]);
+                    dv[db] = mfma32(dh_, pbl, dv[db]);
+                    dv[db] = mfma32(dh_, pbh, dv[db]);
+                }
+            }
+        } else dpds[qb] = zero16();
+        stage_fence();
+    }
+#undef IMG_LOAD
+    __syncthreads();                                                 // every wave is done with the dO planes
+    unsigned char* Qh = R1; unsigned char* Ql = R1 + qbytes;
+    stage_table<DPK>(Qh, QPB, base, ld, T, tid, blockDim.x);
+    stage_table<DPK>(Ql, QPB, base + p.lo_qkv, ld, T, tid, blockDim.x);
+    __syncthreads();
+    // ---- dK^T += Q^T dS' (three plane products)
+    f32x16 dk[DPK];
+#pragma unroll
+    for (int db = 0; db < DPK; ++db) dk[db] = zero16();
+#pragma unroll
+    for (int qb = 0; qb < NT; ++qb) {
+        if (blk_out(qb, w, D)) continue;
+        const int q0 = 32 * qb;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 sbh = __builtin_bit_cast(bf16x8, (f32x4){dpds[qb][4 * s2], dpds[qb][4 * s2 + 1], dpds[qb][4 * s2 + 2], dpds[qb][4 * s2 + 3]});
+            const bf16x8 sbl = __builtin_bit_cast(bf16x8, (f32x4){dpds[qb][8 + 4 * s2], dpds[qb][8 + 4 * s2 + 1], dpds[qb][8 + 4 * s2 + 2], dpds[qb][8 + 4 * s2 + 3]});
+            int r0 = q0 + 16 * s2 + qlane, r1 = r0 + 8;
+            r0 = r0 < T ? r0 : T - 1; r1 = r1 < T ? r1 : T - 1;
+            const int o0 = r0 * QPB + qcol, o1 = r1 * QPB + qcol;
+#pragma unroll
+            for (int db = 0; db < DPK; ++db) {
+                const bf16x8 qh_ = tr_frag(Qh + o0 + 64 * db, Qh + o1 + 64 * db), ql_ = tr_frag(Ql + o0 + 64 * db, Ql + o1 + 64 * db);
+                dk[db] = mfma32(ql_, sbh, dk[db]);
+                dk[db] = mfma32(qh_, sbl, dk[db]);
+                dk[db] = mfma32(qh_, sbh, dk[db]);
+            }
+        }
+    }
+    const int nrows = T - j0 < 32 ? T - j0 : 32;
+    bf16_t* drow = p.dqkv + ((long long)b * T + j0) * ld + hd * p.dp;
+    store_rows_t<DPK, 0>(buf, dk, p.scale * p.oscale, drow + (long long)H * p.dp, ld, nrows, lane);
+    store_rows_t<DPK, 1>(buf, dk, p.scale * p.oscale, drow + p.lo_dqkv + (long long)H * p.dp, ld, nrows, lane);
+    store_rows_t<DPK, 0>(buf, dv, p.oscale, drow + 2LL * H * p.dp, ld, nrows, lane);
+    store_rows_t<DPK, 1>(buf, dv, p.oscale, drow + p.lo_dqkv + 2LL * H * p.dp, ld, nrows, lane);
+}
+
 // =========================================================================== tables
 // E' = E / scale (transformer.py:172-176 embeddings, f32 [H][2D-1][dh]) in MFMA-fragment order, zero outside [0, 2D-2] and beyond dh:
 //   part F  [H][NU][2 DPK][64][8]      A[m = rel][k = d]:  rel = 32 u + D - 32 + (lane & 31),              d = 16 s + 8 (lane >> 5) + e
 //   part B  [H][NU][2][DPK][64][8]     A[m = d][k = rel]:  rel = 32 u + D - 32 + 16 s2 + 8 (lane >> 5) + e, d = 32 db + (lane & 31)
-__global__ void attn_t_tables_kernel(const float* __restrict__ emb, int H, int D, int dh, int DPK, float inv_scale, bf16_t* __restrict__ tab)
+// x3: tab_lo != null -> the value is split, hi = bf16(v) into tab, lo = bf16(v - hi) into tab_lo (same order)
+__global__ void attn_t_tables_kernel(const float* __restrict__ emb, int H, int D, int dh, int DPK, float inv_scale, bf16_t* __restrict__ tab, bf16_t* __restrict__ tab_lo)
 {
     const int KS = 2 * DPK;
     const long long partF = (long long)H * NU * KS * 512, total = 2 * partF;
@@ -773,7 +1434,9 @@ __global__ void attn_t_tables_kernel(const float* __restrict__ emb, int H, int D
         else { const int db = j % DPK; j /= DPK; const int s2 = j & 1; j >>= 1; const int ui = j % NU; hd = (int)(j / NU); rel = 32 * (ui - UOFF) + D - 32 + 16 * s2 + 8 * (lane >> 5) + e; d = 32 * db + (lane & 31); }
         float v = 0.f;
         if (rel >= 0 && rel <= 2 * D - 2 && d < dh) v = emb[((long long)hd * (2 * D - 1) + rel) * dh + d] * inv_scale;
-        tab[i] = f2bf(v);
+        const bf16_t hv = f2bf(v);
+        tab[i] = hv;
+        if (tab_lo) tab_lo[i] = f2bf(v - bf2f(hv));
     }
 }
 
@@ -781,6 +1444,10 @@ size_t bwdq_smem(int T, int dp, int waves) { return dma_table_bytes(T, dp * 2) +
 size_t bwd_smem(int T, int dp, int waves) { return (((size_t)T * dp * 2 + 15) & ~(size_t)15) + (size_t)T * (dp * 2 + KPAD) + (size_t)waves * (32 * 4 + BW_BUF) + 16; }
 size_t fwd_smem(int T, int dp, int waves) { return dma_table_bytes(T, dp * 2 + KPAD) + dma_table_bytes(T, dp * 2) + (size_t)waves * SK_WORDS * 4; }
 const size_t LDS_MAX = 160 * 1024;
+static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+size_t fwd_x3_smem(int T, int dp, int waves) { return 2 * dma_table_bytes(T, dp * 2 + KPAD) + max2(2 * dma_table_bytes(T, dp * 2), (size_t)waves * SK_WORDS * 4); }
+size_t bwdq_x3_smem(int T, int dp, int waves) { return 2 * max2(dma_table_bytes(T, dp * 2), dma_table_bytes(T, dp * 2 + KPAD)) + (size_t)waves * BWX_BUF + 16; }
+size_t bwd_x3_smem(int T, int dp, int waves) { return 2 * max2((((size_t)T * dp * 2 + 15) & ~(size_t)15), (size_t)T * (dp * 2 + KPAD)) + (size_t)waves * (32 * 4 + BWX_BUF) + 16; }
 
 void fill(KP& p, const AttnTArgs& a)
 {
@@ -802,6 +1469,11 @@ void fill(KP& p, const AttnTArgs& a)
     }
 #endif
     p.seedfold = (unsigned)a.seed ^ ((unsigned)(a.seed >> 32) * 0x9E3779B9u) ^ (a.stream_id * 0x85EBCA6Bu);
+    // x3: plane offsets (elements; bytes for the image).  Zero for the bf16 kernels.
+    auto eoff = [](const void* lo, const void* hi) { return (lo && hi) ? (long long)(((const char*)lo - (const char*)hi) / 2) : 0LL; };
+    p.lo_qkv = eoff(a.qkv_lo, a.qkv); p.lo_out = eoff(a.out_lo, a.out); p.lo_dO = eoff(a.dO_lo, a.dO); p.lo_O = eoff(a.O_lo, a.O); p.lo_dqkv = eoff(a.dqkv_lo, a.dqkv);
+    p.lo_tab = a.qkv_lo ? attn_t_table_bytes(a.H, a.dp) / 2 : 0;
+    p.lo_pimg = a.qkv_lo ? attn_t_saved_bytes(a.B, a.H, a.T) : 0;
 }
 
 typedef void (*Kern)(KP);
@@ -825,7 +1497,15 @@ int attn_t_prepare_tables(const float* emb, int H, int D, int dh, int dp, float 
 {
     const long long total = attn_t_table_bytes(H, dp) / 2;
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-    SS_LAUNCH(attn_t_tables_kernel, dim3(blocks), dim3(256), 0, stream, emb, H, D, dh, dp / 32, 1.f / scale, (bf16_t*)tab);
+    SS_LAUNCH(attn_t_tables_kernel, dim3(blocks), dim3(256), 0, stream, emb, H, D, dh, dp / 32, 1.f / scale, (bf16_t*)tab, (bf16_t*)nullptr);
+    return 0;
+}
+// x3: [hi table | lo table], each attn_t_table_bytes(H, dp) long
+int attn_t_prepare_tables_x3(const float* emb, int H, int D, int dh, int dp, float scale, void* tab, void* stream)
+{
+    const long long total = attn_t_table_bytes(H, dp) / 2;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    SS_LAUNCH(attn_t_tables_kernel, dim3(blocks), dim3(256), 0, stream, emb, H, D, dh, dp / 32, 1.f / scale, (bf16_t*)tab, (bf16_t*)tab + total);
     return 0;
 }
 
@@ -883,6 +1563,53 @@ template <int DPK> static Kern bkv_pick(int nt)
     case 1: return attn_t_bwd_kv_kernel<DPK, 1>; case 2: return attn_t_bwd_kv_kernel<DPK, 2>; case 3: return attn_t_bwd_kv_kernel<DPK, 3>; case 4: return attn_t_bwd_kv_kernel<DPK, 4>;
     case 5: return attn_t_bwd_kv_kernel<DPK, 5>; case 6: return attn_t_bwd_kv_kernel<DPK, 6>; default: return attn_t_bwd_kv_kernel<DPK, 7>;
     }
+}
+
+// ---- x3 (hi / lo planes): same grids as the bf16 kernels
+bool attn_t_x3_supported(int T, int dp, int D)
+{
+    if (T < 1 || T > 32 * NTM || dp % 32 != 0 || dp < 32 || dp > 96 || D < 1 || D > 100) return false;
+    const int nt = (T + 31) / 32;
+    return fwd_x3_smem(T, dp, nt) <= LDS_MAX && bwd_x3_smem(T, dp, nt) <= LDS_MAX && bwdq_x3_smem(T, dp, nt) <= LDS_MAX;
+}
+template <int DPK, bool DROP> static Kern fwd_x3_pick(int nt)
+{
+    switch (nt) {
+    case 1: return attn_t_fwd_x3_kernel<DPK, 1, DROP>; case 2: return attn_t_fwd_x3_kernel<DPK, 2, DROP>; case 3: return attn_t_fwd_x3_kernel<DPK, 3, DROP>;
+    case 4: return attn_t_fwd_x3_kernel<DPK, 4, DROP>; case 5: return attn_t_fwd_x3_kernel<DPK, 5, DROP>; case 6: return attn_t_fwd_x3_kernel<DPK, 6, DROP>;
+    default: return attn_t_fwd_x3_kernel<DPK, 7, DROP>;
+    }
+}
+template <int DPK> static Kern bq_x3_pick(int nt)
+{
+    switch (nt) {
+    case 1: return attn_t_bwd_q_x3_kernel<DPK, 1>; case 2: return attn_t_bwd_q_x3_kernel<DPK, 2>; case 3: return attn_t_bwd_q_x3_kernel<DPK, 3>; case 4: return attn_t_bwd_q_x3_kernel<DPK, 4>;
+    case 5: return attn_t_bwd_q_x3_kernel<DPK, 5>; case 6: return attn_t_bwd_q_x3_kernel<DPK, 6>; default: return attn_t_bwd_q_x3_kernel<DPK, 7>;
+    }
+}
+template <int DPK> static Kern bkv_x3_pick(int nt)
+{
+    switch (nt) {
+    case 1: return attn_t_bwd_kv_x3_kernel<DPK, 1>; case 2: return attn_t_bwd_kv_x3_kernel<DPK, 2>; case 3: return attn_t_bwd_kv_x3_kernel<DPK, 3>; case 4: return attn_t_bwd_kv_x3_kernel<DPK, 4>;
+    case 5: return attn_t_bwd_kv_x3_kernel<DPK, 5>; case 6: return attn_t_bwd_kv_x3_kernel<DPK, 6>; default: return attn_t_bwd_kv_x3_kernel<DPK, 7>;
+    }
+}
+int attn_t_forward_x3(const AttnTArgs& a, void* stream)
+{
+    KP p; fill(p, a);
+    const int dpk = a.dp / 32, waves = p.nt;
+    Kern k = dpk == 1 ? (p.drop ? fwd_x3_pick<1, true>(p.nt) : fwd_x3_pick<1, false>(p.nt)) : dpk == 2 ? (p.drop ? fwd_x3_pick<2, true>(p.nt) : fwd_x3_pick<2, false>(p.nt))
+                                                                                            : (p.drop ? fwd_x3_pick<3, true>(p.nt) : fwd_x3_pick<3, false>(p.nt));
+    return launch(k, persistent_blocks(a.B * a.H, a.H), waves + 1, fwd_x3_smem(a.T, a.dp, waves), stream, p);
+}
+int attn_t_backward_x3(const AttnTArgs& a, void* stream)
+{
+    KP p; fill(p, a);
+    const int dpk = a.dp / 32, waves = p.nt;
+    const Kern kq = dpk == 1 ? bq_x3_pick<1>(p.nt) : dpk == 2 ? bq_x3_pick<2>(p.nt) : bq_x3_pick<3>(p.nt);
+    const Kern kkv = dpk == 1 ? bkv_x3_pick<1>(p.nt) : dpk == 2 ? bkv_x3_pick<2>(p.nt) : bkv_x3_pick<3>(p.nt);
+    if (launch(kq, persistent_blocks(a.B * a.H, a.H), waves + 1, bwdq_x3_smem(a.T, a.dp, waves), stream, p)) return 1;      // also writes D' for the key-major kernel
+    return launch(kkv, a.B * a.H, waves, bwd_x3_smem(a.T, a.dp, waves), stream, p);
 }
 
 int attn_t_backward(const AttnTArgs& a, void* stream)

@@ -82,9 +82,17 @@ struct Plan {
     reduce_fn hook = 0; void* hook_user = 0;
     event_fn on_event = 0; void* event_user = 0;
     int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1, regate_on = 1, f32_x3 = 0;
+    int x3_attn = 0;         // option 8: the bound EF tables are the [hi | lo] tables of ss_relpos_attention_x3_prepare_tables -> an f32_x3 plan with planes runs the attention on them
     int x3_planes = 1;       // option 7: an f32_x3 plan runs every GEMM the 8-wave kernel can take on hi / lo bf16 planes (off = operands split in registers on the 128 x 128 kernels, round 4)
     Ctx* cur = nullptr;      // the context of the call in flight (plane cache)
     bool use_planes() const { return D.dtype == SS_F32 && f32_x3 && x3_planes; }
+    // the attention of the parity-grade mode on hi / lo planes (attention_t.hip x3 kernels): its outputs exist ONLY as planes, so every consumer must be a plane GEMM
+    bool use_x3_attention(int T) const { return use_planes() && x3_attn && dw_grouped && ss_relpos_attention_x3_supported(T, D.dp, D.max_rel); }
+    // a buffer that already holds [hi plane | lo plane] (written by a kernel that emits planes): consumers find it in the cache under `key`
+    void adopt_planes(const void* key, void* hi, long long n) {
+        PlaneCache& pc = cur->planes;
+        if (key && pc.n < MAX_PLANES) { pc.key[pc.n] = key; pc.hi[pc.n] = hi; pc.elems[pc.n] = n; ++pc.n; }
+    }
     int keep_input = 0;      // option 6: leave x_raw as it is (the shifted signal is only handed out in `shifted`; a functional caller copies it back itself)
     hipEvent_t ev_fork = 0, ev_join = 0;
     size_t esz() const { return D.dtype == SS_BF16 ? 2 : 4; }
@@ -371,7 +379,8 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
     const int Tp = round_up(T, 8);
     const float scale = 1.0f / sqrtf((float)D.d_qkv);
     c->Tp = Tp; c->scale = scale;
-    c->need_T = ss_relpos_attention_needs_transposed(dt, T, dp, Dr);
+    const bool x3att = use_x3_attention(T);
+    c->need_T = x3att ? 0 : ss_relpos_attention_needs_transposed(dt, T, dp, Dr);
     for (int l = 0; l < D.n_layers; ++l) {
         LayerP& w = layers[l]; LayerCtx& s = c->layer[l];
         s.x = x;
@@ -385,8 +394,17 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         void* o = X.alloc((size_t)M * HD * es);
         float* lse = (float*)X.alloc((size_t)B * H * T * 4);
         // training: the resident forward leaves its probabilities for the backward kernels (no recomputation of the logits there)
-        const size_t pimg_bytes = training ? (size_t)ss_relpos_attention_saved_bytes(dt, B, H, T, dp, Dr) : 0;
+        const size_t pimg_bytes = training ? (size_t)(x3att ? ss_relpos_attention_x3_saved_bytes(B, H, T, dp, Dr) : ss_relpos_attention_saved_bytes(dt, B, H, T, dp, Dr)) : 0;
         void* pimg = pimg_bytes ? X.alloc(pimg_bytes) : nullptr;
+        if (x3att) {
+            // qkv is split once (the backward finds its planes in the cache); o leaves as planes IN the f32-sized buffer: [hi M x HD | lo M x HD] bf16
+            const Pl q = planes(X, qkv, qkv, (long long)M * 3 * HD);
+            adopt_planes(o, o, (long long)M * HD);
+            if (!X.dry) {
+                if (!q.hi) return 1;
+                L_(timed(X, "attn_fwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 3.0, (double)M * 4 * HD * es, stream, [&] { return ss_relpos_attention_x3_forward(q.hi, q.lo, w.EF, o, (char*)o + (size_t)M * HD * 2, lse, pimg, B, H, T, dp, Dr, scale, p_drop, seed, 4 * l, stream); }));
+            }
+        } else
         if (!X.dry) L_(timed(X, "attn_fwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 3.0, (double)M * 4 * HD * es, stream, [&] { return ss_relpos_attention_forward_p(dt == SS_F32 && f32_x3 ? SS_F32X3 : dt, qkv, qkvT, w.E, w.EF, o, lse, pimg, B, H, T, Tp, dp, Dr, scale, p_drop, seed, 4 * l, stream); }));
         s.pimg = pimg;
         void* a = X.alloc((size_t)M * d * es);
@@ -426,6 +444,7 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
     Exec& XS = X;                       // the DwGroups allocate (operand planes) from the same bump allocator
     const bool grouped = (dt == SS_BF16 || use_planes()) && dw_grouped;
     cur = c;
+    const bool x3att = use_x3_attention(T);
 
     // ---- heads (architecture.py:82)
     const void* dh_t = dhead;
@@ -483,6 +502,14 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         } else L_(gemm(X, dt, dA, w.woT, dO, M, HD, d, RM(d), RM(d), RM(HD)));
         void* dqkv = X.alloc((size_t)M * 3 * HD * es);
         float* dsc = (float*)X.alloc((size_t)B * H * T * 4);
+        if (x3att) {
+            const Pl q = planes(X, s.qkv, s.qkv, (long long)M * 3 * HD), ol = planes(X, s.o, s.o, (long long)M * HD), dop = planes(X, dO, dO, (long long)M * HD);
+            adopt_planes(dqkv, dqkv, (long long)M * 3 * HD);
+            if (!X.dry) {
+                if (!q.hi || !ol.hi || !dop.hi) return 1;
+                L_(timed(X, "attn_bwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 5.0, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_x3_backward(q.hi, q.lo, w.EF, ol.hi, ol.lo, dop.hi, dop.lo, dsc, dqkv, (char*)dqkv + (size_t)M * 3 * HD * 2, s.pimg, B, H, T, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
+            }
+        } else
         if (!X.dry) L_(timed(X, "attn_bwd", 2.0 * B * H * band_pairs(T, Dr) * dp * 5.0, (double)M * 8 * HD * es, stream, [&] { return ss_relpos_attention_backward_p(dt == SS_F32 && f32_x3 ? SS_F32X3 : dt, s.qkv, s.qkvT, w.E, w.ET, w.EF, s.o, s.lse, dO, dOT, dsc, dqkv, s.pimg, B, H, T, Tp, dp, Dr, c->scale, p_drop, seed, 4 * l, stream); }));
         L_(grp.add(dqkv, s.x, w.wqkv_stage, 3 * HD, d, M, RM(3 * HD), RM(d), side));
         { ss_gemm_epilogue e = EPI(); e.mode = 1; L_(gemm(X, dt, dqkv, w.wqkvT, G, M, d, 3 * HD, RM(3 * HD), RM(3 * HD), RM(d), &e)); }
@@ -603,6 +630,7 @@ extern "C" int ss_plan_set_option(ss_plan* h, int what, int value)
     else if (what == 5) { old = h->p->f32_x3; h->p->f32_x3 = value != 0; }
     else if (what == 6) { old = h->p->keep_input; h->p->keep_input = value != 0; }
     else if (what == 7) { old = h->p->x3_planes; h->p->x3_planes = value != 0; }
+    else if (what == 8) { old = h->p->x3_attn; h->p->x3_attn = value != 0; }
     return old;
 }
 extern "C" int ss_plan_set_reduce_hook(ss_plan* h, ss_reduce_hook fn, void* user) { SS_CHECK(h, "null plan"); h->p->hook = (reduce_fn)fn; h->p->hook_user = user; return 0; }

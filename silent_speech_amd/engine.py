@@ -99,7 +99,9 @@ class Prepared(object):
             e['ET'] = b1.add(emb, new(H, dp, MPt), (H, dp, MPt), ((2 * D - 1) * dh, 1, dh), valid1=dh, valid2=2 * D - 1)
             # transposed-score attention kernels (bf16 rows of <= 224 frames): E / scale in MFMA-fragment order (ss_relpos_attention_prepare_tables);
             # the embeddings are never trained (transformer.py:214-218), so the table is rebuilt only when their version counter moves
-            nb = int(_lib.lib().ss_relpos_attention_table_bytes(H, dp, D)) if dt == torch.bfloat16 else 0
+            # f32 plans: the [hi | lo] tables of the plane kernels (the parity-grade mode, f32_matmul='bf16x3'; unused by the exact-f32 mode)
+            nb = int(_lib.lib().ss_relpos_attention_table_bytes(H, dp, D)) if dt == torch.bfloat16 else int(_lib.lib().ss_relpos_attention_x3_table_bytes(H, dp, D))
+            e['EF.x3'] = dt != torch.bfloat16 and nb > 0
             e['EF'] = new(max(nb // 2, 8), dtype=torch.bfloat16)
             e['EF.src'], e['EF.version'], e['EF.scale'] = a.relative_positional.embeddings, None, 1.0 / math.sqrt(dh)
             e['w1'] = cast(layer.linear1.weight)
@@ -128,7 +130,7 @@ class Prepared(object):
         for e in self.layers:
             src = e['EF.src']
             if e['EF'].numel() > 8 and e['EF.version'] != (src._version, src.data_ptr()):
-                ops.relpos_attention_tables(src, model.dp, e['EF.scale'], out=e['EF'])
+                (ops.relpos_attention_x3_tables if e['EF.x3'] else ops.relpos_attention_tables)(src, model.dp, e['EF.scale'], out=e['EF'])
                 e['EF.version'] = (src._version, src.data_ptr())
         self.version_sig = self.version_signature(model)
 
@@ -426,6 +428,8 @@ def forward(model, x_raw, training, shift_r, seed):
     L = pb.lib
     L.ss_plan_set_option(pb.handle, 5, int(model.f32_matmul == 'bf16x3'))         # (before the sizing pass: the plane form of that mode allocates operand planes)
     L.ss_plan_set_option(pb.handle, 7, int(os.environ.get('SS_AMD_X3_PLANES', '1') != '0'))
+    L.ss_plan_set_option(pb.handle, 8, int(bool(pr.layers) and all(e['EF.x3'] for e in pr.layers) and os.environ.get('SS_AMD_X3_ATTENTION', '1') != '0'))
+    L.ss_plan_set_option(pb.handle, 1, int(os.environ.get('SS_AMD_DW_GROUPED', '1') != '0'))
     nbytes = int(L.ss_plan_workspace_bytes(pb.handle, B, T0, int(training)))
     if nbytes < 0:
         raise RuntimeError('ss_plan_workspace_bytes failed: %s' % L.ss_last_error().decode())
@@ -462,6 +466,8 @@ def backward(model, ctx, dhead):
     L.ss_plan_set_option(pb.handle, 4, int(os.environ.get('SS_AMD_BN_REGATE', '1') != '0'))
     L.ss_plan_set_option(pb.handle, 5, int(model.f32_matmul == 'bf16x3'))
     L.ss_plan_set_option(pb.handle, 6, 1)
+    L.ss_plan_set_option(pb.handle, 7, int(os.environ.get('SS_AMD_X3_PLANES', '1') != '0'))
+    L.ss_plan_set_option(pb.handle, 8, int(bool(pr.layers) and all(e['EF.x3'] for e in pr.layers) and os.environ.get('SS_AMD_X3_ATTENTION', '1') != '0'))
     rc = L.ss_plan_backward(pb.handle, ctx.buf, _lib.ptr(dhead), _lib.stream_of(dhead), ctypes.c_void_p(side.cuda_stream) if side is not None else None)
     pb.raise_callback_error()
     _lib.check(rc, 'ss_plan_backward')

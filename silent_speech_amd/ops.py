@@ -360,6 +360,42 @@ def relpos_attention_backward(qkv, qkvT, E, ET, out, lse, dO, dOT, dscratch, dqk
     _lib.check(rc, 'ss_relpos_attention_backward')
 
 
+# ---- the parity-grade attention on hi / lo planes (attention_t.hip x3 kernels)
+def relpos_attention_x3_supported(T, dp, D):
+    return bool(_L().ss_relpos_attention_x3_supported(T, dp, D))
+
+
+def relpos_attention_x3_saved_bytes(B, H, T, dp, D):
+    return int(_L().ss_relpos_attention_x3_saved_bytes(B, H, T, dp, D))
+
+
+def relpos_attention_x3_tables(emb, dp, scale, out=None):
+    """E / scale in MFMA-fragment order as [hi | lo] bf16 planes (ss_relpos_attention_x3_prepare_tables); emb: [H][2D-1][dh] f32."""
+    emb = emb.detach().reshape(emb.shape[0], emb.shape[1], -1).float().contiguous()
+    H, NE, dh = emb.shape
+    D = (NE + 1) // 2
+    nbytes = int(_L().ss_relpos_attention_x3_table_bytes(H, dp, D))
+    if nbytes <= 0:
+        raise ValueError('no transposed-score attention tables for H=%d dp=%d' % (H, dp))
+    if out is None:
+        out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=emb.device)
+    _lib.check(_L().ss_relpos_attention_x3_prepare_tables(_p(emb), _p(out), H, D, dh, dp, scale, _s(emb)), 'ss_relpos_attention_x3_prepare_tables')
+    return out
+
+
+def relpos_attention_x3_forward(qkv, tab, out, lse, B, H, T, dp, D, scale, p=0.0, seed=0, rng_stream=0, saved=None):
+    """qkv, out: (hi, lo) bf16 plane pairs (split_planes); saved: uint8 buffer of relpos_attention_x3_saved_bytes or None."""
+    rc = _L().ss_relpos_attention_x3_forward(_p(qkv[0]), _p(qkv[1]), _p(tab), _p(out[0]), _p(out[1]), _p(lse), _p(saved), B, H, T, dp, D, scale, p,
+                                             int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(lse))
+    _lib.check(rc, 'ss_relpos_attention_x3_forward')
+
+
+def relpos_attention_x3_backward(qkv, tab, out, dO, dscratch, dqkv, saved, B, H, T, dp, D, scale, p=0.0, seed=0, rng_stream=0):
+    rc = _L().ss_relpos_attention_x3_backward(_p(qkv[0]), _p(qkv[1]), _p(tab), _p(out[0]), _p(out[1]), _p(dO[0]), _p(dO[1]), _p(dscratch), _p(dqkv[0]), _p(dqkv[1]),
+                                              _p(saved), B, H, T, dp, D, scale, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(dscratch))
+    _lib.check(rc, 'ss_relpos_attention_x3_backward')
+
+
 class PermuteBatch(object):
     """A table of ss_permute3d jobs executed by ONE kernel launch.  Tensors are referenced by address: they must stay
     alive and in place while the batch is in use (parameter arenas / persistent prepared buffers do)."""

@@ -297,3 +297,59 @@ def test_transposed_copies_only_needed_by_the_per_tile_kernels(dev):
         else:
             with pytest.raises(RuntimeError, match='transposed copy'):
                 ops.relpos_attention_forward(qkv, None, E, out, lse, B, H, T, 24, dp, D, 0.25)
+
+
+# ------------------------------------------------------------------ x3 on the transposed-score kernels (round 6): f32 operands as hi / lo bf16 planes
+def _run_x3_planes(dev, B, H, T, dh, D, seed, p=0.0):
+    """ss_relpos_attention_x3_forward / _backward against the f64 closed form: qkv / dO in as plane pairs, O / dqkv out as plane pairs.  The error
+    must be that of the bf16 x 3 arithmetic (about 1e-5 relative; a plain-bf16 path would sit at 1e-2)."""
+    from oracle import dropout_ref
+    dp = (dh + 31) // 32 * 32
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = [(torch.randn(B, H, T, dh, generator=g) * 0.8).double().requires_grad_(True) for _ in range(3)]
+    E = (torch.randn(H, 2 * D - 1, dh, generator=g) * dh ** -0.5)
+    dO = torch.randn(B, H, T, dh, generator=g)
+    drop, kw = None, {}
+    if p > 0:
+        mask = dropout_ref.attention_mask(2, seed + 1000, 8, B, H, T, p)          # the masks of kernel family 2
+        drop = torch.from_numpy(mask).double() / (1.0 - p)
+        kw.update(p=p, seed=seed + 1000, rng_stream=8)
+    O_ref, lse_ref = _reference(q, k, v, E.double(), D, dh, drop=drop)
+    O_ref.backward(dO.double())
+    assert ops.relpos_attention_x3_supported(T, dp, D)
+    qkv = torch.cat([_pack(t.detach().float(), dp).reshape(B * T, H * dp) for t in (q, k, v)], 1).contiguous().to(dev)
+    tab = ops.relpos_attention_x3_tables(E.to(dev), dp, 1.0 / math.sqrt(dh))
+    qkv_p = ops.split_planes(qkv)
+    out_p = [torch.full((B * T, H * dp), 7.0, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    lse = torch.zeros(B, H, T, device=dev)
+    saved = torch.zeros(ops.relpos_attention_x3_saved_bytes(B, H, T, dp, D), dtype=torch.uint8, device=dev)
+    scale = 1.0 / math.sqrt(dh)
+    ops.relpos_attention_x3_forward(qkv_p, tab, out_p, lse, B, H, T, dp, D, scale, saved=saved, **kw)
+    out = out_p[0].float() + out_p[1].float()
+    O = out.view(B, T, H, dp)[..., :dh].permute(0, 2, 1, 3)
+    assert_close_robust(O, O_ref.float(), 1e-4, name='O (x3 planes)', max_outlier_frac=0)
+    assert_close_robust(lse, lse_ref.float(), 1e-4, name='lse (x3 planes)', max_outlier_frac=0)
+    if dp > dh:
+        assert float(out.view(B, T, H, dp)[..., dh:].abs().max()) == 0.0
+    dOd = _pack(dO, dp).reshape(B * T, H * dp).contiguous().to(dev)
+    dqkv_p = [torch.full((B * T, 3 * H * dp), 7.0, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    dsc = torch.empty(B, H, T, device=dev)
+    ops.relpos_attention_x3_backward(qkv_p, tab, out_p, ops.split_planes(dOd), dsc, dqkv_p, saved, B, H, T, dp, D, scale, **kw)
+    dqkv = dqkv_p[0].float() + dqkv_p[1].float()
+    dq, dk, dv = [dqkv.view(B, T, 3, H, dp)[:, :, i, :, :dh].permute(0, 2, 1, 3) for i in range(3)]
+    assert_close_robust(dv, v.grad.float(), 3e-4, name='dV (x3 planes)', max_outlier_frac=0)
+    assert_close_robust(dk, k.grad.float(), 3e-4, name='dK (x3 planes)', max_outlier_frac=0)
+    assert_close_robust(dq, q.grad.float(), 3e-4, name='dQ (x3 planes)', max_outlier_frac=0)
+    if dp > dh:
+        assert float(dqkv.view(B, T, 3, H, dp)[..., dh:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('case', [(37, 8, 9), (70, 32, 100), (65, 32, 20), (97, 64, 33)])
+@pytest.mark.parametrize('p', [0.0, 0.25])
+def test_attention_x3_planes(dev, case, p):
+    T, dh, D = case
+    if not is_emu(dev):
+        # (d_head 96: four K / V plane tables fit the LDS up to T = 201 -- the training rows are 200; longer rows of that width keep the per-tile SS_F32X3 kernels)
+        T, dh, D = {37: (200, 96, 100), 70: (224, 64, 100), 65: (209, 64, 40), 97: (131, 96, 17)}[T]
+        assert not ops.relpos_attention_x3_supported(224, 96, 100)
+    _run_x3_planes(dev, B=2, H=2 if is_emu(dev) else 8, T=T, dh=dh, D=D, seed=T + D, p=p)

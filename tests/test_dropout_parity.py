@@ -121,7 +121,7 @@ def model_step_with_dropout(dev, dt, d, L, B, T, p, seed_base=0xD5, nthreads=Non
     pred, aux = m(None, xd, None)
     ((pred * wp.to(dev)).sum() + (aux * wa.to(dev)).sum()).backward()
     seed = m.last_seed
-    family = _lib.lib().ss_relpos_attention_family(_lib.dtype_code(dt), T, m.dp, m.max_rel) if getattr(m, 'f32_matmul', 'exact') == 'exact' else 0
+    family = m.attention_mask_family(T)
     masks = dropout_ref.layer_masks(seed, L, B, T, d, 8, 3072, p, family)
     ref = {k: v.clone() for k, v in sd.items()}
     for v in ref.values():

@@ -140,7 +140,7 @@ def _full_step_check(cfg2, cuda, dt, p, tag, f32_matmul='exact'):
     the deviation of the oracle itself under bf16 storage (the yardstick; see tests/test_dropout_parity.py)."""
     f32 = dt == torch.float32
     m, pred, aux, loss = _step(cfg2, dt, cuda, p, f32_matmul)
-    resident = _lib.lib().ss_relpos_attention_family(_lib.dtype_code(dt), 200, m.dp, m.max_rel)       # 0 per-tile, 1 resident 16 x 16, 2 transposed 32 x 32: selects the mask restatement
+    resident = m.attention_mask_family(200)       # 0 per-tile, 1 resident 16 x 16, 2 transposed 32 x 32: selects the mask restatement
     ref = _oracle(cfg2, p, resident, m.last_seed)
     yard = None if f32 else _oracle(cfg2, p, resident, m.last_seed, storage=True)
     l1 = float((pred - ref['pred']).abs().mean())
