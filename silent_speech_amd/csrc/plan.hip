@@ -233,8 +233,12 @@ struct Plan {
         ss_gemm_epilogue e = EPI(); e.bias = bias;
         ss_rowmap cm = RM(N);
         float* fused = nullptr;
-        if (!X.dry && stat_slot && fuse_stats && ss_gemm_fuses_column_stats(D.dtype, D.dtype, SS_OP_KC, SS_OP_KC, C, M, N, K, &am, &bm, &cm, &e, 1)) {
-            fused = stat_slot; e.col_sum = fused; e.col_sumsq = fused + N; e.col_shift = bn.rmean;
+        if (!X.dry && stat_slot && fuse_stats) {
+            // the 8-wave kernel accumulates the statistics in its epilogue: bf16 plans, and the plane form of the parity-grade mode (same kernel, f32 out)
+            ss_gemm_epilogue es = e; es.col_sum = stat_slot; es.col_sumsq = stat_slot + N; es.col_shift = bn.rmean;
+            const bool ok = use_planes() ? ss_gemm_planes_supported(SS_F32, C, M, N, K, &am, &bm, &cm, &es) != 0
+                                         : ss_gemm_fuses_column_stats(D.dtype, D.dtype, SS_OP_KC, SS_OP_KC, C, M, N, K, &am, &bm, &cm, &e, 1) != 0;
+            if (ok) { fused = stat_slot; e = es; }
         }
         *rc = gemm(X, D.dtype, A, Bw, C, M, N, K, am, bm, cm, &e);
         return fused;
@@ -484,7 +488,10 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         { ss_gemm_epilogue e = EPI(); e.gate = s.hid; e.gate_scale = keep_scale;
           ss_rowmap am_ = RM(d), bm_ = RM(d), cm_ = RM(ff);
           // linear1.bias.grad = column sums of dHid: accumulated by this GEMM's epilogue when the 8-wave kernel runs the shape
-          if (!X.dry && fuse_stats && ss_gemm_fuses_column_stats(dt, dt, SS_OP_KC, SS_OP_KC, dHid, M, ff, d, &am_, &bm_, &cm_, &e, 1)) { e.col_sum = w.db1; db1_fused = true; }
+          if (!X.dry && fuse_stats) {
+              ss_gemm_epilogue es = e; es.col_sum = w.db1;
+              if (use_planes() ? ss_gemm_planes_supported(SS_F32, dHid, M, ff, d, &am_, &bm_, &cm_, &es) != 0 : ss_gemm_fuses_column_stats(dt, dt, SS_OP_KC, SS_OP_KC, dHid, M, ff, d, &am_, &bm_, &cm_, &e, 1) != 0) { e = es; db1_fused = true; }
+          }
           L_(gemm(X, dt, dF, w.w2T, dHid, M, ff, d, am_, bm_, cm_, &e)); }
         L_(grp.add(dHid, s.y1, w.dw1, ff, d, M, RM(ff), RM(d), side));
         if (!db1_fused) { SIDE_BEGIN(); L_(colsum(X, dHid, M, ff, w.db1, side)); SIDE_END(); }
