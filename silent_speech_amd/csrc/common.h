@@ -128,6 +128,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 #endif
 }
+// lane l receives lane l - 1's value, lane 0 receives `fill` (DPP wave_shr:1: one full-rate VALU operation; __shfl_up would be a ds_bpermute round trip)
+__device__ __forceinline__ float wave_shr1(float v, float fill) {
+#if defined(SS_EMU)
+    const float r = __shfl_up(v, 1);
+    return (threadIdx.x & 63) == 0 ? fill : r;
+#else
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+#endif
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));

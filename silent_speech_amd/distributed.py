@@ -130,6 +130,12 @@ class DataParallel(object):
             # own would issue a collective nobody joins while the others silently kept a sum containing its stale announcement.
             if pend[1] is not None:
                 pend[1].wait()
+            # whether the announcement matched is known per rank only: every rank learns it (one more tiny host-side collective, only on the
+            # prefetch path) and ALL of them raise -- a rank that raised alone would leave the others hanging in the first BatchNorm exchange
+            bad = self._host_sum(torch.tensor([1.0 if pend[0] != local else 0.0], dtype=torch.float64))
+            if float(bad[0]) > 0.0 and pend[0] == local:
+                raise RuntimeError('DataParallel.begin_step: %d rank(s) announced next_counts that do not match the counts of this step; the step is '
+                                   'aborted on every rank (a mismatch is fatal for the whole job: the prefetched sums contain the stale announcement)' % int(bad[0]))
             if pend[0] != local:
                 raise RuntimeError('DataParallel.begin_step: rank %d announced next_counts=%r for this step but was called with %r; next_counts '
                                    'must be exactly the (rows x frames, target frames) pair of the next begin_step on every rank (pass '

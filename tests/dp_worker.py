@@ -106,7 +106,7 @@ def main():
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % os.environ['MASTER_PORT'], rank=rank, world_size=world)
     if os.environ.get('SS_DP_BAD_PREFETCH') == '1':
         # rank 1 announces counts for the next step that it then does not deliver: it must raise (and must NOT issue a collective of its own,
-        # which nobody would join); rank 0, whose announcement was right, consumes the prefetched exchange without blocking
+        # which nobody would join); rank 0, whose announcement was right, learns of the mismatch through the flag exchange and raises as well
         dp = DataParallel()
         dp.begin_step(48, 48.0, next_counts=(48 + (24 if rank == 1 else 0), 48.0))
         try:

@@ -82,9 +82,11 @@ def test_single_encoder_bucket_bf16_transport_and_count_prefetch(tmp_path):
         f.write('max |g_bf16 - g_f32| / max |g| = %.3e\n' % err)
 
 
-def test_wrong_next_counts_raise_on_the_announcing_rank_only(tmp_path):
+def test_wrong_next_counts_raise_on_every_rank(tmp_path):
     """The prefetched count exchange is always consumed; a rank whose announced next_counts do not match what it is called with raises
-    instead of issuing a rank-local extra collective (round-4 advisor finding: that collective had no partner and the job hung)."""
+    instead of issuing a rank-local extra collective (round-4 advisor finding: that collective had no partner and the job hung) -- and so does
+    EVERY other rank (round-5 advisor finding: they would otherwise walk into the first BatchNorm exchange and hang there): the mismatch flag
+    travels over the host-side group before anyone raises."""
     _ensure_emu()
     worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
     port = str(_free_port())
@@ -93,7 +95,7 @@ def test_wrong_next_counts_raise_on_the_announcing_rank_only(tmp_path):
     procs = [subprocess.Popen([sys.executable, worker, out], env=dict(env, WORLD_SIZE='2', RANK=str(r), MASTER_PORT=port, MASTER_ADDR='127.0.0.1')) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
-    assert open(out + '.rank0').read() == 'ok'
+    assert open(out + '.rank0').read().startswith('raised: DataParallel.begin_step: 1 rank(s) announced')
     assert open(out + '.rank1').read().startswith('raised: DataParallel.begin_step: rank 1 announced')
 
 

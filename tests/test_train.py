@@ -142,3 +142,25 @@ def test_bench_self_launches_its_ranks(tmp_path):
                                   env=env, timeout=600).decode()
     d1 = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
     assert d1['n_gpus'] == 1 and 'rccl' not in d1 and d1['roofline']['frac'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_share_one_gpu(tmp_path):
+    """BASELINE configs[3] as far as one GPU can take it: plain `python bench.py --gpus 8` -- the self-launcher, eight sampler shards, the count
+    exchange, 12 BatchNorm exchanges and 10 gradient buckets per step across EIGHT ranks (gloo, all on the one GPU of the test box: a functional
+    run of the N = 8 path and its memory, not a scaling figure).  What the driver's 8-GPU run adds is RCCL itself."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    if torch.cuda.device_count() < 8:
+        env['SS_BENCH_BACKEND'] = 'gloo'
+    out = subprocess.check_output([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--no-profile', '--no-legs', '--no-same'],
+                                  env=env, timeout=1500).decode()
+    d = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 8 and d['steps'] == 2 and d['value'] > 0 and d['config']['parallelism'] == 'dp8' and d['scaling'] == 'weak'
+    assert d['rccl']['world_size'] == 8 and len(d['rccl']['ranks']) == 8 and sorted(r['rank'] for r in d['rccl']['ranks']) == list(range(8))
+    assert d['allreduce']['buckets'] >= 10 and 2.0e8 < d['allreduce']['bytes_per_step'] < 2.3e8 and d['allreduce']['batchnorm_collectives_per_step'] == 12
+    assert len(d['allreduce']['exposed_ms_per_rank']) == 8
+    assert d['config']['final_loss'] == d['config']['final_loss']                     # finite on rank 0 after two 8-way steps
