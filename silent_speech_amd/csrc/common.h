@@ -156,6 +156,23 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // 2^x and 1/x straight on the transcendental unit (v_exp_f32 / v_rcp_f32, 1 ulp; no denormal fix-up code)
+__device__ __forceinline__ void compiler_fence();
+// Words in LDS that one wave writes and another wave of the workgroup polls (progress words, mailboxes).  A `volatile` access through a pointer derived
+// from the dynamic LDS block stays a FLAT access with system scope (the address-space inference pass leaves volatile operations alone):
+// flat_load/store ... sc0 sc1 followed by s_waitcnt vmcnt(0), which on gfx9 also waits for every global store the wave has in flight.  These go through
+// an address-space-3 pointer as relaxed workgroup-scope atomics instead: plain ds_read_b32 / ds_write_b32 the compiler neither caches in a register nor
+// reorders against each other (LDS serves one wave's operations in order, so "data, then progress word" needs no fence on the hardware side).
+#if defined(SS_EMU)
+__device__ __forceinline__ float lds_peek_f32(const float* p) { return *(const volatile float*)p; }
+__device__ __forceinline__ int lds_peek_i32(const int* p) { return *(const volatile int*)p; }
+__device__ __forceinline__ void lds_post_f32(float* p, float v) { *(volatile float*)p = v; }
+__device__ __forceinline__ void lds_post_i32(int* p, int v) { *(volatile int*)p = v; }
+#else
+__device__ __forceinline__ float lds_peek_f32(const float* p) { return __hip_atomic_load((__attribute__((address_space(3))) float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_peek_i32(const int* p) { return __hip_atomic_load((__attribute__((address_space(3))) int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_post_f32(float* p, float v) { __hip_atomic_store((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_post_i32(int* p, int v) { __hip_atomic_store((__attribute__((address_space(3))) int*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
 __device__ __forceinline__ float fast_exp2(float x) {
 #if defined(SS_EMU)
     return exp2f(x);

@@ -19,15 +19,15 @@ constexpr int CTC_MAX_STATES = 1024, CTC_FC = 32;      // 16 states per lane; 32
 
 }
 
-// alpha / beta as a WAVE-LEVEL scan (round 6).  One wave per (utterance, direction) -- both directions of an utterance in one workgroup of two waves --,
-// lane l owns the NS consecutive extended states l NS .. l NS + NS - 1 (NS even: 2, 4, 6, 8 or 16 >= ceil((2S+1) / 64)), so that of the two predecessors
-// of a state only those of a lane's first two states live in another lane: two wave shifts per frame, no workgroup barrier, no LDS column.
+// alpha / beta as a WAVE-LEVEL scan (round 6).  One workgroup per (utterance, direction); its W waves each own 128 consecutive extended states, lane l the
+// states 2 l (a blank) and 2 l + 1 (a label) of the wave's range: of the predecessors s, s - 1, s - 2 of a state only the label state of the lane below lives in
+// another lane -- one DPP wave shift per frame, no workgroup barrier, no LDS column.  beta is the same recursion on the reversed label string and reversed time.
 // The recursion stays in the LOG domain (a probability-domain scan with one normalisation per frame was built first: 3 VALU operations per state, but in f32
 // the paths that are "ahead of schedule" -- the only ones that still reach the last label of a long utterance -- underflow against the bulk of the mass;
-// 0.04 off in the nll of the 267-frame golden case), in base 2 on the transcendental unit, and a lane's states alternate blank / label at COMPILE time (NS even):
+// 0.04 off in the nll of the 267-frame golden case), in base 2 on the transcendental unit:
 //     blank state (two predecessors):   m + log2(1 + 2^(lo - m))                      1 v_exp + 1 v_log
 //     label state (three):              m + log2(1 + 2^(md - m) + 2^(lo - m))         2 v_exp + 1 v_log     (m / md / lo = v_max3 / v_med3 / v_min3)
-// instead of 3 expf + 1 logf (library forms) per state.  Stored: ln alpha_t(s), as before.
+// instead of 3 expf + 1 logf (library forms) per state.  Stored: log2 alpha_t(s), "minus infinity" as the finite sentinel CTC_NEG (ctc_grad_kernel reads it so).
 // (Rounds 3-5: one 256-thread workgroup per (utterance, direction), the previous column in LDS, a workgroup barrier per frame: 0.9 us per frame, 0.785 ms for a
 // 128 000-sample batch whose longest utterance has 860 frames.)
 namespace {
@@ -43,26 +43,37 @@ __device__ __forceinline__ float fast_log2(float x) {
 // 2^(x - CTC_NEG) never occurs with x > CTC_NEG as the larger argument is subtracted), so the per-frame chain carries no NaN guard and no branch --
 // the first version tested m == -inf per state and hipcc made each test a branch around the transcendentals: ~40 taken / not-taken branches per frame.
 constexpr float CTC_NEG = -1e30f;
+// (v_med3_f32 through its builtin: fminf / fmaxf make hipcc canonicalise each operand first -- v_max_f32 x, x, x, seven extra instructions per frame)
+__device__ __forceinline__ float med3(float a, float b, float c) {
+#if defined(SS_EMU)
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+#else
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#endif
+}
 __device__ __forceinline__ float lse2_b2(float a, float b) {
-    const float m = fmaxf(a, b), lo = fminf(a, b);
+    const float m = med3(a, b, INFINITY), lo = med3(a, b, -INFINITY);      // max, min
     return m + fast_log2(1.f + fast_exp2(lo - m));
 }
 __device__ __forceinline__ float lse3_b2(float a, float b, float c) {
-    const float m = fmaxf(a, fmaxf(b, c)), lo = fminf(a, fminf(b, c));
-    const float md = fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));             // the median
+    const float m = fmaxf(a, fmaxf(b, c)), lo = fminf(a, fminf(b, c)), md = med3(a, b, c);
     return m + fast_log2(1.f + fast_exp2(md - m) + fast_exp2(lo - m));
 }
 }
-// The states of one (utterance, direction) are dealt to W WAVES, 128 consecutive states each (lane l: states 2 l (blank), 2 l + 1 (label) of the wave's range).
-// State s only depends on s, s - 1, s - 2 of the previous frame, so wave w needs exactly two numbers per frame from wave w - 1 -- and never the reverse: the
-// waves form a PIPELINE through an LDS ring (CTC_R frames x 2 floats per wave pair) with a progress word per wave, no workgroup barrier; wave w simply runs
-// a frame or more behind wave w - 1.  (One wave per direction was built first: its frame costs ~150 instructions for the 6 states of a lane at SP = 283,
-// 0.47 us -- instruction issue of a single wave, with 250 CUs idle.  Two states per lane: ~45 instructions per frame.)
-// Progress protocol: a wave with a consumer publishes prog = t after writing frame t's pair (same lane, LDS operations of a wave are served in order); a
-// consumer polls the producer's word only when it has caught up with what it last saw.  The ring is protected the other way round: every wave publishes its
-// progress at least every 8 frames and a producer never runs more than CTC_R - 16 frames ahead of what its consumer last published.
+// The waves of a workgroup form a PIPELINE: state s only depends on s, s - 1, s - 2 of the previous frame, so wave w needs exactly one number per frame from
+// wave w - 1 (the label state below its range) -- and never the reverse.  It travels through an LDS ring (CTC_R frames per wave pair) with a progress word per
+// wave, no workgroup barrier; wave w simply runs a few frames behind wave w - 1.  (One wave per direction was built first: its frame costs ~150 instructions
+// for the 6 states of a lane at SP = 283, 0.47 us -- instruction issue of a single wave, with 250 CUs idle.)
+// Progress protocol, per block of CTC_B = 8 frames: a wave publishes prog = (last frame of the block) after writing the block's ring entries (same lane; LDS
+// serves a wave's operations in order); a consumer polls the producer's word before a block, until the block's last frame is there.  The ring is protected
+// the other way round: before a block a producer checks that it is at most 48 frames ahead of what its consumer last published (so never more than 55 < CTC_R).
+// What the measurements of the second version said (tools/bin/ctcdbg variants, 850-frame batch, 0.425 ms): the polled words were `volatile` FLAT accesses with
+// a vmcnt(0) behind each (the alpha stores' round trip on the chain, see common.h lds_peek / lds_post: -0.14 ms), the chunk staging loaded two values at a
+// time behind 20-instruction divisions (0.06 ms), both directions of an utterance shared the four SIMDs of one CU, the loop's lgkmcnt(0) waited for the ring
+// WRITE of the frame, and each alpha store cost five VALU operations (scale to ln, -inf select, 64-bit address).
 namespace {
-constexpr int CTC_NSW = 2, CTC_C = 64 * CTC_NSW, CTC_R = 64, CTC_LAG = 8;
+constexpr int CTC_C = 128, CTC_R = 64, CTC_B = 8;
+static_assert(CTC_FC % CTC_B == 0 && CTC_R % CTC_FC == 0, "a block of frames occupies consecutive ring slots");
 __device__ __forceinline__ void ctc_spin() {
 #if defined(SS_EMU)
     hipemu::yield_to_sched();
@@ -71,125 +82,144 @@ __device__ __forceinline__ void ctc_spin() {
 #endif
 }
 }
-__global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const float* __restrict__ logits, long long ld, int V, int blank, const float* __restrict__ lse,
-                                                              const long long* __restrict__ desc, const int* __restrict__ targets,
-                                                              float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ nll, int W)
+// row[byte offset] = v with the row in scalar registers and a 32-bit lane offset (hipcc forms a 64-bit per-lane address on the VALU for the C expression)
+__device__ __forceinline__ void ctc_store(float* row, unsigned byte_off, float v) {
+#if defined(SS_EMU)
+    *(float*)((char*)row + byte_off) = v;
+#else
+    asm volatile("global_store_dword %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(row) : "memory");
+#endif
+}
+// VP: lanes per frame in the chunk staging (32: two frames per load instruction, V <= 32; 64: one frame, V <= 64; 0: any V, staged in place)
+template <int VP>
+__global__ __launch_bounds__(512) void ctc_alpha_beta_kernel(const float* __restrict__ logits, long long ld, int V, int blank, const float* __restrict__ lse,
+                                                             const long long* __restrict__ desc, const int* __restrict__ targets,
+                                                             float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ nll, int W)
 {
-    constexpr int NS = CTC_NSW;
+    constexpr int FPP = VP ? 64 / VP : 1, NP = VP ? CTC_FC / FPP : 1;  // frames per staging pass, passes per chunk
     SS_DYN_SMEM(smem);
-    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = wave_uniform(tid >> 6);
-    const bool rev = wv >= W;
-    const int w = rev ? wv - W : wv;
+    const int u = blockIdx.x >> 1, tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
+    const bool rev = blockIdx.x & 1;
     const long long f0 = desc[u * CD + 0], T = desc[u * CD + 1], g0 = desc[u * CD + 2], S = desc[u * CD + 3], w0 = desc[u * CD + 4];
     const int SP = (int)(2 * S + 1);
-    float* pc = (float*)smem + (size_t)wv * (CTC_FC * V);                // this wave's [CTC_FC][V] staged log2-probabilities
-    volatile float* rings = (volatile float*)((float*)smem + (size_t)2 * W * (CTC_FC * V));
-    volatile int* prog = (volatile int*)(rings + (size_t)2 * W * CTC_R * 2);
-    if (lane == 0) prog[wv] = -1;
+    float* pc = (float*)smem + (size_t)w * (CTC_FC * V);                 // this wave's [CTC_FC][V] staged log2-probabilities
+    float* rings = (float*)smem + (size_t)W * (CTC_FC * V);             // polled words: lds_peek / lds_post only (see common.h)
+    int* prog = (int*)(rings + (size_t)W * CTC_R);
+    if (lane == 0) lds_post_i32(prog + w, -1);
     __syncthreads();
     float* out = (rev ? beta : alpha) + w0;
-    if (T <= 0) { if (wv == 0 && lane == 0) nll[u] = S == 0 ? 0.f : INFINITY; return; }
+    if (T <= 0) { if (!rev && w == 0 && lane == 0) nll[u] = S == 0 ? 0.f : INFINITY; return; }
     const int s0 = w * CTC_C;
     if (s0 >= SP) return;                                                // this wave owns no state of this utterance
     const bool has_prod = w > 0, has_cons = w + 1 < W && (w + 1) * CTC_C < SP;
-    volatile float* ring_in = rings + (size_t)(wv - 1) * (CTC_R * 2);   // written by wave w - 1 of this direction (has_prod only)
-    volatile float* ring_out = rings + (size_t)wv * (CTC_R * 2);
+    const float* ring_in = rings + (size_t)(w > 0 ? w - 1 : 0) * CTC_R; // written by wave w - 1 (has_prod only)
+    float* ring_out = rings + (size_t)w * CTC_R;
+    float* dump = (float*)(prog + W) + (size_t)w * (64 + CTC_B) + lane; // lanes 0 .. 62: words lane .. lane + 7 of this wave's dump row
 
-    int lab[NS]; bool skip[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const int s = s0 + lane * NS + k;                                // logical state (reversed string when rev); odd k = label states
-        lab[k] = blank; skip[k] = false;
-        if (s < SP && (k & 1)) {
-            const int j = s >> 1;
-            const int c = targets[g0 + (rev ? S - 1 - j : j)];
-            lab[k] = c;
-            if (j >= 1) skip[k] = targets[g0 + (rev ? S - j : j - 1)] != c;
-        }
+    // lane l: states sb = s0 + 2 l (blank) and sb + 1 (label j = sb / 2 of the -- for beta reversed -- string)
+    const int sb = s0 + 2 * lane;
+    int lab1 = blank; bool skip1 = false;
+    if (sb + 1 < SP) {
+        const int j = sb >> 1;
+        lab1 = targets[g0 + (rev ? S - 1 - j : j)];
+        if (j >= 1) skip1 = targets[g0 + (rev ? S - j : j - 1)] != lab1;
     }
-    float a[NS];
-    int oidx[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) { const int s_ = s0 + lane * NS + k; a[k] = CTC_NEG; oidx[k] = rev ? SP - 1 - s_ : s_; }
+    const bool val0 = sb < SP, val1 = sb + 1 < SP;
+    // the state before frame 0: probability 1 in a virtual state 0, nothing anywhere else -- the recursion itself then yields alpha_0(0) = lp(blank),
+    // alpha_0(1) = lp(first label) (2^(CTC_NEG - 0) = 0 exactly, log2(1) = 0 exactly), so that frame 0 is no special case inside the loop
+    float a0 = sb == 0 ? 0.f : CTC_NEG, a1 = CTC_NEG;
+    const unsigned ob0 = 4u * (unsigned)(rev ? SP - 1 - sb : sb), ob1 = 4u * (unsigned)(rev ? SP - 2 - sb : sb + 1);      // 32-bit byte offsets: the stores take the row from scalar registers
     float* row = out + (rev ? (T - 1) * SP : 0);
     const long long rstep = rev ? -(long long)SP : (long long)SP;
     int seen_prod = -1, seen_cons = -1;                                  // what this wave last read of its neighbours' progress words
-    float hn0 = CTC_NEG, hn1 = CTC_NEG;                                  // the producer's pair for the next frame
-    // chunks of CTC_FC frames: stage their log2-probabilities, settle every load, then run the frames of the chunk with NO load in flight -- with the
-    // staging inside one flat frame loop hipcc carried "loads pending" around the back edge and waited vmcnt(0) at the top of EVERY frame, which on gfx9
-    // also waits for the previous frame's alpha stores (a store round trip per frame on the serial chain)
+    float hn1 = CTC_NEG;                                                 // the producer's last label state, for the next frame
+
+    // chunks of CTC_FC frames: their log2-probabilities are staged in LDS and the frames of the chunk run with no load on the chain.  The values of chunk
+    // c + 1 are REQUESTED at the start of chunk c (NP passes of one load per lane: lane = (frame of the pass, class), no division; every lane loads a clamped
+    // address, so there is no branch and no wait between the loads) and written to LDS at the chunk boundary.
+    const float* lg0 = logits + f0 * ld; const float* ls0 = lse + f0;   // this utterance's frames: 32-bit offsets from here on
+    float pf[NP], pl[NP];                                                // raw logit and its frame's log-sum-exp; combined when they are written to LDS
+    const int fl = VP ? lane / VP : 0, vl = VP ? lane % VP : 0, vc = vl < V ? vl : V - 1;
+    auto fetch = [&](int t0) {
+        const int left = (int)T - t0, n = left < CTC_FC ? left : CTC_FC;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int f = p * FPP + fl, fc = f < n ? f : n - 1, fr = rev ? (int)T - 1 - (t0 + fc) : t0 + fc;
+            pf[p] = lg0[fr * (int)ld + vc]; pl[p] = ls0[fr];
+        }
+    };
+    if (VP) fetch(0);
     for (long long t0 = 0; t0 < T; t0 += CTC_FC) {
         const long long left = T - t0; const int nf = left < CTC_FC ? (int)left : CTC_FC;
         wave_lds_sync();
-        for (int i = lane; i < nf * V; i += 64) {
-            const int f = i / V, v = i - f * V;
-            const long long fr = f0 + (rev ? T - 1 - (t0 + f) : t0 + f);
-            pc[f * V + v] = (logits[fr * ld + v] - lse[fr]) * LOG2E_F;
+        if (VP) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { const int f = p * FPP + fl; if (f < nf && vl < V) pc[f * V + vl] = (pf[p] - pl[p]) * LOG2E_F; }
+        } else {
+            for (int i = lane; i < nf * V; i += 64) {
+                const int f = i / V, v = i - f * V;
+                const long long fr = f0 + (rev ? T - 1 - (t0 + f) : t0 + f);
+                pc[f * V + v] = (logits[fr * ld + v] - lse[fr]) * LOG2E_F;
+            }
         }
-#if !defined(SS_EMU)
-        __builtin_amdgcn_s_waitcnt(0);
-#endif
         wave_lds_sync();
-        // Software pipeline over the frames: the log2-probabilities of frame t + 1 and the producer's pair for frame t + 1 (= its frame t) are requested
-        // at the top of frame t, so neither LDS round trip sits on the chain; the producer's progress word is polled only when this wave has used up what
-        // it last saw, and then it waits for CTC_LAG frames at once (a wave that polled every frame ran no faster than one wave doing all the states)
-        float lpn[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) lpn[k] = pc[lab[k]];
-        for (int fi = 0; fi < nf; ++fi) {
-            const int t = (int)t0 + fi;
-            float lp[NS];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) lp[k] = lpn[k];
-            const float h0 = hn0, h1 = hn1;                             // the two states below this wave's range, frame t - 1
-            if (fi + 1 < nf) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) lpn[k] = pc[(fi + 1) * V + lab[k]];
+        if (VP && t0 + CTC_FC < T) fetch((int)t0 + CTC_FC);
+        // Software pipeline over the frames: the log2-probabilities of frame t + 1 and the producer's state for frame t + 1 (= its frame t) are requested
+        // at the top of frame t and SETTLED before the frame's own ring write is issued, so that no LDS round trip sits on the chain.  The frames run in
+        // blocks of CTC_B = 8 (a chunk starts at a multiple of 32, so a block's ring slots are consecutive: immediate offsets) and the pipeline is
+        // synchronised per BLOCK: a consumer waits until its producer has published the block's last frame, a producer checks the ring once and publishes
+        // once per block -- per frame there is one ring read and one ring write (every lane writes: lane 63 into the ring, the others into a dump row, no
+        // exec-mask change).  Per-frame checks had cost ~45 scalar instructions around ~50 of arithmetic.
+        float lpn0 = pc[blank], lpn1 = pc[lab1];
+        const float* pcn0 = pc + blank; const float* pcn1 = pc + lab1;  // frame fi + 1's entries
+        for (int fb = 0; fb < nf; fb += CTC_B) {
+            const int tb = (int)t0 + fb, nb = nf - fb < CTC_B ? nf - fb : CTC_B, tl = tb + nb - 1;       // frames tb .. tl
+            if (has_prod) {
+                // the ring entries read in this block: the producer's frames tb .. min(tl, T - 2)
+                const int want = tl < (int)T - 1 ? tl : (int)T - 1;
+                while (seen_prod < want) { seen_prod = wave_uniform(lds_peek_i32(prog + w - 1)); if (seen_prod < want) ctc_spin(); }
+                compiler_fence();
             }
-            if (has_prod && t + 1 < (int)T) {                            // the pair of frame t, for frame t + 1
-                if (seen_prod < t) {
-                    const int want = t + CTC_LAG < (int)T - 1 ? t + CTC_LAG : (int)T - 1;
-                    while (seen_prod < want) { seen_prod = prog[wv - 1]; if (seen_prod < want) ctc_spin(); }
+            if (has_cons) {                                               // never more than 48 + 7 frames ahead of what the consumer last published
+                while (tb - seen_cons > CTC_R - 16) { seen_cons = wave_uniform(lds_peek_i32(prog + w + 1)); if (tb - seen_cons > CTC_R - 16) ctc_spin(); }
+            }
+            const float* rin = ring_in + (tb & (CTC_R - 1));
+            float* rout = (lane == 63 ? ring_out + (tb & (CTC_R - 1)) : dump);
+#pragma unroll
+            for (int e = 0; e < CTC_B; ++e) {
+                if (e < nb) {
+                    const float lp0 = lpn0, lp1 = lpn1, h1 = hn1;
+                    pcn0 += V; pcn1 += V;
+                    if (fb + e + 1 < nf) { lpn0 = *pcn0; lpn1 = *pcn1; }
+                    if (has_prod) hn1 = lds_peek_f32(rin + e);           // (the last frame's entry is read and never used)
+                    const float p1 = wave_shr1(a1, h1);                  // the label state below this lane's blank (lane 0: of the wave below)
+                    const float n0 = fmaxf(lse2_b2(a0, p1) + lp0, CTC_NEG);             // (lp = -inf, a class of probability 0, lands on the sentinel;
+                    const float n1 = fmaxf(lse3_b2(a1, a0, skip1 ? p1 : CTC_NEG) + lp1, CTC_NEG);      //  phantom states beyond SP only ever feed higher phantom states)
+                    a0 = n0; a1 = n1;
+                    if (val0) ctc_store(row, ob0, a0);
+                    if (val1) ctc_store(row, ob1, a1);
+                    row += rstep;
+                    pin_vgpr(lpn0); pin_vgpr(lpn1); pin_vgpr(hn1);       // the reads have landed HERE (else the wait sits behind the ring write below and waits for it too)
+                    if (has_cons) lds_post_f32(rout + e, a1);
                 }
-                hn0 = ring_in[(t & (CTC_R - 1)) * 2]; hn1 = ring_in[(t & (CTC_R - 1)) * 2 + 1];
             }
-            float nv[NS];
-            if (t == 0) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) { const int s_ = s0 + lane * NS + k; nv[k] = s_ < 2 && s_ < SP ? lp[k] : CTC_NEG; }
-            } else {
-                // predecessors of a lane's first two states: the last two states of the lane below (lane 0: of the wave below)
-                const float p1 = wave_shr1(a[NS - 1], h1), p2 = wave_shr1(a[NS - 2], h0);
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const float a1 = k >= 1 ? a[k >= 1 ? k - 1 : 0] : p1, a2 = k >= 2 ? a[k >= 2 ? k - 2 : 0] : (k == 1 ? p1 : p2);
-                    const float v = (k & 1) ? lse3_b2(a[k], a1, skip[k] ? a2 : CTC_NEG) : lse2_b2(a[k], a1);
-                    nv[k] = fmaxf(v + lp[k], CTC_NEG);                  // (lp = -inf, a class of probability 0, lands on the sentinel; phantom states beyond SP only ever feed higher phantom states)
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                a[k] = nv[k];
-                if (s0 + lane * NS + k < SP) row[oidx[k]] = a[k] > 0.5f * CTC_NEG ? a[k] * LN2_F : -INFINITY;
-            }
-            row += rstep;
-            if (has_cons) {
-                // never more than CTC_R - 16 frames ahead of what the consumer last published (it publishes at least every 8 frames)
-                while (t - seen_cons > CTC_R - 16) { seen_cons = prog[wv + 1]; if (t - seen_cons > CTC_R - 16) ctc_spin(); }
-                if (lane == 63) { ring_out[(t & (CTC_R - 1)) * 2] = a[0]; ring_out[(t & (CTC_R - 1)) * 2 + 1] = a[1]; prog[wv] = t; }
-            } else if ((t & 7) == 7 && lane == 63) prog[wv] = t;
+            compiler_fence();
+            if (lane == 63) lds_post_i32(prog + w, tl);
         }
     }
-    if (lane == 63) prog[wv] = (int)T - 1 + CTC_R;                       // done: a producer still ahead of this wave never waits for it again
+    if (lane == 63) lds_post_i32(prog + w, (int)T - 1 + CTC_R);         // done: a producer still ahead of this wave never waits for it again
     if (!rev && s0 <= SP - 1 && SP - 1 < s0 + CTC_C) {
         // nll = -ln(alpha_T(SP-1) + alpha_T(SP-2)); SP - 2 may be the last state of the wave below (its last ring entry)
         float e1 = CTC_NEG, e2 = CTC_NEG;
-#pragma unroll
-        for (int k = 0; k < NS; ++k) { const int s_ = s0 + lane * NS + k; if (s_ == SP - 1) e1 = a[k]; if (s_ == SP - 2) e2 = a[k]; }
+        if (sb == SP - 1) e1 = a0;
+        if (sb + 1 == SP - 1) e1 = a1;
+        if (sb == SP - 2) e2 = a0;
+        if (sb + 1 == SP - 2) e2 = a1;
         e1 = wave_max(e1); e2 = wave_max(e2);
         if (SP - 2 >= 0 && SP - 2 < s0) {
-            while (seen_prod < (int)T - 1) { seen_prod = prog[wv - 1]; if (seen_prod < (int)T - 1) ctc_spin(); }
-            e2 = ring_in[(((int)T - 1) & (CTC_R - 1)) * 2 + 1];
+            while (seen_prod < (int)T - 1) { seen_prod = wave_uniform(lds_peek_i32(prog + w - 1)); if (seen_prod < (int)T - 1) ctc_spin(); }
+            compiler_fence();
+            e2 = lds_peek_f32(ring_in + (((int)T - 1) & (CTC_R - 1)));
         }
         const float l2 = lse2_b2(e1, e2);
         if (lane == 0) nll[u] = l2 > 0.5f * CTC_NEG ? -l2 * LN2_F : INFINITY;
@@ -217,22 +247,23 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         if (n_utt == 0 || r < f0 || r >= f0 + T) { for (int c = lane; c < ld; c += 64) d[c] = 0.f; continue; }
         const int SP = (int)(2 * S + 1);
         const float* a = alpha + w0 + (r - f0) * SP; const float* b = beta + w0 + (r - f0) * SP;
-        float m = -INFINITY;
+        // alpha / beta are log2 values with the finite sentinel CTC_NEG for "no path" (a sum with a sentinel in it stays below CTC_NEG / 2)
+        float m = CTC_NEG;
         for (int s = lane; s < SP; s += 64) m = fmaxf(m, a[s] + b[s]);
         m = wave_max(m);
         for (int c = lane; c < V; c += 64) bins[c] = 0.f;
         wave_lds_sync();
         for (int s = lane; s < SP; s += 64) {
             const float v = a[s] + b[s];
-            if (v > -INFINITY) atomicAdd(&bins[(s & 1) ? targets[g0 + (s >> 1)] : blank], expf(v - m));
+            if (v > 0.5f * CTC_NEG) atomicAdd(&bins[(s & 1) ? targets[g0 + (s >> 1)] : blank], fast_exp2(v - m));
         }
         wave_lds_sync();
-        const float L = lse[r], nl = nll[lo], sc = inv_n / (float)(S > 1 ? S : 1);
+        const float L = lse[r], nl = nll[lo], sc = inv_n / (float)(S > 1 ? S : 1), mln = m * LN2_F;
         for (int c = lane; c < ld; c += 64) {
             float g = 0.f;
             if (c < V) {
                 const float lp = logits[r * ld + c] - L, occ = bins[c];
-                g = expf(lp) - (occ > 0.f ? expf(logf(occ) + m + nl - lp) : 0.f);
+                g = expf(lp) - (occ > 0.f ? expf(logf(occ) + mln + nl - lp) : 0.f);
                 if (nl == INFINITY) g = NAN;                        // no valid alignment: ATen's exp(-inf + inf - lp), stated explicitly
             }
             d[c] = g * sc;
@@ -252,12 +283,17 @@ extern "C" int ss_ctc_loss(const float* logits, int64_t ld, int V, int blank, co
     if (n_utt > 0) {
         SS_CHECK(desc && alpha_ws && beta_ws && nll, "ss_ctc_loss: null workspace");
         SS_CHECK(targets || max_target_len == 0, "ss_ctc_loss: null targets");
-        const int W = (sp_cap + CTC_C - 1) / CTC_C;                      // waves per direction: 128 states each
-        const size_t smem = sizeof(float) * ((size_t)2 * W * CTC_FC * V + (size_t)2 * W * CTC_R * 2 + 2 * W);
+        const int W = (sp_cap + CTC_C - 1) / CTC_C;                      // waves per (utterance, direction): 128 states each
+        const size_t smem = sizeof(float) * ((size_t)W * CTC_FC * V + (size_t)W * CTC_R + W + (size_t)W * (64 + CTC_B));
         SS_CHECK(smem <= 160 * 1024, "ss_ctc_loss: %zu bytes of LDS needed", smem);
-        static size_t granted = 0;
-        if (granted < smem) { if (!ss_grant_lds((const void*)ctc_alpha_beta_kernel, smem)) { ss_set_error("ss_ctc_loss: cannot reserve %zu bytes of LDS", smem); return 1; } granted = smem; }
-        SS_LAUNCH(ctc_alpha_beta_kernel, dim3(n_utt), dim3(2 * W * 64), smem, stream, logits, (long long)ld, V, blank, lse, (const long long*)desc, targets, alpha_ws, beta_ws, nll, W);
+        const int vp = V <= 32 ? 32 : (V <= 64 ? 64 : 0);
+        const void* kern = vp == 32 ? (const void*)ctc_alpha_beta_kernel<32> : vp == 64 ? (const void*)ctc_alpha_beta_kernel<64> : (const void*)ctc_alpha_beta_kernel<0>;
+        static size_t granted[3] = {0, 0, 0};
+        size_t& gr = granted[vp == 32 ? 0 : vp == 64 ? 1 : 2];
+        if (gr < smem) { if (!ss_grant_lds(kern, smem)) { ss_set_error("ss_ctc_loss: cannot reserve %zu bytes of LDS", smem); return 1; } gr = smem; }
+        if (vp == 32) SS_LAUNCH(SS_KERNEL(ctc_alpha_beta_kernel<32>), dim3(2 * n_utt), dim3(W * 64), smem, stream, logits, (long long)ld, V, blank, lse, (const long long*)desc, targets, alpha_ws, beta_ws, nll, W);
+        else if (vp == 64) SS_LAUNCH(SS_KERNEL(ctc_alpha_beta_kernel<64>), dim3(2 * n_utt), dim3(W * 64), smem, stream, logits, (long long)ld, V, blank, lse, (const long long*)desc, targets, alpha_ws, beta_ws, nll, W);
+        else SS_LAUNCH(SS_KERNEL(ctc_alpha_beta_kernel<0>), dim3(2 * n_utt), dim3(W * 64), smem, stream, logits, (long long)ld, V, blank, lse, (const long long*)desc, targets, alpha_ws, beta_ws, nll, W);
         SS_LAUNCH_CHECK("ss_ctc_loss(alpha/beta)");
     }
     {
