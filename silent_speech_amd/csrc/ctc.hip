@@ -15,7 +15,7 @@
 
 namespace {
 constexpr int CD = 5;                      // descriptor row: frame0, T, target0, S, workspace offset (floats)
-constexpr int CTC_MAX_STATES = 1024, CTC_FC = 32;      // 16 states per lane; 32 frames of class probabilities staged per wave
+constexpr int CTC_MAX_STATES = 1024, CTC_FC = 32;      // 8 compute waves of 128 states; frames per staged chunk
 
 }
 
@@ -72,7 +72,7 @@ __device__ __forceinline__ float lse3_b2(float a, float b, float c) {
 // time behind 20-instruction divisions (0.06 ms), both directions of an utterance shared the four SIMDs of one CU, the loop's lgkmcnt(0) waited for the ring
 // WRITE of the frame, and each alpha store cost five VALU operations (scale to ln, -inf select, 64-bit address).
 namespace {
-constexpr int CTC_C = 128, CTC_R = 64, CTC_B = 8;
+constexpr int CTC_C = 128, CTC_R = 64, CTC_B = 8, CTC_NB = 4;
 static_assert(CTC_FC % CTC_B == 0 && CTC_R % CTC_FC == 0, "a block of frames occupies consecutive ring slots");
 __device__ __forceinline__ void ctc_spin() {
 #if defined(SS_EMU)
@@ -90,31 +90,59 @@ __device__ __forceinline__ void ctc_store(float* row, unsigned byte_off, float v
     asm volatile("global_store_dword %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(row) : "memory");
 #endif
 }
-// VP: lanes per frame in the chunk staging (32: two frames per load instruction, V <= 32; 64: one frame, V <= 64; 0: any V, staged in place)
-template <int VP>
-__global__ __launch_bounds__(512) void ctc_alpha_beta_kernel(const float* __restrict__ logits, long long ld, int V, int blank, const float* __restrict__ lse,
+// Waves 0 .. W - 1 compute; wave W is the LOADER: it stages the log2-probabilities of chunk after chunk (CTC_FC = 32 frames x V classes) into a ring of
+// CTC_NB chunk buffers that all compute waves read (they need the same frames, a few frames apart), so that a compute wave's chunk boundary is one
+// progress-word poll instead of 64 loads + 32 LDS writes + their address arithmetic (~1.4 us per chunk on the chain of every wave, 27 chunks).
+__global__ __launch_bounds__(576) void ctc_alpha_beta_kernel(const float* __restrict__ logits, long long ld, int V, int blank, const float* __restrict__ lse,
                                                              const long long* __restrict__ desc, const int* __restrict__ targets,
                                                              float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ nll, int W)
 {
-    constexpr int FPP = VP ? 64 / VP : 1, NP = VP ? CTC_FC / FPP : 1;  // frames per staging pass, passes per chunk
     SS_DYN_SMEM(smem);
     const int u = blockIdx.x >> 1, tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
     const bool rev = blockIdx.x & 1;
     const long long f0 = desc[u * CD + 0], T = desc[u * CD + 1], g0 = desc[u * CD + 2], S = desc[u * CD + 3], w0 = desc[u * CD + 4];
     const int SP = (int)(2 * S + 1);
-    float* pc = (float*)smem + (size_t)w * (CTC_FC * V);                 // this wave's [CTC_FC][V] staged log2-probabilities
-    float* rings = (float*)smem + (size_t)W * (CTC_FC * V);             // polled words: lds_peek / lds_post only (see common.h)
-    int* prog = (int*)(rings + (size_t)W * CTC_R);
+    float* chunks = (float*)smem;                                        // [CTC_NB][CTC_FC][V] staged log2-probabilities
+    float* rings = (float*)smem + (size_t)CTC_NB * (CTC_FC * V);        // polled words: lds_peek / lds_post only (see common.h)
+    int* prog = (int*)(rings + (size_t)W * CTC_R);                       // [0, W): frames done per compute wave; [W]: chunks staged
     if (lane == 0) lds_post_i32(prog + w, -1);
     __syncthreads();
     float* out = (rev ? beta : alpha) + w0;
     if (T <= 0) { if (!rev && w == 0 && lane == 0) nll[u] = S == 0 ? 0.f : INFINITY; return; }
+    if (w == W) {
+        // ---- the loader.  Chunk c goes to buffer c % CTC_NB once the LAST active compute wave is done with chunk c - CTC_NB; 8 values per lane are in
+        // flight at a time (the divisions are off everybody's chain here).
+        const int wl = (SP - 1) / CTC_C;                                  // last compute wave that owns a state
+        const float* lg0 = logits + f0 * ld; const float* ls0 = lse + f0;
+        int seen = -1;
+        for (int c = 0, t0 = 0; t0 < (int)T; ++c, t0 += CTC_FC) {
+            const int left = (int)T - t0, n = (left < CTC_FC ? left : CTC_FC) * V;
+            const int need = (c - CTC_NB + 1) * CTC_FC - 1;              // last frame of chunk c - CTC_NB
+            while (seen < need) { seen = wave_uniform(lds_peek_i32(prog + wl)); if (seen < need) ctc_spin(); }
+            compiler_fence();
+            float* pc = chunks + (size_t)(c % CTC_NB) * (CTC_FC * V);
+            for (int base = 0; base < n; base += 64 * 8) {
+                float x[8], l[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = base + e * 64 + lane, ic = i < n ? i : n - 1;
+                    const int f = ic / V, v = ic - f * V, fr = rev ? (int)T - 1 - (t0 + f) : t0 + f;
+                    x[e] = lg0[fr * (int)ld + v]; l[e] = ls0[fr];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int i = base + e * 64 + lane; if (i < n) pc[i] = (x[e] - l[e]) * LOG2E_F; }
+            }
+            compiler_fence();
+            if (lane == 0) lds_post_i32(prog + W, c);
+        }
+        return;
+    }
     const int s0 = w * CTC_C;
     if (s0 >= SP) return;                                                // this wave owns no state of this utterance
     const bool has_prod = w > 0, has_cons = w + 1 < W && (w + 1) * CTC_C < SP;
     const float* ring_in = rings + (size_t)(w > 0 ? w - 1 : 0) * CTC_R; // written by wave w - 1 (has_prod only)
     float* ring_out = rings + (size_t)w * CTC_R;
-    float* dump = (float*)(prog + W) + (size_t)w * (64 + CTC_B) + lane; // lanes 0 .. 62: words lane .. lane + 7 of this wave's dump row
+    float* dump = (float*)(prog + W + 1) + (size_t)w * (64 + CTC_B) + lane; // lanes 0 .. 62: words lane .. lane + 7 of this wave's dump row
 
     // lane l: states sb = s0 + 2 l (blank) and sb + 1 (label j = sb / 2 of the -- for beta reversed -- string)
     const int sb = s0 + 2 * lane;
@@ -131,39 +159,15 @@ __global__ __launch_bounds__(512) void ctc_alpha_beta_kernel(const float* __rest
     const unsigned ob0 = 4u * (unsigned)(rev ? SP - 1 - sb : sb), ob1 = 4u * (unsigned)(rev ? SP - 2 - sb : sb + 1);      // 32-bit byte offsets: the stores take the row from scalar registers
     float* row = out + (rev ? (T - 1) * SP : 0);
     const long long rstep = rev ? -(long long)SP : (long long)SP;
-    int seen_prod = -1, seen_cons = -1;                                  // what this wave last read of its neighbours' progress words
+    int seen_prod = -1, seen_cons = -1, seen_staged = -1;                                  // what this wave last read of its neighbours' progress words
     float hn1 = CTC_NEG;                                                 // the producer's last label state, for the next frame
 
-    // chunks of CTC_FC frames: their log2-probabilities are staged in LDS and the frames of the chunk run with no load on the chain.  The values of chunk
-    // c + 1 are REQUESTED at the start of chunk c (NP passes of one load per lane: lane = (frame of the pass, class), no division; every lane loads a clamped
-    // address, so there is no branch and no wait between the loads) and written to LDS at the chunk boundary.
-    const float* lg0 = logits + f0 * ld; const float* ls0 = lse + f0;   // this utterance's frames: 32-bit offsets from here on
-    float pf[NP], pl[NP];                                                // raw logit and its frame's log-sum-exp; combined when they are written to LDS
-    const int fl = VP ? lane / VP : 0, vl = VP ? lane % VP : 0, vc = vl < V ? vl : V - 1;
-    auto fetch = [&](int t0) {
-        const int left = (int)T - t0, n = left < CTC_FC ? left : CTC_FC;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int f = p * FPP + fl, fc = f < n ? f : n - 1, fr = rev ? (int)T - 1 - (t0 + fc) : t0 + fc;
-            pf[p] = lg0[fr * (int)ld + vc]; pl[p] = ls0[fr];
-        }
-    };
-    if (VP) fetch(0);
-    for (long long t0 = 0; t0 < T; t0 += CTC_FC) {
-        const long long left = T - t0; const int nf = left < CTC_FC ? (int)left : CTC_FC;
-        wave_lds_sync();
-        if (VP) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) { const int f = p * FPP + fl; if (f < nf && vl < V) pc[f * V + vl] = (pf[p] - pl[p]) * LOG2E_F; }
-        } else {
-            for (int i = lane; i < nf * V; i += 64) {
-                const int f = i / V, v = i - f * V;
-                const long long fr = f0 + (rev ? T - 1 - (t0 + f) : t0 + f);
-                pc[f * V + v] = (logits[fr * ld + v] - lse[fr]) * LOG2E_F;
-            }
-        }
-        wave_lds_sync();
-        if (VP && t0 + CTC_FC < T) fetch((int)t0 + CTC_FC);
+    // chunks of CTC_FC frames, staged by the loader wave
+    for (int c = 0, t0 = 0; t0 < (int)T; ++c, t0 += CTC_FC) {
+        const int left = (int)T - t0, nf = left < CTC_FC ? left : CTC_FC;
+        while (seen_staged < c) { seen_staged = wave_uniform(lds_peek_i32(prog + W)); if (seen_staged < c) ctc_spin(); }
+        compiler_fence();
+        const float* pc = chunks + (size_t)(c % CTC_NB) * (CTC_FC * V);
         // Software pipeline over the frames: the log2-probabilities of frame t + 1 and the producer's state for frame t + 1 (= its frame t) are requested
         // at the top of frame t and SETTLED before the frame's own ring write is issued, so that no LDS round trip sits on the chain.  The frames run in
         // blocks of CTC_B = 8 (a chunk starts at a multiple of 32, so a block's ring slots are consecutive: immediate offsets) and the pipeline is
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(512) void ctc_alpha_beta_kernel(const float* __rest
         float lpn0 = pc[blank], lpn1 = pc[lab1];
         const float* pcn0 = pc + blank; const float* pcn1 = pc + lab1;  // frame fi + 1's entries
         for (int fb = 0; fb < nf; fb += CTC_B) {
-            const int tb = (int)t0 + fb, nb = nf - fb < CTC_B ? nf - fb : CTC_B, tl = tb + nb - 1;       // frames tb .. tl
+            const int tb = t0 + fb, nb = nf - fb < CTC_B ? nf - fb : CTC_B, tl = tb + nb - 1;       // frames tb .. tl
             if (has_prod) {
                 // the ring entries read in this block: the producer's frames tb .. min(tl, T - 2)
                 const int want = tl < (int)T - 1 ? tl : (int)T - 1;
@@ -283,17 +287,12 @@ extern "C" int ss_ctc_loss(const float* logits, int64_t ld, int V, int blank, co
     if (n_utt > 0) {
         SS_CHECK(desc && alpha_ws && beta_ws && nll, "ss_ctc_loss: null workspace");
         SS_CHECK(targets || max_target_len == 0, "ss_ctc_loss: null targets");
-        const int W = (sp_cap + CTC_C - 1) / CTC_C;                      // waves per (utterance, direction): 128 states each
-        const size_t smem = sizeof(float) * ((size_t)W * CTC_FC * V + (size_t)W * CTC_R + W + (size_t)W * (64 + CTC_B));
+        const int W = (sp_cap + CTC_C - 1) / CTC_C;                      // compute waves per (utterance, direction): 128 states each; + 1 loader wave
+        const size_t smem = sizeof(float) * ((size_t)CTC_NB * CTC_FC * V + (size_t)W * CTC_R + W + 1 + (size_t)W * (64 + CTC_B));
         SS_CHECK(smem <= 160 * 1024, "ss_ctc_loss: %zu bytes of LDS needed", smem);
-        const int vp = V <= 32 ? 32 : (V <= 64 ? 64 : 0);
-        const void* kern = vp == 32 ? (const void*)ctc_alpha_beta_kernel<32> : vp == 64 ? (const void*)ctc_alpha_beta_kernel<64> : (const void*)ctc_alpha_beta_kernel<0>;
-        static size_t granted[3] = {0, 0, 0};
-        size_t& gr = granted[vp == 32 ? 0 : vp == 64 ? 1 : 2];
-        if (gr < smem) { if (!ss_grant_lds(kern, smem)) { ss_set_error("ss_ctc_loss: cannot reserve %zu bytes of LDS", smem); return 1; } gr = smem; }
-        if (vp == 32) SS_LAUNCH(SS_KERNEL(ctc_alpha_beta_kernel<32>), dim3(2 * n_utt), dim3(W * 64), smem, stream, logits, (long long)ld, V, blank, lse, (const long long*)desc, targets, alpha_ws, beta_ws, nll, W);
-        else if (vp == 64) SS_LAUNCH(SS_KERNEL(ctc_alpha_beta_kernel<64>), dim3(2 * n_utt), dim3(W * 64), smem, stream, logits, (long long)ld, V, blank, lse, (const long long*)desc, targets, alpha_ws, beta_ws, nll, W);
-        else SS_LAUNCH(SS_KERNEL(ctc_alpha_beta_kernel<0>), dim3(2 * n_utt), dim3(W * 64), smem, stream, logits, (long long)ld, V, blank, lse, (const long long*)desc, targets, alpha_ws, beta_ws, nll, W);
+        static size_t granted = 0;
+        if (granted < smem) { if (!ss_grant_lds((const void*)ctc_alpha_beta_kernel, smem)) { ss_set_error("ss_ctc_loss: cannot reserve %zu bytes of LDS", smem); return 1; } granted = smem; }
+        SS_LAUNCH(ctc_alpha_beta_kernel, dim3(2 * n_utt), dim3((W + 1) * 64), smem, stream, logits, (long long)ld, V, blank, lse, (const long long*)desc, targets, alpha_ws, beta_ws, nll, W);
         SS_LAUNCH_CHECK("ss_ctc_loss(alpha/beta)");
     }
     {
