@@ -334,6 +334,18 @@ int ss_reflect_pad(const float* y, float* out, int B, int L, int pad, int64_t ld
 int ss_reflect_pad_ragged(const float* y, const int64_t* offsets_dev, const int32_t* lengths_dev, float* out, int B, int min_len,
                           int pad, int64_t ld_out, int clip, void* stream);
 int ss_stft_magnitude(const float* spec, int64_t ld_spec, int n_bins, float* mag, int64_t ld_mag, int rows, void* stream);
+/* The whole of data_utils.py:51-60 (and :76's np.clip when clip != 0) for n_fft = 1024 as ONE kernel (csrc/mel.hip: an LDS radix-8 FFT per frame, one
+ * wave per frame), reading the caller's signals in place: signal b is y[offsets_dev[b] .. + lengths_dev[b]) (a ragged batch) or, with both arrays NULL,
+ * row b of a [B][uniform_len] matrix.  Frame f (< F) of a signal covers its reflect-padded samples f * hop - pad .. + 1024 (F.pad(..., 'reflect'), :51;
+ * pad < length; samples behind the padded signal count as 0, as in the zero-filled rows of ss_reflect_pad_ragged), windowed by window[1024]
+ * (torch.hann_window, :49), one-sided spectrum, sqrt(re^2 + im^2 + 1e-9) (:57), the mel filterbank (:59) in SPARSE form -- band m = sum_j
+ * band_w[band_off[m] + j] * mag[band_lo[m] + j], j < band_cnt[m]: the non-zero run of row m of librosa.filters.mel, padded with zero weights to a
+ * multiple of 4 (band_lo[m] + band_cnt[m] <= 520), n_w packed weights in all; lane_bands[2][64] deals the bands to the 64 lanes (-1 = none) --,
+ * log(clamp(., log_clamp)) (:60, spectral_normalize_torch) written to out[b * stride_b + f * stride_f + m * stride_m].  n_mels <= 128, n_w <= 4096. */
+int ss_stft_logmel_fft(const float* y, const int64_t* offsets_dev, const int32_t* lengths_dev, int64_t uniform_len, int B, int F, int pad, int clip,
+                       int n_fft, int hop, const float* window,
+                       const int32_t* band_lo, const int32_t* band_cnt, const int32_t* band_off, const float* band_w, const int32_t* lane_bands, int n_mels, int n_w,
+                       float log_clamp, float* out, int64_t stride_b, int64_t stride_f, int64_t stride_m, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head self-attention with learned relative-position logits (transformer.py:87-112 and

@@ -102,6 +102,7 @@ SIGNATURES = {
     'ss_iir_filtfilt_batch': [_P, _P, _P, _I, _I, _I, _P, _P, _L, _P],
     'ss_linear_resample_batch': [_P, _P, _P, _I, _I, ctypes.c_double, ctypes.c_double, _L, _P],
     'ss_stft_magnitude': [_P, _L, _I, _P, _L, _I, _P],
+    'ss_stft_logmel_fft': [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _L, _L, _L, _P],
 }
 _LP = ctypes.POINTER(ctypes.c_int64)
 _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int64),

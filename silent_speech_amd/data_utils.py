@@ -99,6 +99,12 @@ def _mel_spectrogram_impl(y, n_fft, num_mels, sampling_rate, hop_size, win_size,
     pad = int((n_fft - hop_size) / 2)
     Lp = L + 2 * pad
     dev = y.device
+    if not center and y.dtype == torch.float32 and L > pad and Lp >= n_fft:
+        # n_fft = 1024: one kernel straight from y (reflection is index arithmetic in the frames that touch the ends): no padded copy
+        F = 1 + (Lp - n_fft) // hop_size
+        out = torch.empty(B, num_mels, F, dtype=torch.float32, device=dev)
+        if _logmel_fft(y, None, None, L, B, F, pad, False, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major=False):
+            return out
     ldp = (Lp + 3) // 4 * 4
     ypad = torch.zeros(B, ldp, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().ss_reflect_pad(_lib.ptr(y), _lib.ptr(ypad), B, L, pad, ldp, _lib.stream_of(y)), 'ss_reflect_pad')
@@ -116,13 +122,73 @@ def _mel_spectrogram_impl(y, n_fft, num_mels, sampling_rate, hop_size, win_size,
         raise ValueError('signal too short for one frame')
     F = 1 + (Lp - n_fft) // hop_size
     out = torch.empty(B, num_mels, F, dtype=torch.float32, device=dev)
-    _stft_logmel(ypad, B, F, ldp, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major=False)
+    if not _logmel_fft(ypad, None, None, ldp, B, F, 0, False, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major=False):    # (center=True: rows already padded twice)
+        _stft_logmel(ypad, B, F, ldp, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major=False)
     return out
 
 
+_fft_cache = {}
+
+
+def _fft_tables(n_fft, win_size, num_mels, sampling_rate, fmin, fmax, device):
+    """What ss_stft_logmel_fft reads besides the signal: the f32 hann window (torch.hann_window, periodic, centred in n_fft like torch.stft does) and
+    the mel filterbank in sparse form -- per band the first non-zero bin, the length of the run up to the last non-zero bin (padded to a multiple of 4
+    with zero weights) and the packed weights --, and the deal of the bands to the 64 lanes of a wave (longest band first onto the least loaded lane,
+    two bands per lane at most).  None when the filterbank does not fit the kernel's tables."""
+    key = (n_fft, win_size, num_mels, sampling_rate, fmin, fmax, str(device))
+    if key not in _fft_cache:
+        win = np.zeros(n_fft, dtype=np.float32)
+        off = (n_fft - win_size) // 2
+        win[off:off + win_size] = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win_size) / win_size)).astype(np.float32)
+        basis = slaney_mel_filterbank(sampling_rate, n_fft, num_mels, fmin, fmax)
+        nb = n_fft // 2 + 1
+        lo, cnt, offs, ws = [], [], [], []
+        for m in range(num_mels):
+            nz = np.nonzero(basis[m])[0]
+            a, n = (int(nz[0]), int(nz[-1]) - int(nz[0]) + 1) if len(nz) else (0, 0)
+            n4 = (n + 3) // 4 * 4
+            run = np.zeros(n4, dtype=np.float32)
+            run[:n] = basis[m, a:a + n]
+            lo.append(a); cnt.append(n4); offs.append(sum(len(w) for w in ws)); ws.append(run)
+        n_w = int(sum(cnt))
+        load, lanes = [0] * 64, [[] for _ in range(64)]
+        for m in sorted(range(num_mels), key=lambda m: -cnt[m]):
+            l = min((l for l in range(64) if len(lanes[l]) < 2), key=lambda l: load[l], default=None)
+            if l is None:
+                break
+            lanes[l].append(m); load[l] += cnt[m]
+        ok = num_mels <= 128 and n_w <= 4096 and sum(len(x) for x in lanes) == num_mels and all(lo[m] + cnt[m] <= nb + 7 for m in range(num_mels))
+        if not ok:
+            _fft_cache[key] = None
+        else:
+            lb = np.full((2, 64), -1, dtype=np.int32)
+            for l in range(64):
+                for it, m in enumerate(lanes[l]):
+                    lb[it, l] = m
+            w = np.concatenate(ws) if n_w else np.zeros(1, dtype=np.float32)
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dt))).to(device)
+            _fft_cache[key] = (t(win, np.float32), t(lo, np.int32), t(cnt, np.int32), t(offs, np.int32), t(w, np.float32), t(lb, np.int32), n_w)
+    return _fft_cache[key]
+
+
+def _logmel_fft(y, offs, lens, uniform_len, B, F, pad, clip, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major):
+    """One ss_stft_logmel_fft launch (csrc/mel.hip) on the caller's signals; False when this configuration needs the GEMM formulation."""
+    if n_fft != 1024 or win_size > n_fft:
+        return False
+    tabs = _fft_tables(n_fft, win_size, num_mels, sampling_rate, fmin, fmax, y.device)
+    if tabs is None:
+        return False
+    win, lo, cnt, boff, w, lb, n_w = tabs
+    sb, sf, sm = (F * num_mels, num_mels, 1) if frame_major else (num_mels * F, 1, F)
+    _lib.check(_lib.lib().ss_stft_logmel_fft(_lib.ptr(y), _lib.ptr(offs) if offs is not None else None, _lib.ptr(lens) if lens is not None else None, int(uniform_len), B, F,
+                                             pad, int(bool(clip)), n_fft, hop_size, _lib.ptr(win), _lib.ptr(lo), _lib.ptr(cnt), _lib.ptr(boff), _lib.ptr(w), _lib.ptr(lb),
+                                             num_mels, n_w, 1e-5, _lib.ptr(out), sb, sf, sm, _lib.stream_of(y)), 'ss_stft_logmel_fft')
+    return True
+
+
 def _stft_logmel(ypad, B, F, ldp, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major):
-    """padded signals [B][ldp] -> log-mel of frames 0..F-1 of every row: two f32 GEMMs around the magnitude kernel.
-    frame_major: out is [B*F][num_mels] (frames of a signal are contiguous rows) instead of the reference's (B, num_mels, F)."""
+    """padded signals [B][ldp] -> log-mel of frames 0..F-1 of every row: the GEMM formulation (any n_fft): two f32 GEMMs (windowed DFT matrix, mel basis)
+    around the magnitude kernel.  frame_major: out is [B*F][num_mels] (frames of a signal are contiguous rows) instead of the reference's (B, num_mels, F)."""
     dev = ypad.device
     nb = n_fft // 2 + 1
     W = _windowed_dft(n_fft, win_size, dev)
@@ -169,10 +235,12 @@ def mel_spectrogram_batch(signals, n_fft=1024, num_mels=80, sampling_rate=22050,
     ldp = (max(lens) + 2 * pad + 3) // 4 * 4
     offs_d = torch.from_numpy(offs).to(dev, non_blocking=True)
     lens_d = torch.from_numpy(np.asarray(lens, dtype=np.int32)).to(dev, non_blocking=True)
+    out = torch.empty(B, F, num_mels, dtype=torch.float32, device=dev)
+    if _logmel_fft(flat, offs_d, lens_d, 0, B, F, pad, clip, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major=True):
+        return out, frames
     ypad = torch.empty(B, ldp, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().ss_reflect_pad_ragged(_lib.ptr(flat), _lib.ptr(offs_d), _lib.ptr(lens_d), _lib.ptr(ypad), B, min(lens), pad, ldp, int(bool(clip)),
                                                 _lib.stream_of(flat)), 'ss_reflect_pad_ragged')
-    out = torch.empty(B, F, num_mels, dtype=torch.float32, device=dev)
     _stft_logmel(ypad, B, F, ldp, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, out, frame_major=True)
     return out, frames
 

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+from silent_speech_amd import _lib as _lib_mod
 import pytest
 import torch
 
@@ -99,6 +100,42 @@ def test_mel_spectrogram_golden(dev):
     assert float(np.abs(d).mean()) < 1e-4, float(np.abs(d).mean())          # north_star: mel-L1 within 1e-4
     assert float(np.abs(d).max()) < 2e-2
     assert np.array_equal(data_utils.slaney_mel_filterbank(22050, 1024, 80, 0, 8000), z['basis'])
+
+
+def test_mel_fft_kernel_vs_oracle_and_vs_the_gemm_formulation(dev, monkeypatch):
+    """ss_stft_logmel_fft (csrc/mel.hip: one wave per frame, LDS radix-8 FFT, sparse filterbank) against the numpy oracle (oracle/mel_ref.py, numpy rfft) and against
+    the dense-DFT GEMM formulation it replaces for n_fft = 1024, in both output layouts (the reference's (B, mels, F) and the loader's frame-major one), with
+    frame counts that leave waves idle / give a wave several frames.  Tolerance: 1e-4 (north_star's mel-L1) on the mean, 2e-5 on every element -- the two
+    device paths are both f32 and differ only in summation order."""
+    rng = np.random.default_rng(5)
+    for B, frames in ((1, 2), (3, 7)) if is_emu(dev) else ((1, 2), (3, 7), (5, 1030)):
+        L = 256 * frames
+        y = np.clip(0.2 * rng.standard_normal((B, L)), -1, 1).astype(np.float32)
+        y[0, :min(L, 300)] = 0.0                                                # silence: the 1e-9 under the root and the 1e-5 clamp decide
+        yd = torch.from_numpy(y).to(dev)
+        got = data_utils.mel_spectrogram(yd, 1024, 80, 22050, 256, 1024, 0, 8000).cpu().numpy()
+        want = mel_ref.mel_spectrogram_ref(y)
+        assert got.shape == want.shape == (B, 80, frames)
+        assert float(np.abs(got - want).mean()) < 1e-4 and float(np.abs(got - want).max()) < 2e-3
+        buf, fr = data_utils.mel_spectrogram_batch([yd[b] for b in range(B)])
+        assert fr == [frames] * B
+        assert float(np.abs(buf.cpu().numpy() - want.transpose(0, 2, 1)).max()) < 2e-3
+        if B >= 3:                                                              # ragged lengths (odd offsets), clipping, frames that run past a signal's padded end
+            lens = [L - 131, L, 700]
+            sig = [3.0 * yd[b, :lens[b]] for b in range(3)]
+            buf, fr = data_utils.mel_spectrogram_batch(sig)
+            for b in range(3):
+                wb = mel_ref.mel_spectrogram_ref(np.clip(3.0 * y[b:b + 1, :lens[b]], -1, 1))[0].T
+                assert fr[b] == wb.shape[0]
+                assert float(np.abs(buf[b, :fr[b]].cpu().numpy() - wb).max()) < 2e-3, b
+        if frames <= 7:                                                         # the GEMM formulation on the same input
+            calls = []
+            real = _lib_mod.lib().ss_stft_logmel_fft
+            monkeypatch.setattr(data_utils, '_fft_tables', lambda *a, **k: calls.append(1))      # 'does not fit the kernel's tables' -> the GEMM formulation
+            dense = data_utils.mel_spectrogram(yd, 1024, 80, 22050, 256, 1024, 0, 8000).cpu().numpy()
+            monkeypatch.undo()
+            assert calls and real is not None
+            assert float(np.abs(dense - got).max()) < 2e-3 and float(np.abs(dense - got).mean()) < 2e-5
 
 
 def test_pack_roundtrip_golden():
