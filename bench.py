@@ -748,7 +748,7 @@ def main():
             for k, v in prof.summary().items():
                 table[k] = v
             pmc, pmc_src, pmc_stale = {}, None, None
-            for fn in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            for fn in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
                 try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc_summary.py)
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
                     pmc_src = 'profiles/' + fn
@@ -799,6 +799,11 @@ def main():
                 if k['traffic']:        # the measured HBM bytes of a launch over its duration: what share of the 8 TB/s the kernel actually drew
                     k['traffic_frac_of_hbm_peak'] = k['traffic'] / (k['avg_launch_us'] * 1e-6) / 1e9 / PEAK_HBM_GBPS
                 if name in ('attn_fwd', 'attn_bwd'):
+                    # the roof that binds at this shape is HBM: Q, K, V in + O out (forward), Q, K, V, dO, O in + dQ, dK, dV out (backward) -- the
+                    # plan's byte count -- plus the saved probability image once per launch (bf16, 88 MB for the 22 000 frames x 8 heads of the reference batch)
+                    alg = v['bytes'] / v['calls'] + 88.0e6 * (v['bytes'] / v['calls']) / ((4 if name == 'attn_fwd' else 8) * 22000 * 768 * 2.0)
+                    k['hbm'] = {'bound': 'hbm', 'algorithmic_bytes_per_launch': alg, 'achieved': alg / (k['avg_launch_us'] * 1e-6) / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                                'frac': alg / (k['avg_launch_us'] * 1e-6) / 1e9 / PEAK_HBM_GBPS}
                     k['note'] = ('counted as MFMA work (band-limited flops: 3 products forward, 5 backward); transposed-score kernels of round 5 '
                                  '(csrc/attention_t.hip: S^T = K Q^T on 32x32x16 MFMAs, backward = query-major + key-major kernel on the saved probabilities, '
                                  'D folded into the query-major one).  At T = 200 / d_head = 96 with the saved image the forward moves ~75 flops per HBM byte '
@@ -812,7 +817,7 @@ def main():
                                'serial_kernel_ms_per_step': total_s / psteps * 1e3,
                                'timing': 'HIP events around every kernel launch (inside the native plan: ss_plan_profile; Python-launched kernels: '
                                          'torch events on the launch stream) on every 10th (runs of <= 20 steps) / every (steps/2)-th timed step; those steps run without the side stream '
-                                         '(exclusive durations); rocprofv3 counterpart: profiles/r05_serial_kernel_stats.txt',
+                                         '(exclusive durations); rocprofv3 counterpart: profiles/r06_serial_kernel_stats.txt',
                                'kernels': kernels[:16]}
         if world == 1 and args.cpu_rows > 0:
             base, sub, ref_pred = cpu_baseline(batch_cpu, args.cpu_rows, args.cpu_warmup, args.cpu_steps, init_sd, dev)

@@ -16,7 +16,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf -o pf -- python bench.py --st
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw -o pw -- python bench.py --steps 4 --warmup 1 --cpu-rows 0 --no-legs --no-profile --no-same > $O/pw.log 2>&1
 python tools/pmc_summary.py $(find $O/pf -name "*.db" | head -1) $(find $O/pw -name "*.db" | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt
 rm -rf $O/kt $O/ks $O/pf $O/pw
-cp $O/pmc_traffic.json profiles/r05_pmc_traffic.json            # the bench line's `traffic` fields come from THIS run's counters
+cp $O/pmc_traffic.json profiles/r06_pmc_traffic.json            # the bench line's `traffic` fields come from THIS run's counters
 python bench.py > $O/bench.json.log 2>$O/bench.err
 for ss in 1 0; do SS_AMD_SIDE_STREAM=$ss python bench.py --no-profile --no-legs --cpu-rows 0 --steps 20 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('side_stream=$ss', d['ms_per_step'], d['config']['unprofiled'])"; done > $O/side_stream_ab.txt 2>&1
 bash tools/attn_trace.sh > /dev/null 2>&1; cp gpurun_out/attn_trace/kernel_stats.txt $O/attention_kernel_stats.txt
