@@ -38,4 +38,4 @@ if [ -x tools/bin/g8_stamps ] && [ -f tools/bin/stamplib/libsilent_speech_hip.so
 fi
 if [ -f tools/bin/ablib/libsilent_speech_hip.so ]; then bash tools/ab_seq.sh tools/bin/ablib gemm8_kc 66 2>&1 | grep -v "^W2026" > $O/g8_ab_in_step.txt; fi
 timeout 300 python tools/pipeline_profile.py > $O/pipeline_profile.txt 2>&1
-cat $O/pytest_gpu.log; cat $O/side_stream_ab.txt; cat $O/mfma_peak.txt; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/gpu_idle_rotated.txt; cat $O/attention_bench.txt; cat $O/dtw_bench.txt
+cat $O/pytest_gpu.log; cat $O/side_stream_ab.txt; cat $O/mfma_peak.txt; tail -1 $O/bench.json.log | cut -c1-400; head -8 $O/kernel_stats.txt | cut -c1-60,100-170; head -6 $O/serial_kernel_stats.txt | cut -c1-60,100-170; head -8 $O/pmc_traffic.txt; cat $O/gpu_idle_rotated.txt; cat $O/attention_bench.txt; cat $O/dtw_bench.txt; PYTHONPATH=. python tools/mel_probe.py > $O/mel_probe.txt 2>&1; PYTHONPATH=. python tools/ctc_probe.py 2>&1 | grep utterances > $O/ctc_probe.txt; cat $O/mel_probe.txt $O/ctc_probe.txt
