@@ -30,9 +30,9 @@ extern "C" {
 const char* ss_last_error(void);
 /* Library/ABI version and the GPU architecture the kernels were compiled for ("gfx950"). */
 /* Bumped whenever a struct layout or an entry-point signature changes (3: ss_gemm_epilogue column-statistics fields, the plan /
- * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative; 4: ss_loss_index_tables; 5: gate recomputation arguments of ss_bn_backward_sums / ss_bn_backward_apply; 7: ss_split_planes / ss_gemm_planes, ss_dw_job.flags, up to 24 jobs per grouped launch).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
+ * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative; 4: ss_loss_index_tables; 5: gate recomputation arguments of ss_bn_backward_sums / ss_bn_backward_apply; 7: ss_split_planes / ss_gemm_planes, ss_dw_job.flags, up to 24 jobs per grouped launch; 8: ss_stft_logmel_fft, the rejected-frame counter behind the matrix of ss_phoneme_confusion).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
  * library paired with newer headers would otherwise read garbage struct fields instead of failing. */
-#define SS_ABI_VERSION 7
+#define SS_ABI_VERSION 8
 int ss_abi_version(void);
 const char* ss_target_arch(void);
 
@@ -294,7 +294,9 @@ int ss_silent_loss(const float* head, int64_t ld, int n_mel, int n_phone, const 
                    int32_t* correct_accum, void* stream);
 /* Phoneme confusion matrix of the evaluation path (transduction_model.py:130-137 silent, :147-152 voiced), accumulated ON the device:
  * confusion[pred * n_phone + target] += 1 for every target frame, pred = argmax (ss_frame_lse) of the aligned prediction row -- through
- * `results` (ss_dtw_align_skewed) for silent utterances.  Index tables as produced by ss_loss_index_tables; int32 matrix, += . */
+ * `results` (ss_dtw_align_skewed) for silent utterances.  Index tables as produced by ss_loss_index_tables; int32 matrix, += .
+ * `confusion` holds n_phone * n_phone + 1 ints: the last one counts the frames whose prediction or target label lies outside [0, n_phone) (the
+ * reference's numpy indexing raises IndexError for those, :134-137); they are left out of the matrix and the caller decides (DeviceConfusion raises). */
 int ss_phoneme_confusion(const int32_t* argmax, const int64_t* phones, const int32_t* results, const int32_t* vo_pred, const int32_t* vo_tgt,
                          int n_voiced, const int32_t* si_tgt, const int32_t* si_base, const int32_t* si_res, int n_silent_frames,
                          int32_t* confusion, int n_phone, void* stream);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('SS_AMD_LIBRARY') or os.path.join(_HERE, 'lib', 'libsilent_speech_hip.so')      # override: A/B runs of two builds on one box
 
 SS_F32, SS_BF16, SS_F64, SS_F32X3 = 0, 1, 2, 3
-ABI_VERSION = 7          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
+ABI_VERSION = 8          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
 OP_KC, OP_OC = 0, 1
 
 

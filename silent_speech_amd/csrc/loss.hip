@@ -316,6 +316,7 @@ __global__ void phoneme_confusion_kernel(const int* __restrict__ amax, const lon
         if (i < n_voiced) { p = amax[vo_pred[i]]; t = (int)phones[vo_tgt[i]]; }
         else { const int k = i - n_voiced; p = amax[si_base[k] + results[si_res[k]]]; t = (int)phones[si_tgt[k]]; }
         if ((unsigned)p < (unsigned)n_phone && (unsigned)t < (unsigned)n_phone) atomicAdd(conf + p * n_phone + t, 1);
+        else atomicAdd(conf + n_phone * n_phone, 1);     // a label outside the inventory: the reference raises IndexError (or wraps a negative one); counted, the host checks
     }
 }
 

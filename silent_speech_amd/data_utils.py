@@ -56,6 +56,14 @@ _dft_cache = {}
 _mel_cache = {}
 
 
+def _settle_cache(device):
+    """A cached constant (DFT matrix, mel basis, FFT tables) is uploaded on whichever stream misses the cache first and read from every stream after that
+    (pipeline.DeviceBatchBuilder runs the audio half of a batch on a side stream): the upload is followed by ONE device-wide synchronisation, so that no
+    later reader on another stream can start before the bytes are there (round-5 advisor finding; a cache miss happens once per configuration)."""
+    if getattr(device, 'type', str(device)) == 'cuda' and torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+
+
 def _windowed_dft(n_fft, win_size, device):
     """[2*nb][n_fft] f32: rows 0..nb-1 = hann(n) cos(2 pi k n / N), rows nb..2nb-1 = hann(n) sin(.)   (nb = N/2+1)"""
     key = (n_fft, win_size, str(device))
@@ -68,6 +76,7 @@ def _windowed_dft(n_fft, win_size, device):
         ang = 2.0 * np.pi * np.outer(np.arange(nb), n) / n_fft
         mat = np.concatenate([np.cos(ang) * win[None, :], np.sin(ang) * win[None, :]], 0).astype(np.float32)
         _dft_cache[key] = torch.from_numpy(mat).to(device)
+        _settle_cache(device)
     return _dft_cache[key]
 
 
@@ -78,6 +87,7 @@ def _mel_basis(sampling_rate, n_fft, num_mels, fmin, fmax, device, ld):
         pad = np.zeros((num_mels, ld), dtype=np.float32)
         pad[:, :b.shape[1]] = b
         _mel_cache[key] = torch.from_numpy(pad).to(device)
+        _settle_cache(device)
     return _mel_cache[key]
 
 
@@ -168,6 +178,7 @@ def _fft_tables(n_fft, win_size, num_mels, sampling_rate, fmin, fmax, device):
             w = np.concatenate(ws) if n_w else np.zeros(1, dtype=np.float32)
             t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dt))).to(device)
             _fft_cache[key] = (t(win, np.float32), t(lo, np.int32), t(cnt, np.int32), t(offs, np.int32), t(w, np.float32), t(lb, np.int32), n_w)
+            _settle_cache(device)
     return _fft_cache[key]
 
 

@@ -209,7 +209,7 @@ class DeviceConfusion(object):
 
     def __init__(self, n_phone, device):
         self.n = int(n_phone)
-        self.mat = torch.zeros(self.n * self.n, dtype=torch.int32, device=device)
+        self.mat = torch.zeros(self.n * self.n + 1, dtype=torch.int32, device=device)      # + 1: frames with a label outside the inventory (see numpy())
 
     def add(self, plan):
         L = _lib.lib()
@@ -220,7 +220,13 @@ class DeviceConfusion(object):
                    'ss_phoneme_confusion')
 
     def numpy(self):
-        return self.mat.view(self.n, self.n).cpu().numpy()
+        """The matrix on the host (one read-back).  Raises IndexError when a prediction or target label fell outside [0, n_phone) in any batch added since
+        construction -- the reference's `phoneme_confusion[p, t] += 1` (transduction_model.py:134-137, :150-152) raises on such a label; silently dropping the
+        frame would hand back a matrix whose total is smaller than the number of target frames."""
+        host = self.mat.cpu().numpy()
+        if int(host[-1]) != 0:
+            raise IndexError('DeviceConfusion: %d frame(s) carried a predicted or target phoneme label outside [0, %d)' % (int(host[-1]), self.n))
+        return host[:-1].reshape(self.n, self.n)
 
 
 class EnsembleModel(torch.nn.Module):

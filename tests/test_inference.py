@@ -107,6 +107,17 @@ def test_confusion_matrix_on_the_device_equals_the_host_loop(dev):
     assert got.sum() == 2 * sum(int(a.shape[0]) for a in cpu['audio_features'])
     assert np.array_equal(got, host.astype(np.int64))
     assert np.array_equal(got, 2 * want.astype(np.int64))
+    # a label outside the inventory (the reference's numpy indexing raises IndexError, :134-137): counted on the device, raised at the read-back
+    bad = dict(batch)
+    bad['phonemes'] = [t.clone() for t in batch['phonemes']]
+    bad['phonemes'][0][3] = 48
+    with torch.no_grad():
+        X, X_raw, sess = tm._pack_batch(bad, dev, seq_len=40)
+        pred, aux = m(X, X_raw, sess)
+        dc2 = tm.DeviceConfusion(48, dev)
+        tm.dtw_loss(pred, aux, bad, True, dc2, phoneme_loss_weight=0.0)
+    with pytest.raises(IndexError, match='1 frame'):
+        dc2.numpy()
 
 
 def test_ensemble_model_averages(dev):
