@@ -343,7 +343,21 @@ def ctc_leg(dev, warm=2, timed=6):
         gl.backward()
     e1.record()
     torch.cuda.synchronize()
-    t_loss = e0.elapsed_time(e1) * 1e-3 / iters
+    t_call = e0.elapsed_time(e1) * 1e-3 / iters
+    # the device time of the op itself (lse + alpha/beta + gradient kernels): the utterance tables built once, the launches back to back -- the loop above is bound by
+    # the host (numpy tables, one pinned upload, dispatcher, autograd) at this size: ~0.35 ms per call against ~0.18 ms of kernels
+    from silent_speech_amd.recognition_model import _CtcPlan
+    plan = _CtcPlan(b['lengths'], b['text_int'], int(logits.shape[0] * logits.shape[1]), dev)
+    flat = logits.detach().reshape(-1, 38).contiguous()
+    for _ in range(3):
+        torch.ops.silent_speech.ctc_loss(flat, plan.desc, plan.targets, plan.n, plan.max_s, plan.ws_floats, 38, 37)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        torch.ops.silent_speech.ctc_loss(flat, plan.desc, plan.targets, plan.n, plan.max_s, plan.ws_floats, 38, 37)
+    e1.record()
+    torch.cuda.synchronize()
+    t_loss = e0.elapsed_time(e1) * 1e-3 / 20
     # the reference's own lines on the host
     from silent_speech_amd.data_utils import decollate_tensor
     cpu_logits = pred.cpu().requires_grad_(True)
@@ -363,10 +377,10 @@ def ctc_leg(dev, warm=2, timed=6):
     return {'workload': 'configs[4]: recognition step, 768-d / 6-layer encoder bf16 + CTC (38 classes), 2 batches of a 128 000-sample budget per optimiser step, dropout 0.2',
             'frames_per_unit': frames, 'utterances': [len(x['lengths']) for x in batches], 'ms_per_unit': dt * 1e3, 'frames_per_s': frames / dt,
             'final_loss': float(loss.detach()),
-            'ctc_loss': {'hip_ms': t_loss * 1e3, 'frames': int(sum(lens)), 'cpu_ms': t_cpu * 1e3, 'cpu_kind': 'torch CPU log_softmax + pad_sequence + F.ctc_loss + backward (the reference\'s own lines, recognition_model.py:96-101), %d threads' % torch.get_num_threads(),
+            'ctc_loss': {'hip_ms': t_loss * 1e3, 'call_ms': t_call * 1e3, 'frames': int(sum(lens)), 'cpu_ms': t_cpu * 1e3, 'cpu_kind': 'torch CPU log_softmax + pad_sequence + F.ctc_loss + backward (the reference\'s own lines, recognition_model.py:96-101), %d threads' % torch.get_num_threads(),
                          'loss_hip': float(gl.detach()), 'loss_cpu': float(ref.detach()), 'grad_max_err_over_max': derr,
                          'roofline': {'bound': 'hbm', 'achieved': byts / t_loss / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': byts / t_loss / 1e9 / PEAK_HBM_GBPS,
-                                      'note': 'latency-bound: T dependent alpha/beta columns per utterance, one workgroup per (utterance, direction)'}}}
+                                      'note': 'latency-bound: T dependent alpha/beta columns per utterance; one workgroup per (utterance, direction), its waves a pipeline over the states + a loader wave (csrc/ctc.hip, round 6); hip_ms = device time of the op (its three kernels, tables built once, 20 launches back to back; rounds 3-5 reported the host-bound call here: 0.785 ms); call_ms = the whole ctc_loss(...).backward() call incl. building and uploading the utterance tables (host-bound at this size)'}}}
 
 
 def eval_leg(dev):

@@ -61,12 +61,11 @@ def rowwise_mask(seed, stream, rows, C, p):
 
 
 def gemm_epilogue_mask(seed, stream, M, N, p):
-    """Keep mask (M, N) of the GEMM epilogue dropout (csrc/gemm_common.h): element (row, col) <-> group (row >> 2)*N + col,
-    slot row & 3."""
-    Mp = (M + 3) // 4 * 4
-    g4 = np.arange(Mp // 4, dtype=np.uint64)[:, None] * np.uint64(N) + np.arange(N, dtype=np.uint64)[None, :]
-    k = keep4(seed, stream, g4, p)                    # (Mp/4, N, 4)
-    return np.ascontiguousarray(k.transpose(0, 2, 1)).reshape(Mp, N)[:M]
+    """Keep mask (M, N) of the GEMM epilogue dropout (csrc/common.h dropout_keep1 / the epilogues of gemm_common.h and gemm8.hip): element (row, col) is
+    element e = row * N + col of the stream: group e >> 2, slot e & 3 (round 6: row-major like add_dropout_layernorm's mask; rounds 1-5 grouped four ROWS of a column)."""
+    n = M * N
+    g4 = np.arange((n + 3) // 4, dtype=np.uint64)
+    return keep4(seed, stream, g4, p).reshape(-1)[:n].reshape(M, N)
 
 
 def attention_mask_tiled(seed, stream, B, H, T, p):

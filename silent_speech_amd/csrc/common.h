@@ -362,6 +362,17 @@ __device__ __forceinline__ void dropout_keep4(unsigned long long seed, unsigned 
     const unsigned t16 = thresh >> 16;
     keep[0] = (a & 0xffffu) >= t16; keep[1] = (a >> 16) >= t16; keep[2] = (b & 0xffffu) >= t16; keep[3] = (b >> 16) >= t16;
 }
+// One element of the same stream: element e <-> group e >> 2, slot e & 3 (only the word that holds the slot is mixed).  The GEMM epilogues draw by the ROW-MAJOR
+// element index e = row * N + col (round 6; before: group (row >> 2) * N + col, slot row & 3): a lane of the transposed accumulator layout holds four consecutive
+// columns of one row, i.e. exactly one group -- the dropout epilogue of the 8-wave kernel can leave through the register epilogue (direct_store8) instead of the LDS
+// C piece.  Kernels whose lanes hold four ROWS of one column draw element by element.
+__device__ __forceinline__ bool dropout_keep1(unsigned long long seed, unsigned stream, unsigned long long e, unsigned thresh) {
+    const unsigned long long g4 = e >> 2;
+    const unsigned lo = (unsigned)g4, hi = (unsigned)(g4 >> 32), slot = (unsigned)e & 3u;
+    const unsigned key = (unsigned)seed ^ ((unsigned)(seed >> 32) * 0x9E3779B9u) ^ (stream * 0x85EBCA6Bu) ^ (hi * 0xC2B2AE35u);
+    const unsigned w = (slot & 2u) ? mix32(lo * 2u + 1u + (key ^ 0x68E31DA4u)) : mix32(lo * 2u + key);
+    return ((slot & 1u) ? (w >> 16) : (w & 0xffffu)) >= (thresh >> 16);
+}
 static inline unsigned dropout_threshold(float p) {
     double t = (double)p * 4294967296.0;
     if (t <= 0) return 0u;

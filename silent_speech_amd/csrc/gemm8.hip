@@ -131,7 +131,10 @@ __device__ __forceinline__ void stage8(const f32x4& a, TO* __restrict__ ct, int 
 {
     const float lo = epi.relu ? 0.f : -INFINITY;
     bool kp[4] = {true, true, true, true};
-    if (GEN == 1) dropout_keep4(epi.seed, epi.stream, (unsigned long long)(row0 >> 2) * (unsigned)N + col, epi.drop_thresh, kp);
+    if (GEN == 1) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) kp[reg] = dropout_keep1(epi.seed, epi.stream, (unsigned long long)(row0 + reg) * (unsigned)N + col, epi.drop_thresh);
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         float x = fmaxf(a[reg] * epi.alpha + bias, lo);
@@ -144,13 +147,19 @@ __device__ __forceinline__ void stage8(const f32x4& a, TO* __restrict__ ct, int 
 // The same for the TRANSPOSED accumulator layout of the kernels without dropout (MFMA operands swapped): lane (r, q) holds row r and columns
 // 4 q .. 4 q + 3 of the 16 x 16 tile, so the four values leave as ONE 8-byte (bf16) / 16-byte (f32) LDS store instead of four 2-byte ones
 // (a store's cost is its address + data transfer: 4 cycles for a 2-byte ds_write, 6 for 8 bytes)
-template <class TO>
-__device__ __forceinline__ void stage8_sw(const f32x4& a, TO* __restrict__ ct, int ldc, int lrow, int lcol0, const GemmEpi& epi, const f32x4& bias)
+template <class TO, bool DROP = false>
+__device__ __forceinline__ void stage8_sw(const f32x4& a, TO* __restrict__ ct, int ldc, int lrow, int lcol0, const GemmEpi& epi, const f32x4& bias, int row = 0, int col0 = 0, int N = 0)
 {
     const float lo = epi.relu ? 0.f : -INFINITY;
     float x[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] = fmaxf(a[e] * epi.alpha + bias[e], lo);
+    if constexpr (DROP) {               // the lane's four columns are ONE group of the row-major stream (N % 4 == 0, col0 % 4 == 0)
+        bool kp[4];
+        dropout_keep4(epi.seed, epi.stream, ((unsigned long long)row * (unsigned)N + col0) >> 2, epi.drop_thresh, kp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = kp[e] ? x[e] * epi.drop_scale : 0.f;
+    }
     if constexpr (sizeof(TO) == 2) { u32x2 w; w[0] = pack_bf16(x[0], x[1]); w[1] = pack_bf16(x[2], x[3]); *(u32x2*)(ct + lrow * ldc + lcol0) = w; }
     else { f32x4 w = {x[0], x[1], x[2], x[3]}; *(f32x4*)(ct + lrow * ldc + lcol0) = w; }
 }
@@ -181,7 +190,7 @@ __device__ __forceinline__ void lane16_swap(unsigned& x, unsigned& y) {
 // one atomic per column, wave and tile.
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
-template <int NI, bool INTERIOR, int STATS>
+template <int NI, bool INTERIOR, int STATS, bool DROP = false>
 __device__ __forceinline__ void direct_store8(const f32x4 (&acc)[NI][4], bf16_t* __restrict__ C, const GemmEpi& epi, int m0, int n0, int M, int N, int wm, int wn, int r, int q,
                                               const f32x4 (&b16)[4])
 {
@@ -223,6 +232,12 @@ __device__ __forceinline__ void direct_store8(const f32x4 (&acc)[NI][4], bf16_t*
                 float x[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = fmaxf(acc[i][2 * jp + t][e] * alpha + b16[2 * jp + t][e], lo);
+                if constexpr (DROP) {       // before the lane16 swap: columns 4 q .. 4 q + 3 of tile 2 jp + t = one group of the row-major stream
+                    bool kp[4];
+                    dropout_keep4(epi.seed, epi.stream, ((unsigned long long)row * (unsigned)N + (n0 + wn * 64 + (2 * jp + t) * 16 + 4 * q)) >> 2, epi.drop_thresh, kp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = kp[e] ? x[e] * epi.drop_scale : 0.f;
+                }
                 w[t][0] = pack_bf16(x[0], x[1]); w[t][1] = pack_bf16(x[2], x[3]);
             }
             lane16_swap(w[0][0], w[1][0]);
@@ -369,7 +384,8 @@ struct Passes8 {
             if (I0 + ii < NI) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if constexpr (SW) stage8_sw<TO>(acc[I0 + ii < NI ? I0 + ii : 0][j], ct, ldc, (wm * IPP + ii) * 16 + r, wn * 64 + j * 16 + q * 4, epi, b16[j]);
+                    if constexpr (SW) stage8_sw<TO, GEN == 1>(acc[I0 + ii < NI ? I0 + ii : 0][j], ct, ldc, (wm * IPP + ii) * 16 + r, wn * 64 + j * 16 + q * 4, epi, b16[j],
+                                                             m0 + (wm * NI + I0 + ii) * 16 + r, n0 + wn * 64 + j * 16 + q * 4, N);
                     else stage8<TO, GEN>(acc[I0 + ii < NI ? I0 + ii : 0][j], ct, ldc, (wm * IPP + ii) * 16 + q * 4, wn * 64 + j * 16 + r, epi,
                                          m0 + (wm * NI + I0 + ii) * 16 + q * 4, n0 + wn * 64 + j * 16 + r, N, bias4[j]);
                 }
@@ -410,7 +426,8 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
                                                        int M, int N, int K, RowMap amap, RowMap bmap, GemmEpi epi, int tiles_n, int nitems, long long a_lo, long long b_lo)
 {
     using namespace g8;
-    constexpr bool SWAP = GENSEL == 0;                       // kernels that can never run the dropout epilogue: transposed accumulator tiles (see stage8_sw)
+    constexpr bool SWAP = GENSEL == 0 || GENSEL == 1;        // one epilogue path known at compile time (none / dropout): transposed accumulator tiles (see stage8_sw);
+                                                             // the dropout draws follow the row-major element index, so a lane's four columns are one group (common.h)
     constexpr int BMT = 2 * NI * 16, STAGE = (BMT + TBN) * RB;
     constexpr int HRSEL = PIN >> 2;                         // PIN bits 2..3: rows of 16 per phase -- 0: 3 or 4, 1: one, 2: two (even NI)
     constexpr int HR = HRSEL == 1 ? 1 : (HRSEL == 2 && NI % 2 == 0 ? 2 : (NI % 3 == 0 ? 3 : 4));                 // 16-row MFMA tiles per phase
@@ -597,14 +614,14 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
         const int pf = STATS == 1 ? 0 : (epi.gate ? 1 : (epi.mode == 1 ? 2 : 0));
         const TO* pf_src = pf == 1 ? (const TO*)epi.gate : C;
         // bf16 results of the transposed accumulator layout leave straight from the registers (direct_store8: alpha / bias / ReLU, gate, C += v,
-        // column sums); the C piece in LDS remains for the dropout kernels (untransposed layout), the BatchNorm statistics and f32 output
+        // column sums, and -- round 6 -- the dropout of linear1's epilogue); the C piece in LDS remains for the BatchNorm statistics and f32 output
         constexpr bool DIRECT = SWAP && sizeof(TO) == 2 && STATS == 0;
         if constexpr (DIRECT) {
             G8_STAMP(item, 3);
             if (cm0 + BMT <= M && cn0 + TBN <= N) {
-                direct_store8<NI, true, STATS>(acc, (bf16_t*)C, epi, cm0, cn0, M, N, wm, wn, r_e, q_e, b16);
+                direct_store8<NI, true, STATS, GENSEL == 1>(acc, (bf16_t*)C, epi, cm0, cn0, M, N, wm, wn, r_e, q_e, b16);
                 stores_behind_tile0 = ring_next;
-            } else direct_store8<NI, false, STATS>(acc, (bf16_t*)C, epi, cm0, cn0, M, N, wm, wn, r_e, q_e, b16);
+            } else direct_store8<NI, false, STATS, GENSEL == 1>(acc, (bf16_t*)C, epi, cm0, cn0, M, N, wm, wn, r_e, q_e, b16);
         } else {
             // ("some value", fixed per item: left plainly undefined on the paths without a side input, the 24 registers became a value carried
             // around the item loop -- spilled before the K loop and reloaded, behind the global stores, in the epilogue; zeroed, they are live
@@ -638,7 +655,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
 #pragma unroll
                     for (int e = 0; e < EV; ++e) { const int col = cn0 + ch * EV + e; sh[e] = col < N ? epi.col_shift[col] : 0.f; }
                 }
-                if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+                if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
                 else Passes8<TO, 0, NI, IPP, 0, NPASS, STATS, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
                 if (CPR == 32) {                  // bf16 out: lanes l and l + 32 of a wave hold the same column chunk
 #pragma unroll
@@ -663,7 +680,7 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
                     }
                 }
             } else {
-                if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, 0>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+                if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, 0, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
                 else Passes8<TO, 0, NI, IPP, 0, NPASS, 0, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
             }
         }

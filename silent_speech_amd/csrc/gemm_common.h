@@ -69,10 +69,8 @@ __device__ __forceinline__ void epilogue_tile(const f32x4& a, TO* __restrict__ C
             const long long off = rowmap_off(epi.cmap, row) + pcol;
             float v = a[reg] * epi.alpha + bias;
             if (epi.relu) v = fmaxf(v, 0.f);
-            if (epi.drop_thresh) {   // element (row, col) <-> Philox block (row>>2)*N + col, word row & 3  (row0 is a multiple of 4)
-                bool kp[4]; dropout_keep4(epi.seed, epi.stream, (unsigned long long)(row >> 2) * (unsigned)N + col, epi.drop_thresh, kp);
-                v = kp[reg] ? v * epi.drop_scale : 0.f;
-            }
+            if (epi.drop_thresh)     // element (row, col) <-> element row * N + col of the stream (common.h: dropout_keep1)
+                v = dropout_keep1(epi.seed, epi.stream, (unsigned long long)row * (unsigned)N + col, epi.drop_thresh) ? v * epi.drop_scale : 0.f;
             if (epi.gate) v = ldf((const TO*)epi.gate + off) > 0.f ? v * epi.gate_scale : 0.f;
             if (epi.log_clamp > 0.f) v = logf(fmaxf(v, epi.log_clamp));
             out_add(C + off, v, epi.mode);
@@ -92,7 +90,10 @@ __device__ __forceinline__ void epilogue_stage(const f32x4& a, TO* __restrict__ 
     const float bias = (epi.bias && col < N) ? epi.bias[col] : 0.f;
     const float lo = epi.relu ? 0.f : -INFINITY;
     bool kp[4] = {true, true, true, true};
-    if (GENERAL == 1) dropout_keep4(epi.seed, epi.stream, (unsigned long long)(row0 >> 2) * (unsigned)N + col, epi.drop_thresh, kp);
+    if (GENERAL == 1) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) kp[reg] = dropout_keep1(epi.seed, epi.stream, (unsigned long long)(row0 + reg) * (unsigned)N + col, epi.drop_thresh);
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         float x = fmaxf(a[reg] * epi.alpha + bias, lo);

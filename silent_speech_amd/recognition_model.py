@@ -18,7 +18,7 @@ import string
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, staging
 from .pipeline import SizeAwareSampler
 from .architecture import Model
 from .flags import FLAGS
@@ -58,9 +58,16 @@ class _CtcPlan(object):
         ws = np.concatenate([[0], np.cumsum([n * (2 * s + 1) for n, s in zip(lengths, tl)])])
         desc = np.stack([f0[:-1], lengths, g0[:-1], tl, ws[:-1]], 1).astype(np.int64) if lengths else np.zeros((0, 5), np.int64)
         self.n, self.max_s, self.ws_floats = len(lengths), max(tl) if tl else 0, int(ws[-1])
-        self.desc = torch.from_numpy(desc).to(device, non_blocking=True)
-        flat = torch.cat([t.reshape(-1).to(torch.int32) for t in targets]) if sum(tl) else torch.zeros(1, dtype=torch.int32)
-        self.targets = flat.to(device, non_blocking=True).contiguous()
+        # both tables cross PCIe in ONE pinned copy on the current stream (staging.upload): two pageable .to(device) calls cost a blocking
+        # copy each -- more than the CTC kernels of the batch (bench.py ctc.ctc_loss.hip_ms 0.34 ms with them against 0.18 ms of kernels)
+        if all(torch.is_tensor(t) and t.device.type == 'cpu' for t in targets) or not targets:
+            flat = np.concatenate([t.reshape(-1).numpy().astype(np.int32) for t in targets]) if sum(tl) else np.zeros(1, dtype=np.int32)
+            self.desc, self.targets = staging.upload([desc if desc.size else np.zeros((1, 5), np.int64), flat], device)
+            self.desc = self.desc[:len(lengths)]
+        else:                                                            # labels that already live on the device
+            self.desc, = staging.upload([desc if desc.size else np.zeros((1, 5), np.int64)], device)
+            self.desc = self.desc[:len(lengths)]
+            self.targets = torch.cat([t.reshape(-1).to(device=device, dtype=torch.int32) for t in targets]).contiguous() if sum(tl) else torch.zeros(1, dtype=torch.int32, device=device)
         self.lengths, self.tlens = lengths, tl
 
 
