@@ -380,7 +380,7 @@ def ctc_leg(dev, warm=2, timed=6):
             'ctc_loss': {'hip_ms': t_loss * 1e3, 'call_ms': t_call * 1e3, 'frames': int(sum(lens)), 'cpu_ms': t_cpu * 1e3, 'cpu_kind': 'torch CPU log_softmax + pad_sequence + F.ctc_loss + backward (the reference\'s own lines, recognition_model.py:96-101), %d threads' % torch.get_num_threads(),
                          'loss_hip': float(gl.detach()), 'loss_cpu': float(ref.detach()), 'grad_max_err_over_max': derr,
                          'roofline': {'bound': 'hbm', 'achieved': byts / t_loss / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': byts / t_loss / 1e9 / PEAK_HBM_GBPS,
-                                      'note': 'latency-bound: T dependent alpha/beta columns per utterance; one workgroup per (utterance, direction), its waves a pipeline over the states + a loader wave (csrc/ctc.hip, round 6); hip_ms = device time of the op (its three kernels, tables built once, 20 launches back to back; rounds 3-5 reported the host-bound call here: 0.785 ms); call_ms = the whole ctc_loss(...).backward() call incl. building and uploading the utterance tables (host-bound at this size)'}}}
+                                      'note': 'latency-bound: T dependent alpha/beta columns per utterance; one workgroup per (utterance, direction), its waves a pipeline over the states + a loader wave (csrc/ctc.hip, round 6); hip_ms = device time of the op (its three kernels, tables built once, 20 launches back to back; rounds 3-5 timed the whole call here: 0.785 ms, kernel-bound then); call_ms = the whole ctc_loss(...).backward() call incl. building and uploading the utterance tables (host-bound at this size)'}}}
 
 
 def eval_leg(dev):
