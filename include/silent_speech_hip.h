@@ -30,9 +30,9 @@ extern "C" {
 const char* ss_last_error(void);
 /* Library/ABI version and the GPU architecture the kernels were compiled for ("gfx950"). */
 /* Bumped whenever a struct layout or an entry-point signature changes (3: ss_gemm_epilogue column-statistics fields, the plan /
- * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative; 4: ss_loss_index_tables; 5: gate recomputation arguments of ss_bn_backward_sums / ss_bn_backward_apply; 7: ss_split_planes / ss_gemm_planes, ss_dw_job.flags, up to 24 jobs per grouped launch; 8: ss_stft_logmel_fft, the rejected-frame counter behind the matrix of ss_phoneme_confusion).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
+ * attention-image / LayerNorm-workspace entry points, ss_dtw_cumulative; 4: ss_loss_index_tables; 5: gate recomputation arguments of ss_bn_backward_sums / ss_bn_backward_apply; 7: ss_split_planes / ss_gemm_planes, ss_dw_job.flags, up to 24 jobs per grouped launch; 8: ss_stft_logmel_fft, the rejected-frame counter behind the matrix of ss_phoneme_confusion; 9: planes_hi / planes_lo / planes_only of ss_gemm_epilogue, dropout groups of the GEMM epilogue are row-major).  Bindings must compare it with SS_ABI_VERSION at load time: a stale
  * library paired with newer headers would otherwise read garbage struct fields instead of failing. */
-#define SS_ABI_VERSION 8
+#define SS_ABI_VERSION 9
 int ss_abi_version(void);
 const char* ss_target_arch(void);
 
@@ -58,7 +58,7 @@ typedef struct ss_gemm_epilogue {
     int32_t relu;           /* F.relu  (architecture.py:32; transformer.py:57)                        */
     float dropout_p;        /* nn.Dropout in training mode (transformer.py:57); counter-based hash RNG  */
     uint64_t seed;
-    uint32_t rng_stream;    /* dropout site id; 4 consecutive rows of one column share one RNG draw group */
+    uint32_t rng_stream;    /* dropout site id; element (row, col) is element row * N + col of the stream (4 consecutive elements share a draw group) */
     int32_t mode;           /* 0 store, 1 C += v, 2 atomicAdd(C, v) (f32 out; required for split_k>1) */
     int32_t col_mod, col_mul, col_div_mul; /* optional output column permutation
                                col -> (col % col_mod)*col_mul + (col / col_mod)*col_div_mul           */
@@ -76,6 +76,13 @@ typedef struct ss_gemm_epilogue {
     float* col_sum;
     float* col_sumsq;
     const float* col_shift;
+    /* ss_gemm_planes only (ABI 9): the stored result ALSO leaves as hi / lo bf16 planes -- hi = bf16(v), lo = bf16(v - hi), the arithmetic of
+       ss_split_planes on the f32 value the kernel stores -- addressed like C (same row map, 2-byte elements), so that a consumer that is a plane
+       GEMM / plane attention needs no split pass over C.  planes_only != 0: C itself is not written (C is still the address the row map refers to
+       and must be non-NULL).  Column statistics, gate and accumulation apply before the split, as they do before the store.  NULL = off. */
+    void* planes_hi;
+    void* planes_lo;
+    int32_t planes_only;
 } ss_gemm_epilogue;
 
 #define SS_OP_KC 0   /* reduction index contiguous:  elem(o, r) = p[rowmap(o) + r] */
@@ -459,7 +466,7 @@ void ss_plan_destroy(ss_plan* plan);                                /* [host] */
 int ss_plan_slot_count(const ss_plan* plan);                        /* [host] */
 const char* ss_plan_slot_name(const ss_plan* plan, int slot);       /* [host] */
 int ss_plan_bind(ss_plan* plan, int slot, void* device_ptr_or_value); /* [host] slots named *.total / *.all_f32 / *.bytes take integers */
-int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off, 4 BatchNorm backward recomputes the ReLU gate (on) or reads the saved output (off), 5 an SS_F32 plan runs its GEMMs as SS_F32X3 (bf16 x 3 MFMA on f32 operands) on/off (default off = exact f32), 6 the training-mode forward leaves x_raw untouched and only hands the shifted signal out in shifted_scratch (default off = written back in place like architecture.py:67-68), 7 an SS_F32X3 plan runs every GEMM the 8-wave kernel can take on hi / lo bf16 planes (ss_split_planes / ss_gemm_planes; default on), 8 the bound EF tables are the [hi | lo] tables of ss_relpos_attention_x3_prepare_tables: such a plan also runs its attention on planes (default off) */
+int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off, 4 BatchNorm backward recomputes the ReLU gate (on) or reads the saved output (off), 5 an SS_F32 plan runs its GEMMs as SS_F32X3 (bf16 x 3 MFMA on f32 operands) on/off (default off = exact f32), 6 the training-mode forward leaves x_raw untouched and only hands the shifted signal out in shifted_scratch (default off = written back in place like architecture.py:67-68), 7 an SS_F32X3 plan runs every GEMM the 8-wave kernel can take on hi / lo bf16 planes (ss_split_planes / ss_gemm_planes; default on), 8 the bound EF tables are the [hi | lo] tables of ss_relpos_attention_x3_prepare_tables: such a plan also runs its attention on planes (default off), 9 plane GEMMs whose consumers take planes (qkv, the FFN hidden activation and its gradient, dO) write them from their epilogue instead of a split pass on first use (default on) */
 int ss_plan_set_reduce_hook(ss_plan* plan, ss_reduce_hook fn, void* user); /* [host] */
 int ss_plan_set_event_hook(ss_plan* plan, ss_event_hook fn, void* user);   /* [host] */
 int64_t ss_plan_ctx_bytes(void);                                    /* [host] */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get('SS_AMD_LIBRARY') or os.path.join(_HERE, 'lib', 'libsilent_speech_hip.so')      # override: A/B runs of two builds on one box
 
 SS_F32, SS_BF16, SS_F64, SS_F32X3 = 0, 1, 2, 3
-ABI_VERSION = 8          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
+ABI_VERSION = 9          # include/silent_speech_hip.h: SS_ABI_VERSION (struct layouts / signatures this binding was written against)
 OP_KC, OP_OC = 0, 1
 
 
@@ -29,7 +29,8 @@ class GemmEpilogue(ctypes.Structure):
                 ('seed', ctypes.c_uint64), ('rng_stream', ctypes.c_uint32), ('mode', ctypes.c_int32),
                 ('col_mod', ctypes.c_int32), ('col_mul', ctypes.c_int32), ('col_div_mul', ctypes.c_int32),
                 ('log_clamp', ctypes.c_float), ('c2', ctypes.c_void_p), ('cmap2', RowMap), ('col_stride2', ctypes.c_int64),
-                ('col_sum', ctypes.c_void_p), ('col_sumsq', ctypes.c_void_p), ('col_shift', ctypes.c_void_p)]
+                ('col_sum', ctypes.c_void_p), ('col_sumsq', ctypes.c_void_p), ('col_shift', ctypes.c_void_p),
+                ('planes_hi', ctypes.c_void_p), ('planes_lo', ctypes.c_void_p), ('planes_only', ctypes.c_int32)]
 
 
 class DwJob(ctypes.Structure):

@@ -889,6 +889,10 @@ static int build_epi(GemmEpi& epi, int dtype_out, const void* C, int M, int N, c
         epi.log_clamp = e->log_clamp;
         if (e->c2) { epi.c2 = e->c2; epi.cmap2 = to_rowmap(&e->cmap2); epi.col_stride2 = e->col_stride2; }
         epi.col_sum = e->col_sum; epi.col_sumsq = e->col_sumsq; epi.col_shift = e->col_shift;
+        epi.planes_hi = e->planes_hi; epi.planes_lo = e->planes_lo; epi.planes_only = e->planes_only;
+        SS_CHECK((e->planes_hi != nullptr) == (e->planes_lo != nullptr) && !(e->planes_only && !e->planes_hi), "ss_gemm: planes_hi / planes_lo come together (planes_only needs them)");
+        SS_CHECK(!e->planes_hi || (dtype_out == SS_F32 && e->mode != 2 && !e->c2 && !e->col_mod && ((uintptr_t)e->planes_hi | (uintptr_t)e->planes_lo) % 8 == 0),
+                 "ss_gemm: plane output needs f32 results, no atomic mode / second copy / column permutation and 8-byte aligned planes");
         SS_CHECK(!(e->col_sumsq && !e->col_sum), "ss_gemm: col_sumsq needs col_sum");
         SS_CHECK(e->mode >= 0 && e->mode <= 2, "ss_gemm: bad output mode %d", e->mode);
         SS_CHECK(!(e->mode == 2 && dtype_out != SS_F32), "ss_gemm: atomic accumulation needs f32 output");
@@ -943,6 +947,7 @@ extern "C" int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, cons
     (void)esz;
     GemmEpi epi;
     if (build_epi(epi, dtype_out, C, M, N, cmap, e, split_k)) return 1;
+    SS_CHECK(!epi.planes_hi, "ss_gemm: plane output is an epilogue of ss_gemm_planes only");
     RowMap am = to_rowmap(amap), bm = to_rowmap(bmap);
     if (dtype_in == SS_BF16 && dtype_out == SS_BF16) return launch_gemm<bf16_t, bf16_t>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);
     if (dtype_in == SS_BF16 && dtype_out == SS_F32) return launch_gemm<bf16_t, float>(a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k, stream);

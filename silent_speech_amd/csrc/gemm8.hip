@@ -336,7 +336,7 @@ __device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* _
         int lr, ch, row, col;
         if (F::map(H * (F::NIT / 2) + i, tid, pass, m0, n0, M, N, lr, ch, row, col)) {
             const long long off = rowmap_off(epi.cmap, row) + col;
-            if (STATS == 0 && !epi.gate && epi.mode != 1) {
+            if (STATS == 0 && !epi.gate && epi.mode != 1 && !(sizeof(TO) == 4 && epi.planes_hi)) {
                 // nothing is applied per element here (bias / ReLU / dropout went in before the LDS piece): the 16 bytes leave as they are --
                 // unpacking 8 bf16 to f32 and rounding them back was ~60 of this chunk's instructions, on every plain tile of the step
                 *(u32x4*)(C + off) = *(const u32x4*)(ct + lr * ldc + ch * EV);
@@ -357,7 +357,16 @@ __device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* _
 #pragma unroll
                 for (int e = 0; e < EV; ++e) v[e] += o[e];
             }
-            outvec_store(C + off, v);
+            if constexpr (sizeof(TO) == 4) {
+                if (epi.planes_hi) {            // the value that is stored, as hi / lo bf16 planes addressed like C (planes.hip: split_planes_kernel's arithmetic)
+                    const unsigned h0 = pack_bf16(v[0], v[1]), h1 = pack_bf16(v[2], v[3]);
+                    const u32x2 hw = {h0, h1};
+                    const u32x2 lw = {pack_bf16(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u)),
+                                      pack_bf16(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u))};
+                    *(u32x2*)((bf16_t*)epi.planes_hi + off) = hw; *(u32x2*)((bf16_t*)epi.planes_lo + off) = lw;
+                }
+                if (!epi.planes_only) outvec_store(C + off, v);
+            } else outvec_store(C + off, v);
             if (STATS == 1) {
 #pragma unroll
                 for (int e = 0; e < EV; ++e) { const float x = rnd<TO>(v[e]) - sh[e]; cs[e] += x; cq[e] += x * x; }

@@ -35,6 +35,9 @@ struct GemmEpi {
     float* col_sumsq;
     const float* col_shift;
     int debug;               // tuning experiments only (SS_GEMM_DEBUG): 1 skip flush stores, 2 skip stage, 4 skip MFMA
+    void* planes_hi;         // plane GEMMs (8-wave kernel, f32 out): the stored value also leaves as hi / lo bf16 planes addressed like C
+    void* planes_lo;
+    int planes_only;         // ... and C itself is not written
 };
 
 template <class T> struct Elem;

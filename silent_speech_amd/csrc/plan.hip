@@ -83,6 +83,7 @@ struct Plan {
     event_fn on_event = 0; void* event_user = 0;
     int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1, regate_on = 1, f32_x3 = 0;
     int x3_attn = 0;         // option 8: the bound EF tables are the [hi | lo] tables of ss_relpos_attention_x3_prepare_tables -> an f32_x3 plan with planes runs the attention on them
+    int x3_emit = 1;         // option 9: plane GEMMs whose consumers take planes emit them from their epilogue (off = a split pass per consumer-side first use, the first form of round 6)
     int x3_planes = 1;       // option 7: an f32_x3 plan runs every GEMM the 8-wave kernel can take on hi / lo bf16 planes (off = operands split in registers on the 128 x 128 kernels, round 4)
     Ctx* cur = nullptr;      // the context of the call in flight (plane cache)
     bool use_planes() const { return D.dtype == SS_F32 && f32_x3 && x3_planes; }
@@ -188,15 +189,24 @@ struct Plan {
     }
 
     int gemm(Exec& X, int dt_out, const void* A, const void* B, void* C, int M, int N, int K, ss_rowmap am, ss_rowmap bm, ss_rowmap cm, const ss_gemm_epilogue* e = 0,
-             int a_mode = SS_OP_KC, int b_mode = SS_OP_KC, int split = 1, void* stream = 0, const void* wkey = nullptr) {
+             int a_mode = SS_OP_KC, int b_mode = SS_OP_KC, int split = 1, void* stream = 0, const void* wkey = nullptr, int emit = 0) {
+        // emit (plane GEMMs only): 1 = the result also leaves as hi / lo planes, written by the epilogue and found by its consumers in the plane cache under C
+        // (no split pass over C: 12 -> 8 bytes of traffic per element); 2 = ... and the f32 C is not written at all (every consumer takes planes: 12 -> 4)
         void* st = stream ? stream : X.stream;
         if (use_planes() && st == X.stream && a_mode == SS_OP_KC && b_mode == SS_OP_KC && dt_out == SS_F32 && split == 1 &&
             ss_gemm_planes_supported(SS_F32, C, M, N, K, &am, &bm, &cm, e)) {
             const Pl a = planes(X, A, A, extent(am, M, K)), b = planes(X, wkey ? wkey : B, B, extent(bm, N, K));
+            ss_gemm_epilogue ee = e ? *e : EPI();
+            if (emit && x3_emit) {
+                const long long n = (extent(cm, M, N) + 7) & ~7LL;
+                void* hi = X.alloc((size_t)n * 4);
+                adopt_planes(C, hi, n);
+                ee.planes_hi = hi; ee.planes_lo = (char*)hi + n * 2; ee.planes_only = emit == 2;
+            }
             if (X.dry) return 0;
             if (!a.hi || !b.hi) return 1;
             return timed(X, "gemm", 2.0 * M * N * K, ((double)M * K + (double)N * K) * 4 + (double)M * N * 4.0, st,
-                         [&] { return ss_gemm_planes(SS_F32, a.hi, a.lo, b.hi, b.lo, C, M, N, K, &am, &bm, &cm, e, st); }, true);
+                         [&] { return ss_gemm_planes(SS_F32, a.hi, a.lo, b.hi, b.lo, C, M, N, K, &am, &bm, &cm, &ee, st); }, true);
         }
         if (X.dry) return 0;
         const double ob = dt_out == SS_BF16 ? 2.0 : 4.0;
@@ -394,7 +404,7 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
             qkvT = X.alloc((size_t)B * 3 * HD * Tp * es);
             ss_gemm_epilogue e = EPI(); e.c2 = qkvT; e.cmap2 = RM(1, T, (long long)3 * HD * Tp); e.col_stride2 = Tp;
             L_(gemm(X, dt, x, w.wqkv, qkv, M, 3 * HD, d, RM(d), RM(d), RM(3 * HD), &e));
-        } else L_(gemm(X, dt, x, w.wqkv, qkv, M, 3 * HD, d, RM(d), RM(d), RM(3 * HD)));
+        } else L_(gemm(X, dt, x, w.wqkv, qkv, M, 3 * HD, d, RM(d), RM(d), RM(3 * HD), nullptr, SS_OP_KC, SS_OP_KC, 1, 0, nullptr, x3att ? 2 : 0));      // x3 attention: qkv exists as planes only
         void* o = X.alloc((size_t)M * HD * es);
         float* lse = (float*)X.alloc((size_t)B * H * T * 4);
         // training: the resident forward leaves its probabilities for the backward kernels (no recomputation of the logits there)
@@ -418,7 +428,7 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         if (!X.dry) L_(timed(X, "add_dropout_ln_fwd", 0, (double)M * d * es * 5, stream, [&] { return ss_add_dropout_layernorm_forward(dt, x, a, w.g1, w.be1, y1, mean1, rstd1, M, d, D.ln_eps, p_drop, seed, 4 * l + 1, stream); }));
         void* hid = X.alloc((size_t)M * ff * es);
         { ss_gemm_epilogue e = EPI(); e.bias = w.b1; e.relu = 1; e.dropout_p = p_drop; e.seed = seed; e.rng_stream = 4 * l + 2;
-          L_(gemm(X, dt, y1, w.w1, hid, M, ff, d, RM(d), RM(d), RM(ff), &e)); }
+          L_(gemm(X, dt, y1, w.w1, hid, M, ff, d, RM(d), RM(d), RM(ff), &e, SS_OP_KC, SS_OP_KC, 1, 0, nullptr, 1)); }      // planes for linear2 and dW2; the f32 copy is the backward's gate
         void* f = X.alloc((size_t)M * d * es);
         { ss_gemm_epilogue e = EPI(); e.bias = w.b2; L_(gemm(X, dt, hid, w.w2, f, M, d, ff, RM(ff), RM(ff), RM(d), &e)); }
         void* y2 = X.alloc((size_t)M * d * es);
@@ -492,7 +502,7 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
               ss_gemm_epilogue es = e; es.col_sum = w.db1;
               if (use_planes() ? ss_gemm_planes_supported(SS_F32, dHid, M, ff, d, &am_, &bm_, &cm_, &es) != 0 : ss_gemm_fuses_column_stats(dt, dt, SS_OP_KC, SS_OP_KC, dHid, M, ff, d, &am_, &bm_, &cm_, &e, 1) != 0) { e = es; db1_fused = true; }
           }
-          L_(gemm(X, dt, dF, w.w2T, dHid, M, ff, d, am_, bm_, cm_, &e)); }
+          L_(gemm(X, dt, dF, w.w2T, dHid, M, ff, d, am_, bm_, cm_, &e, SS_OP_KC, SS_OP_KC, 1, 0, nullptr, db1_fused ? 2 : 1)); }      // consumers: dW1 and the dX GEMM (planes); the f32 copy only feeds an unfused bias gradient
         L_(grp.add(dHid, s.y1, w.dw1, ff, d, M, RM(ff), RM(d), side));
         if (!db1_fused) { SIDE_BEGIN(); L_(colsum(X, dHid, M, ff, w.db1, side)); SIDE_END(); }
         { ss_gemm_epilogue e = EPI(); e.mode = 1; L_(gemm(X, dt, dHid, w.w1T, G, M, d, ff, RM(ff), RM(ff), RM(d), &e)); }
@@ -506,7 +516,7 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
             dOT = X.alloc((size_t)B * HD * Tp * es);
             ss_gemm_epilogue e = EPI(); e.c2 = dOT; e.cmap2 = RM(1, T, (long long)HD * Tp); e.col_stride2 = Tp;
             L_(gemm(X, dt, dA, w.woT, dO, M, HD, d, RM(d), RM(d), RM(HD), &e));
-        } else L_(gemm(X, dt, dA, w.woT, dO, M, HD, d, RM(d), RM(d), RM(HD)));
+        } else L_(gemm(X, dt, dA, w.woT, dO, M, HD, d, RM(d), RM(d), RM(HD), nullptr, SS_OP_KC, SS_OP_KC, 1, 0, nullptr, x3att ? 2 : 0));      // x3 attention backward: dO as planes only
         void* dqkv = X.alloc((size_t)M * 3 * HD * es);
         float* dsc = (float*)X.alloc((size_t)B * H * T * 4);
         if (x3att) {
@@ -637,6 +647,7 @@ extern "C" int ss_plan_set_option(ss_plan* h, int what, int value)
     else if (what == 5) { old = h->p->f32_x3; h->p->f32_x3 = value != 0; }
     else if (what == 6) { old = h->p->keep_input; h->p->keep_input = value != 0; }
     else if (what == 7) { old = h->p->x3_planes; h->p->x3_planes = value != 0; }
+    else if (what == 9) { old = h->p->x3_emit; h->p->x3_emit = value != 0; }
     else if (what == 8) { old = h->p->x3_attn; h->p->x3_attn = value != 0; }
     return old;
 }

@@ -188,10 +188,15 @@ def gemm_planes_supported(C, M, N, K, amap, bmap, cmap, epi=None):
 
 
 def gemm_planes(A, B, C, M, N, K, amap, bmap, cmap, bias=None, relu=False, gate=None, gate_scale=1.0, alpha=1.0, dropout_p=0.0, seed=0, rng_stream=0,
-                mode=0, col_stats=None):
+                mode=0, col_stats=None, planes_out=None, planes_only=False):
     """C = epilogue(A . B^T) with A = (A_hi, A_lo), B = (B_hi, B_lo) plane pairs (split_planes), f32 C: the bf16 x 3 arithmetic of
-    gemm(f32_math='bf16x3') as ONE bf16 contraction of length 3 K on the 8-wave kernel (ss_gemm_planes)."""
+    gemm(f32_math='bf16x3') as ONE bf16 contraction of length 3 K on the 8-wave kernel (ss_gemm_planes).
+    planes_out = (hi, lo): bf16 tensors laid out like C that receive the stored value as planes (what split_planes(C) would give);
+    planes_only: C itself is not written."""
     epi = GemmEpilogue()
+    if planes_out is not None:
+        assert all(t.dtype == torch.bfloat16 for t in planes_out)
+        epi.planes_hi, epi.planes_lo, epi.planes_only = _p(planes_out[0]).value, _p(planes_out[1]).value, int(bool(planes_only))
     if col_stats is not None:
         cs, cq, sh = col_stats
         epi.col_sum, epi.col_sumsq, epi.col_shift = _p(cs).value, (_p(cq).value if cq is not None else None), (_p(sh).value if sh is not None else None)

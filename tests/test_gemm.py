@@ -515,6 +515,51 @@ def test_gemm_planes_epilogues_and_conv(dev, gemm_opts):
     assert float(y[:, 0::2].abs().max()) == 0.0
 
 
+def test_gemm_planes_emits_its_result_as_planes(dev, gemm_opts):
+    """ss_gemm_epilogue.planes_hi / planes_lo / planes_only (ABI 9): the value a plane GEMM stores also leaves as hi / lo bf16 planes addressed like C --
+    bit for bit what ss_split_planes gives on the stored C --, with bias + ReLU, with gate + C += v + column sums, on both tile heights and ragged M / N;
+    planes_only leaves C untouched.  (The training plan lets the qkv / FFN-hidden / dO GEMMs of the parity-grade mode feed their consumers this way.)"""
+    big = not is_emu(dev)
+    g = torch.Generator().manual_seed(23)
+    for ni, (M, N, K) in ((9, (3000, 776, 128) if big else (600, 264, 128)), (8, (1000, 264, 64) if big else (330, 520, 64))):
+        gemm_opts(ops.GEMM_OPT_G8_NI, ni)
+        a = torch.randn(M, K, generator=g); b = torch.randn(N, K, generator=g); bias = torch.randn(N, generator=g)
+        A, B = ops.split_planes(a.to(dev)), ops.split_planes(b.to(dev))
+        rm = (ops.rowmap(K), ops.rowmap(K), ops.rowmap(N))
+        C = torch.zeros(M, N, dtype=torch.float32, device=dev)
+        hi = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=dev); lo = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=dev)
+        ops.gemm_planes(A, B, C, M, N, K, *rm, bias=bias.to(dev), relu=True, planes_out=(hi, lo))
+        want_hi, want_lo = ops.split_planes(C)
+        assert torch.equal(hi.view(torch.int16), want_hi.view(torch.int16).view(M, N)) and torch.equal(lo.view(torch.int16), want_lo.view(torch.int16).view(M, N))
+        ref = torch.zeros(M, N, dtype=torch.float32, device=dev)
+        ops.gemm_planes(A, B, ref, M, N, K, *rm, bias=bias.to(dev), relu=True)
+        assert torch.equal(C, ref)                                            # the f32 result does not notice
+        # planes only: C keeps what it held
+        C2 = torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+        hi2 = torch.zeros_like(hi); lo2 = torch.zeros_like(lo)
+        ops.gemm_planes(A, B, C2, M, N, K, *rm, bias=bias.to(dev), relu=True, planes_out=(hi2, lo2), planes_only=True)
+        assert float((C2 - 7.0).abs().max()) == 0.0
+        assert torch.equal(hi2.view(torch.int16), hi.view(torch.int16)) and torch.equal(lo2.view(torch.int16), lo.view(torch.int16))
+        # gate + accumulate + column sums: the planes follow the value that is stored
+        gate = (torch.randn(M, N, generator=g) > 0).float().to(dev); base = torch.randn(M, N, generator=g).to(dev)
+        cs = torch.zeros(N, device=dev)
+        C3 = base.clone()
+        ops.gemm_planes(A, B, C3, M, N, K, *rm, gate=gate, gate_scale=1.25, mode=1, col_stats=(cs, None, None), planes_out=(hi, lo))
+        w_hi, w_lo = ops.split_planes(C3)
+        assert torch.equal(hi.view(torch.int16), w_hi.view(torch.int16).view(M, N)) and torch.equal(lo.view(torch.int16), w_lo.view(torch.int16).view(M, N))
+        assert_close_robust(cs, C3.double().sum(0).float(), 1e-4, name='col_sum beside planes', max_outlier_frac=0)
+    C = torch.zeros(64, 64, dtype=torch.float32, device=dev)
+    with pytest.raises(RuntimeError, match='ss_gemm_planes only'):           # the epilogue of ss_gemm has no plane output
+        e = ops.GemmEpilogue(); e.alpha = 1.0; e.gate_scale = 1.0
+        h = torch.zeros(64, 64, dtype=torch.bfloat16, device=dev)
+        e.planes_hi = e.planes_lo = ops._p(h).value
+        import ctypes as _ct
+        from silent_speech_amd import _lib as _l
+        x = torch.zeros(64, 64, dtype=torch.float32, device=dev)
+        m = ops.rowmap(64)
+        _l.check(_l.lib().ss_gemm(_l.SS_F32, _l.SS_F32, 0, 0, ops._p(x), ops._p(x), ops._p(C), 64, 64, 64, _ct.byref(m), _ct.byref(m), _ct.byref(m), _ct.byref(e), 1, ops._s(C)), 'ss_gemm')
+
+
 def test_gemm_planes_refuses_what_the_8_wave_kernel_cannot_run(dev):
     C = torch.zeros(64, 64, dtype=torch.float32, device=dev)
     assert not ops.gemm_planes_supported(C, 64, 64, 96, ops.rowmap(96), ops.rowmap(96), ops.rowmap(64))      # K % 64
