@@ -83,6 +83,16 @@ typedef struct ss_gemm_epilogue {
     void* planes_hi;
     void* planes_lo;
     int32_t planes_only;
+    /* The sign of a stored activation as ONE BIT per element (ABI 9), for the backward of ReLU (+ inverted dropout) -- transformer.py:57 --:
+       sign_out (producer, bf16 results): byte [row * sign_pitch + col / 8], bit col % 8 = [stored C(row, col) > 0], rows = the GEMM's logical rows.
+       gate_bits (consumer): out = bit ? out * gate_scale : 0 -- what `gate` does from the saved tensor, from 1/16 of its bytes; a thread requests the bits of
+       its whole tile at once, so the 18 exposed load round trips per tile of the tensor form shrink to one.  N % 8 == 0.  Only some kernels of the 8-wave
+       family carry these paths: ask ss_gemm_sign_bits_supported() (producer) / ss_gemm_fuses_column_stats() with gate_bits set (consumer: it rides the
+       column-sum epilogue) and keep `gate` otherwise; ss_gemm refuses a launch that would ignore them. */
+    void* sign_out;
+    int64_t sign_pitch;
+    const void* gate_bits;
+    int64_t gate_bits_pitch;
 } ss_gemm_epilogue;
 
 #define SS_OP_KC 0   /* reduction index contiguous:  elem(o, r) = p[rowmap(o) + r] */
@@ -112,6 +122,10 @@ int ss_gemm(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* A, 
 int ss_split_planes(const float* x, void* hi, void* lo, int64_t n, void* stream);
 int ss_gemm_planes(int dtype_out, const void* A_hi, const void* A_lo, const void* B_hi, const void* B_lo, void* C, int M, int N, int K,
                    const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap, const ss_gemm_epilogue* epilogue, void* stream);
+/* [host] 1 when ss_gemm with these arguments (epilogue->sign_out set or not) runs on the kernel that writes sign bits (8-wave kernel, bf16 results, no column
+ * statistics, default schedule, N % 8 == 0). */
+int ss_gemm_sign_bits_supported(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* C, int M, int N, int K, const ss_rowmap* amap,
+                                const ss_rowmap* bmap, const ss_rowmap* cmap, const ss_gemm_epilogue* epilogue, int split_k);
 int ss_gemm_planes_supported(int dtype_out, const void* C, int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap,
                              const ss_gemm_epilogue* epilogue); /* [host] */
 
@@ -466,7 +480,7 @@ void ss_plan_destroy(ss_plan* plan);                                /* [host] */
 int ss_plan_slot_count(const ss_plan* plan);                        /* [host] */
 const char* ss_plan_slot_name(const ss_plan* plan, int slot);       /* [host] */
 int ss_plan_bind(ss_plan* plan, int slot, void* device_ptr_or_value); /* [host] slots named *.total / *.all_f32 / *.bytes take integers */
-int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off, 4 BatchNorm backward recomputes the ReLU gate (on) or reads the saved output (off), 5 an SS_F32 plan runs its GEMMs as SS_F32X3 (bf16 x 3 MFMA on f32 operands) on/off (default off = exact f32), 6 the training-mode forward leaves x_raw untouched and only hands the shifted signal out in shifted_scratch (default off = written back in place like architecture.py:67-68), 7 an SS_F32X3 plan runs every GEMM the 8-wave kernel can take on hi / lo bf16 planes (ss_split_planes / ss_gemm_planes; default on), 8 the bound EF tables are the [hi | lo] tables of ss_relpos_attention_x3_prepare_tables: such a plan also runs its attention on planes (default off), 9 plane GEMMs whose consumers take planes (qkv, the FFN hidden activation and its gradient, dO) write them from their epilogue instead of a split pass on first use (default on) */
+int ss_plan_set_option(ss_plan* plan, int what, int value);         /* [host] 0 side stream on/off, 1 grouped dW on/off, 2 side-stream blocks per CU, 3 BatchNorm statistics / bias column sums from GEMM epilogues on/off, 4 BatchNorm backward recomputes the ReLU gate (on) or reads the saved output (off), 5 an SS_F32 plan runs its GEMMs as SS_F32X3 (bf16 x 3 MFMA on f32 operands) on/off (default off = exact f32), 6 the training-mode forward leaves x_raw untouched and only hands the shifted signal out in shifted_scratch (default off = written back in place like architecture.py:67-68), 7 an SS_F32X3 plan runs every GEMM the 8-wave kernel can take on hi / lo bf16 planes (ss_split_planes / ss_gemm_planes; default on), 8 the bound EF tables are the [hi | lo] tables of ss_relpos_attention_x3_prepare_tables: such a plan also runs its attention on planes (default off), 9 plane GEMMs whose consumers take planes (qkv, the FFN hidden activation and its gradient, dO) write them from their epilogue instead of a split pass on first use (default on), 10 a bf16 training plan keeps [FFN hidden > 0] as sign bits (ss_gemm_epilogue.sign_out) and the FFN input gradient gates from them (gate_bits; default on) */
 int ss_plan_set_reduce_hook(ss_plan* plan, ss_reduce_hook fn, void* user); /* [host] */
 int ss_plan_set_event_hook(ss_plan* plan, ss_event_hook fn, void* user);   /* [host] */
 int64_t ss_plan_ctx_bytes(void);                                    /* [host] */

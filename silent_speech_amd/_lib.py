@@ -30,7 +30,8 @@ class GemmEpilogue(ctypes.Structure):
                 ('col_mod', ctypes.c_int32), ('col_mul', ctypes.c_int32), ('col_div_mul', ctypes.c_int32),
                 ('log_clamp', ctypes.c_float), ('c2', ctypes.c_void_p), ('cmap2', RowMap), ('col_stride2', ctypes.c_int64),
                 ('col_sum', ctypes.c_void_p), ('col_sumsq', ctypes.c_void_p), ('col_shift', ctypes.c_void_p),
-                ('planes_hi', ctypes.c_void_p), ('planes_lo', ctypes.c_void_p), ('planes_only', ctypes.c_int32)]
+                ('planes_hi', ctypes.c_void_p), ('planes_lo', ctypes.c_void_p), ('planes_only', ctypes.c_int32),
+                ('sign_out', ctypes.c_void_p), ('sign_pitch', ctypes.c_int64), ('gate_bits', ctypes.c_void_p), ('gate_bits_pitch', ctypes.c_int64)]
 
 
 class DwJob(ctypes.Structure):
@@ -117,6 +118,8 @@ _HOST_FUNCS = {'ss_dtw_workspace_bytes': ([_I, _I, _LP, _LP, _LP], ctypes.c_int6
                'ss_gemm_set_option': ([_I, _I], ctypes.c_int),
                'ss_gemm_fuses_column_stats': ([_I, _I, _I, _I, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), ctypes.POINTER(RowMap),
                                                ctypes.POINTER(GemmEpilogue), _I], ctypes.c_int),
+               'ss_gemm_sign_bits_supported': ([_I, _I, _I, _I, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), ctypes.POINTER(RowMap),
+                                                ctypes.POINTER(GemmEpilogue), _I], ctypes.c_int),
                'ss_gemm_planes_supported': ([_I, _P, _I, _I, _I, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), ctypes.POINTER(GemmEpilogue)], ctypes.c_int),
                'ss_gemm_dw_set_option': ([_I, _I], ctypes.c_int),
                'ss_plan_create': ([_P], _P), 'ss_plan_destroy': ([_P], None), 'ss_plan_slot_count': ([_P], ctypes.c_int),

@@ -753,6 +753,14 @@ static int gemm_slots() {
 // streams; a last round of `rem` tiles runs faster (0.55 + 0.45 rem / CUs of a tile).  The 128-wide kernels sustain ~560 TFLOP/s at
 // K <= 1024 and ~680 beyond, plus ~6 us.
 // kmul = 3: the hi / lo plane form (ss_gemm_planes) -- the contraction the K loop walks is 3 K long, and there is no 128-wide alternative to compare with
+// which of the 8-wave kernel's epilogues carries the sign-bit paths: the producer sits in the register epilogue (bf16 out, no column statistics), the consumer in
+// the C-piece epilogue of the column-sum instantiations (bf16 out)
+template <class TO> static bool sign_paths_ok(const GemmEpi& epi) {
+    if (sizeof(TO) != 2) return false;
+    if (epi.sign_out && (epi.col_sum || epi.general == 2)) return false;
+    if (epi.gate_bits && !(epi.col_sum && !epi.col_sumsq && !epi.col_shift)) return false;
+    return true;
+}
 static bool pick_gemm8(bool bf16_in, int a_mode, int b_mode, int M, int N, int K, const RowMap& am, const RowMap& bm, const GemmEpi& epi, int split_k, int* ni_out, int* pin_out, int kmul = 1)
 {
     if (!(bf16_in && gemm_opt(OPT_G8) && a_mode == OP_KC && b_mode == OP_KC && epi.fast && !epi.c2 && split_k == 1 && K % 64 == 0 && K > 0)) return false;
@@ -806,6 +814,16 @@ static int launch_gemm(int a_mode, int b_mode, const void* A, const void* B, voi
     const int nitems = tiles_m * tiles_n * split_k;
     const int slots = gemm_slots();
     dim3 grid(nitems < slots ? nitems : slots), block(256);
+    if (epi.sign_out || epi.gate_bits) {          // only the 8-wave kernel carries these epilogue paths: anything else would silently ignore them
+        int ni = 0, pin = 0;
+        if (!sign_paths_ok<TO>(epi) || !pick_gemm8(sizeof(T) == 2, a_mode, b_mode, M, N, K, am, bm, epi, split_k, &ni, &pin) || (epi.sign_out && pin != 3)) {
+            ss_set_error("ss_gemm: sign_out / gate_bits need the 8-wave kernel (bf16; sign_out: no column statistics, default schedule; gate_bits: with col_sum) -- ask ss_gemm_sign_bits_supported / ss_gemm_fuses_column_stats first");
+            return 1;
+        }
+        if (gemm8_launch_kc<TO>(ni, pin, A, B, C, M, N, K, am, bm, epi, stream)) return 1;
+        g_last_kernel = ni == 9 ? 4 : 3;
+        return 0;
+    }
     if (gemm_opt(OPT_SMALLK) && gemm_smallk_ok(sizeof(T) == 2 ? SS_BF16 : SS_F32, sizeof(TO) == 2 ? SS_BF16 : SS_F32, a_mode, b_mode, A, B, C, M, N, K, am, bm, epi, split_k)) {
         if (gemm_smallk_launch(A, B, C, M, N, K, am, bm, epi, stream)) return 1;       // K <= 32: register-resident weights, no LDS (gemm_smallk.hip)
         g_last_kernel = 5;
@@ -890,6 +908,10 @@ static int build_epi(GemmEpi& epi, int dtype_out, const void* C, int M, int N, c
         if (e->c2) { epi.c2 = e->c2; epi.cmap2 = to_rowmap(&e->cmap2); epi.col_stride2 = e->col_stride2; }
         epi.col_sum = e->col_sum; epi.col_sumsq = e->col_sumsq; epi.col_shift = e->col_shift;
         epi.planes_hi = e->planes_hi; epi.planes_lo = e->planes_lo; epi.planes_only = e->planes_only;
+        epi.sign_out = (unsigned char*)e->sign_out; epi.sign_pitch = e->sign_pitch; epi.gate_bits = (const unsigned char*)e->gate_bits; epi.gate_bits_pitch = e->gate_bits_pitch;
+        SS_CHECK(!(e->sign_out || e->gate_bits) || N % 8 == 0, "ss_gemm: sign bits need N %% 8 == 0 (N = %d)", N);
+        SS_CHECK(!e->sign_out || (dtype_out == SS_BF16 && e->sign_pitch * 8 >= N && !e->col_mod), "ss_gemm: sign_out needs bf16 results, sign_pitch >= N / 8 and no column permutation");
+        SS_CHECK(!e->gate_bits || (!e->gate && e->gate_bits_pitch * 8 >= N && !e->col_mod), "ss_gemm: gate_bits replaces gate (not both), gate_bits_pitch >= N / 8, no column permutation");
         SS_CHECK((e->planes_hi != nullptr) == (e->planes_lo != nullptr) && !(e->planes_only && !e->planes_hi), "ss_gemm: planes_hi / planes_lo come together (planes_only needs them)");
         SS_CHECK(!e->planes_hi || (dtype_out == SS_F32 && e->mode != 2 && !e->c2 && !e->col_mod && ((uintptr_t)e->planes_hi | (uintptr_t)e->planes_lo) % 8 == 0),
                  "ss_gemm: plane output needs f32 results, no atomic mode / second copy / column permutation and 8-byte aligned planes");
@@ -963,6 +985,7 @@ static int planes_setup(int dtype_out, const void* A_hi, const void* A_lo, const
     if (amap->base % 8 || amap->batch_stride % 8 || amap->row_stride % 8 || bmap->base % 8 || bmap->batch_stride % 8 || bmap->row_stride % 8) return 0;
     if (((uintptr_t)A_hi | (uintptr_t)A_lo | (uintptr_t)B_hi | (uintptr_t)B_lo) % 16) return 0;
     if (build_epi(epi, dtype_out, C, M, N, cmap, e, 1)) return 0;
+    if (epi.sign_out || epi.gate_bits) return 0;                      // (bf16 results only)
     return pick_gemm8(true, OP_KC, OP_KC, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, 1, ni, pin, 3) ? 1 : 0;
 }
 extern "C" int ss_gemm_planes_supported(int dtype_out, const void* C, int M, int N, int K, const ss_rowmap* amap, const ss_rowmap* bmap, const ss_rowmap* cmap, const ss_gemm_epilogue* e)
@@ -991,7 +1014,21 @@ extern "C" int ss_gemm_fuses_column_stats(int dtype_in, int dtype_out, int a_mod
     if (!amap || !bmap || !cmap || dtype_in != SS_BF16 || (dtype_out != SS_BF16 && dtype_out != SS_F32) || M <= 0 || N <= 0) return 0;
     GemmEpi epi;
     if (build_epi(epi, dtype_out, C, M, N, cmap, e, split_k)) return 0;
-    if (gemm_opt(OPT_SMALLK) && gemm_smallk_ok(dtype_in, dtype_out, a_mode, b_mode, (const void*)16, (const void*)16, C, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, split_k)) return 1;
+    if (epi.gate_bits && !(dtype_out == SS_BF16 && sign_paths_ok<bf16_t>(epi))) return 0;
+    if (!epi.gate_bits && gemm_opt(OPT_SMALLK) && gemm_smallk_ok(dtype_in, dtype_out, a_mode, b_mode, (const void*)16, (const void*)16, C, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, split_k)) return 1;
     int ni = 0, pin = 0;
     return pick_gemm8(true, a_mode, b_mode, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, split_k, &ni, &pin) ? 1 : 0;
+}
+
+extern "C" int ss_gemm_sign_bits_supported(int dtype_in, int dtype_out, int a_mode, int b_mode, const void* C, int M, int N, int K, const ss_rowmap* amap,
+                                           const ss_rowmap* bmap, const ss_rowmap* cmap, const ss_gemm_epilogue* e, int split_k)
+{
+    if (!amap || !bmap || !cmap || dtype_in != SS_BF16 || dtype_out != SS_BF16 || M <= 0 || N <= 0 || N % 8) return 0;
+    GemmEpi epi;
+    if (build_epi(epi, dtype_out, C, M, N, cmap, e, split_k)) return 0;
+    GemmEpi probe = epi; probe.sign_out = (unsigned char*)16; probe.sign_pitch = N / 8;
+    if (!sign_paths_ok<bf16_t>(probe)) return 0;
+    if (gemm_opt(OPT_SMALLK) && gemm_smallk_ok(dtype_in, dtype_out, a_mode, b_mode, (const void*)16, (const void*)16, C, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, split_k)) return 0;
+    int ni = 0, pin = 0;
+    return pick_gemm8(true, a_mode, b_mode, M, N, K, to_rowmap(amap), to_rowmap(bmap), epi, split_k, &ni, &pin) && pin == 3 ? 1 : 0;
 }

@@ -190,6 +190,26 @@ __device__ __forceinline__ void lane16_swap(unsigned& x, unsigned& y) {
 // one atomic per column, wave and tile.
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+// [x > 0] of the eight bf16 values of four packed words as one byte (bit 2 d = low half of word d, bit 2 d + 1 = high half): a bf16 is positive exactly when
+// its 16 bits, read as a signed integer, are > 0 -- packed max(.,0) / min(.,1) give (hi > 0) << 16 | (lo > 0) per word
+__device__ __forceinline__ unsigned sign_byte8(const unsigned (&v)[4]) {
+    unsigned sacc = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+#if defined(SS_EMU)
+        const unsigned r = (unsigned)((short)(v[d] & 0xffffu) > 0) | ((unsigned)((short)(v[d] >> 16) > 0) << 16);
+#else
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const s16x2 z = {0, 0}; const u16x2 one = {1, 1};
+        const s16x2 w = __builtin_bit_cast(s16x2, v[d]);
+        const s16x2 c = __builtin_elementwise_max(w, z);
+        const unsigned r = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, c), one));
+#endif
+        sacc |= r << (2 * d);
+    }
+    return (sacc & 0x55u) | ((sacc >> 15) & 0xAAu);
+}
 template <int NI, bool INTERIOR, int STATS, bool DROP = false>
 __device__ __forceinline__ void direct_store8(const f32x4 (&acc)[NI][4], bf16_t* __restrict__ C, const GemmEpi& epi, int m0, int n0, int M, int N, int wm, int wn, int r, int q,
                                               const f32x4 (&b16)[4])
@@ -262,6 +282,7 @@ __device__ __forceinline__ void direct_store8(const f32x4 (&acc)[NI][4], bf16_t*
             if (ok) {
                 const u32x4 o = {v[0], v[1], v[2], v[3]};
                 *(u32x4*)(C + ro + col) = o;
+                if (epi.sign_out) epi.sign_out[(long long)row * epi.sign_pitch + (col >> 3)] = (unsigned char)sign_byte8(v);      // the ReLU / dropout backward's gate, 1 bit per element
                 if constexpr (STATS == 2) {
 #pragma unroll
                     for (int d = 0; d < 4; ++d) { cs[jp][2 * d] += bf_lo(v[d]); cs[jp][2 * d + 1] += bf_hi(v[d]); }
@@ -327,7 +348,7 @@ __device__ __forceinline__ void flush8_prefetch(const TO* __restrict__ src, cons
 template <class TO, int NI, int IPP, int STATS, int H>
 __device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* __restrict__ C, const GemmEpi& epi, int m0, int n0, int pass, int M, int N, int tid,
                                        float (&cs)[OutVec<TO>::N], float (&cq)[OutVec<TO>::N], const float (&sh)[OutVec<TO>::N],
-                                       const u32x4 (&pre)[Flush8<TO, NI, IPP>::NIT / 2], int pf)
+                                       const u32x4 (&pre)[Flush8<TO, NI, IPP>::NIT / 2], int pf, const unsigned* gb = nullptr)
 {
     using F = Flush8<TO, NI, IPP>;
     constexpr int EV = F::EV;
@@ -336,7 +357,7 @@ __device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* _
         int lr, ch, row, col;
         if (F::map(H * (F::NIT / 2) + i, tid, pass, m0, n0, M, N, lr, ch, row, col)) {
             const long long off = rowmap_off(epi.cmap, row) + col;
-            if (STATS == 0 && !epi.gate && epi.mode != 1 && !(sizeof(TO) == 4 && epi.planes_hi)) {
+            if (STATS == 0 && !epi.gate && !epi.gate_bits && epi.mode != 1 && !(sizeof(TO) == 4 && epi.planes_hi)) {
                 // nothing is applied per element here (bias / ReLU / dropout went in before the LDS piece): the 16 bytes leave as they are --
                 // unpacking 8 bf16 to f32 and rounding them back was ~60 of this chunk's instructions, on every plain tile of the step
                 *(u32x4*)(C + off) = *(const u32x4*)(ct + lr * ldc + ch * EV);
@@ -350,6 +371,10 @@ __device__ __forceinline__ void flush8(const TO* __restrict__ ct, int ldc, TO* _
                 if (pf == 1) raw_to_float(pre[i], g); else outvec_load((const TO*)epi.gate + off, g);
 #pragma unroll
                 for (int e = 0; e < EV; ++e) v[e] = g[e] > 0.f ? v[e] * epi.gate_scale : 0.f;
+            } else if (epi.gate_bits) {         // the same gate from one bit per element; the tile's bytes were requested together before the first pass
+                const unsigned bits = gb[pass * F::NIT + H * (F::NIT / 2) + i] >> (col & 7);
+#pragma unroll
+                for (int e = 0; e < EV; ++e) v[e] = ((bits >> e) & 1u) ? v[e] * epi.gate_scale : 0.f;
             }
             if (epi.mode == 1) {
                 float o[EV];
@@ -386,7 +411,7 @@ struct Passes8 {
     static __device__ __forceinline__ void run(const f32x4 (&acc)[NI][4], TO* ct, int ldc, TO* C, const GemmEpi& epi, int m0, int n0, int M, int N, int tid, int wm, int wn, int r, int q,
                                                float (&cs)[OutVec<TO>::N], float (&cq)[OutVec<TO>::N], const float (&sh)[OutVec<TO>::N],
                                                const float (&bias4)[4], u32x4 (&pa)[Flush8<TO, NI, IPP>::NIT / 2], u32x4 (&pb)[Flush8<TO, NI, IPP>::NIT / 2], int pf, const TO* pf_src,
-                                               const f32x4 (&b16)[4]) {
+                                               const f32x4 (&b16)[4], const unsigned* gb = nullptr) {
 #pragma unroll
         for (int ii = 0; ii < IPP; ++ii) {
             constexpr int I0 = P * IPP;
@@ -402,11 +427,11 @@ struct Passes8 {
         }
         barrier_keep_vm();
         if (pf) flush8_prefetch<TO, NI, IPP, 1>(pf_src, epi, m0, n0, P, M, N, tid, pb);
-        flush8<TO, NI, IPP, STATS, 0>(ct, ldc, C, epi, m0, n0, P, M, N, tid, cs, cq, sh, pa, pf);
+        flush8<TO, NI, IPP, STATS, 0>(ct, ldc, C, epi, m0, n0, P, M, N, tid, cs, cq, sh, pa, pf, gb);
         if (P + 1 < NPASS && pf) flush8_prefetch<TO, NI, IPP, 0>(pf_src, epi, m0, n0, P + 1, M, N, tid, pa);
-        flush8<TO, NI, IPP, STATS, 1>(ct, ldc, C, epi, m0, n0, P, M, N, tid, cs, cq, sh, pb, pf);
+        flush8<TO, NI, IPP, STATS, 1>(ct, ldc, C, epi, m0, n0, P, M, N, tid, cs, cq, sh, pb, pf, gb);
         if (P + 1 < NPASS) barrier_keep_vm();
-        Passes8<TO, GEN, NI, IPP, P + 1, NPASS, STATS, SW>::run(acc, ct, ldc, C, epi, m0, n0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+        Passes8<TO, GEN, NI, IPP, P + 1, NPASS, STATS, SW>::run(acc, ct, ldc, C, epi, m0, n0, M, N, tid, wm, wn, r, q, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16, gb);
     }
 };
 template <class TO, int GEN, int NI, int IPP, int NPASS, int STATS, bool SW>
@@ -414,7 +439,7 @@ struct Passes8<TO, GEN, NI, IPP, NPASS, NPASS, STATS, SW> {
     static __device__ __forceinline__ void run(const f32x4 (&)[NI][4], TO*, int, TO*, const GemmEpi&, int, int, int, int, int, int, int, int, int,
                                                float (&)[OutVec<TO>::N], float (&)[OutVec<TO>::N], const float (&)[OutVec<TO>::N],
                                                const float (&)[4], u32x4 (&)[Flush8<TO, NI, IPP>::NIT / 2], u32x4 (&)[Flush8<TO, NI, IPP>::NIT / 2], int, const TO*,
-                                               const f32x4 (&)[4]) {}
+                                               const f32x4 (&)[4], const unsigned* = nullptr) {}
 };
 
 }  // namespace g8
@@ -643,6 +668,22 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
             for (int i = 0; i < Flush8<TO, NI, IPP>::NIT / 2; ++i) { const u32x4 z = {0u, 0u, 0u, 0u}; pa[i] = z; pb[i] = z; }
 #endif
             if (pf) flush8_prefetch<TO, NI, IPP, 0>(pf_src, epi, cm0, cn0, 0, M, N, tid_e, pa);
+            // gate as sign bits (column-sum instantiations: the FFN input gradient): ALL bytes of this thread's chunks of the tile are requested here, at
+            // once -- one exposed round trip per tile where the tensor form pays one per half pass (6 per tile: +15 us per 288 x 256 tile, tools/gemm_bench epi)
+            unsigned gbits[STATS == 2 ? NPASS * Flush8<TO, NI, IPP>::NIT : 1];
+            if constexpr (STATS == 2) {
+#pragma unroll
+                for (int i = 0; i < NPASS * Flush8<TO, NI, IPP>::NIT; ++i) gbits[i] = 0u;
+                if (epi.gate_bits) {
+#pragma unroll
+                    for (int pp = 0; pp < NPASS; ++pp)
+#pragma unroll
+                        for (int it = 0; it < Flush8<TO, NI, IPP>::NIT; ++it) {
+                            int lr, ch, row, col;
+                            if (Flush8<TO, NI, IPP>::map(it, tid_e, pp, cm0, cn0, M, N, lr, ch, row, col)) gbits[pp * Flush8<TO, NI, IPP>::NIT + it] = epi.gate_bits[(long long)row * epi.gate_bits_pitch + (col >> 3)];
+                        }
+                }
+            }
             barrier_keep_vm();                                   // every wave is done reading stage cur^1 -> it becomes the C piece
             G8_STAMP(item, 3);
             TO* ct = (TO*)(lds + (cur ^ 1) * STAGE);
@@ -664,8 +705,8 @@ __global__ __launch_bounds__(512) void gemm8_kc_kernel(const bf16_t* __restrict_
 #pragma unroll
                     for (int e = 0; e < EV; ++e) { const int col = cn0 + ch * EV + e; sh[e] = col < N ? epi.col_shift[col] : 0.f; }
                 }
-                if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
-                else Passes8<TO, 0, NI, IPP, 0, NPASS, STATS, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16);
+                if (GENSEL == 1 || (GENSEL < 0 && epi.general == 1)) Passes8<TO, 1, NI, IPP, 0, NPASS, STATS, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16, gbits);
+                else Passes8<TO, 0, NI, IPP, 0, NPASS, STATS, SWAP>::run(acc, ct, LDC, C, epi, cm0, cn0, M, N, tid_e, wm, wn, r_e, q_e, cs, cq, sh, bias4, pa, pb, pf, pf_src, b16, gbits);
                 if (CPR == 32) {                  // bf16 out: lanes l and l + 32 of a wave hold the same column chunk
 #pragma unroll
                     for (int e = 0; e < EV; ++e) { cs[e] += __shfl_xor(cs[e], 32); if (STATS == 1) cq[e] += __shfl_xor(cq[e], 32); }

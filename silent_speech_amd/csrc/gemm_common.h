@@ -38,6 +38,10 @@ struct GemmEpi {
     void* planes_hi;         // plane GEMMs (8-wave kernel, f32 out): the stored value also leaves as hi / lo bf16 planes addressed like C
     void* planes_lo;
     int planes_only;         // ... and C itself is not written
+    unsigned char* sign_out; // 8-wave register epilogue (bf16 out): byte [row * sign_pitch + col / 8], bit col % 8 = [stored value > 0]
+    long long sign_pitch;
+    const unsigned char* gate_bits;      // 8-wave C-piece epilogue: the gate as such bits instead of the saved tensor
+    long long gate_bits_pitch;
 };
 
 template <class T> struct Elem;

@@ -40,7 +40,7 @@ struct LayerP {
 
 // pointers saved by forward for backward (all into the caller's workspace)
 struct BlockCtx { void *xin, *c1, *cr, *h1, *c2, *y; float *m1, *i1, *m2, *i2, *mr, *ir, *scratch; int Tin, Cin, Tout, O, pad_y; };
-struct LayerCtx { void *x, *qkv, *qkvT, *o, *z1, *y1, *hid, *z2, *pimg; float *lse, *mean1, *rstd1, *mean2, *rstd2; };
+struct LayerCtx { void *x, *qkv, *qkvT, *o, *z1, *y1, *hid, *z2, *pimg; float *lse, *mean1, *rstd1, *mean2, *rstd2; unsigned char* hid_sign; };
 constexpr int MAX_LAYERS = 16;
 // hi / lo bf16 planes of f32 buffers (parity-grade mode on the 8-wave kernels): every GEMM operand is split ONCE per step, on first use, into
 // [2][elems] bf16 carved from the workspace (hi plane, then lo); forward activations keep theirs for the weight-gradient GEMMs of the backward.
@@ -83,6 +83,7 @@ struct Plan {
     event_fn on_event = 0; void* event_user = 0;
     int side_enabled = 1, dw_grouped = 1, side_blocks = 2, fuse_stats = 1, regate_on = 1, f32_x3 = 0;
     int x3_attn = 0;         // option 8: the bound EF tables are the [hi | lo] tables of ss_relpos_attention_x3_prepare_tables -> an f32_x3 plan with planes runs the attention on them
+    int sign_gate = 1;       // option 10: bf16 training plans keep the sign of the FFN hidden activation as one bit per element (written by linear1's epilogue) and the FFN input gradient gates from it
     int x3_emit = 1;         // option 9: plane GEMMs whose consumers take planes emit them from their epilogue (off = a split pass per consumer-side first use, the first form of round 6)
     int x3_planes = 1;       // option 7: an f32_x3 plan runs every GEMM the 8-wave kernel can take on hi / lo bf16 planes (off = operands split in registers on the 128 x 128 kernels, round 4)
     Ctx* cur = nullptr;      // the context of the call in flight (plane cache)
@@ -427,15 +428,23 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         float* mean1 = (float*)X.alloc((size_t)M * 4); float* rstd1 = (float*)X.alloc((size_t)M * 4);
         if (!X.dry) L_(timed(X, "add_dropout_ln_fwd", 0, (double)M * d * es * 5, stream, [&] { return ss_add_dropout_layernorm_forward(dt, x, a, w.g1, w.be1, y1, mean1, rstd1, M, d, D.ln_eps, p_drop, seed, 4 * l + 1, stream); }));
         void* hid = X.alloc((size_t)M * ff * es);
+        unsigned char* hid_sign = nullptr;
         { ss_gemm_epilogue e = EPI(); e.bias = w.b1; e.relu = 1; e.dropout_p = p_drop; e.seed = seed; e.rng_stream = 4 * l + 2;
-          L_(gemm(X, dt, y1, w.w1, hid, M, ff, d, RM(d), RM(d), RM(ff), &e, SS_OP_KC, SS_OP_KC, 1, 0, nullptr, 1)); }      // planes for linear2 and dW2; the f32 copy is the backward's gate
+          ss_rowmap am_ = RM(d), bm_ = RM(d), cm_ = RM(ff);
+          // training, bf16: the epilogue also writes [hid > 0] as one bit per element (M x ff / 8 bytes): the backward's ReLU / dropout gate reads those instead of
+          // the 16 x larger tensor, all bytes of a tile in one request (transformer.py:57)
+          if (training && dt == SS_BF16 && sign_gate && ff % 8 == 0 && ss_gemm_sign_bits_supported(dt, dt, SS_OP_KC, SS_OP_KC, hid, M, ff, d, &am_, &bm_, &cm_, &e, 1)) {
+              hid_sign = (unsigned char*)X.alloc((size_t)M * (ff / 8));
+              e.sign_out = hid_sign; e.sign_pitch = ff / 8;
+          }
+          L_(gemm(X, dt, y1, w.w1, hid, M, ff, d, am_, bm_, cm_, &e, SS_OP_KC, SS_OP_KC, 1, 0, nullptr, 1)); }      // planes for linear2 and dW2; the f32 copy is the backward's gate
         void* f = X.alloc((size_t)M * d * es);
         { ss_gemm_epilogue e = EPI(); e.bias = w.b2; L_(gemm(X, dt, hid, w.w2, f, M, d, ff, RM(ff), RM(ff), RM(d), &e)); }
         void* y2 = X.alloc((size_t)M * d * es);
         float* mean2 = (float*)X.alloc((size_t)M * 4); float* rstd2 = (float*)X.alloc((size_t)M * 4);
         if (!X.dry) L_(timed(X, "add_dropout_ln_fwd", 0, (double)M * d * es * 5, stream, [&] { return ss_add_dropout_layernorm_forward(dt, y1, f, w.g2, w.be2, y2, mean2, rstd2, M, d, D.ln_eps, p_drop, seed, 4 * l + 3, stream); }));
         s.qkv = qkv; s.qkvT = qkvT; s.o = o; s.lse = lse; s.z1 = a; s.mean1 = mean1; s.rstd1 = rstd1; s.y1 = y1;
-        s.hid = hid; s.z2 = f; s.mean2 = mean2; s.rstd2 = rstd2;
+        s.hid = hid; s.hid_sign = hid_sign; s.z2 = f; s.mean2 = mean2; s.rstd2 = rstd2;
         x = y2;
     }
     c->x_final = x;
@@ -500,7 +509,12 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
           // linear1.bias.grad = column sums of dHid: accumulated by this GEMM's epilogue when the 8-wave kernel runs the shape
           if (!X.dry && fuse_stats) {
               ss_gemm_epilogue es = e; es.col_sum = w.db1;
-              if (use_planes() ? ss_gemm_planes_supported(SS_F32, dHid, M, ff, d, &am_, &bm_, &cm_, &es) != 0 : ss_gemm_fuses_column_stats(dt, dt, SS_OP_KC, SS_OP_KC, dHid, M, ff, d, &am_, &bm_, &cm_, &e, 1) != 0) { e = es; db1_fused = true; }
+              if (s.hid_sign && !use_planes()) {          // the gate from the sign bits linear1's epilogue left (rides the column-sum epilogue of the 8-wave kernel)
+                  ss_gemm_epilogue eb = es; eb.gate = nullptr; eb.gate_bits = s.hid_sign; eb.gate_bits_pitch = ff / 8;
+                  if (ss_gemm_fuses_column_stats(dt, dt, SS_OP_KC, SS_OP_KC, dHid, M, ff, d, &am_, &bm_, &cm_, &eb, 1) != 0) { e = eb; db1_fused = true; }
+              }
+              if (db1_fused) {}
+              else if (use_planes() ? ss_gemm_planes_supported(SS_F32, dHid, M, ff, d, &am_, &bm_, &cm_, &es) != 0 : ss_gemm_fuses_column_stats(dt, dt, SS_OP_KC, SS_OP_KC, dHid, M, ff, d, &am_, &bm_, &cm_, &e, 1) != 0) { e = es; db1_fused = true; }
           }
           L_(gemm(X, dt, dF, w.w2T, dHid, M, ff, d, am_, bm_, cm_, &e, SS_OP_KC, SS_OP_KC, 1, 0, nullptr, db1_fused ? 2 : 1)); }      // consumers: dW1 and the dX GEMM (planes); the f32 copy only feeds an unfused bias gradient
         L_(grp.add(dHid, s.y1, w.dw1, ff, d, M, RM(ff), RM(d), side));
@@ -648,6 +662,7 @@ extern "C" int ss_plan_set_option(ss_plan* h, int what, int value)
     else if (what == 6) { old = h->p->keep_input; h->p->keep_input = value != 0; }
     else if (what == 7) { old = h->p->x3_planes; h->p->x3_planes = value != 0; }
     else if (what == 9) { old = h->p->x3_emit; h->p->x3_emit = value != 0; }
+    else if (what == 10) { old = h->p->sign_gate; h->p->sign_gate = value != 0; }
     else if (what == 8) { old = h->p->x3_attn; h->p->x3_attn = value != 0; }
     return old;
 }

@@ -429,6 +429,7 @@ def forward(model, x_raw, training, shift_r, seed):
     L.ss_plan_set_option(pb.handle, 5, int(model.f32_matmul == 'bf16x3'))         # (before the sizing pass: the plane form of that mode allocates operand planes)
     L.ss_plan_set_option(pb.handle, 7, int(os.environ.get('SS_AMD_X3_PLANES', '1') != '0'))
     L.ss_plan_set_option(pb.handle, 9, int(os.environ.get('SS_AMD_X3_EMIT', '1') != '0'))           # plane GEMMs write their consumers' planes from the epilogue (A/B: 0 = split passes)
+    L.ss_plan_set_option(pb.handle, 10, int(os.environ.get('SS_AMD_SIGN_GATE', '1') != '0'))        # FFN ReLU / dropout gate as sign bits (A/B: 0 = the saved activation)
     L.ss_plan_set_option(pb.handle, 8, int(bool(pr.layers) and all(e['EF.x3'] for e in pr.layers) and os.environ.get('SS_AMD_X3_ATTENTION', '1') != '0'))
     L.ss_plan_set_option(pb.handle, 1, int(os.environ.get('SS_AMD_DW_GROUPED', '1') != '0'))
     nbytes = int(L.ss_plan_workspace_bytes(pb.handle, B, T0, int(training)))

@@ -87,11 +87,12 @@ def _dt(t):
     return _lib.dtype_code(t.dtype)
 
 
-_epi_defaults = dict(log_clamp=0.0, c2=None, cmap2=None, col_stride2=0)
+_epi_defaults = dict(log_clamp=0.0, c2=None, cmap2=None, col_stride2=0, sign_out=None, gate_bits=None)
 
 
 def gemm_ex(A, B, C, M, N, K, amap, bmap, cmap, **kw):
-    """gemm() plus the rarely used epilogue extras: log_clamp, c2/cmap2/col_stride2."""
+    """gemm() plus the rarely used epilogue extras: log_clamp, c2/cmap2/col_stride2, sign_out / gate_bits (uint8 [M][N / 8] tensors: the sign of the
+    stored result as one bit per element, and a gate read from such bits instead of a tensor)."""
     extras = {k: kw.pop(k) for k in list(kw) if k in _epi_defaults}
     if not extras:
         return gemm(A, B, C, M, N, K, amap, bmap, cmap, **kw)
@@ -114,6 +115,12 @@ def _gemm_full(A, B, C, M, N, K, amap, bmap, cmap, extras, a_mode=OP_KC, b_mode=
     if col_perm is not None:
         epi.col_mod, epi.col_mul, epi.col_div_mul = col_perm
     epi.log_clamp = float(extras.get('log_clamp', 0.0))
+    if extras.get('sign_out') is not None:
+        assert extras['sign_out'].dtype == torch.uint8 and extras['sign_out'].numel() >= M * (N // 8)
+        epi.sign_out, epi.sign_pitch = _p(extras['sign_out']).value, N // 8
+    if extras.get('gate_bits') is not None:
+        assert extras['gate_bits'].dtype == torch.uint8 and extras['gate_bits'].numel() >= M * (N // 8)
+        epi.gate_bits, epi.gate_bits_pitch = _p(extras['gate_bits']).value, N // 8
     c2 = extras.get('c2')
     if c2 is not None:
         assert c2.dtype == C.dtype

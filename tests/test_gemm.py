@@ -1,4 +1,5 @@
 """ss_gemm parity: every operand-mode / dtype / epilogue combination against a torch fp32 matmul."""
+import numpy as np
 import pytest
 import torch
 
@@ -513,6 +514,44 @@ def test_gemm_planes_epilogues_and_conv(dev, gemm_opts):
     sc = torch.nn.functional.conv1d(x.abs().double().transpose(1, 2), w.abs().double(), None, stride=2, padding=1).transpose(1, 2)
     assert _x3_err(y[:, 1::2], want, sc) < 2.0 ** -16
     assert float(y[:, 0::2].abs().max()) == 0.0
+
+
+def test_gemm_sign_bits_producer_and_gate_consumer(dev, gemm_opts):
+    """ss_gemm_epilogue.sign_out / gate_bits (ABI 9; transformer.py:57 relu + dropout and its backward).  Producer: the register epilogue of the 8-wave kernel writes
+    [stored value > 0] as one bit per element beside the bf16 result -- equal to packbits of the result's sign, with bias + ReLU + dropout, ragged M, both tile heights.
+    Consumer: the column-sum epilogue gates from those bits -- bit-identical to gating from the tensor itself.  Kernels that do not carry the paths refuse."""
+    import ctypes as ct
+    from silent_speech_amd import _lib
+    big = not is_emu(dev)
+    g = torch.Generator().manual_seed(31)
+    for ni, (M, N, K) in ((9, (3000, 776, 128) if big else (600, 264, 128)), (8, (1000, 264, 64) if big else (330, 520, 64))):
+        gemm_opts(ops.GEMM_OPT_G8_NI, ni); gemm_opts(ops.GEMM_OPT_G8, 2)
+        a = torch.randn(M, K, generator=g).bfloat16().to(dev); b = torch.randn(N, K, generator=g).bfloat16().to(dev); bias = torch.randn(N, generator=g).to(dev)
+        rm = (ops.rowmap(K), ops.rowmap(K), ops.rowmap(N))
+        e = ops.GemmEpilogue(); e.alpha = 1.0; e.gate_scale = 1.0; e.relu = 1; e.dropout_p = 0.2
+        Cq = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        assert _lib.lib().ss_gemm_sign_bits_supported(_lib.SS_BF16, _lib.SS_BF16, 0, 0, ops._p(Cq), M, N, K, ct.byref(rm[0]), ct.byref(rm[1]), ct.byref(rm[2]), ct.byref(e), 1) == 1
+        H = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        sign = torch.full((M, N // 8), 0xAA, dtype=torch.uint8, device=dev)
+        ops.gemm_ex(a, b, H, M, N, K, *rm, bias=bias, relu=True, dropout_p=0.2, seed=7, rng_stream=2, sign_out=sign)
+        want = np.packbits((H.cpu().float().numpy() > 0).reshape(M, N // 8, 8), axis=-1, bitorder='little').reshape(M, N // 8)
+        assert np.array_equal(sign.cpu().numpy(), want)
+        H2 = torch.zeros_like(H)
+        ops.gemm(a, b, H2, M, N, K, *rm, bias=bias, relu=True, dropout_p=0.2, seed=7, rng_stream=2)
+        assert torch.equal(H.view(torch.int16), H2.view(torch.int16))          # the result does not notice
+        # consumer: dX-like GEMM of the same shape with gate + column sums
+        dy = torch.randn(M, K, generator=g).bfloat16().to(dev); w = torch.randn(N, K, generator=g).bfloat16().to(dev)
+        D1 = torch.zeros(M, N, dtype=torch.bfloat16, device=dev); D2 = torch.zeros_like(D1)
+        s1 = torch.zeros(N, device=dev); s2 = torch.zeros(N, device=dev)
+        ops.gemm(dy, w, D1, M, N, K, *rm, gate=H, gate_scale=1.25, col_stats=(s1, None, None))
+        ops.gemm_ex(dy, w, D2, M, N, K, *rm, gate_scale=1.25, col_stats=(s2, None, None), gate_bits=sign)
+        assert torch.equal(D1.view(torch.int16), D2.view(torch.int16))
+        assert_close_robust(s2, s1, 1e-6, name='col_sum with bit gate', max_outlier_frac=0)
+    # a kernel without the paths must refuse instead of ignoring the request
+    x = torch.randn(64, 96, generator=g).bfloat16().to(dev); C = torch.zeros(64, 64, dtype=torch.bfloat16, device=dev)
+    sg = torch.zeros(64, 8, dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match='sign_out / gate_bits need the 8-wave kernel'):
+        ops.gemm_ex(x, x[:64], C, 64, 64, 96, ops.rowmap(96), ops.rowmap(96), ops.rowmap(64), sign_out=sg)      # K % 64 != 0: the 128 x 128 kernels would run
 
 
 def test_gemm_planes_emits_its_result_as_planes(dev, gemm_opts):
