@@ -283,6 +283,13 @@ int64_t ss_layernorm_backward_scratch_floats(int rows, int C); /* [host] */
 int ss_layernorm_backward_ws(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                              void* dres, void* dbranch, float* dgamma, float* dbeta, float* dbranch_colsum, float* scratch, int64_t scratch_floats,
                              int rows, int C, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream);
+/* The parity-grade mode (f32 data): the LayerNorm output / the branch gradient ALSO leave as hi / lo bf16 planes (ss_split_planes' arithmetic on the stored f32
+ * value), so that the plane GEMMs that consume them need no split pass (ABI 9).  NULL planes = the plain forms above. */
+int ss_add_dropout_layernorm_forward_planes(int dtype, const void* x, void* branch_inout, const float* gamma, const float* beta, void* y, void* y_hi, void* y_lo,
+                                            float* mean, float* rstd, int rows, int C, float eps, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream);
+int ss_layernorm_backward_ws_planes(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                    void* dres, void* dbranch, void* dbranch_hi, void* dbranch_lo, float* dgamma, float* dbeta, float* dbranch_colsum, float* scratch,
+                                    int64_t scratch_floats, int rows, int C, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream);
 
 /* EMG input conditioning: training-time shift augmentation (architecture.py:64-68: x[:, :-r] = x[:, r:],
  * x[:, -r:] = 0), cast to the compute dtype and zero halo rows: x_raw (B,T0,Cin) f32 ->

@@ -84,9 +84,11 @@ SIGNATURES = {
     'ss_bn_backward_apply': [_I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, ctypes.c_double, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     'ss_colsum': [_I, _P, _I, _I, _L, _P, _P, _P],
     'ss_add_dropout_layernorm_forward': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U32, _P],
+    'ss_add_dropout_layernorm_forward_planes': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _U32, _P],
     'ss_layernorm_backward': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _P],
     'ss_layernorm_backward_bias': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _U32, _P],
     'ss_layernorm_backward_ws': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _U64, _U32, _P],
+    'ss_layernorm_backward_ws_planes': [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _U64, _U32, _P],
     'ss_emg_prepare': [_I, _P, _P, _P, _I, _I, _I, _I, _P],
     'ss_frame_lse': [_P, _L, _I, _I, _I, _P, _P, _P],
     'ss_loss_index_tables': [_P, _I, _P, _P, _P, _P, _P, _P],

@@ -686,8 +686,10 @@ extern "C" int ss_colsum(int dtype, const void* x, int rows, int C, int64_t ld, 
 template <class T, int NV>
 __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ a_z, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int rows, int C, float eps,
-                                                                 unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id)
+                                                                 unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id,
+                                                                 bf16_t* __restrict__ y_hi = nullptr, bf16_t* __restrict__ y_lo = nullptr)
 {
+    // y_hi / y_lo (f32 only; the parity-grade mode): y also leaves as hi / lo bf16 planes (planes.hip's arithmetic) for the plane GEMMs that consume it
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6, CV = C >> 3;
     // gamma / beta of this lane's chunks stay in registers for all of its rows (they were re-read -- 4 x 16 bytes per chunk -- behind their own wait on
     // every row), and the raw chunks of the NEXT row are requested before the current row is reduced: a wave otherwise runs load -> wait -> reduce -> load
@@ -768,6 +770,17 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __rest
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (z[i][e] - mu) * rs * gm[HOIST ? i : 0][e] + bt[HOIST ? i : 0][e];
                 Vec8<T>::store(y + (long long)r * C + cx * 8, o);
+                if constexpr (sizeof(T) == 4) {
+                    if (y_hi) {
+                        u32x4 h, l;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const unsigned hp = pack_bf16(o[2 * p], o[2 * p + 1]);
+                            h[p] = hp; l[p] = pack_bf16(o[2 * p] - __uint_as_float(hp << 16), o[2 * p + 1] - __uint_as_float(hp & 0xffff0000u));
+                        }
+                        *(u32x4*)(y_hi + (long long)r * C + cx * 8) = h; *(u32x4*)(y_lo + (long long)r * C + cx * 8) = l;
+                    }
+                }
             }
         }
     }
@@ -913,8 +926,10 @@ template <class T, int P, bool BS, bool DROP>
 __global__ __launch_bounds__(LNB2_WAVES * 64) void ln_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   const float* __restrict__ gamma, T* __restrict__ dres, T* __restrict__ dbranch, float* __restrict__ partial,
                                                                   int rows, unsigned thresh, float keep_scale, unsigned long long seed, unsigned stream_id,
-                                                                  float* dgamma, float* dbeta, float* dbsum, int direct)
+                                                                  float* dgamma, float* dbeta, float* dbsum, int direct,
+                                                                  bf16_t* __restrict__ db_hi = nullptr, bf16_t* __restrict__ db_lo = nullptr)
 {
+    // db_hi / db_lo (f32 only; the parity-grade mode): dbranch also leaves as hi / lo bf16 planes for the plane GEMMs that consume it
     constexpr int C = P * 256;
     __shared__ float red[LNB2_WAVES][C];
     typedef typename Piece4<T>::raw Raw;
@@ -965,6 +980,15 @@ __global__ __launch_bounds__(LNB2_WAVES * 64) void ln_bwd2_kernel(const T* __res
             }
             Piece4<T>::store(dres + (long long)r * C + col, o);
             Piece4<T>::store(dbranch + (long long)r * C + col, ob);
+            if constexpr (sizeof(T) == 4) {
+                if (db_hi) {
+                    const unsigned h0 = pack_bf16(ob[0], ob[1]), h1 = pack_bf16(ob[2], ob[3]);
+                    const u32x2 hw = {h0, h1};
+                    const u32x2 lw = {pack_bf16(ob[0] - __uint_as_float(h0 << 16), ob[1] - __uint_as_float(h0 & 0xffff0000u)),
+                                      pack_bf16(ob[2] - __uint_as_float(h1 << 16), ob[3] - __uint_as_float(h1 & 0xffff0000u))};
+                    *(u32x2*)(db_hi + (long long)r * C + col) = hw; *(u32x2*)(db_lo + (long long)r * C + col) = lw;
+                }
+            }
         }
 #pragma unroll
         for (int p = 0; p < P; ++p) { dcur[p] = dnx[p]; zcur[p] = znx[p]; }
@@ -1034,13 +1058,20 @@ extern "C" int64_t ss_layernorm_backward_scratch_floats(int rows, int C)
 extern "C" int ss_add_dropout_layernorm_forward(int dtype, const void* x, void* branch_inout, const float* gamma, const float* beta, void* y,
                                                 float* mean, float* rstd, int rows, int C, float eps, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
+    return ss_add_dropout_layernorm_forward_planes(dtype, x, branch_inout, gamma, beta, y, nullptr, nullptr, mean, rstd, rows, C, eps, dropout_p, seed, rng_stream, stream);
+}
+
+extern "C" int ss_add_dropout_layernorm_forward_planes(int dtype, const void* x, void* branch_inout, const float* gamma, const float* beta, void* y, void* y_hi, void* y_lo,
+                                                       float* mean, float* rstd, int rows, int C, float eps, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
+{
     SS_CHECK(x && branch_inout && gamma && beta && y && mean && rstd, "ss_add_dropout_layernorm_forward: null pointer");
+    SS_CHECK((y_hi != nullptr) == (y_lo != nullptr) && (!y_hi || (dtype == SS_F32 && ((uintptr_t)y_hi | (uintptr_t)y_lo) % 16 == 0)), "ss_add_dropout_layernorm_forward_planes: planes come as a pair, for f32 data, 16-byte aligned");
     SS_CHECK(C % 8 == 0 && C > 0 && C <= 4096, "ss_add_dropout_layernorm_forward: C=%d must be a multiple of 8 and <= 4096", C);
     SS_CHECK(dropout_p >= 0.f && dropout_p < 1.f, "dropout p out of range");
     if (rows <= 0) return 0;
     const unsigned th = dropout_threshold(dropout_p); const float ks = 1.f / (1.f - dropout_p);
     int blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096;
-#define SS_LNF(TT, NV) SS_LAUNCH(SS_KERNEL(add_dropout_ln_fwd_kernel<TT, NV>), dim3(blocks), dim3(256), 0, stream, (const TT*)x, (TT*)branch_inout, gamma, beta, (TT*)y, mean, rstd, rows, C, eps, th, ks, (unsigned long long)seed, rng_stream)
+#define SS_LNF(TT, NV) SS_LAUNCH(SS_KERNEL(add_dropout_ln_fwd_kernel<TT, NV>), dim3(blocks), dim3(256), 0, stream, (const TT*)x, (TT*)branch_inout, gamma, beta, (TT*)y, mean, rstd, rows, C, eps, th, ks, (unsigned long long)seed, rng_stream, (bf16_t*)y_hi, (bf16_t*)y_lo)
     if (dtype == SS_BF16) { if (C <= 1024) SS_LNF(bf16_t, 2); else SS_LNF(bf16_t, 8); }
     else { if (C <= 1024) SS_LNF(float, 2); else SS_LNF(float, 8); }
 #undef SS_LNF
@@ -1065,6 +1096,16 @@ extern "C" int ss_layernorm_backward_ws(int dtype, const void* dy, const void* z
                                         void* dres, void* dbranch, float* dgamma, float* dbeta, float* dbranch_colsum, float* scratch, int64_t scratch_floats,
                                         int rows, int C, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
 {
+    return ss_layernorm_backward_ws_planes(dtype, dy, z, mean, rstd, gamma, dres, dbranch, nullptr, nullptr, dgamma, dbeta, dbranch_colsum, scratch, scratch_floats, rows, C, dropout_p, seed, rng_stream, stream);
+}
+
+// the same with dbranch ALSO written as hi / lo bf16 planes (f32 data, the workspace form only: returns an error when the shape would take the atomic form)
+extern "C" int ss_layernorm_backward_ws_planes(int dtype, const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                               void* dres, void* dbranch, void* dbranch_hi, void* dbranch_lo, float* dgamma, float* dbeta, float* dbranch_colsum, float* scratch,
+                                               int64_t scratch_floats, int rows, int C, float dropout_p, uint64_t seed, uint32_t rng_stream, void* stream)
+{
+    SS_CHECK((dbranch_hi != nullptr) == (dbranch_lo != nullptr) && (!dbranch_hi || (dtype == SS_F32 && dbranch && ((uintptr_t)dbranch_hi | (uintptr_t)dbranch_lo) % 8 == 0)),
+             "ss_layernorm_backward_ws_planes: planes come as a pair, for f32 data with dbranch, 8-byte aligned");
     SS_CHECK(dy && z && mean && rstd && gamma && dres && dgamma && dbeta, "ss_layernorm_backward: null pointer");
     SS_CHECK(!dbranch_colsum || dbranch, "ss_layernorm_backward_bias: the column sums are those of dbranch");
     SS_CHECK(C % 8 == 0 && C > 0 && C <= 4096, "ss_layernorm_backward: C=%d must be a multiple of 8 and <= 4096", C);
@@ -1076,7 +1117,7 @@ extern "C" int ss_layernorm_backward_ws(int dtype, const void* dy, const void* z
         if (scratch && dbranch && want > 0 && scratch_floats >= want && !(e && e[0] == '0')) {
             const int nb = lnb2_blocks(rows);
             int direct = 1; { const char* e2 = getenv("SS_LN_DIRECT"); if (e2) direct = atoi(e2); }
-#define SS_LNB2K(TT, PP, BSV, DRV) SS_LAUNCH(SS_KERNEL(ln_bwd2_kernel<TT, PP, BSV, DRV>), dim3(nb), dim3(LNB2_WAVES * 64), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, scratch, rows, th, ks, (unsigned long long)seed, rng_stream, dgamma, dbeta, dbranch_colsum, direct)
+#define SS_LNB2K(TT, PP, BSV, DRV) SS_LAUNCH(SS_KERNEL(ln_bwd2_kernel<TT, PP, BSV, DRV>), dim3(nb), dim3(LNB2_WAVES * 64), 0, stream, (const TT*)dy, (const TT*)z, mean, rstd, gamma, (TT*)dres, (TT*)dbranch, scratch, rows, th, ks, (unsigned long long)seed, rng_stream, dgamma, dbeta, dbranch_colsum, direct, (bf16_t*)dbranch_hi, (bf16_t*)dbranch_lo)
 #define SS_LNB2(TT, PP) do { if (dbranch_colsum) { if (th) SS_LNB2K(TT, PP, true, true); else SS_LNB2K(TT, PP, true, false); } \
                              else { if (th) SS_LNB2K(TT, PP, false, true); else SS_LNB2K(TT, PP, false, false); } } while (0)
             if (dtype == SS_BF16) { if (C == 256) SS_LNB2(bf16_t, 1); else if (C == 512) SS_LNB2(bf16_t, 2); else SS_LNB2(bf16_t, 3); }
@@ -1088,6 +1129,7 @@ extern "C" int ss_layernorm_backward_ws(int dtype, const void* dy, const void* z
             return 0;
         }
     }
+    SS_CHECK(!dbranch_hi, "ss_layernorm_backward_ws_planes: plane output needs the workspace form (C = 256, 512 or 768 with scratch of ss_layernorm_backward_scratch_floats)");
     // 2 blocks per CU (~200 registers).  On gfx9 a wait for the prefetched loads also drains the previous row's stores (one vmcnt for both),
     // so consecutive rows of one wave overlap only partly; forcing 3 waves per SIMD (168 registers) spills the column accumulators.
     int blocks = (rows + 15) / 16; if (blocks > 512) blocks = 512;

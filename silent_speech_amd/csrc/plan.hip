@@ -176,6 +176,14 @@ struct Plan {
     // hi plane of the f32 buffer [src, src + n) (lo plane n elements behind it); split on first use, on the MAIN stream (every consumer -- side-stream
     // launches included -- is ordered behind it by the fork that precedes them).  key: what identifies the buffer (its address; a weight: its slot)
     struct Pl { void* hi; void* lo; };
+    // planes a producer kernel will write for the dense f32 buffer `key` of n elements (registered in the cache; nullptr pair when the mode is off)
+    Pl new_planes(Exec& X, const void* key, long long n) {
+        if (!(use_planes() && x3_emit)) return Pl{nullptr, nullptr};
+        n = (n + 7) & ~7LL;
+        void* hi = X.alloc((size_t)n * 4);
+        adopt_planes(key, hi, n);
+        return Pl{hi, (char*)hi + n * 2};
+    }
     Pl planes(Exec& X, const void* key, const void* src, long long n) {
         PlaneCache& pc = cur->planes;
         // (a null key is never reused: in the sizing pass the first workspace buffer and the caller's dhead both have address 0)
@@ -388,7 +396,7 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
     const int T = Tin, M = B * T;
     c->T = T; c->M = M; c->conv_out = xin;
     void* x = X.alloc((size_t)M * d * es);
-    { ss_gemm_epilogue e = EPI(); e.bias = b_raw_in; L_(gemm(X, dt, xin, w_raw_in, x, M, d, d, RM(d), RM(d), RM(d), &e)); }
+    { ss_gemm_epilogue e = EPI(); e.bias = b_raw_in; L_(gemm(X, dt, xin, w_raw_in, x, M, d, d, RM(d), RM(d), RM(d), &e, SS_OP_KC, SS_OP_KC, 1, 0, nullptr, 1)); }
 
     const int H = D.n_head, dp = D.dp, Dr = D.max_rel, ff = D.ff, HD = H * dp;
     const int Tp = round_up(T, 8);
@@ -426,7 +434,8 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         L_(gemm(X, dt, o, w.wo, a, M, d, HD, RM(HD), RM(HD), RM(d)));
         void* y1 = X.alloc((size_t)M * d * es);
         float* mean1 = (float*)X.alloc((size_t)M * 4); float* rstd1 = (float*)X.alloc((size_t)M * 4);
-        if (!X.dry) L_(timed(X, "add_dropout_ln_fwd", 0, (double)M * d * es * 5, stream, [&] { return ss_add_dropout_layernorm_forward(dt, x, a, w.g1, w.be1, y1, mean1, rstd1, M, d, D.ln_eps, p_drop, seed, 4 * l + 1, stream); }));
+        const Pl y1p = new_planes(X, y1, (long long)M * d);      // (parity-grade mode: linear1 and dW1 take y1 as planes)
+        if (!X.dry) L_(timed(X, "add_dropout_ln_fwd", 0, (double)M * d * es * 5, stream, [&] { return ss_add_dropout_layernorm_forward_planes(dt, x, a, w.g1, w.be1, y1, y1p.hi, y1p.lo, mean1, rstd1, M, d, D.ln_eps, p_drop, seed, 4 * l + 1, stream); }));
         void* hid = X.alloc((size_t)M * ff * es);
         unsigned char* hid_sign = nullptr;
         { ss_gemm_epilogue e = EPI(); e.bias = w.b1; e.relu = 1; e.dropout_p = p_drop; e.seed = seed; e.rng_stream = 4 * l + 2;
@@ -442,7 +451,8 @@ int Plan::forward(Exec& X, const float* x_raw, float* shifted, int B, int T0, in
         { ss_gemm_epilogue e = EPI(); e.bias = w.b2; L_(gemm(X, dt, hid, w.w2, f, M, d, ff, RM(ff), RM(ff), RM(d), &e)); }
         void* y2 = X.alloc((size_t)M * d * es);
         float* mean2 = (float*)X.alloc((size_t)M * 4); float* rstd2 = (float*)X.alloc((size_t)M * 4);
-        if (!X.dry) L_(timed(X, "add_dropout_ln_fwd", 0, (double)M * d * es * 5, stream, [&] { return ss_add_dropout_layernorm_forward(dt, y1, f, w.g2, w.be2, y2, mean2, rstd2, M, d, D.ln_eps, p_drop, seed, 4 * l + 3, stream); }));
+        const Pl y2p = new_planes(X, y2, (long long)M * d);      // (the next layer's qkv GEMM / dWqkv, or the output heads)
+        if (!X.dry) L_(timed(X, "add_dropout_ln_fwd", 0, (double)M * d * es * 5, stream, [&] { return ss_add_dropout_layernorm_forward_planes(dt, y1, f, w.g2, w.be2, y2, y2p.hi, y2p.lo, mean2, rstd2, M, d, D.ln_eps, p_drop, seed, 4 * l + 3, stream); }));
         s.qkv = qkv; s.qkvT = qkvT; s.o = o; s.lse = lse; s.z1 = a; s.mean1 = mean1; s.rstd1 = rstd1; s.y1 = y1;
         s.hid = hid; s.hid_sign = hid_sign; s.z2 = f; s.mean2 = mean2; s.rstd2 = rstd2;
         x = y2;
@@ -500,7 +510,8 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         // (its grouped weight-gradient launch) while the main stream is already inside the next layer, so nothing is recycled before join()
         void* dF = X.alloc((size_t)M * d * es);
         // linear2.bias.grad = column sums of dF: accumulated by the LayerNorm backward kernel itself
-        if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward_ws(dt, G, s.z2, s.mean2, s.rstd2, w.g2, G, dF, w.dg2, w.dbe2, w.db2, ln_scratch, ln_floats, M, d, p_drop, seed, 4 * l + 3, stream); }));
+        const Pl dFp = ln_floats ? new_planes(X, dF, (long long)M * d) : Pl{nullptr, nullptr};      // (parity-grade mode: dW2 and the FFN input-gradient GEMM take dF as planes)
+        if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward_ws_planes(dt, G, s.z2, s.mean2, s.rstd2, w.g2, G, dF, dFp.hi, dFp.lo, w.dg2, w.dbe2, w.db2, ln_scratch, ln_floats, M, d, p_drop, seed, 4 * l + 3, stream); }));
         L_(grp.add(dF, s.hid, w.dw2, d, ff, M, RM(d), RM(ff), side));
         void* dHid = X.alloc((size_t)M * ff * es);
         bool db1_fused = false;
@@ -521,7 +532,8 @@ int Plan::backward(Exec& X, Ctx* c, const float* dhead)
         if (!db1_fused) { SIDE_BEGIN(); L_(colsum(X, dHid, M, ff, w.db1, side)); SIDE_END(); }
         { ss_gemm_epilogue e = EPI(); e.mode = 1; L_(gemm(X, dt, dHid, w.w1T, G, M, d, ff, RM(ff), RM(ff), RM(d), &e)); }
         void* dA = X.alloc((size_t)M * d * es);
-        if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward_ws(dt, G, s.z1, s.mean1, s.rstd1, w.g1, G, dA, w.dg1, w.dbe1, nullptr, ln_scratch, ln_floats, M, d, p_drop, seed, 4 * l + 1, stream); }));
+        const Pl dAp = ln_floats ? new_planes(X, dA, (long long)M * d) : Pl{nullptr, nullptr};      // (dWo and the dO GEMM)
+        if (!X.dry) L_(timed(X, "ln_bwd", 0, (double)M * d * es * 4, stream, [&] { return ss_layernorm_backward_ws_planes(dt, G, s.z1, s.mean1, s.rstd1, w.g1, G, dA, dAp.hi, dAp.lo, w.dg1, w.dbe1, nullptr, ln_scratch, ln_floats, M, d, p_drop, seed, 4 * l + 1, stream); }));
         // output projection  out[t,b,f] = sum_{h,a} o[b,h,t,a] w_o[h,a,f]   (transformer.py:111)
         L_(grp.add(dA, s.o, w.wo_stage, d, HD, M, RM(d), RM(HD), side));
         void* dO = X.alloc((size_t)M * HD * es);

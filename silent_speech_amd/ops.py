@@ -276,11 +276,12 @@ def colsum(x, rows, C, ld, out_accum):
     _lib.check(_L().ss_colsum(_dt(x), _p(x), rows, C, ld, _p(scratch), _p(out_accum), _s(x)), 'ss_colsum')
 
 
-def add_dropout_layernorm(x, branch_inout, gamma, beta, y, rows, C, eps=1e-5, p=0.0, seed=0, rng_stream=0):
+def add_dropout_layernorm(x, branch_inout, gamma, beta, y, rows, C, eps=1e-5, p=0.0, seed=0, rng_stream=0, planes=None):
+    """planes = (hi, lo): bf16 tensors shaped like y (f32 data only) that also receive y as hi / lo planes (what split_planes(y) gives)."""
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    rc = _L().ss_add_dropout_layernorm_forward(_dt(x), _p(x), _p(branch_inout), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd),
-                                               rows, C, eps, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(x))
+    rc = _L().ss_add_dropout_layernorm_forward_planes(_dt(x), _p(x), _p(branch_inout), _p(gamma), _p(beta), _p(y), _p(planes[0]) if planes else None, _p(planes[1]) if planes else None,
+                                                      _p(mean), _p(rstd), rows, C, eps, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(x))
     _lib.check(rc, 'ss_add_dropout_layernorm_forward')
     return mean, rstd
 
@@ -288,7 +289,7 @@ def add_dropout_layernorm(x, branch_inout, gamma, beta, y, rows, C, eps=1e-5, p=
 _ln_scratch = {}
 
 
-def layernorm_backward(dy, z, mean, rstd, gamma, dres, dbranch, dgamma, dbeta, rows, C, p=0.0, seed=0, rng_stream=0, dbranch_colsum=None):
+def layernorm_backward(dy, z, mean, rstd, gamma, dres, dbranch, dgamma, dbeta, rows, C, p=0.0, seed=0, rng_stream=0, dbranch_colsum=None, planes=None):
     """dres / dbranch / (+=) dgamma, dbeta [, dbranch_colsum]; the per-workgroup column sums go through a cached scratch buffer when the
     width has the 16-wave form (ss_layernorm_backward_scratch_floats > 0), through atomics otherwise."""
     n = int(_L().ss_layernorm_backward_scratch_floats(rows, C))
@@ -298,8 +299,9 @@ def layernorm_backward(dy, z, mean, rstd, gamma, dres, dbranch, dgamma, dbeta, r
         scratch = _ln_scratch.get(key)
         if scratch is None:
             scratch = _ln_scratch[key] = torch.empty(n, dtype=torch.float32, device=dy.device)
-    rc = _L().ss_layernorm_backward_ws(_dt(dy), _p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dbranch), _p(dgamma), _p(dbeta),
-                                       _p(dbranch_colsum), _p(scratch), n, rows, C, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(dy))
+    rc = _L().ss_layernorm_backward_ws_planes(_dt(dy), _p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dbranch), _p(planes[0]) if planes else None,
+                                              _p(planes[1]) if planes else None, _p(dgamma), _p(dbeta),
+                                              _p(dbranch_colsum), _p(scratch), n, rows, C, p, int(seed) & 0xFFFFFFFFFFFFFFFF, rng_stream, _s(dy))
     _lib.check(rc, 'ss_layernorm_backward')
 
 

@@ -93,6 +93,35 @@ def test_batchnorm_eval_mode(dev):
     assert_close_robust(y, want, 1e-5, name='bn_eval', max_outlier_frac=0)
 
 
+def test_layernorm_plane_outputs(dev):
+    """ss_add_dropout_layernorm_forward_planes / ss_layernorm_backward_ws_planes (the parity-grade mode, transformer.py:55-60): y and the branch gradient also
+    leave as hi / lo bf16 planes -- bit for bit ss_split_planes of the stored f32 tensors --, with dropout, and the f32 results are those of the plain entry points."""
+    rows, C = (9, 768) if is_emu(dev) else (1003, 768)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(rows, C, generator=g); a = torch.randn(rows, C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    dy = torch.randn(rows, C, generator=g)
+    xd, ad = x.to(dev), a.clone().to(dev)
+    y = torch.empty(rows, C, device=dev); hi = torch.zeros(rows, C, dtype=torch.bfloat16, device=dev); lo = torch.zeros_like(hi)
+    mean, rstd = ops.add_dropout_layernorm(xd, ad, gamma.to(dev), beta.to(dev), y, rows, C, p=0.2, seed=5, rng_stream=3, planes=(hi, lo))
+    a2 = a.clone().to(dev); y2 = torch.empty_like(y)
+    ops.add_dropout_layernorm(xd, a2, gamma.to(dev), beta.to(dev), y2, rows, C, p=0.2, seed=5, rng_stream=3)
+    assert torch.equal(y, y2) and torch.equal(ad, a2)
+    wh, wl = ops.split_planes(y)
+    assert torch.equal(hi.view(torch.int16), wh.view(torch.int16).view(rows, C)) and torch.equal(lo.view(torch.int16), wl.view(torch.int16).view(rows, C))
+    dres = dy.clone().to(dev); dbr = torch.empty(rows, C, device=dev); bh = torch.zeros_like(hi); bl = torch.zeros_like(hi)
+    dg, db, cs = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.layernorm_backward(dres, ad, mean, rstd, gamma.to(dev), dres, dbr, dg, db, rows, C, p=0.2, seed=5, rng_stream=3, dbranch_colsum=cs, planes=(bh, bl))
+    dres2 = dy.clone().to(dev); dbr2 = torch.empty_like(dbr)
+    dg2, db2, cs2 = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.layernorm_backward(dres2, ad, mean, rstd, gamma.to(dev), dres2, dbr2, dg2, db2, rows, C, p=0.2, seed=5, rng_stream=3, dbranch_colsum=cs2)
+    assert torch.equal(dres, dres2) and torch.equal(dbr, dbr2)
+    wh, wl = ops.split_planes(dbr)
+    assert torch.equal(bh.view(torch.int16), wh.view(torch.int16).view(rows, C)) and torch.equal(bl.view(torch.int16), wl.view(torch.int16).view(rows, C))
+    with pytest.raises(RuntimeError, match='planes'):                       # bf16 data has no plane output
+        ops.add_dropout_layernorm(xd.bfloat16(), ad.bfloat16(), gamma.to(dev), beta.to(dev), y.bfloat16(), rows, C, planes=(hi, lo))
+
+
 @pytest.mark.parametrize('dt', DTS)
 @pytest.mark.parametrize('C', [64, 768])
 def test_add_dropout_layernorm_fwd_bwd(dev, dt, C):
